@@ -1,0 +1,150 @@
+/* madicp_hip.h — C ABI of libmadicp_hip.so: the MI355X (gfx950) implementation of MAD-ICP's
+ * data-association + registration hot path.
+ *
+ * This is the boundary the host C++ classes (mad_icp_amd/csrc/host: MADtree, MADicp, Pipeline) bind to,
+ * and what a reference maintainer would bind to from mad_icp/src.  Plain pointers
+ * and sizes only; no C++/torch types; no exceptions cross it.
+ *
+ * Conventions
+ *   - every call returns 0 on success, <0 on error; madicp_last_error() gives the message of the last
+ *     failing call on the calling thread.
+ *   - host buffers are owned by the caller, device buffers by the library (referred to by integer ids).
+ *   - 3x3 rotations / 6x6 matrices cross the ABI ROW-major; a pose is 12 doubles: R (9, row-major), t (3).
+ *     (The reference holds them as column-major Eigen objects; the host classes convert.)
+ *   - clouds are (N,3) float64, C-contiguous — the memory layout of std::vector<Eigen::Vector3d>
+ *     (mad_icp/src/tools/mad_tree.h:42, mad_icp/src/pybind/eigen_stl_bindings.h:73-81).
+ *   - all arithmetic on the path is IEEE fp64 with the reference's operation order and no FMA contraction,
+ *     so descent/gate decisions are bit-identical to the CPU path.
+ *   - a context is bound to one device and one stream; calls on one context are not re-entrant.
+ *     Calls without the `_enqueue` suffix are synchronous on return.
+ */
+#ifndef MADICP_HIP_H
+#define MADICP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADICP_OK 0
+#define MADICP_ERR_INVALID (-1)   /* bad argument / unknown id            */
+#define MADICP_ERR_DEVICE (-2)    /* HIP runtime error (no device, OOM …) */
+#define MADICP_ERR_COMM (-3)      /* RCCL error                           */
+#define MADICP_ERR_CAPACITY (-4)  /* more trees / scans than the ABI caps */
+
+#define MADICP_MAX_TREES 128 /* keyframe trees one registration may reference (reference README suggests 16) */
+#define MADICP_MAX_BATCH 64  /* scans in flight in one batched registration                                  */
+
+/* One MAD-tree node, 64 bytes, nodes stored in DFS preorder (left child = this + 1).
+ * Replaces the heap-allocated `struct MADtree` (mad_icp/src/tools/mad_tree.h:47-102): only the fields the
+ * hot path reads are kept — mean_ (:96), the split axis eigenvectors_.col(2) for internal nodes
+ * (mad_tree.cpp:147-148) or the normal eigenvectors_.col(0) for leaves (mad_icp.cpp:65), bbox_(0)
+ * (mad_icp.cpp:97) and the child links. */
+typedef struct madicp_node {
+  double mean[3]; /* internal: centroid; leaf: the surface point nearest to it (mad_tree.cpp:76-86) */
+  double dir[3];  /* internal: split-plane normal (col 2); leaf: surface normal (col 0)             */
+  int32_t right;  /* internal: index of the right child minus own index (>= 2); leaf: 0            */
+  int32_t leaf_id;/* leaf: ordinal in getLeafs() order (mad_tree.cpp:154-163); internal: -1         */
+  double bbox0;   /* bbox_(0): extent along the normal                                              */
+} madicp_node;
+
+/* MADicp constructor arguments (mad_icp/src/odometry/mad_icp.cpp:31-32).  rho_ker is passed as the user
+ * gives it; the library takes the square root exactly where the reference constructor does. */
+typedef struct madicp_icp_params {
+  double min_ball; /* = b_max of the fixed trees (pipeline.cpp:52, mad_icp_wrapper.h:59) */
+  double rho_ker;
+  double b_ratio;
+} madicp_icp_params;
+
+typedef struct madicp_ctx madicp_ctx;
+
+const char* madicp_last_error(void);
+/* ABI version: bumped on any incompatible change. */
+int madicp_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream) or NULL to let the library
+ * create its own non-blocking stream on `device_id`. */
+int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out);
+int madicp_ctx_destroy(madicp_ctx* ctx);
+int madicp_ctx_synchronize(madicp_ctx* ctx);
+/* Tuning knobs (all optional): key in {"grid_blocks_per_cu", "use_graph", "lds_top_levels",
+ * "queries_per_thread", "time_kernels"}. */
+int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
+/* When option "time_kernels" is on, every icp_linearize launch is bracketed by hipEvents on the ctx
+ * stream; this returns the number of launches timed since the last reset and their total duration. */
+int madicp_ctx_kernel_time(madicp_ctx* ctx, int reset, int64_t* n_launches, double* total_ms);
+
+/* ---- MAD-tree (fixed side) ---------------------------------------------------------------------- */
+/* Upload a linearised tree.  Replaces keeping `MADtree*` alive in Frame::tree_ (frame.h:47). */
+int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id);
+int madicp_tree_release(madicp_ctx* ctx, int tree_id);
+int madicp_tree_download(madicp_ctx* ctx, int tree_id, madicp_node* out_nodes, int32_t n_nodes);
+/* MADtree::applyTransform (mad_tree.cpp:165-172): mean <- R mean + t, dir <- R dir on every node. */
+int madicp_tree_transform(madicp_ctx* ctx, int tree_id, const double R[9], const double t[3]);
+/* Batched MADtree::bestMatchingLeafFast (mad_tree.cpp:144-152) as used by MADtreeWrapper::search /
+ * searchCloud / searchCloudDist (mad_tree_wrapper.h:42-67).  queries: host (n,3).  Any output may be NULL.
+ * out_leaf_id = getLeafs() ordinal, out_node = index into the node array, out_dist = |q - leaf.mean|,
+ * out_depth = internal nodes visited. */
+int madicp_nn_search(madicp_ctx* ctx, int tree_id, const double* queries, int64_t n, uint32_t* out_leaf_id,
+                     uint32_t* out_node, double* out_dist, int32_t* out_depth);
+/* Same with queries / outputs already resident on the device (device pointers), asynchronous. */
+int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* d_queries, int64_t n,
+                                    uint32_t* d_out_leaf_id, uint32_t* d_out_node, double* d_out_dist,
+                                    int32_t* d_out_depth);
+
+/* ---- moving side -------------------------------------------------------------------------------- */
+/* MADicp::setMoving (mad_icp.cpp:53-55): the sensor-frame means of the current scan's leaves, (L,3). */
+int madicp_moving_upload(madicp_ctx* ctx, const double* leaf_means, int32_t L, int* out_moving_id);
+int madicp_moving_release(madicp_ctx* ctx, int moving_id);
+
+/* ---- registration ------------------------------------------------------------------------------- */
+/* One linearisation at a given pose, no state update: resetAdders + update() over K trees
+ * (mad_icp.cpp:43-51,74-103 under pipeline.cpp:178-183).  out_H (36, row-major) and out_b (6) are the
+ * summed adders; out_corr (K*L, optional) gets for tree k / moving leaf i the NN leaf ordinal, with bit 31
+ * set when the gate at mad_icp.cpp:81-83 rejected the pair; out_matched (L, optional) the OR over trees of
+ * the accepted pairs; out_visits (optional) the total number of internal nodes visited. */
+int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, int K, const double X[12],
+                         const madicp_icp_params* params, double out_H[36], double out_b[6], uint32_t* out_corr,
+                         uint8_t* out_matched, uint64_t* out_visits);
+
+/* The whole GN loop on the device, no host round trip between iterations: n_iters rounds of
+ * {resetAdders; update() over the K trees; updateState()} — pipeline.cpp:166-193 and
+ * mad_icp_wrapper.h:72-81.  X is MADicp::X_ (in: initial guess, out: estimate); out_H/out_b are
+ * MADicp::H_adder_/b_adder_ of the LAST round (pipeline.cpp:223 reads H_adder_); out_matched (L, optional)
+ * are the matched_ flags of the last round (cleared before it, pipeline.cpp:172-176);
+ * out_X_iters (n_iters*12, optional) the pose BEFORE each round. */
+int madicp_icp_register(madicp_ctx* ctx, int moving_id, const int* tree_ids, int K, double X[12],
+                        const madicp_icp_params* params, int n_iters, double out_H[36], double out_b[6],
+                        uint8_t* out_matched, double* out_X_iters, uint64_t* out_visits);
+
+/* n_scans independent registrations against the same K trees, advanced in lock-step by the same
+ * launches (BASELINE config 5: scans batched in flight).  X: n_scans*12, out_H: n_scans*36,
+ * out_b: n_scans*6, out_n_matched: n_scans (count of matched leaves of the last round). */
+int madicp_icp_register_batch(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
+                              double* X, const madicp_icp_params* params, int n_iters, double* out_H,
+                              double* out_b, int32_t* out_n_matched, uint64_t* out_visits);
+
+/* Asynchronous form for throughput measurement: everything stays on the device; results are fetched
+ * later with madicp_icp_fetch (which synchronises).  X0: n_scans*12 initial guesses (copied on call). */
+int madicp_icp_register_batch_enqueue(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids,
+                                      int K, const double* X0, const madicp_icp_params* params, int n_iters);
+int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H, double* out_b,
+                     int32_t* out_n_matched, uint64_t* out_visits);
+/* matched_ flags of scan `scan` of the last batch (L bytes). */
+int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, int32_t L);
+
+/* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
+/* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte
+ * ncclUniqueId produced by madicp_comm_unique_id on rank 0 and distributed by the caller (e.g. a
+ * torch.distributed broadcast).  After this call every registration on the context all-reduces
+ * [H(21) b(6) n] over the communicator after each round and ORs the matched flags after the last. */
+int madicp_comm_unique_id(uint8_t out_id[128]);
+int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks, int rank);
+int madicp_comm_destroy(madicp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADICP_HIP_H */

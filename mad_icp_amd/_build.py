@@ -1,0 +1,99 @@
+"""Builds the native parts of mad_icp_amd in-tree (the .so files travel with the repo snapshot).
+
+  libmadicp_hip.so   hipcc, gfx950 only: HIP kernels + the C ABI of include/madicp_hip.h
+  libmadicp_host.so  g++: host MAD-tree builder, C ABI of include/madicp_host.h
+  pybind/*.so        g++ + pybind11: pyvector, pymadtree, pymadicp, pypeline (the reference's module names)
+
+No CPU fallback is ever built for the HIP entry points.
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+INC = os.path.join(ROOT, "include")
+CSRC = os.path.join(PKG, "csrc")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+             "-Wno-unused-value"]
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-fopenmp"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("[mad_icp_amd build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def _glob(d, exts):
+    out = []
+    for base, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(exts):
+                out.append(os.path.join(base, f))
+    return sorted(out)
+
+
+def build_hip(force=False):
+    out = os.path.join(PKG, "libmadicp_hip.so")
+    srcs = [os.path.join(CSRC, "hip", "madicp_capi.hip")]
+    deps = srcs + _glob(os.path.join(CSRC, "hip"), (".h",)) + _glob(INC, (".h",))
+    if force or _newer(out, deps):
+        _run([HIPCC] + HIP_FLAGS + ["-I" + INC, "-I" + os.path.join(CSRC, "hip")] + srcs + ["-o", out, "-lrccl"])
+    return out
+
+
+def build_host(force=False):
+    out = os.path.join(PKG, "libmadicp_host.so")
+    hdir = os.path.join(CSRC, "host")
+    srcs = [os.path.join(hdir, "tree_builder.cpp"), os.path.join(hdir, "host_capi.cpp")]
+    deps = srcs + _glob(hdir, (".h",)) + _glob(INC, (".h",))
+    if force or _newer(out, deps):
+        _run([CXX] + HOST_FLAGS + ["-shared", "-I" + INC, "-I" + hdir] + srcs + ["-o", out, "-pthread"])
+    return out
+
+
+def build_pybind(force=False):
+    import pybind11
+
+    hdir = os.path.join(CSRC, "host")
+    pdir = os.path.join(CSRC, "pybind")
+    outdir = os.path.join(PKG, "pybind")
+    os.makedirs(outdir, exist_ok=True)
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    common = [os.path.join(hdir, f) for f in ("tree_builder.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp",
+                                              "pipeline.cpp")]
+    common = [c for c in common if os.path.exists(c)]
+    deps_h = _glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(INC, (".h",))
+    built = []
+    for mod in ("pyvector", "pymadtree", "pymadicp", "pypeline"):
+        src = os.path.join(pdir, mod + ".cpp")
+        if not os.path.exists(src):
+            continue
+        out = os.path.join(outdir, mod + suffix)
+        if force or _newer(out, [src] + common + deps_h):
+            _run([CXX] + HOST_FLAGS + ["-shared", "-fvisibility=hidden", "-I" + INC, "-I" + hdir, "-I" + pdir,
+                                       "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+                                       src] + common +
+                 ["-o", out, "-L" + PKG, "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..", "-pthread"])
+        built.append(out)
+    return built
+
+
+def build_all(force=False):
+    return [build_hip(force), build_host(force)] + build_pybind(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

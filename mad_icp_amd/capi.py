@@ -1,0 +1,327 @@
+"""ctypes binding of the two C ABIs (include/madicp_hip.h, include/madicp_host.h).
+
+This is plumbing for tests and bench.py; the product classes with the reference's names live in
+mad_icp_amd.pybind.{pyvector,pymadtree,pymadicp,pypeline} (C++), which bind to the same ABI.
+There is no CPU implementation behind any HIP entry point: without libmadicp_hip.so, or without a GPU,
+the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+NODE_DTYPE = np.dtype([("mean", "<f8", (3,)), ("dir", "<f8", (3,)), ("right", "<i4"), ("leaf_id", "<i4"),
+                       ("bbox0", "<f8")])
+assert NODE_DTYPE.itemsize == 64
+
+MAX_TREES = 128
+MAX_BATCH = 64
+
+
+class MadIcpError(RuntimeError):
+    pass
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("min_ball", C.c_double), ("rho_ker", C.c_double), ("b_ratio", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+
+_hip = None
+_host = None
+
+
+def _load(name):
+    path = os.path.join(_PKG, name)
+    if not os.path.exists(path):
+        raise MadIcpError(f"{name} is not built (run `python -m mad_icp_amd._build`); there is no fallback path")
+    return C.CDLL(path)
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        L = _load("libmadicp_hip.so")
+        L.madicp_last_error.restype = C.c_char_p
+        L.madicp_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.madicp_ctx_destroy.argtypes = [C.c_void_p]
+        L.madicp_ctx_synchronize.argtypes = [C.c_void_p]
+        L.madicp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.madicp_ctx_kernel_time.argtypes = [C.c_void_p, C.c_int, _i64p, _dp]
+        L.madicp_tree_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _ip]
+        L.madicp_tree_release.argtypes = [C.c_void_p, C.c_int]
+        L.madicp_tree_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
+        L.madicp_tree_transform.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.madicp_nn_search.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, _u32p, _u32p, _dp, _i32p]
+        L.madicp_nn_search_device_enqueue.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.madicp_moving_upload.argtypes = [C.c_void_p, _dp, C.c_int32, _ip]
+        L.madicp_moving_release.argtypes = [C.c_void_p, C.c_int]
+        L.madicp_icp_linearize.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), _dp, _dp,
+                                           _u32p, _u8p, _u64p]
+        L.madicp_icp_register.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _dp,
+                                          _dp, _u8p, _dp, _u64p]
+        L.madicp_icp_register_batch.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams),
+                                                C.c_int, _dp, _dp, _i32p, _u64p]
+        L.madicp_icp_register_batch_enqueue.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp,
+                                                        C.POINTER(IcpParams), C.c_int]
+        L.madicp_icp_fetch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
+        L.madicp_icp_fetch_matched.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int32]
+        L.madicp_comm_unique_id.argtypes = [_u8p]
+        L.madicp_comm_init.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
+        L.madicp_comm_destroy.argtypes = [C.c_void_p]
+        _hip = L
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        L = _load("libmadicp_host.so")
+        L.madicp_host_tree_build.restype = C.c_void_p
+        L.madicp_host_tree_build.argtypes = [_dp, C.c_int64, C.c_double, C.c_double, C.c_int]
+        L.madicp_host_tree_free.argtypes = [C.c_void_p]
+        L.madicp_host_tree_num_nodes.restype = C.c_int32
+        L.madicp_host_tree_num_nodes.argtypes = [C.c_void_p]
+        L.madicp_host_tree_num_leaves.restype = C.c_int32
+        L.madicp_host_tree_num_leaves.argtypes = [C.c_void_p]
+        L.madicp_host_tree_nodes.restype = C.c_void_p
+        L.madicp_host_tree_nodes.argtypes = [C.c_void_p]
+        L.madicp_host_tree_leaf_nodes.restype = C.c_void_p
+        L.madicp_host_tree_leaf_nodes.argtypes = [C.c_void_p]
+        L.madicp_host_tree_leaf_means.argtypes = [C.c_void_p, _dp]
+        L.madicp_host_tree_transform.argtypes = [C.c_void_p, _dp, _dp]
+        _host = L
+    return _host
+
+
+def _check(rc):
+    if rc != 0:
+        raise MadIcpError(f"madicp error {rc}: {hip_lib().madicp_last_error().decode()}")
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def pose12(T):
+    T = np.asarray(T, dtype=np.float64)
+    if T.shape == (12,):
+        return T.copy()
+    return np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]).copy()
+
+
+def pose44(x):
+    T = np.eye(4)
+    T[:3, :3] = np.asarray(x[:9]).reshape(3, 3)
+    T[:3, 3] = x[9:12]
+    return T
+
+
+class HostTree:
+    """Linear MAD-tree built on the host (include/madicp_host.h)."""
+
+    def __init__(self, points, b_max, b_min, max_parallel_level=0):
+        pts = _f64(points)
+        if pts.ndim != 2 or pts.shape[1] != 3 or pts.shape[0] == 0:
+            raise ValueError("points must be a non-empty (N,3) array")
+        self._h = host_lib().madicp_host_tree_build(pts.ctypes.data_as(_dp), pts.shape[0], b_max, b_min,
+                                                    max_parallel_level)
+        if not self._h:
+            raise MadIcpError("tree build failed")
+        self.num_nodes = host_lib().madicp_host_tree_num_nodes(self._h)
+        self.num_leaves = host_lib().madicp_host_tree_num_leaves(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            host_lib().madicp_host_tree_free(self._h)
+            self._h = None
+
+    @property
+    def nodes(self):
+        """numpy view (NODE_DTYPE) of the library-owned node array; valid while this object lives."""
+        ptr = host_lib().madicp_host_tree_nodes(self._h)
+        buf = (C.c_char * (64 * self.num_nodes)).from_address(ptr)
+        return np.frombuffer(buf, dtype=NODE_DTYPE)
+
+    @property
+    def leaf_nodes(self):
+        ptr = host_lib().madicp_host_tree_leaf_nodes(self._h)
+        buf = (C.c_char * (4 * self.num_leaves)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.int32)
+
+    def leaf_means(self):
+        out = np.empty((self.num_leaves, 3))
+        host_lib().madicp_host_tree_leaf_means(self._h, out.ctypes.data_as(_dp))
+        return out
+
+    def transform(self, R, t):
+        R = _f64(R, (9,))
+        t = _f64(t, (3,))
+        host_lib().madicp_host_tree_transform(self._h, R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+
+
+class Context:
+    """One device + one stream (include/madicp_hip.h)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        _check(hip_lib().madicp_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            hip_lib().madicp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def synchronize(self):
+        _check(hip_lib().madicp_ctx_synchronize(self._h))
+
+    def set_option(self, key, value):
+        _check(hip_lib().madicp_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def kernel_time(self, reset=True):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        _check(hip_lib().madicp_ctx_kernel_time(self._h, int(reset), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # ---- trees ----
+    def tree_upload(self, nodes, n_leaves):
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        tid = C.c_int(0)
+        _check(hip_lib().madicp_tree_upload(self._h, nodes.ctypes.data_as(C.c_void_p), nodes.shape[0], n_leaves,
+                                            C.byref(tid)))
+        return tid.value
+
+    def upload(self, host_tree):
+        return self.tree_upload(host_tree.nodes, host_tree.num_leaves)
+
+    def tree_release(self, tid):
+        _check(hip_lib().madicp_tree_release(self._h, tid))
+
+    def tree_download(self, tid, n_nodes):
+        out = np.empty(n_nodes, dtype=NODE_DTYPE)
+        _check(hip_lib().madicp_tree_download(self._h, tid, out.ctypes.data_as(C.c_void_p), n_nodes))
+        return out
+
+    def tree_transform(self, tid, R, t):
+        R = _f64(R, (9,))
+        t = _f64(t, (3,))
+        _check(hip_lib().madicp_tree_transform(self._h, tid, R.ctypes.data_as(_dp), t.ctypes.data_as(_dp)))
+
+    def nn_search(self, tid, queries, want=("leaf", "node", "dist", "depth")):
+        q = _f64(queries)
+        n = q.shape[0]
+        leaf = np.empty(n, np.uint32) if "leaf" in want else None
+        node = np.empty(n, np.uint32) if "node" in want else None
+        dist = np.empty(n, np.float64) if "dist" in want else None
+        depth = np.empty(n, np.int32) if "depth" in want else None
+        _check(hip_lib().madicp_nn_search(
+            self._h, tid, q.ctypes.data_as(_dp), n,
+            leaf.ctypes.data_as(_u32p) if leaf is not None else None,
+            node.ctypes.data_as(_u32p) if node is not None else None,
+            dist.ctypes.data_as(_dp) if dist is not None else None,
+            depth.ctypes.data_as(_i32p) if depth is not None else None))
+        return dict(leaf=leaf, node=node, dist=dist, depth=depth)
+
+    def nn_search_device(self, tid, d_queries_ptr, n, d_leaf=None, d_node=None, d_dist=None, d_depth=None):
+        _check(hip_lib().madicp_nn_search_device_enqueue(self._h, tid, d_queries_ptr, n, d_leaf, d_node, d_dist,
+                                                         d_depth))
+
+    # ---- moving ----
+    def moving_upload(self, leaf_means):
+        m = _f64(leaf_means)
+        mid = C.c_int(0)
+        _check(hip_lib().madicp_moving_upload(self._h, m.ctypes.data_as(_dp), m.shape[0], C.byref(mid)))
+        return mid.value
+
+    def moving_release(self, mid):
+        _check(hip_lib().madicp_moving_release(self._h, mid))
+
+    # ---- registration ----
+    @staticmethod
+    def _ids(ids):
+        arr = (C.c_int * len(ids))(*[int(i) for i in ids])
+        return arr
+
+    def icp_linearize(self, mid, tree_ids, T, params, L, want_corr=True):
+        K = len(tree_ids)
+        X = pose12(T)
+        H, b = np.empty((6, 6)), np.empty(6)
+        corr = np.empty((K, L), np.uint32) if want_corr else None
+        matched = np.empty(L, np.uint8)
+        visits = C.c_uint64(0)
+        p = IcpParams(*params)
+        _check(hip_lib().madicp_icp_linearize(self._h, mid, self._ids(tree_ids), K, X.ctypes.data_as(_dp), C.byref(p),
+                                              H.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                              corr.ctypes.data_as(_u32p) if want_corr else None,
+                                              matched.ctypes.data_as(_u8p), C.byref(visits)))
+        return dict(H=H, b=b, corr=corr, matched=matched, visits=visits.value)
+
+    def icp_register(self, mid, tree_ids, T, params, n_iters, L):
+        K = len(tree_ids)
+        X = pose12(T)
+        H, b = np.empty((6, 6)), np.empty(6)
+        matched = np.empty(L, np.uint8)
+        X_iters = np.empty((n_iters, 12))
+        visits = C.c_uint64(0)
+        p = IcpParams(*params)
+        _check(hip_lib().madicp_icp_register(self._h, mid, self._ids(tree_ids), K, X.ctypes.data_as(_dp), C.byref(p),
+                                             n_iters, H.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                             matched.ctypes.data_as(_u8p), X_iters.ctypes.data_as(_dp),
+                                             C.byref(visits)))
+        return dict(T=pose44(X), X=X, H=H, b=b, matched=matched, X_iters=X_iters, visits=visits.value)
+
+    def icp_register_batch_enqueue(self, mids, tree_ids, X0, params, n_iters):
+        X0 = _f64(X0, (len(mids), 12))
+        p = IcpParams(*params)
+        _check(hip_lib().madicp_icp_register_batch_enqueue(self._h, len(mids), self._ids(mids), self._ids(tree_ids),
+                                                           len(tree_ids), X0.ctypes.data_as(_dp), C.byref(p), n_iters))
+
+    def icp_fetch(self, n_scans):
+        X, H, b = np.empty((n_scans, 12)), np.empty((n_scans, 6, 6)), np.empty((n_scans, 6))
+        nm = np.empty(n_scans, np.int32)
+        visits = np.empty(n_scans, np.uint64)
+        _check(hip_lib().madicp_icp_fetch(self._h, n_scans, X.ctypes.data_as(_dp), H.ctypes.data_as(_dp),
+                                          b.ctypes.data_as(_dp), nm.ctypes.data_as(_i32p),
+                                          visits.ctypes.data_as(_u64p)))
+        return dict(X=X, H=H, b=b, n_matched=nm, visits=visits)
+
+    def icp_fetch_matched(self, scan, L):
+        out = np.empty(L, np.uint8)
+        _check(hip_lib().madicp_icp_fetch_matched(self._h, scan, out.ctypes.data_as(_u8p), L))
+        return out
+
+    def icp_register_batch(self, mids, tree_ids, X0, params, n_iters):
+        self.icp_register_batch_enqueue(mids, tree_ids, X0, params, n_iters)
+        return self.icp_fetch(len(mids))
+
+    # ---- multi-GPU ----
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        _check(hip_lib().madicp_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        buf = (C.c_uint8 * 128)(*unique_id)
+        _check(hip_lib().madicp_comm_init(self._h, buf, n_ranks, rank))
+
+    def comm_destroy(self):
+        _check(hip_lib().madicp_comm_destroy(self._h))

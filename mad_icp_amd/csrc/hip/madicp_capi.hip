@@ -1,0 +1,690 @@
+// libmadicp_hip.so — implementation of the C ABI declared in include/madicp_hip.h.
+// Context / buffer management, launch sequencing (eager or captured hipGraph), optional RCCL all-reduce.
+#include "kernels.hip.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+using namespace madicp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(MADICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+  } while (0)
+
+#define NCCL_TRY(expr)                                                                            \
+  do {                                                                                            \
+    ncclResult_t r_ = (expr);                                                                     \
+    if (r_ != ncclSuccess)                                                                        \
+      return fail(MADICP_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));          \
+  } while (0)
+
+struct DevTree {
+  madicp_node* nodes = nullptr;
+  int32_t n_nodes = 0, n_leaves = 0;
+};
+struct DevMoving {
+  double* xyzn = nullptr;  // (L,4)
+  uint8_t* matched = nullptr;
+  int32_t L = 0;
+};
+
+struct GraphKey {
+  int grid, batch, iters, qpt, comm;
+  bool operator<(const GraphKey& o) const {
+    return std::tie(grid, batch, iters, qpt, comm) < std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm);
+  }
+};
+
+}  // namespace
+
+struct madicp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cus = 256;
+
+  std::unordered_map<int, DevTree> trees;
+  std::unordered_map<int, DevMoving> movings;
+  int next_id = 1;
+
+  // registration state
+  Job* d_jobs = nullptr;       // [MADICP_MAX_BATCH]
+  // pinned staging ring: the host may run kStageSlots-1 batches ahead of the device
+  static constexpr int kStageSlots = 4;
+  Job* h_stage[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_next = 0;
+  Job* h_fetch = nullptr;      // pinned read-back block
+  double* d_partials = nullptr;
+  size_t partials_cap = 0;     // doubles
+  double* d_totals = nullptr;  // [MADICP_MAX_BATCH][kAcc]
+  double* d_scratch = nullptr; // 12 doubles (R,t for tree_transform)
+  int last_batch = 0;
+  std::vector<int> last_moving;
+
+  // options
+  int blocks_per_cu = 4;
+  int use_graph = 1;
+  int qpt = 1;
+  int time_kernels = 0;
+
+  std::map<GraphKey, hipGraphExec_t> graphs;
+
+  // kernel timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+  std::vector<hipEvent_t> ev_pool;
+  int64_t timed_launches = 0;
+  double timed_ms = 0.0;
+
+  // multi-GPU
+  ncclComm_t comm = nullptr;
+  int n_ranks = 1, rank = 0;
+};
+
+namespace {
+
+int ensure_partials(madicp_ctx* ctx, size_t doubles) {
+  if (doubles <= ctx->partials_cap) return MADICP_OK;
+  if (ctx->d_partials) HIP_TRY(hipFree(ctx->d_partials));
+  ctx->d_partials = nullptr;
+  ctx->partials_cap = 0;
+  HIP_TRY(hipMalloc(&ctx->d_partials, doubles * sizeof(double)));
+  ctx->partials_cap = doubles;
+  // cached graphs hold the old pointer
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+  ctx->graphs.clear();
+  return MADICP_OK;
+}
+
+// launch geometry: 8 XCDs x slots; enough workgroups to cover the units once, capped by residency
+int pick_grid(const madicp_ctx* ctx, int max_L, int K, int qpt) {
+  const long long chunk = (long long)kBlock * qpt;
+  const long long C = (max_L + chunk - 1) / chunk;
+  const long long U = std::max<long long>(1, C * K);
+  long long slots = (U + 7) / 8;
+  const long long cap = std::max(1, ctx->blocks_per_cu * ctx->n_cus / 8);
+  slots = std::min(slots, cap);
+  return static_cast<int>(8 * slots);
+}
+
+hipEvent_t get_event(madicp_ctx* ctx) {
+  if (!ctx->ev_pool.empty()) {
+    hipEvent_t e = ctx->ev_pool.back();
+    ctx->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+
+void launch_linearize(madicp_ctx* ctx, int grid, int batch, int qpt) {
+  dim3 g(grid, batch), b(kBlock);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->time_kernels) {
+    e0 = get_event(ctx);
+    e1 = get_event(ctx);
+    hipEventRecord(e0, ctx->stream);
+  }
+  switch (qpt) {
+    case 2: hipLaunchKernelGGL(icp_linearize<2>, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials); break;
+    case 4: hipLaunchKernelGGL(icp_linearize<4>, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials); break;
+    default: hipLaunchKernelGGL(icp_linearize<1>, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials); break;
+  }
+  if (ctx->time_kernels) {
+    hipEventRecord(e1, ctx->stream);
+    ctx->ev_pending.emplace_back(e0, e1);
+  }
+}
+
+// the launch sequence of one (batched) registration; valid both eagerly and under stream capture
+int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+  for (int it = 0; it < iters; ++it) {
+    launch_linearize(ctx, grid, batch, qpt);
+    if (ctx->comm) {
+      hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+                         grid, ctx->d_totals);
+      NCCL_TRY(ncclAllReduce(ctx->d_totals, ctx->d_totals, (size_t)batch * kAcc, ncclDouble, ncclSum, ctx->comm,
+                             ctx->stream));
+      hipLaunchKernelGGL(icp_update, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_jobs, ctx->d_totals,
+                         batch);
+    } else {
+      hipLaunchKernelGGL(icp_solve, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+                         grid);
+    }
+  }
+  if (ctx->comm) {
+    // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204)
+    for (int s = 0; s < batch; ++s) {
+      const DevMoving& mv = ctx->movings.at(ctx->last_moving[s]);
+      NCCL_TRY(ncclAllReduce(mv.matched, mv.matched, (size_t)mv.L, ncclUint8, ncclMax, ctx->comm, ctx->stream));
+    }
+  }
+  hipLaunchKernelGGL(icp_finish, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_jobs);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
+}
+
+int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+  // graphs: only without per-launch events, and (conservatively) only without a communicator
+  const bool graph_ok = ctx->use_graph && !ctx->time_kernels && !ctx->comm;
+  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters, qpt);
+  const GraphKey key{grid, batch, iters, qpt, ctx->comm ? 1 : 0};
+  auto it = ctx->graphs.find(key);
+  if (it == ctx->graphs.end()) {
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_rounds(ctx, grid, batch, iters, qpt);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc != MADICP_OK) return rc;
+    if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    hipGraphDestroy(graph);
+    it = ctx->graphs.emplace(key, exec).first;
+  }
+  HIP_TRY(hipGraphLaunch(it->second, ctx->stream));
+  return MADICP_OK;
+}
+
+struct RegArgs {
+  int n_scans;
+  const int* moving_ids;
+  const int* tree_ids;
+  int K;
+  const double* X0;
+  const madicp_icp_params* params;
+  int n_iters;
+  int flags;
+  uint32_t* d_corr;     // single-scan debug trace (device) or null
+  double* d_x_iters;    // single-scan (device) or null
+};
+
+int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
+  if (!ctx || !a.moving_ids || !a.tree_ids || !a.X0 || !a.params) return fail(MADICP_ERR_INVALID, "null argument");
+  if (a.n_scans < 1 || a.n_scans > MADICP_MAX_BATCH) return fail(MADICP_ERR_CAPACITY, "n_scans out of range");
+  if (a.K < 1) return fail(MADICP_ERR_INVALID, "K must be >= 1");
+  if (a.K > MADICP_MAX_TREES) return fail(MADICP_ERR_CAPACITY, "K exceeds MADICP_MAX_TREES");
+  if (a.n_iters < 1) return fail(MADICP_ERR_INVALID, "n_iters must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  // next slot of the pinned staging ring; wait until the H2D copy that last used it has executed
+  const int slot = ctx->stage_next;
+  ctx->stage_next = (slot + 1) % madicp_ctx::kStageSlots;
+  HIP_TRY(hipEventSynchronize(ctx->stage_ev[slot]));
+  Job* h_jobs = ctx->h_stage[slot];
+
+  int max_L = 0;
+  ctx->last_moving.assign(a.moving_ids, a.moving_ids + a.n_scans);
+  for (int s = 0; s < a.n_scans; ++s) {
+    auto mit = ctx->movings.find(a.moving_ids[s]);
+    if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+    const DevMoving& mv = mit->second;
+    Job& j = h_jobs[s];
+    std::memset(&j, 0, offsetof(Job, trees));
+    j.moving = mv.xyzn;
+    j.matched = mv.matched;
+    j.corr = (s == 0) ? a.d_corr : nullptr;
+    j.x_iters = (s == 0) ? a.d_x_iters : nullptr;
+    j.L = mv.L;
+    j.K = a.K;
+    j.n_iters = a.n_iters;
+    j.iter = 0;
+    j.flags = a.flags;
+    std::memcpy(j.X, a.X0 + 12 * s, 12 * sizeof(double));
+    j.min_ball = a.params->min_ball;
+    j.rho = std::sqrt(a.params->rho_ker);  // MADicp ctor, mad_icp.cpp:32
+    j.b_ratio = a.params->b_ratio;
+    for (int k = 0; k < a.K; ++k) {
+      auto tit = ctx->trees.find(a.tree_ids[k]);
+      if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+      j.trees[k] = TreeRef{tit->second.nodes, tit->second.n_nodes, tit->second.n_leaves};
+    }
+    max_L = std::max(max_L, mv.L);
+    // flags are cleared on the device before the last round; with a single round that is "now"
+    if (a.n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
+  }
+  const int grid = pick_grid(ctx, max_L, std::max(1, a.K), ctx->qpt);
+  const int rc0 = ensure_partials(ctx, (size_t)a.n_scans * grid * kAcc);
+  if (rc0 != MADICP_OK) return rc0;
+  const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeRef) * (size_t)std::max(1, a.K);
+  for (int s = 0; s < a.n_scans; ++s)
+    HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipEventRecord(ctx->stage_ev[slot], ctx->stream));
+  ctx->last_batch = a.n_scans;
+  return run_rounds(ctx, grid, a.n_scans, a.n_iters, ctx->qpt);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* madicp_last_error(void) { return g_err.c_str(); }
+int madicp_abi_version(void) { return 1; }
+
+int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
+  if (!out) return fail(MADICP_ERR_INVALID, "out is null");
+  *out = nullptr;
+  int n_dev = 0;
+  HIP_TRY(hipGetDeviceCount(&n_dev));
+  if (device_id < 0 || device_id >= n_dev) return fail(MADICP_ERR_DEVICE, "no such HIP device");
+  HIP_TRY(hipSetDevice(device_id));
+  madicp_ctx* ctx = new madicp_ctx;
+  ctx->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(MADICP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+  }
+  hipError_t e = hipMalloc(&ctx->d_jobs, sizeof(Job) * MADICP_MAX_BATCH);
+  for (int i = 0; i < madicp_ctx::kStageSlots && e == hipSuccess; ++i) {
+    e = hipHostMalloc(&ctx->h_stage[i], sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipHostMalloc(&ctx->h_fetch, sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&ctx->d_totals, sizeof(double) * kAcc * MADICP_MAX_BATCH);
+  if (e == hipSuccess) e = hipMalloc(&ctx->d_scratch, sizeof(double) * 12);
+  if (e != hipSuccess) {
+    madicp_ctx_destroy(ctx);
+    return fail(MADICP_ERR_DEVICE, std::string("context allocation: ") + hipGetErrorString(e));
+  }
+  *out = ctx;
+  return MADICP_OK;
+}
+
+int madicp_ctx_destroy(madicp_ctx* ctx) {
+  if (!ctx) return MADICP_OK;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) ncclCommDestroy(ctx->comm);
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+  for (auto& t : ctx->trees) hipFree(t.second.nodes);
+  for (auto& m : ctx->movings) {
+    hipFree(m.second.xyzn);
+    hipFree(m.second.matched);
+  }
+  for (auto& p : ctx->ev_pending) {
+    hipEventDestroy(p.first);
+    hipEventDestroy(p.second);
+  }
+  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->d_jobs) hipFree(ctx->d_jobs);
+  for (int i = 0; i < madicp_ctx::kStageSlots; ++i) {
+    if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+    if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
+  }
+  if (ctx->h_fetch) hipHostFree(ctx->h_fetch);
+  if (ctx->d_partials) hipFree(ctx->d_partials);
+  if (ctx->d_totals) hipFree(ctx->d_totals);
+  if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MADICP_OK;
+}
+
+int madicp_ctx_synchronize(madicp_ctx* ctx) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MADICP_OK;
+}
+
+int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return fail(MADICP_ERR_INVALID, "null argument");
+  const std::string k(key);
+  if (k == "grid_blocks_per_cu") {
+    if (value < 1 || value > 8) return fail(MADICP_ERR_INVALID, "grid_blocks_per_cu must be in 1..8");
+    ctx->blocks_per_cu = (int)value;
+  } else if (k == "use_graph") {
+    ctx->use_graph = value ? 1 : 0;
+  } else if (k == "queries_per_thread") {
+    if (value != 1 && value != 2 && value != 4) return fail(MADICP_ERR_INVALID, "queries_per_thread must be 1, 2 or 4");
+    ctx->qpt = (int)value;
+  } else if (k == "time_kernels") {
+    ctx->time_kernels = value ? 1 : 0;
+  } else {
+    return fail(MADICP_ERR_INVALID, "unknown option: " + k);
+  }
+  return MADICP_OK;
+}
+
+int madicp_ctx_kernel_time(madicp_ctx* ctx, int reset, int64_t* n_launches, double* total_ms) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto& p : ctx->ev_pending) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+    ctx->timed_ms += ms;
+    ctx->timed_launches += 1;
+    ctx->ev_pool.push_back(p.first);
+    ctx->ev_pool.push_back(p.second);
+  }
+  ctx->ev_pending.clear();
+  if (n_launches) *n_launches = ctx->timed_launches;
+  if (total_ms) *total_ms = ctx->timed_ms;
+  if (reset) {
+    ctx->timed_launches = 0;
+    ctx->timed_ms = 0.0;
+  }
+  return MADICP_OK;
+}
+
+// ---- trees ------------------------------------------------------------------------------------------
+int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id) {
+  if (!ctx || !nodes || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n_nodes < 1 || n_leaves < 1 || n_nodes != 2 * n_leaves - 1)
+    return fail(MADICP_ERR_INVALID, "a MAD-tree has n_nodes == 2*n_leaves-1 >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevTree t;
+  t.n_nodes = n_nodes;
+  t.n_leaves = n_leaves;
+  HIP_TRY(hipMalloc(&t.nodes, sizeof(madicp_node) * (size_t)n_nodes));
+  hipError_t e = hipMemcpyAsync(t.nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    hipFree(t.nodes);
+    return fail(MADICP_ERR_DEVICE, std::string("tree upload: ") + hipGetErrorString(e));
+  }
+  const int id = ctx->next_id++;
+  ctx->trees[id] = t;
+  *out_tree_id = id;
+  return MADICP_OK;
+}
+
+int madicp_tree_release(madicp_ctx* ctx, int tree_id) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  auto it = ctx->trees.find(tree_id);
+  if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(it->second.nodes));
+  ctx->trees.erase(it);
+  return MADICP_OK;
+}
+
+int madicp_tree_download(madicp_ctx* ctx, int tree_id, madicp_node* out_nodes, int32_t n_nodes) {
+  if (!ctx || !out_nodes) return fail(MADICP_ERR_INVALID, "null argument");
+  auto it = ctx->trees.find(tree_id);
+  if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  if (n_nodes != it->second.n_nodes) return fail(MADICP_ERR_INVALID, "n_nodes mismatch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(out_nodes, it->second.nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MADICP_OK;
+}
+
+int madicp_tree_transform(madicp_ctx* ctx, int tree_id, const double R[9], const double t[3]) {
+  if (!ctx || !R || !t) return fail(MADICP_ERR_INVALID, "null argument");
+  auto it = ctx->trees.find(tree_id);
+  if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  double Rt[12];
+  std::memcpy(Rt, R, 9 * sizeof(double));
+  std::memcpy(Rt + 9, t, 3 * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(ctx->d_scratch, Rt, sizeof(Rt), hipMemcpyHostToDevice, ctx->stream));
+  const int n = it->second.n_nodes;
+  hipLaunchKernelGGL(tree_transform, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, it->second.nodes, n,
+                     ctx->d_scratch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MADICP_OK;
+}
+
+int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* d_queries, int64_t n,
+                                    uint32_t* d_out_leaf_id, uint32_t* d_out_node, double* d_out_dist,
+                                    int32_t* d_out_depth) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  auto it = ctx->trees.find(tree_id);
+  if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  if (n <= 0) return MADICP_OK;
+  if (!d_queries) return fail(MADICP_ERR_INVALID, "queries is null");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const long long blocks = std::min<long long>((n + 255) / 256, (long long)ctx->n_cus * 8);
+  hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.nodes, d_queries,
+                     (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
+}
+
+int madicp_nn_search(madicp_ctx* ctx, int tree_id, const double* queries, int64_t n, uint32_t* out_leaf_id,
+                     uint32_t* out_node, double* out_dist, int32_t* out_depth) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (ctx->trees.find(tree_id) == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  if (n <= 0) return MADICP_OK;
+  if (!queries) return fail(MADICP_ERR_INVALID, "queries is null");
+  HIP_TRY(hipSetDevice(ctx->device));
+  double* d_q = nullptr;
+  uint32_t *d_leaf = nullptr, *d_node = nullptr;
+  double* d_dist = nullptr;
+  int32_t* d_depth = nullptr;
+  int rc = MADICP_OK;
+  auto cleanup = [&]() {
+    hipFree(d_q); hipFree(d_leaf); hipFree(d_node); hipFree(d_dist); hipFree(d_depth);
+  };
+#define NN_TRY(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      cleanup();                                                                                          \
+      return fail(MADICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    }                                                                                                     \
+  } while (0)
+  NN_TRY(hipMalloc(&d_q, sizeof(double) * 3 * (size_t)n));
+  if (out_leaf_id) NN_TRY(hipMalloc(&d_leaf, sizeof(uint32_t) * (size_t)n));
+  if (out_node) NN_TRY(hipMalloc(&d_node, sizeof(uint32_t) * (size_t)n));
+  if (out_dist) NN_TRY(hipMalloc(&d_dist, sizeof(double) * (size_t)n));
+  if (out_depth) NN_TRY(hipMalloc(&d_depth, sizeof(int32_t) * (size_t)n));
+  NN_TRY(hipMemcpyAsync(d_q, queries, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  rc = madicp_nn_search_device_enqueue(ctx, tree_id, d_q, n, d_leaf, d_node, d_dist, d_depth);
+  if (rc != MADICP_OK) { cleanup(); return rc; }
+  if (out_leaf_id) NN_TRY(hipMemcpyAsync(out_leaf_id, d_leaf, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_node) NN_TRY(hipMemcpyAsync(out_node, d_node, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_dist) NN_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_depth) NN_TRY(hipMemcpyAsync(out_depth, d_depth, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  NN_TRY(hipStreamSynchronize(ctx->stream));
+#undef NN_TRY
+  cleanup();
+  return MADICP_OK;
+}
+
+// ---- moving side ------------------------------------------------------------------------------------
+int madicp_moving_upload(madicp_ctx* ctx, const double* leaf_means, int32_t L, int* out_moving_id) {
+  if (!ctx || !leaf_means || !out_moving_id) return fail(MADICP_ERR_INVALID, "null argument");
+  if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevMoving m;
+  m.L = L;
+  double* d_xyz = nullptr;
+  HIP_TRY(hipMalloc(&d_xyz, sizeof(double) * 3 * (size_t)L));
+  hipError_t e = hipMalloc(&m.xyzn, sizeof(double) * 4 * (size_t)L);
+  if (e == hipSuccess) e = hipMalloc(&m.matched, (size_t)L);
+  if (e == hipSuccess) e = hipMemsetAsync(m.matched, 0, (size_t)L, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, leaf_means, sizeof(double) * 3 * (size_t)L, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(moving_prep, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, m.xyzn, L);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_xyz);
+  if (e != hipSuccess) {
+    hipFree(m.xyzn);
+    hipFree(m.matched);
+    return fail(MADICP_ERR_DEVICE, std::string("moving upload: ") + hipGetErrorString(e));
+  }
+  const int id = ctx->next_id++;
+  ctx->movings[id] = m;
+  *out_moving_id = id;
+  return MADICP_OK;
+}
+
+int madicp_moving_release(madicp_ctx* ctx, int moving_id) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  auto it = ctx->movings.find(moving_id);
+  if (it == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  hipFree(it->second.xyzn);
+  hipFree(it->second.matched);
+  ctx->movings.erase(it);
+  return MADICP_OK;
+}
+
+// ---- registration -----------------------------------------------------------------------------------
+int madicp_icp_register_batch_enqueue(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids,
+                                      int K, const double* X0, const madicp_icp_params* params, int n_iters) {
+  RegArgs a{n_scans, moving_ids, tree_ids, K, X0, params, n_iters, 0, nullptr, nullptr};
+  return enqueue_registration(ctx, a);
+}
+
+int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H, double* out_b, int32_t* out_n_matched,
+                     uint64_t* out_visits) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (n_scans < 1 || n_scans > ctx->last_batch) return fail(MADICP_ERR_INVALID, "n_scans exceeds the last batch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int s = 0; s < n_scans; ++s)
+    HIP_TRY(hipMemcpyAsync(ctx->h_fetch + s, ctx->d_jobs + s, offsetof(Job, trees), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < n_scans; ++s) {
+    const Job& j = ctx->h_fetch[s];
+    if (out_X) std::memcpy(out_X + 12 * s, j.X, 12 * sizeof(double));
+    if (out_H) std::memcpy(out_H + 36 * s, j.H, 36 * sizeof(double));
+    if (out_b) std::memcpy(out_b + 6 * s, j.b, 6 * sizeof(double));
+    if (out_n_matched) out_n_matched[s] = j.n_matched;
+    if (out_visits) out_visits[s] = j.visits;
+  }
+  return MADICP_OK;
+}
+
+int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, int32_t L) {
+  if (!ctx || !out_matched) return fail(MADICP_ERR_INVALID, "null argument");
+  if (scan < 0 || scan >= ctx->last_batch) return fail(MADICP_ERR_INVALID, "scan index out of range");
+  auto it = ctx->movings.find(ctx->last_moving[scan]);
+  if (it == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "moving buffer was released");
+  if (L != it->second.L) return fail(MADICP_ERR_INVALID, "L mismatch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(out_matched, it->second.matched, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MADICP_OK;
+}
+
+int madicp_icp_register_batch(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
+                              double* X, const madicp_icp_params* params, int n_iters, double* out_H, double* out_b,
+                              int32_t* out_n_matched, uint64_t* out_visits) {
+  const int rc = madicp_icp_register_batch_enqueue(ctx, n_scans, moving_ids, tree_ids, K, X, params, n_iters);
+  if (rc != MADICP_OK) return rc;
+  return madicp_icp_fetch(ctx, n_scans, X, out_H, out_b, out_n_matched, out_visits);
+}
+
+int madicp_icp_register(madicp_ctx* ctx, int moving_id, const int* tree_ids, int K, double X[12],
+                        const madicp_icp_params* params, int n_iters, double out_H[36], double out_b[6],
+                        uint8_t* out_matched, double* out_X_iters, uint64_t* out_visits) {
+  if (!ctx || !X) return fail(MADICP_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  double* d_xi = nullptr;
+  if (out_X_iters && n_iters > 0) HIP_TRY(hipMalloc(&d_xi, sizeof(double) * 12 * (size_t)n_iters));
+  RegArgs a{1, &moving_id, tree_ids, K, X, params, n_iters, 0, nullptr, d_xi};
+  int rc = enqueue_registration(ctx, a);
+  if (rc == MADICP_OK) rc = madicp_icp_fetch(ctx, 1, X, out_H, out_b, nullptr, out_visits);
+  if (rc == MADICP_OK && out_matched) rc = madicp_icp_fetch_matched(ctx, 0, out_matched, ctx->movings.at(moving_id).L);
+  if (rc == MADICP_OK && d_xi) {
+    hipError_t e = hipMemcpy(out_X_iters, d_xi, sizeof(double) * 12 * (size_t)n_iters, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("x_iters copy: ") + hipGetErrorString(e));
+  }
+  if (d_xi) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_xi);
+  }
+  return rc;
+}
+
+int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, int K, const double X[12],
+                         const madicp_icp_params* params, double out_H[36], double out_b[6], uint32_t* out_corr,
+                         uint8_t* out_matched, uint64_t* out_visits) {
+  if (!ctx || !X) return fail(MADICP_ERR_INVALID, "null argument");
+  auto mit = ctx->movings.find(moving_id);
+  if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+  const int L = mit->second.L;
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint32_t* d_corr = nullptr;
+  if (out_corr && K > 0) HIP_TRY(hipMalloc(&d_corr, sizeof(uint32_t) * (size_t)K * L));
+  RegArgs a{1, &moving_id, tree_ids, K, X, params, 1, kFlagNoUpdate, d_corr, nullptr};
+  const int saved_graph = ctx->use_graph;
+  ctx->use_graph = 0;  // pointers in the job differ per call; nothing to gain from a graph for one round
+  int rc = enqueue_registration(ctx, a);
+  ctx->use_graph = saved_graph;
+  if (rc == MADICP_OK) rc = madicp_icp_fetch(ctx, 1, nullptr, out_H, out_b, nullptr, out_visits);
+  if (rc == MADICP_OK && out_matched) rc = madicp_icp_fetch_matched(ctx, 0, out_matched, L);
+  if (rc == MADICP_OK && d_corr) {
+    hipError_t e = hipMemcpy(out_corr, d_corr, sizeof(uint32_t) * (size_t)K * L, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("corr copy: ") + hipGetErrorString(e));
+  }
+  if (d_corr) {
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_corr);
+  }
+  return rc;
+}
+
+// ---- multi-GPU --------------------------------------------------------------------------------------
+int madicp_comm_unique_id(uint8_t out_id[128]) {
+  if (!out_id) return fail(MADICP_ERR_INVALID, "out_id is null");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCL_TRY(ncclGetUniqueId(&id));
+  std::memcpy(out_id, &id, 128);
+  return MADICP_OK;
+}
+
+int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks, int rank) {
+  if (!ctx || !unique_id) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MADICP_ERR_INVALID, "bad rank / n_ranks");
+  if (ctx->comm) return fail(MADICP_ERR_INVALID, "communicator already initialised");
+  HIP_TRY(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, 128);
+  NCCL_TRY(ncclCommInitRank(&ctx->comm, n_ranks, id, rank));
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return MADICP_OK;
+}
+
+int madicp_comm_destroy(madicp_ctx* ctx) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (ctx->comm) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    NCCL_TRY(ncclCommDestroy(ctx->comm));
+    ctx->comm = nullptr;
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+  }
+  return MADICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// libmadicp_host.so — C ABI over the host tree builder (include/madicp_host.h).
+#include <cstring>
+#include <vector>
+
+#include "madicp_host.h"
+#include "tree_builder.h"
+
+struct madicp_host_tree {
+  madicp_host::LinearTree tree;
+};
+
+extern "C" {
+
+madicp_host_tree* madicp_host_tree_build(const double* points, int64_t n, double b_max, double b_min,
+                                         int max_parallel_level) {
+  if (!points || n <= 0) return nullptr;
+  std::vector<double> copy(points, points + 3 * n);
+  madicp_host_tree* t = new madicp_host_tree;
+  t->tree = madicp_host::build_tree(copy.data(), n, b_max, b_min, max_parallel_level);
+  return t;
+}
+void madicp_host_tree_free(madicp_host_tree* t) { delete t; }
+int32_t madicp_host_tree_num_nodes(const madicp_host_tree* t) { return t ? t->tree.num_nodes() : 0; }
+int32_t madicp_host_tree_num_leaves(const madicp_host_tree* t) { return t ? t->tree.num_leaves() : 0; }
+const madicp_node* madicp_host_tree_nodes(const madicp_host_tree* t) { return t ? t->tree.nodes.data() : nullptr; }
+const int32_t* madicp_host_tree_leaf_nodes(const madicp_host_tree* t) { return t ? t->tree.leaf_nodes.data() : nullptr; }
+void madicp_host_tree_leaf_means(const madicp_host_tree* t, double* out) {
+  if (!t || !out) return;
+  for (size_t i = 0; i < t->tree.leaf_nodes.size(); ++i)
+    std::memcpy(out + 3 * i, t->tree.nodes[t->tree.leaf_nodes[i]].mean, 3 * sizeof(double));
+}
+void madicp_host_tree_transform(madicp_host_tree* t, const double R[9], const double tr[3]) {
+  if (t) madicp_host::transform_tree(t->tree, R, tr);
+}
+
+}  // extern "C"

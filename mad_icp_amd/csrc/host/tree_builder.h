@@ -1,0 +1,32 @@
+// MAD-tree construction on the host, emitting the linear 64-byte node array the GPU kernels walk.
+// Replaces MADtree::build / makeSubtree / getLeafs (reference mad_tree.cpp:47-142,154-163 and the helpers
+// in utils.h:37-97).  Same decisions and the same fp64 operation order as the reference, different data
+// structure: no per-node heap objects, no parent pointers — a DFS-preorder array with relative child
+// offsets, so sub-trees built by different threads are position independent and are spliced by memcpy.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "madicp_hip.h"
+
+namespace madicp_host {
+
+struct LinearTree {
+  std::vector<madicp_node> nodes;   // DFS preorder; left child = i + 1, right child = i + nodes[i].right
+  std::vector<int32_t> leaf_nodes;  // node index of leaf `leaf_id`, i.e. getLeafs() order
+  int32_t num_leaves() const { return static_cast<int32_t>(leaf_nodes.size()); }
+  int32_t num_nodes() const { return static_cast<int32_t>(nodes.size()); }
+};
+
+// points: n x 3 doubles, permuted in place exactly like the reference permutes its private copy.
+// max_parallel_level: sub-trees above this depth are built by std::async tasks (reference: the
+// `level >= max_parallel_level` test at mad_tree.cpp:99).
+LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int max_parallel_level);
+
+// MADtree::applyTransform (mad_tree.cpp:165-172) on the linear form; R row-major.
+void transform_tree(LinearTree& tree, const double* R, const double* t);
+
+// descent on the host copy (used for single-point MADtree.search when no device round trip is wanted
+// is NOT provided on purpose: every search goes through the HIP path).
+
+}  // namespace madicp_host

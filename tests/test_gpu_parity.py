@@ -1,0 +1,226 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bar (BASELINE.json north_star): correspondence indices bit-exact; pose within 1e-5 m / 1e-5 rad."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fixtures import B_MAX, B_MIN, B_RATIO, PARAMS, RHO_KER, four_walls, street_problem
+from mad_icp_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-5
+POSE_TOL_RAD = 1e-5
+
+
+def pose_err(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    ang = np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1))
+    return np.linalg.norm(d[:3, 3]), ang
+
+
+def build_pair(points, b_max=B_MAX, T=None):
+    """Same cloud -> product host tree (uploaded) and oracle tree, optionally moved to the map frame."""
+    ht = capi.HostTree(points, b_max, B_MIN, 2)
+    ot = O.Tree(points, b_max, B_MIN, 2)
+    if T is not None:
+        ht.transform(T[:3, :3], T[:3, 3])
+        ot.transform(T[:3, :3], T[:3, 3])
+    return ht, ot
+
+
+def test_device_sqrt_and_norm_bit_exact(ctx):
+    """fp64 sqrt on gfx950 must round like the CPU's: the gate compares sqrt() results."""
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(4096, 3)) * rng.uniform(1e-3, 1e3, size=(4096, 1))
+    ht, ot = build_pair(pts, b_max=1e-5)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    q = rng.normal(size=(20000, 3)) * 5
+    g = ctx.nn_search(tid, q)
+    leaf, depth, dist = ot.search(q, want_dist=True)
+    assert np.array_equal(g["leaf"], leaf)
+    assert np.array_equal(g["depth"], depth)
+    assert np.array_equal(g["dist"], dist)  # bit-exact, includes a device sqrt
+    ctx.tree_release(tid)
+
+
+def test_nn_self_query_known_answer(ctx):
+    """apps/utils/tools/nn_search.py: every point queried against the one-leaf-per-point tree of the same
+    cloud returns itself -> total matching error exactly 0 (apps/utils/tools/README.md:9-10)."""
+    np.random.seed(42)
+    cloud = four_walls(10000)
+    ht = capi.HostTree(cloud, 1e-5, 0.1, 2)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    g = ctx.nn_search(tid, cloud)
+    assert g["dist"].sum() == 0.0
+    nodes = ht.nodes
+    assert np.array_equal(nodes["mean"][g["node"]], cloud)
+    ctx.tree_release(tid)
+
+
+@pytest.mark.parametrize("b_max", [0.2, 1e-5])
+def test_nn_search_matches_oracle(ctx, b_max):
+    pb = street_problem(2)
+    ht, ot = build_pair(pb["keyframe_scans"][0], b_max=b_max, T=pb["keyframe_poses"][0])
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    q = (pb["query_scans"][0] @ pb["query_gt"][0][:3, :3].T) + pb["query_gt"][0][:3, 3]
+    g = ctx.nn_search(tid, q)
+    leaf, depth, dist = ot.search(q, want_dist=True)
+    assert np.array_equal(g["leaf"], leaf)
+    assert np.array_equal(g["depth"], depth)
+    assert np.array_equal(g["dist"], dist)
+    ctx.tree_release(tid)
+
+
+def test_tree_transform_matches_host_and_oracle(ctx):
+    pb = street_problem(2)
+    T = pb["keyframe_poses"][1]
+    ht = capi.HostTree(pb["keyframe_scans"][1], B_MAX, B_MIN, 2)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    ctx.tree_transform(tid, T[:3, :3], T[:3, 3])
+    dev = ctx.tree_download(tid, ht.num_nodes)
+    ht.transform(T[:3, :3], T[:3, 3])
+    host = ht.nodes
+    for f in ("mean", "dir", "right", "leaf_id", "bbox0"):
+        assert np.array_equal(dev[f], host[f], equal_nan=True), f
+    ot = O.Tree(pb["keyframe_scans"][1], B_MAX, B_MIN, 2)
+    ot.transform(T[:3, :3], T[:3, 3])
+    assert np.array_equal(dev["mean"], ot.export()["mean"])
+    ctx.tree_release(tid)
+
+
+def _setup_registration(ctx, K, n_queries=1):
+    pb = street_problem(K, n_queries=n_queries)
+    hts, ots, tids = [], [], []
+    for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        ht, ot = build_pair(s, T=T)
+        hts.append(ht)
+        ots.append(ot)
+        tids.append(ctx.tree_upload(ht.nodes, ht.num_leaves))
+    qh, qo, mids = [], [], []
+    for s in pb["query_scans"]:
+        h = capi.HostTree(s, B_MAX, B_MIN, 2)
+        qh.append(h)
+        qo.append(O.Tree(s, B_MAX, B_MIN, 2))
+        mids.append(ctx.moving_upload(h.leaf_means()))
+    return pb, hts, ots, tids, qh, qo, mids
+
+
+def _teardown(ctx, tids, mids):
+    for t in tids:
+        ctx.tree_release(t)
+    for m in mids:
+        ctx.moving_release(m)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_linearize_correspondences_bit_exact(ctx, K):
+    """Per (leaf, tree): NN leaf ordinal and gate decision identical to MADicp::update; H, b agree to
+    summation-order rounding."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
+    T = pb["query_guess"][0]
+    L = qh[0].num_leaves
+    g = ctx.icp_linearize(mids[0], tids, T, PARAMS, L)
+    H = np.zeros((6, 6))
+    b = np.zeros(6)
+    matched = np.zeros(L, np.uint8)
+    visits = 0
+    for k in range(K):
+        Hk, bk, corr, rej, mat, depth = O.icp_linearize(qo[0], ots[k], T, B_MAX, RHO_KER, B_RATIO)
+        assert np.array_equal(g["corr"][k] & 0x7FFFFFFF, corr), f"tree {k}: NN leaf ordinals differ"
+        assert np.array_equal((g["corr"][k] >> 31).astype(np.uint8), rej), f"tree {k}: gate decisions differ"
+        H += Hk
+        b += bk
+        matched |= mat
+        visits += depth
+    assert np.array_equal(g["matched"], matched)
+    assert g["visits"] == visits
+    scale = np.abs(H).max()
+    assert np.allclose(g["H"], (np.tril(H) + np.tril(H, -1).T), rtol=0, atol=1e-10 * scale)
+    assert np.allclose(g["b"], b, rtol=0, atol=1e-10 * max(1.0, np.abs(b).max()))
+    _teardown(ctx, tids, mids)
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_register_pose_and_per_iteration_correspondences(ctx, K):
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
+    T0 = pb["query_guess"][0]
+    L = qh[0].num_leaves
+    o = O.icp_register(qo[0], ots, T0, 15, B_MAX, RHO_KER, B_RATIO, num_threads=2)
+    g = ctx.icp_register(mids[0], tids, T0, PARAMS, 15, L)
+    dt, da = pose_err(o["T"], g["T"])
+    assert dt <= POSE_TOL_M and da <= POSE_TOL_RAD, (dt, da)
+    # pose before every round agrees too
+    for it in range(15):
+        dt, da = pose_err(O.pose44(o["X_iters"][it]), capi.pose44(g["X_iters"][it]))
+        assert dt <= POSE_TOL_M and da <= POSE_TOL_RAD, (it, dt, da)
+    assert g["visits"] > 0
+    # matched flags of the last round: identical unless a borderline pair flipped (poses differ by ~1e-15)
+    assert (g["matched"] != o["matched"]).sum() <= 2
+    # inject the oracle's pose of every round: correspondences must be bit-exact at that pose
+    for it in (0, 7, 14):
+        Tit = O.pose44(o["X_iters"][it])
+        gi = ctx.icp_linearize(mids[0], tids, Tit, PARAMS, L)
+        for k in range(K):
+            _, _, corr, rej, _, _ = O.icp_linearize(qo[0], ots[k], Tit, B_MAX, RHO_KER, B_RATIO)
+            assert np.array_equal(gi["corr"][k] & 0x7FFFFFFF, corr)
+            assert np.array_equal((gi["corr"][k] >> 31).astype(np.uint8), rej)
+    # converged near ground truth (sanity of the whole problem, loose)
+    dt, da = pose_err(pb["query_gt"][0], g["T"])
+    assert dt < 0.05 and da < 0.01
+    _teardown(ctx, tids, mids)
+
+
+def test_register_batch_equals_single(ctx):
+    """Scans batched in flight advance exactly like the same scans registered one by one."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 2, n_queries=3)
+    X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
+    gb = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+    for s in range(3):
+        gs = ctx.icp_register(mids[s], tids, pb["query_guess"][s], PARAMS, 15, qh[s].num_leaves)
+        assert np.array_equal(gb["X"][s], gs["X"]), "batched and single registration must be bit-identical"
+        assert np.array_equal(gb["H"][s], gs["H"])
+        assert gb["n_matched"][s] == int(gs["matched"].sum())
+    _teardown(ctx, tids, mids)
+
+
+def test_register_is_deterministic_and_graph_equals_eager(ctx):
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 2)
+    L = qh[0].num_leaves
+    a = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, 15, L)
+    b = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, 15, L)
+    assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["H"], b["H"])
+    ctx.set_option("use_graph", 0)
+    c = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, 15, L)
+    ctx.set_option("use_graph", 1)
+    assert np.array_equal(a["X"], c["X"]) and np.array_equal(a["H"], c["H"])
+    _teardown(ctx, tids, mids)
+
+
+def test_pairwise_registration_known_answer(ctx):
+    """apps/utils/tools/mad_registration.py:51-68 — query = copy of reference, guess = euler-xyz(0.1,0.1,0.1)
+    + rand(3) translation drawn after the cloud; ground truth is the identity."""
+    from scipy.spatial.transform import Rotation
+
+    np.random.seed(42)
+    ref = four_walls(1000)
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_euler("xyz", [0.1, 0.1, 0.1]).as_matrix()
+    T[:3, 3] = np.random.rand(3)
+    rt = capi.HostTree(ref, 0.2, 0.1, 0)
+    qt = capi.HostTree(ref.copy(), 0.2, 0.1, 0)
+    tid = ctx.tree_upload(rt.nodes, rt.num_leaves)
+    mid = ctx.moving_upload(qt.leaf_means())
+    g = ctx.icp_register(mid, [tid], T, (0.2, 0.1, 0.02), 15, qt.num_leaves)
+    assert np.abs(g["T"] - np.eye(4)).max() < 1e-6  # the reference states no tolerance ("gt T = identity")
+    assert g["matched"].all()
+    _teardown(ctx, [tid], [mid])
+
+
+def test_abi_errors_are_loud(ctx):
+    with pytest.raises(capi.MadIcpError):
+        ctx.tree_release(123456)
+    with pytest.raises(capi.MadIcpError):
+        ctx.nn_search(98765, np.zeros((4, 3)))
+    with pytest.raises(capi.MadIcpError):
+        ctx.icp_register(4242, [1], np.eye(4), PARAMS, 15, 10)
