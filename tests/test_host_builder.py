@@ -1,0 +1,86 @@
+"""CPU tests of the product's host tree builder: bit-identical to the oracle's restatement of
+mad_tree.cpp:47-130 on the same clouds, including the degenerate ones."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fixtures import four_walls, street_problem
+from mad_icp_amd import capi
+
+
+def assert_same_tree(points, b_max, b_min, par):
+    ht = capi.HostTree(points, b_max, b_min, par)
+    ot = O.Tree(points, b_max, b_min, par)
+    ex = ot.export()
+    nodes = ht.nodes
+    assert ht.num_nodes == ot.num_nodes and ht.num_leaves == ot.num_leaves
+    leaf = ex["left"] < 0
+    assert np.array_equal(nodes["right"] == 0, leaf)
+    assert np.array_equal(nodes["mean"], ex["mean"])
+    want_dir = np.where(leaf[:, None], ex["evecs"][:, :, 0], ex["evecs"][:, :, 2])
+    assert np.array_equal(nodes["dir"], want_dir, equal_nan=True)
+    assert np.array_equal(nodes["bbox0"], ex["bbox"][:, 0])
+    idx = np.arange(len(nodes))
+    assert np.array_equal((idx + nodes["right"])[~leaf], ex["right"][~leaf])
+    assert np.array_equal((idx + 1)[~leaf], ex["left"][~leaf])
+    # leaf ordinals follow getLeafs() (DFS, left first)
+    assert np.array_equal(nodes["leaf_id"][leaf], np.arange(leaf.sum()))
+    assert np.array_equal(ht.leaf_nodes, idx[leaf])
+    m, n, b0 = ot.leaves()
+    assert np.array_equal(ht.leaf_means(), m)
+    assert np.array_equal(nodes["dir"][leaf], n, equal_nan=True)
+    return ht, ot
+
+
+@pytest.mark.parametrize("b_max,par", [(0.2, 0), (0.2, 3), (1e-5, 2), (1.0, 1)])
+def test_street_scan(b_max, par):
+    pb = street_problem(2)
+    assert_same_tree(pb["keyframe_scans"][0], b_max, 0.1, par)
+
+
+def test_four_walls_one_leaf_per_point():
+    np.random.seed(42)
+    cloud = four_walls(2000)
+    ht, _ = assert_same_tree(cloud, 1e-5, 0.1, 2)
+    assert ht.num_leaves == cloud.shape[0]
+
+
+@pytest.mark.parametrize("case", ["one", "two", "three_collinear", "duplicates", "planar", "line", "huge_coords"])
+def test_degenerate_clouds(case):
+    rng = np.random.default_rng(11)
+    pts = {
+        "one": np.array([[0.5, -1.0, 2.0]]),
+        "two": np.array([[0.0, 0, 0], [3.0, 1, 0]]),
+        "three_collinear": np.array([[0.0, 0, 0], [1.0, 1, 1], [2.0, 2, 2]]),
+        "duplicates": np.repeat(rng.normal(size=(7, 3)), 9, axis=0),
+        "planar": np.column_stack([rng.uniform(-5, 5, 800), rng.uniform(-5, 5, 800), np.zeros(800)]),
+        "line": np.column_stack([np.linspace(0, 50, 500), np.zeros(500), np.zeros(500)]),
+        "huge_coords": rng.normal(size=(1000, 3)) + 1e6,
+    }[case]
+    assert_same_tree(pts, 0.2, 0.1, 0)
+    assert_same_tree(pts, 1e-5, 0.1, 2)
+
+
+def test_transform_matches_oracle():
+    pb = street_problem(2)
+    T = pb["keyframe_poses"][1]
+    ht, ot = assert_same_tree(pb["keyframe_scans"][1], 0.2, 0.1, 2)
+    ht.transform(T[:3, :3], T[:3, 3])
+    ot.transform(T[:3, :3], T[:3, 3])
+    ex = ot.export()
+    leaf = ex["left"] < 0
+    assert np.array_equal(ht.nodes["mean"], ex["mean"])
+    assert np.array_equal(ht.nodes["dir"], np.where(leaf[:, None], ex["evecs"][:, :, 0], ex["evecs"][:, :, 2]))
+
+
+def test_input_cloud_is_not_modified():
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(3000, 3))
+    keep = pts.copy()
+    capi.HostTree(pts, 0.2, 0.1, 2)
+    assert np.array_equal(pts, keep)
+
+
+def test_empty_cloud_raises():
+    with pytest.raises(ValueError):
+        capi.HostTree(np.zeros((0, 3)), 0.2, 0.1, 0)
