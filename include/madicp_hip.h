@@ -69,11 +69,11 @@ int madicp_abi_version(void);
 int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out);
 int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
-/* Tuning knobs (all optional): key in {"grid_blocks_per_cu", "use_graph", "lds_top_levels",
- * "queries_per_thread", "time_kernels"}. */
+/* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..8), "use_graph" (0/1), "time_kernels" (0/1)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
-/* When option "time_kernels" is on, every icp_linearize launch is bracketed by hipEvents on the ctx
- * stream; this returns the number of launches timed since the last reset and their total duration. */
+/* When option "time_kernels" is on, every icp_linearize launch carries start/stop hipEvents attached to the
+ * dispatch (hipExtLaunchKernelGGL) on the ctx stream; this returns the number of launches timed since the last
+ * reset and the sum of their execution times. */
 int madicp_ctx_kernel_time(madicp_ctx* ctx, int reset, int64_t* n_launches, double* total_ms);
 
 /* ---- MAD-tree (fixed side) ---------------------------------------------------------------------- */

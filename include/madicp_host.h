@@ -32,6 +32,13 @@ void madicp_host_tree_leaf_means(const madicp_host_tree* t, double* out);
 /* MADtree::applyTransform on the host copy (mad_tree.cpp:165-172); R row-major */
 void madicp_host_tree_transform(madicp_host_tree* t, const double R[9], const double tr[3]);
 
+/* MADicp::updateState after the adders have been joined (mad_icp.cpp:111-116): dx = LDLT(H).solve(-b),
+ * X <- X * [expSO3(dx[3:6]), dx[0:3]].  H row-major 36 (lower triangle read), X: R row-major 9 + t 3, in place.
+ * Host counterpart of the device-side solve; used by the staged multi-rank driver (mad_icp_amd/sharded.py). */
+void madicp_host_gn_update(const double H[36], const double b[6], double X[12]);
+/* det(H^-1), the keyframe weight of pipeline.cpp:223 */
+double madicp_host_det_of_inverse6(const double H[36]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,13 +54,19 @@ def build_hip(force=False):
     return out
 
 
+HOST_SRCS = ("tree_builder.cpp", "host_capi.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp", "pipeline.cpp")
+
+
 def build_host(force=False):
+    """libmadicp_host.so: tree builder + the host classes (MADtree, MADicp, VelEstimator, Pipeline).  Links
+    against libmadicp_hip.so — the host classes have no other implementation to call."""
     out = os.path.join(PKG, "libmadicp_host.so")
     hdir = os.path.join(CSRC, "host")
-    srcs = [os.path.join(hdir, "tree_builder.cpp"), os.path.join(hdir, "host_capi.cpp")]
-    deps = srcs + _glob(hdir, (".h",)) + _glob(INC, (".h",))
+    srcs = [os.path.join(hdir, f) for f in HOST_SRCS]
+    deps = srcs + _glob(hdir, (".h",)) + _glob(INC, (".h",)) + [os.path.join(PKG, "libmadicp_hip.so")]
     if force or _newer(out, deps):
-        _run([CXX] + HOST_FLAGS + ["-shared", "-I" + INC, "-I" + hdir] + srcs + ["-o", out, "-pthread"])
+        _run([CXX] + HOST_FLAGS + ["-shared", "-I" + INC, "-I" + hdir] + srcs +
+             ["-o", out, "-L" + PKG, "-lmadicp_hip", "-Wl,-rpath,$ORIGIN", "-pthread"])
     return out
 
 
@@ -72,21 +78,16 @@ def build_pybind(force=False):
     outdir = os.path.join(PKG, "pybind")
     os.makedirs(outdir, exist_ok=True)
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
-    common = [os.path.join(hdir, f) for f in ("tree_builder.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp",
-                                              "pipeline.cpp")]
-    common = [c for c in common if os.path.exists(c)]
-    deps_h = _glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(INC, (".h",))
+    deps_h = _glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(INC, (".h",)) + [os.path.join(PKG, "libmadicp_host.so")]
     built = []
     for mod in ("pyvector", "pymadtree", "pymadicp", "pypeline"):
         src = os.path.join(pdir, mod + ".cpp")
-        if not os.path.exists(src):
-            continue
         out = os.path.join(outdir, mod + suffix)
-        if force or _newer(out, [src] + common + deps_h):
+        if force or _newer(out, [src] + deps_h):
             _run([CXX] + HOST_FLAGS + ["-shared", "-fvisibility=hidden", "-I" + INC, "-I" + hdir, "-I" + pdir,
-                                       "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
-                                       src] + common +
-                 ["-o", out, "-L" + PKG, "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..", "-pthread"])
+                                       "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src,
+                                       "-o", out, "-L" + PKG, "-lmadicp_host", "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..",
+                                       "-pthread"])
         built.append(out)
     return built
 

@@ -100,6 +100,9 @@ def host_lib():
         L.madicp_host_tree_leaf_nodes.argtypes = [C.c_void_p]
         L.madicp_host_tree_leaf_means.argtypes = [C.c_void_p, _dp]
         L.madicp_host_tree_transform.argtypes = [C.c_void_p, _dp, _dp]
+        L.madicp_host_gn_update.argtypes = [_dp, _dp, _dp]
+        L.madicp_host_det_of_inverse6.restype = C.c_double
+        L.madicp_host_det_of_inverse6.argtypes = [_dp]
         _host = L
     return _host
 
@@ -128,6 +131,15 @@ def pose44(x):
     T[:3, :3] = np.asarray(x[:9]).reshape(3, 3)
     T[:3, 3] = x[9:12]
     return T
+
+
+def gn_update(H, b, X12):
+    """MADicp::updateState on joined adders (host): returns the updated pose (12,)."""
+    H = _f64(H, (36,))
+    b = _f64(b, (6,))
+    X = _f64(X12, (12,)).copy()
+    host_lib().madicp_host_gn_update(H.ctypes.data_as(_dp), b.ctypes.data_as(_dp), X.ctypes.data_as(_dp))
+    return X
 
 
 class HostTree:

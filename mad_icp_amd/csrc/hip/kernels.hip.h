@@ -37,10 +37,39 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kAcc = 29;             // 21 (lower triangle of H, column by column) + 6 (b) + accepted pairs + nodes visited
 constexpr int kSolveThreads = 1024;
 
-struct TreeRef {
+// 16-byte screening record of one node, same index as the exact 64-byte madicp_node.
+//
+// The descent test of the reference, s = fl((q-m).n) < 0 (mad_tree.cpp:148), needs 52 bytes of fp64 per
+// visit = four 16-byte loads per lane, and with 64 lanes walking 64 different nodes it is the L1/TA
+// address path, not arithmetic or HBM, that bounds the kernel.  The screening record lets almost every
+// visit decide with ONE 16-byte load:
+//     n~  = the split normal rounded to 3 x 21-bit fixed point (|n~_i - n_i| <= 2^-20)
+//     c~  = fl32( n~ . (m - o) )          o = the tree's origin (root centroid)
+//     s^  = n~ . (q - o) - c~             evaluated in fp64
+// For every query that can reach the node,  |s^ - s| <= E := (2^-20 + 32u)(|q-o|_1 + rho) + 2^-24 |c~|
+// (u = 2^-53, rho >= |m-o|_1 for every node of the tree; derivation in DESIGN.md "Exact screening").
+// If |s^| > E the sign of s^ IS the sign of the reference's fp64 s; otherwise the lane loads the exact
+// record and evaluates the reference expression.  The decision is therefore bit-identical by construction
+// (and the parity tests check it against the oracle), while ~99.9 % of the visits cost a quarter of the
+// L1 transactions and the screening array (16 B x nodes) of a keyframe pair fits an XCD's 4 MiB L2.
+struct CNode {
+  unsigned long long npack;  // n~: k0 | k1 << 21 | k2 << 42, k_i two's complement 21 bit, n~_i = k_i * 2^-20
+  float c;                   // c~ ; +inf marks "always take the exact path" (non-finite node)
+  unsigned int right;        // same as madicp_node::right (0 = leaf)
+};
+static_assert(sizeof(CNode) == 16, "screening record is 16 bytes");
+
+constexpr double kScreenDelta = 9.6e-7;   // > 2^-20 + 32u, covers the rounding of |q-o|_1 and rho too
+constexpr double kScreenC = 6.0e-8;       // > 2^-24 (1 + 2^-23)
+
+// device-resident description of one uploaded tree
+struct TreeMeta {
   const madicp_node* nodes;
+  const CNode* cnodes;
   int32_t n_nodes;
   int32_t n_leaves;
+  double origin[3];              // o: mean of node 0
+  unsigned long long rho2_bits;  // bits of max_i |m_i - o|_2 (non-negative doubles order like integers)
 };
 
 // One registration in flight; lives in device memory, written by the host before each launch sequence
@@ -63,7 +92,7 @@ struct Job {
   double H[36];          // row-major, of the last round
   double b[6];
   double n_pairs;        // accepted (leaf,tree) pairs of the last round
-  TreeRef trees[MADICP_MAX_TREES];
+  const TreeMeta* trees[MADICP_MAX_TREES];
 };
 constexpr int kFlagNoUpdate = 1;
 
@@ -86,13 +115,16 @@ struct NodeV {
   int right, leaf_id;
   double bbox0;
 };
-// one 64 B record = four 16 B loads from one cache line
 // (pointers that were themselves loaded from memory are "generic" to the compiler; the explicit global
 // address space turns flat_load into global_load)
 typedef double vd2 __attribute__((ext_vector_type(2)));
 typedef double vd4 __attribute__((ext_vector_type(4)));
+typedef unsigned int vu4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) vd2* gptr_d2;
 typedef const __attribute__((address_space(1))) vd4* gptr_d4;
+typedef const __attribute__((address_space(1))) vu4* gptr_u4;
+
+// exact record: one 64 B cache line, up to four 16 B loads
 __device__ __forceinline__ NodeV load_node(const madicp_node* __restrict__ nodes, int idx) {
   gptr_d2 p = (gptr_d2)(uintptr_t)(nodes + idx);
   const vd2 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -105,24 +137,100 @@ __device__ __forceinline__ NodeV load_node(const madicp_node* __restrict__ nodes
   n.bbox0 = d.y;
   return n;
 }
+// the reference's side test on the exact record (mad_tree.cpp:148)
+__device__ __forceinline__ bool exact_goes_left(const madicp_node* __restrict__ nodes, int idx, double q0, double q1,
+                                                double q2) {
+  gptr_d2 p = (gptr_d2)(uintptr_t)(nodes + idx);
+  const vd2 a = p[0], b = p[1], c = p[2];
+  return dotc(q0 - a.x, q1 - a.y, q2 - b.x, b.y, c.x, c.y) < 0.0;
+}
 
-// greedy root->leaf descent, no backtracking (mad_tree.cpp:144-152)
-__device__ __forceinline__ NodeV descend(const madicp_node* __restrict__ nodes, double q0, double q1, double q2,
-                                         int& node_idx, int& depth) {
+// per (query, tree) constants of the screening test
+struct Screen {
+  double r0, r1, r2;  // (q - o) * 2^-20
+  double slack;       // kScreenDelta * (|q-o|_1 + rho)
+};
+__device__ __forceinline__ Screen make_screen(const TreeMeta* __restrict__ tm, double q0, double q1, double q2) {
+  const double e0 = q0 - tm->origin[0], e1 = q1 - tm->origin[1], e2 = q2 - tm->origin[2];
+  const double rho = 1.7320508075688774 * __longlong_as_double((long long)tm->rho2_bits);  // |.|_1 <= sqrt3 |.|_2
+  Screen s;
+  s.r0 = e0 * 9.5367431640625e-07;  // 2^-20, exact scaling
+  s.r1 = e1 * 9.5367431640625e-07;
+  s.r2 = e2 * 9.5367431640625e-07;
+  s.slack = kScreenDelta * ((fabs(e0) + fabs(e1) + fabs(e2)) + rho);
+  return s;
+}
+
+// greedy root->leaf descent, no backtracking (mad_tree.cpp:144-152), screened.  Returns the leaf's index.
+__device__ __forceinline__ int descend(const TreeMeta* __restrict__ tm, double q0, double q1, double q2, int& depth) {
+  const madicp_node* __restrict__ nodes = tm->nodes;
+  gptr_u4 cn = (gptr_u4)(uintptr_t)tm->cnodes;
+  const Screen sc = make_screen(tm, q0, q1, q2);
   int idx = 0, d = 0;
-  NodeV n = load_node(nodes, 0);
-  while (n.right != 0) {
-    const double side = dotc(q0 - n.m0, q1 - n.m1, q2 - n.m2, n.d0, n.d1, n.d2);
-    idx = (side < 0.0) ? idx + 1 : idx + n.right;
-    n = load_node(nodes, idx);
+  for (;;) {
+    const vu4 w = cn[idx];
+    if (w.w == 0u) break;
+    const int k0 = ((int)(w.x << 11)) >> 11;
+    const int k1 = ((int)(((w.y << 22) | (w.x >> 10)) & 0xfffff800u)) >> 11;
+    const int k2 = ((int)(w.y << 1)) >> 11;
+    const double c = (double)__uint_as_float(w.z);
+    const double sh = (sc.r0 * (double)k0 + sc.r1 * (double)k1) + sc.r2 * (double)k2 - c;
+    bool left;
+    if (fabs(sh) > sc.slack + kScreenC * fabs(c)) {
+      left = sh < 0.0;
+    } else {
+      left = exact_goes_left(nodes, idx, q0, q1, q2);
+    }
+    idx = left ? idx + 1 : idx + (int)w.w;
     ++d;
   }
-  node_idx = idx;
   depth = d;
-  return n;
+  return idx;
 }
 
 // ---------------------------------------------------------------------------------------------------
+// builds the screening records of a tree (after upload and after every transform); grid over nodes
+__global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnodes, int n) {
+  const madicp_node* __restrict__ nodes = tm->nodes;
+  const double o0 = nodes[0].mean[0], o1 = nodes[0].mean[1], o2 = nodes[0].mean[2];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double r = 0.0;
+  if (i < n) {
+    const madicp_node nd = nodes[i];
+    CNode c;
+    c.right = (unsigned int)nd.right;
+    const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
+    const bool finite = isfinite(e0) && isfinite(e1) && isfinite(e2) && fabs(nd.dir[0]) <= 1.0000001 &&
+                        fabs(nd.dir[1]) <= 1.0000001 && fabs(nd.dir[2]) <= 1.0000001;  // false on NaN
+    if (nd.right != 0 && finite) {
+      long long k[3];
+      double nt[3];
+      for (int a = 0; a < 3; ++a) {
+        double v = rint(nd.dir[a] * 1048576.0);
+        v = fmin(fmax(v, -1048575.0), 1048575.0);
+        k[a] = (long long)v;
+        nt[a] = v * 9.5367431640625e-07;
+      }
+      c.npack = ((unsigned long long)k[0] & 0x1fffffull) | (((unsigned long long)k[1] & 0x1fffffull) << 21) |
+                (((unsigned long long)k[2] & 0x1fffffull) << 42);
+      c.c = (float)((nt[0] * e0 + nt[1] * e1) + nt[2] * e2);
+      r = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+    } else {
+      c.npack = 0ull;
+      c.c = __uint_as_float(0x7f800000u);  // +inf: the screening test can never pass -> exact path
+    }
+    cnodes[i] = c;
+  }
+  // rho2 = max |m - o|_2 over the internal nodes; max is order independent -> deterministic
+  for (int off = 32; off > 0; off >>= 1) r = fmax(r, __shfl_down(r, off, 64));
+  if ((threadIdx.x & 63) == 0 && r > 0.0) atomicMax(&tm->rho2_bits, (unsigned long long)__double_as_longlong(r));
+  if (i == 0) {
+    tm->origin[0] = o0;
+    tm->origin[1] = o1;
+    tm->origin[2] = o2;
+  }
+}
+
 __global__ void moving_prep(const double* __restrict__ xyz, double* __restrict__ out, int L) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
@@ -133,13 +241,14 @@ __global__ void moving_prep(const double* __restrict__ xyz, double* __restrict__
   reinterpret_cast<double4*>(out)[i] = o;
 }
 
-__global__ void nn_descend(const madicp_node* __restrict__ nodes, const double* __restrict__ q, long long n,
+__global__ void nn_descend(const TreeMeta* __restrict__ tm, const double* __restrict__ q, long long n,
                            uint32_t* __restrict__ out_leaf, uint32_t* __restrict__ out_node,
                            double* __restrict__ out_dist, int32_t* __restrict__ out_depth) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
-    int idx, depth;
-    const NodeV leaf = descend(nodes, q0, q1, q2, idx, depth);
+    int depth;
+    const int idx = descend(tm, q0, q1, q2, depth);
+    const NodeV leaf = load_node(tm->nodes, idx);
     if (out_leaf) out_leaf[i] = static_cast<uint32_t>(leaf.leaf_id);
     if (out_node) out_node[i] = static_cast<uint32_t>(idx);
     if (out_depth) out_depth[i] = depth;
@@ -171,9 +280,39 @@ __global__ void tree_transform(madicp_node* __restrict__ nodes, int n, const dou
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Sum of kAcc per-lane accumulators over the 64 lanes of a wave, as a reduce-scatter: at every step a
+// lane keeps one half of its slots, hands the other half to its partner (lane ^ 32, 16, 8, 4, 2) and adds
+// what it receives, so the slot count halves each time: 16+8+4+2+1 exchanges plus one final pair-wise add
+// instead of 6 per slot (32 cross-lane moves of a double instead of 174).  The tree is fixed, so the result
+// is bit-reproducible.  Afterwards lane l holds the wave total of slot l>>1; even lanes store it.
+// ---------------------------------------------------------------------------------------------------
+template <int N, int MASK>
+__device__ __forceinline__ void butterfly_step(double* a, int lane) {
+  const bool upper = (lane & MASK) != 0;
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const double keep = upper ? a[j + N / 2] : a[j];
+    const double give = upper ? a[j] : a[j + N / 2];
+    a[j] = keep + __shfl_xor(give, MASK, 64);
+  }
+}
+__device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane, double* out32 /*LDS, 32 slots*/) {
+  double a[32];
+#pragma unroll
+  for (int v = 0; v < 32; ++v) a[v] = (v < kAcc) ? acc[v] : 0.0;
+  butterfly_step<32, 32>(a, lane);
+  butterfly_step<16, 16>(a, lane);
+  butterfly_step<8, 8>(a, lane);
+  butterfly_step<4, 4>(a, lane);
+  butterfly_step<2, 2>(a, lane);
+  const double tot = a[0] + __shfl_xor(a[0], 1, 64);
+  if ((lane & 1) == 0) out32[lane >> 1] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // icp_linearize
 //
-// Work decomposition.  A *unit* is (tree k, chunk c): kBlock*QPT consecutive moving leaves against one
+// Work decomposition.  A *unit* is (tree k, chunk c): kBlock consecutive moving leaves against one
 // keyframe tree.  Units are ordered tree-major and cut into 8 contiguous ranges, one per XCD; workgroup
 // b runs on XCD b % 8 (observed dispatch rule — used for speed only, never for correctness), so every
 // XCD's private 4 MiB L2 only serves the nodes of its own ~K/8 trees.  Inside an XCD the workgroups
@@ -184,7 +323,6 @@ __global__ void tree_transform(madicp_node* __restrict__ nodes, int n, const dou
 // grid = (8 * slots, n_scans); blockIdx.y selects the registration (scans batched in flight).
 // partials: [scan][gridDim.x][kAcc]
 // ---------------------------------------------------------------------------------------------------
-template <int QPT>
 __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, double* __restrict__ partials) {
   Job* job = jobs + blockIdx.y;
   const int L = job->L;
@@ -206,8 +344,7 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
   for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
   unsigned int visits = 0;
 
-  constexpr int kChunk = kBlock * QPT;
-  const int C = (L + kChunk - 1) / kChunk;
+  const int C = (L + kBlock - 1) / kBlock;
   const long long U = (long long)K * C;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
@@ -218,112 +355,87 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
   for (long long u = lo + slot; u < hi; u += nslots) {
     const int k = static_cast<int>(u / C);
     const int c = static_cast<int>(u - (long long)k * C);
-    const madicp_node* __restrict__ nodes = job->trees[k].nodes;
+    const int i = c * kBlock + threadIdx.x;
+    if (i >= L) continue;
+    const TreeMeta* __restrict__ tm = job->trees[k];
 
-    // QPT independent descents per lane, advanced together so their loads overlap
-    double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT];
-    int idx[QPT];
-    bool live[QPT], valid[QPT];
-    NodeV nd[QPT];
-#pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-      const int i = c * kChunk + j * kBlock + threadIdx.x;
-      valid[j] = i < L;
-      vd4 p = {0.0, 0.0, 0.0, 0.0};
-      if (valid[j]) p = ((gptr_d4)(uintptr_t)moving)[i];
-      px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
-      // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
-      q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
-      q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
-      q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
-      idx[j] = 0;
+    const vd4 p = ((gptr_d4)(uintptr_t)moving)[i];
+    // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
+    const double q0 = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
+    const double q1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
+    const double q2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+
+    int depth;
+#ifdef MADICP_ABLATE
+    int idx = 0;
+    if (job->flags & 4) { depth = 0; idx = tm->n_nodes - 1; }  // profiling only: no descent (last node is a leaf)
+    else idx = descend(tm, q0, q1, q2, depth);
+#else
+    const int idx = descend(tm, q0, q1, q2, depth);
+#endif
+    visits += depth;
+
+    // gate (mad_icp.cpp:81-83) needs only the leaf's surface point: fetch the rest when the pair survives
+    gptr_d2 lp = (gptr_d2)(uintptr_t)(tm->nodes + idx);
+    const vd2 la = lp[0], lb = lp[1];
+    const double g0 = q0 - la.x, g1 = q1 - la.y, g2 = q2 - lb.x;
+    const double src_ball = min_ball + b_ratio * p.w;
+    const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
+    if (corr) {
+      const int leaf_id = (int)(__double_as_longlong(lp[3].x) >> 32);
+      corr[(long long)k * L + i] = static_cast<uint32_t>(leaf_id) | (rejected ? 0x80000000u : 0u);
     }
-#pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-      nd[j] = load_node(nodes, 0);
-      live[j] = valid[j] && nd[j].right != 0;
-    }
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < QPT; ++j) any |= live[j];
-    while (any) {
-      any = false;
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        if (live[j]) {
-          const double side = dotc(q0[j] - nd[j].m0, q1[j] - nd[j].m1, q2[j] - nd[j].m2, nd[j].d0, nd[j].d1, nd[j].d2);
-          idx[j] = (side < 0.0) ? idx[j] + 1 : idx[j] + nd[j].right;
-          ++visits;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        if (live[j]) {
-          nd[j] = load_node(nodes, idx[j]);
-          live[j] = nd[j].right != 0;
-          any |= live[j];
-        }
-      }
-    }
+    if (rejected) continue;
+    if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 
-#pragma unroll
-    for (int j = 0; j < QPT; ++j) {
-      if (!valid[j]) continue;
-      const int i = c * kChunk + j * kBlock + threadIdx.x;
-      const NodeV& f = nd[j];
-      // gate (mad_icp.cpp:81-83)
-      const double src_ball = min_ball + b_ratio * pn[j];
-      const double g0 = q0[j] - f.m0, g1 = q1[j] - f.m1, g2 = q2[j] - f.m2;
-      const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-      if (corr) corr[(long long)k * L + i] = static_cast<uint32_t>(f.leaf_id) | (rejected ? 0x80000000u : 0u);
-      if (rejected) continue;
-      if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
+    const vd2 lc = lp[2];
+    const double bbox0 = lp[3].y;
+    const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
 
-      // errorAndJacobian (mad_icp.cpp:59-72)
-      const double e = dotc(g0, g1, g2, f.d0, f.d1, f.d2);
-      double J[6];
-      J[0] = dotc(f.d0, f.d1, f.d2, R[0], R[3], R[6]);
-      J[1] = dotc(f.d0, f.d1, f.d2, R[1], R[4], R[7]);
-      J[2] = dotc(f.d0, f.d1, f.d2, R[2], R[5], R[8]);
-      // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
-      const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
-      J[3] = dotc(a0, a1, a2, 0.0, pz[j], -py[j]);
-      J[4] = dotc(a0, a1, a2, -pz[j], 0.0, px[j]);
-      J[5] = dotc(a0, a1, a2, py[j], -px[j], 0.0);
+    // errorAndJacobian (mad_icp.cpp:59-72)
+    const double e = dotc(g0, g1, g2, n0, n1, n2);
+    double J[6];
+    J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
+    J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
+    J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
+    // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
+    const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
+    J[3] = dotc(a0, a1, a2, 0.0, p.z, -p.y);
+    J[4] = dotc(a0, a1, a2, -p.z, 0.0, p.x);
+    J[5] = dotc(a0, a1, a2, p.y, -p.x, 0.0);
 
-      // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
-      double scale = 1.0;
-      const double chi = fabs(e);
-      if (chi > rho) scale = rho / chi;
-      const double w = 1.0 - f.bbox0 / min_ball;
-      scale *= w * w;
+    // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
+    double scale = 1.0;
+    const double chi = fabs(e);
+    if (chi > rho) scale = rho / chi;
+    const double w = 1.0 - bbox0 / min_ball;
+    scale *= w * w;
 
-      double sJ[6];
+    double sJ[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) sJ[r] = scale * J[r];
-      int v = 0;
+    for (int r = 0; r < 6; ++r) sJ[r] = scale * J[r];
+    int v = 0;
 #pragma unroll
-      for (int cc = 0; cc < 6; ++cc)
+    for (int cc = 0; cc < 6; ++cc)
 #pragma unroll
-        for (int r = cc; r < 6; ++r) acc[v++] += sJ[r] * J[cc];
+      for (int r = cc; r < 6; ++r) acc[v++] += sJ[r] * J[cc];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) acc[21 + r] += sJ[r] * e;
-      acc[27] += 1.0;
-    }
+    for (int r = 0; r < 6; ++r) acc[21 + r] += sJ[r] * e;
+    acc[27] += 1.0;
   }
 
-  // deterministic reduction: lanes (xor-free shuffle-down tree) -> waves (LDS, fixed order) -> partial
+  // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
   acc[28] = static_cast<double>(visits);  // integer-valued: its sums are exact in any order
-  __shared__ double red[kWaves][kAcc];
+  __shared__ double red[kWaves][32];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int v = 0; v < kAcc; ++v) {
-    double x = acc[v];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    if (lane == 0) red[wave][v] = x;
+#ifdef MADICP_ABLATE
+  if (job->flags & 2) {  // profiling only: skip the cross-lane reduction
+    if (threadIdx.x < kAcc) partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * kAcc + threadIdx.x] = acc[0];
+    return;
   }
+#endif
+  wave_reduce_scatter(acc, lane, red[wave]);
   __syncthreads();
   if (threadIdx.x < kAcc) {
     double s = red[0][threadIdx.x];
@@ -336,81 +448,119 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
 // ---------------------------------------------------------------------------------------------------
 // 6x6 LDLT (lower, diagonal pivoting) factor + solve — the algorithm of Eigen::LDLT that
 // `H_adder_.ldlt().solve(-b_adder_)` runs (mad_icp.cpp:111).  A: row-major, only the lower triangle is
-// read.  One lane; dynamic indexing goes through private scratch, which is irrelevant at this size.
+// read.  One lane, everything unrolled so the matrix lives in registers (a scratch-memory version of the
+// same code cost ~15 us per GN round; this one ~1 us).
 // ---------------------------------------------------------------------------------------------------
-__device__ inline void ldlt6_solve(const double* A, const double* rhs, double* x) {
+#define MADICP_SWAP(a, b) do { const double t_ = (a); (a) = (b); (b) = t_; } while (0)
+__device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, double* x) {
   double m[6][6];
   int tr[6];
-  double tmp[6];
+#pragma unroll
   for (int r = 0; r < 6; ++r)
+#pragma unroll
     for (int c = 0; c < 6; ++c) m[r][c] = A[r * 6 + c];
+  bool zero_matrix = false;
+#pragma unroll
   for (int k = 0; k < 6; ++k) {
     int big = k;
     double best = fabs(m[k][k]);
+#pragma unroll
     for (int i = k + 1; i < 6; ++i) {
       const double a = fabs(m[i][i]);
       if (a > best) { best = a; big = i; }
     }
+    if (zero_matrix) big = k;
     tr[k] = big;
-    if (k != big) {
-      for (int j = 0; j < k; ++j) { const double s = m[k][j]; m[k][j] = m[big][j]; m[big][j] = s; }
-      for (int i = big + 1; i < 6; ++i) { const double s = m[i][k]; m[i][k] = m[i][big]; m[i][big] = s; }
-      { const double s = m[k][k]; m[k][k] = m[big][big]; m[big][big] = s; }
-      for (int i = k + 1; i < big; ++i) { const double s = m[i][k]; m[i][k] = m[big][i]; m[big][i] = s; }
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p) {
+      if (big == p) {
+#pragma unroll
+        for (int j = 0; j < k; ++j) MADICP_SWAP(m[k][j], m[p][j]);
+#pragma unroll
+        for (int i = p + 1; i < 6; ++i) MADICP_SWAP(m[i][k], m[i][p]);
+        MADICP_SWAP(m[k][k], m[p][p]);
+#pragma unroll
+        for (int i = k + 1; i < p; ++i) MADICP_SWAP(m[i][k], m[p][i]);
+      }
     }
-    if (k > 0) {
+    if (k > 0 && !zero_matrix) {
+      double tmp[6];
+#pragma unroll
       for (int j = 0; j < k; ++j) tmp[j] = m[j][j] * m[k][j];
       double a = m[k][0] * tmp[0];
+#pragma unroll
       for (int j = 1; j < k; ++j) a += m[k][j] * tmp[j];
       m[k][k] -= a;
+#pragma unroll
       for (int i = k + 1; i < 6; ++i) {
         double s = m[i][0] * tmp[0];
+#pragma unroll
         for (int j = 1; j < k; ++j) s += m[i][j] * tmp[j];
         m[i][k] -= s;
       }
     }
     const double akk = m[k][k];
     const bool ok = fabs(akk) > 0.0;
-    if (k == 0 && !ok) {
-      for (int j = 0; j < 6; ++j) tr[j] = j;
-      break;
-    }
-    if (ok)
+    if (k == 0 && !ok) zero_matrix = true;  // whole diagonal is zero: identity transpositions, no scaling
+    if (ok && !zero_matrix) {
+#pragma unroll
       for (int i = k + 1; i < 6; ++i) m[i][k] /= akk;
+    }
   }
-  for (int i = 0; i < 6; ++i) x[i] = rhs[i];
-  for (int k = 0; k < 6; ++k)
-    if (tr[k] != k) { const double s = x[k]; x[k] = x[tr[k]]; x[tr[k]] = s; }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = rhs[i];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) MADICP_SWAP(y[k], y[p]);
+  }
+#pragma unroll
   for (int i = 1; i < 6; ++i) {
-    double a = m[i][0] * x[0];
-    for (int j = 1; j < i; ++j) a += m[i][j] * x[j];
-    x[i] -= a;
+    double a = m[i][0] * y[0];
+#pragma unroll
+    for (int j = 1; j < i; ++j) a += m[i][j] * y[j];
+    y[i] -= a;
   }
   const double tol = 2.2250738585072014e-308;  // numeric_limits<double>::min()
-  for (int i = 0; i < 6; ++i) x[i] = (fabs(m[i][i]) > tol) ? x[i] / m[i][i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = (fabs(m[i][i]) > tol) ? y[i] / m[i][i] : 0.0;
+#pragma unroll
   for (int i = 4; i >= 0; --i) {
-    double a = m[i + 1][i] * x[i + 1];
-    for (int j = i + 2; j < 6; ++j) a += m[j][i] * x[j];
-    x[i] -= a;
+    double a = m[i + 1][i] * y[i + 1];
+#pragma unroll
+    for (int j = i + 2; j < 6; ++j) a += m[j][i] * y[j];
+    y[i] -= a;
   }
-  for (int k = 5; k >= 0; --k)
-    if (tr[k] != k) { const double s = x[k]; x[k] = x[tr[k]]; x[tr[k]] = s; }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) MADICP_SWAP(y[k], y[p]);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
 // lie_algebra.h:39-52, R row-major
-__device__ inline void exp_so3(const double* w, double* R) {
+__device__ __forceinline__ void exp_so3(const double* w, double* R) {
   const double th2 = dotc(w[0], w[1], w[2], w[0], w[1], w[2]);
   const double th = sqrt(th2);
   const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
   if (th2 < 1e-8) {
+#pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + W[i];
     return;
   }
   double Kx[9], cK[9];
   const double omc = 2.0 * sin(th / 2.0) * sin(th / 2.0);
   const double s = sin(th);
+#pragma unroll
   for (int i = 0; i < 9; ++i) { Kx[i] = W[i] / th; cK[i] = omc * Kx[i]; }
+#pragma unroll
   for (int r = 0; r < 3; ++r)
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
       const double kk = dots(cK[3 * r], cK[3 * r + 1], cK[3 * r + 2], Kx[c], Kx[3 + c], Kx[6 + c]);
       R[3 * r + c] = (((r == c) ? 1.0 : 0.0) + s * Kx[3 * r + c]) + kk;
@@ -418,43 +568,54 @@ __device__ inline void exp_so3(const double* w, double* R) {
 }
 
 // total: kAcc sums of this round (already joined over workgroups / ranks).  One lane.
-__device__ inline void gn_update(Job* job, const double* total) {
+__device__ __forceinline__ void gn_update(Job* job, const double* total) {
   double H[36], b[6];
-  int v = 0;
-  for (int c = 0; c < 6; ++c)
-    for (int r = c; r < 6; ++r) {
-      H[r * 6 + c] = total[v];
-      H[c * 6 + r] = total[v];  // mirror: see DESIGN.md "H symmetry"
-      ++v;
-    }
+  {
+    int v = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int r = c; r < 6; ++r) {
+        H[r * 6 + c] = total[v];
+        H[c * 6 + r] = total[v];  // mirror: see DESIGN.md "H symmetry"
+        ++v;
+      }
+  }
+#pragma unroll
   for (int r = 0; r < 6; ++r) b[r] = total[21 + r];
+#pragma unroll
   for (int i = 0; i < 36; ++i) job->H[i] = H[i];
+#pragma unroll
   for (int i = 0; i < 6; ++i) job->b[i] = b[i];
   job->n_pairs = total[27];
   job->visits += static_cast<unsigned long long>(total[28]);
   const int it = job->iter;
-  if (job->x_iters)
-    for (int i = 0; i < 12; ++i) job->x_iters[(long long)it * 12 + i] = job->X[i];
+  double X[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) X[i] = job->X[i];
+  if (job->x_iters) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) job->x_iters[(long long)it * 12 + i] = X[i];
+  }
   if (!(job->flags & kFlagNoUpdate)) {
-    double nb[6], dx[6], dR[9], Rn[9], tn[3];
+    double nb[6], dx[6], dR[9];
+#pragma unroll
     for (int r = 0; r < 6; ++r) nb[r] = -b[r];
     ldlt6_solve(H, nb, dx);
     exp_so3(dx + 3, dR);
-    const double* R = job->X;
-    const double* t = job->X + 9;
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
+#pragma unroll
       for (int c = 0; c < 3; ++c)
-        Rn[3 * r + c] = dots(R[3 * r], R[3 * r + 1], R[3 * r + 2], dR[c], dR[3 + c], dR[6 + c]);
-      tn[r] = dots(R[3 * r], R[3 * r + 1], R[3 * r + 2], dx[0], dx[1], dx[2]) + t[r];
+        job->X[3 * r + c] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dR[c], dR[3 + c], dR[6 + c]);
+      job->X[9 + r] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dx[0], dx[1], dx[2]) + X[9 + r];
     }
-    for (int i = 0; i < 9; ++i) job->X[i] = Rn[i];
-    for (int i = 0; i < 3; ++i) job->X[9 + i] = tn[i];
   }
   job->iter = it + 1;
 }
 
 // join of the per-workgroup partials in a fixed order: 32 segments summed in parallel, then in sequence
-__device__ inline void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
+__device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
   __shared__ double seg[32][kAcc];
   const int j = threadIdx.x & 31;
   const int s = threadIdx.x >> 5;
@@ -463,12 +624,14 @@ __device__ inline void join_partials(const double* __restrict__ partials, int nb
     double a = 0.0;
     const int b0 = s * seg_len;
     const int b1 = min(nblocks, b0 + seg_len);
+#pragma unroll 8
     for (int b = b0; b < b1; ++b) a += partials[(long long)b * kAcc + j];
     seg[s][j] = a;
   }
   __syncthreads();
   if (threadIdx.x < kAcc) {
     double a = seg[0][threadIdx.x];
+#pragma unroll
     for (int k = 1; k < 32; ++k) a += seg[k][threadIdx.x];
     total[threadIdx.x] = a;
   }
@@ -476,9 +639,13 @@ __device__ inline void join_partials(const double* __restrict__ partials, int nb
 }
 
 // before the last round the matched_ flags are cleared (pipeline.cpp:172-176)
-__device__ inline void clear_matched_if_next_is_last(Job* job) {
-  if (job->iter + 1 == job->n_iters - 1)
-    for (int i = threadIdx.x; i < job->L; i += blockDim.x) job->matched[i] = 0;
+__device__ __forceinline__ void clear_matched_if_next_is_last(Job* job) {
+  if (job->iter + 1 == job->n_iters - 1) {
+    const int L = job->L;
+    uint4* m16 = reinterpret_cast<uint4*>(job->matched);  // hipMalloc'ed: 256-byte aligned
+    for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) m16[i] = make_uint4(0, 0, 0, 0);
+    for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) job->matched[i] = 0;
+  }
 }
 
 // single-GPU: join + solve + update in one launch; grid = n_scans, block = kSolveThreads
@@ -505,18 +672,24 @@ __global__ void icp_update(Job* __restrict__ jobs, const double* __restrict__ to
   if (s < n_scans) gn_update(jobs + s, totals + s * kAcc);
 }
 
-// matched-leaf count (pipeline.cpp:197-204); grid = n_scans
-__global__ __launch_bounds__(kBlock) void icp_finish(Job* __restrict__ jobs) {
+// matched-leaf count (pipeline.cpp:197-204); grid = n_scans, block = kSolveThreads
+__global__ __launch_bounds__(kSolveThreads) void icp_finish(Job* __restrict__ jobs) {
   Job* job = jobs + blockIdx.x;
-  __shared__ int cnt[kWaves];
+  __shared__ int cnt[kSolveThreads / 64];
+  const int L = job->L;
+  const uint4* m16 = reinterpret_cast<const uint4*>(job->matched);
   int c = 0;
-  for (int i = threadIdx.x; i < job->L; i += blockDim.x) c += job->matched[i] ? 1 : 0;
+  for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) {
+    const uint4 v = m16[i];  // flags are 0/1 bytes: popcount counts them
+    c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+  }
+  for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) c += job->matched[i] ? 1 : 0;
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     int s = 0;
-    for (int w = 0; w < kWaves; ++w) s += cnt[w];
+    for (int w = 0; w < kSolveThreads / 64; ++w) s += cnt[w];
     job->n_matched = s;
   }
 }

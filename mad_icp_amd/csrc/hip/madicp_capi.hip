@@ -2,11 +2,13 @@
 // Context / buffer management, launch sequencing (eager or captured hipGraph), optional RCCL all-reduce.
 #include "kernels.hip.h"
 
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -41,6 +43,8 @@ int fail(int code, const std::string& msg) {
 
 struct DevTree {
   madicp_node* nodes = nullptr;
+  CNode* cnodes = nullptr;    // 16-byte screening records, same indexing
+  TreeMeta* meta = nullptr;   // device-resident descriptor the kernels read
   int32_t n_nodes = 0, n_leaves = 0;
 };
 struct DevMoving {
@@ -50,9 +54,9 @@ struct DevMoving {
 };
 
 struct GraphKey {
-  int grid, batch, iters, qpt, comm;
+  int grid, batch, iters, comm;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, qpt, comm) < std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm);
+    return std::tie(grid, batch, iters, comm) < std::tie(o.grid, o.batch, o.iters, o.comm);
   }
 };
 
@@ -86,7 +90,6 @@ struct madicp_ctx {
   // options
   int blocks_per_cu = 4;
   int use_graph = 1;
-  int qpt = 1;
   int time_kernels = 0;
 
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -118,8 +121,8 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
 }
 
 // launch geometry: 8 XCDs x slots; enough workgroups to cover the units once, capped by residency
-int pick_grid(const madicp_ctx* ctx, int max_L, int K, int qpt) {
-  const long long chunk = (long long)kBlock * qpt;
+int pick_grid(const madicp_ctx* ctx, int max_L, int K) {
+  const long long chunk = kBlock;
   const long long C = (max_L + chunk - 1) / chunk;
   const long long U = std::max<long long>(1, C * K);
   long long slots = (U + 7) / 8;
@@ -139,29 +142,22 @@ hipEvent_t get_event(madicp_ctx* ctx) {
   return e;
 }
 
-void launch_linearize(madicp_ctx* ctx, int grid, int batch, int qpt) {
+void launch_linearize(madicp_ctx* ctx, int grid, int batch) {
   dim3 g(grid, batch), b(kBlock);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->time_kernels) {
-    e0 = get_event(ctx);
-    e1 = get_event(ctx);
-    hipEventRecord(e0, ctx->stream);
-  }
-  switch (qpt) {
-    case 2: hipLaunchKernelGGL(icp_linearize<2>, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials); break;
-    case 4: hipLaunchKernelGGL(icp_linearize<4>, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials); break;
-    default: hipLaunchKernelGGL(icp_linearize<1>, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials); break;
-  }
-  if (ctx->time_kernels) {
-    hipEventRecord(e1, ctx->stream);
+    // start/stop events attached to the dispatch itself: kernel execution time, like the profiler reports
+    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+    hipExtLaunchKernelGGL(icp_linearize, g, b, 0, ctx->stream, e0, e1, 0, ctx->d_jobs, ctx->d_partials);
     ctx->ev_pending.emplace_back(e0, e1);
+  } else {
+    hipLaunchKernelGGL(icp_linearize, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials);
   }
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
-int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters) {
   for (int it = 0; it < iters; ++it) {
-    launch_linearize(ctx, grid, batch, qpt);
+    launch_linearize(ctx, grid, batch);
     if (ctx->comm) {
       hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
                          grid, ctx->d_totals);
@@ -181,21 +177,21 @@ int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
       NCCL_TRY(ncclAllReduce(mv.matched, mv.matched, (size_t)mv.L, ncclUint8, ncclMax, ctx->comm, ctx->stream));
     }
   }
-  hipLaunchKernelGGL(icp_finish, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_jobs);
+  hipLaunchKernelGGL(icp_finish, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
 
-int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters) {
   // graphs: only without per-launch events, and (conservatively) only without a communicator
   const bool graph_ok = ctx->use_graph && !ctx->time_kernels && !ctx->comm;
-  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters, qpt);
-  const GraphKey key{grid, batch, iters, qpt, ctx->comm ? 1 : 0};
+  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters);
+  const GraphKey key{grid, batch, iters, ctx->comm ? 1 : 0};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_rounds(ctx, grid, batch, iters, qpt);
+    const int rc = enqueue_rounds(ctx, grid, batch, iters);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != MADICP_OK) return rc;
     if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -251,6 +247,9 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     j.n_iters = a.n_iters;
     j.iter = 0;
     j.flags = a.flags;
+#ifdef MADICP_ABLATE
+    if (const char* f = getenv("MADICP_ABLATE_FLAGS")) j.flags |= atoi(f);  // profiling builds only
+#endif
     std::memcpy(j.X, a.X0 + 12 * s, 12 * sizeof(double));
     j.min_ball = a.params->min_ball;
     j.rho = std::sqrt(a.params->rho_ker);  // MADicp ctor, mad_icp.cpp:32
@@ -258,21 +257,21 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     for (int k = 0; k < a.K; ++k) {
       auto tit = ctx->trees.find(a.tree_ids[k]);
       if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
-      j.trees[k] = TreeRef{tit->second.nodes, tit->second.n_nodes, tit->second.n_leaves};
+      j.trees[k] = tit->second.meta;
     }
     max_L = std::max(max_L, mv.L);
     // flags are cleared on the device before the last round; with a single round that is "now"
     if (a.n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
   }
-  const int grid = pick_grid(ctx, max_L, std::max(1, a.K), ctx->qpt);
+  const int grid = pick_grid(ctx, max_L, std::max(1, a.K));
   const int rc0 = ensure_partials(ctx, (size_t)a.n_scans * grid * kAcc);
   if (rc0 != MADICP_OK) return rc0;
-  const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeRef) * (size_t)std::max(1, a.K);
+  const size_t job_bytes = offsetof(Job, trees) + sizeof(const TreeMeta*) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipEventRecord(ctx->stage_ev[slot], ctx->stream));
   ctx->last_batch = a.n_scans;
-  return run_rounds(ctx, grid, a.n_scans, a.n_iters, ctx->qpt);
+  return run_rounds(ctx, grid, a.n_scans, a.n_iters);
 }
 
 }  // namespace
@@ -325,7 +324,11 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
-  for (auto& t : ctx->trees) hipFree(t.second.nodes);
+  for (auto& t : ctx->trees) {
+    hipFree(t.second.nodes);
+    hipFree(t.second.cnodes);
+    hipFree(t.second.meta);
+  }
   for (auto& m : ctx->movings) {
     hipFree(m.second.xyzn);
     hipFree(m.second.matched);
@@ -363,9 +366,6 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->blocks_per_cu = (int)value;
   } else if (k == "use_graph") {
     ctx->use_graph = value ? 1 : 0;
-  } else if (k == "queries_per_thread") {
-    if (value != 1 && value != 2 && value != 4) return fail(MADICP_ERR_INVALID, "queries_per_thread must be 1, 2 or 4");
-    ctx->qpt = (int)value;
   } else if (k == "time_kernels") {
     ctx->time_kernels = value ? 1 : 0;
   } else {
@@ -396,6 +396,22 @@ int madicp_ctx_kernel_time(madicp_ctx* ctx, int reset, int64_t* n_launches, doub
 }
 
 // ---- trees ------------------------------------------------------------------------------------------
+namespace {
+// (re)build the 16-byte screening records and the tree's origin / radius on the device
+int compact_tree(madicp_ctx* ctx, DevTree& t) {
+  HIP_TRY(hipMemsetAsync(&t.meta->rho2_bits, 0, sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL(tree_compact, dim3((t.n_nodes + 255) / 256), dim3(256), 0, ctx->stream, t.meta, t.cnodes, t.n_nodes);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
+}
+void free_tree(DevTree& t) {
+  hipFree(t.nodes);
+  hipFree(t.cnodes);
+  hipFree(t.meta);
+  t = DevTree{};
+}
+}  // namespace
+
 int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id) {
   if (!ctx || !nodes || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
   if (n_nodes < 1 || n_leaves < 1 || n_nodes != 2 * n_leaves - 1)
@@ -404,12 +420,23 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   DevTree t;
   t.n_nodes = n_nodes;
   t.n_leaves = n_leaves;
-  HIP_TRY(hipMalloc(&t.nodes, sizeof(madicp_node) * (size_t)n_nodes));
-  hipError_t e = hipMemcpyAsync(t.nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    hipFree(t.nodes);
-    return fail(MADICP_ERR_DEVICE, std::string("tree upload: ") + hipGetErrorString(e));
+  hipError_t e = hipMalloc(&t.nodes, sizeof(madicp_node) * (size_t)n_nodes);
+  if (e == hipSuccess) e = hipMalloc(&t.cnodes, sizeof(CNode) * (size_t)n_nodes);
+  if (e == hipSuccess) e = hipMalloc(&t.meta, sizeof(TreeMeta));
+  TreeMeta hm{};
+  hm.nodes = t.nodes;
+  hm.cnodes = t.cnodes;
+  hm.n_nodes = n_nodes;
+  hm.n_leaves = n_leaves;
+  if (e == hipSuccess) e = hipMemcpyAsync(t.meta, &hm, sizeof(hm), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(t.nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyHostToDevice, ctx->stream);
+  int rc = MADICP_OK;
+  if (e == hipSuccess) rc = compact_tree(ctx, t);
+  if (e == hipSuccess && rc == MADICP_OK) e = hipStreamSynchronize(ctx->stream);  // hm / nodes are caller memory
+  if (e != hipSuccess || rc != MADICP_OK) {
+    free_tree(t);
+    return rc != MADICP_OK ? rc : fail(MADICP_ERR_DEVICE, std::string("tree upload: ") + hipGetErrorString(e));
   }
   const int id = ctx->next_id++;
   ctx->trees[id] = t;
@@ -423,7 +450,7 @@ int madicp_tree_release(madicp_ctx* ctx, int tree_id) {
   if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipFree(it->second.nodes));
+  free_tree(it->second);
   ctx->trees.erase(it);
   return MADICP_OK;
 }
@@ -453,6 +480,8 @@ int madicp_tree_transform(madicp_ctx* ctx, int tree_id, const double R[9], const
   hipLaunchKernelGGL(tree_transform, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, it->second.nodes, n,
                      ctx->d_scratch);
   HIP_TRY(hipGetLastError());
+  const int rc = compact_tree(ctx, it->second);  // screening records follow the nodes
+  if (rc != MADICP_OK) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return MADICP_OK;
 }
@@ -467,7 +496,7 @@ int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* 
   if (!d_queries) return fail(MADICP_ERR_INVALID, "queries is null");
   HIP_TRY(hipSetDevice(ctx->device));
   const long long blocks = std::min<long long>((n + 255) / 256, (long long)ctx->n_cus * 8);
-  hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.nodes, d_queries,
+  hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.meta, d_queries,
                      (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;

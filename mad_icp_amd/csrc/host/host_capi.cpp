@@ -2,6 +2,7 @@
 #include <cstring>
 #include <vector>
 
+#include "linalg.h"
 #include "madicp_host.h"
 #include "tree_builder.h"
 
@@ -32,5 +33,21 @@ void madicp_host_tree_leaf_means(const madicp_host_tree* t, double* out) {
 void madicp_host_tree_transform(madicp_host_tree* t, const double R[9], const double tr[3]) {
   if (t) madicp_host::transform_tree(t->tree, R, tr);
 }
+
+void madicp_host_gn_update(const double H[36], const double b[6], double X[12]) {
+  using namespace madicp_host;
+  double nb[6], dx[6];
+  for (int i = 0; i < 6; ++i) nb[i] = -b[i];
+  ldlt6_solve(H, nb, dx);
+  Pose cur, d;
+  std::memcpy(cur.R, X, sizeof(cur.R));
+  std::memcpy(cur.t, X + 9, sizeof(cur.t));
+  exp_so3(dx + 3, d.R);
+  d.t[0] = dx[0]; d.t[1] = dx[1]; d.t[2] = dx[2];
+  const Pose out = compose(cur, d);
+  std::memcpy(X, out.R, sizeof(out.R));
+  std::memcpy(X + 9, out.t, sizeof(out.t));
+}
+double madicp_host_det_of_inverse6(const double H[36]) { return madicp_host::det_of_inverse6(H); }
 
 }  // extern "C"

@@ -1,0 +1,51 @@
+// MADicp — point-to-plane Gauss-Newton registration of a scan's leaves against K keyframe trees.
+// Mirrors the reference class (mad_icp/src/odometry/mad_icp.h:41-79): same constructor arguments, the
+// public X_ / H_adder_ / b_adder_ that Pipeline reads (pipeline.cpp:195,223).  The per-round methods of the
+// reference (resetAdders / update / updateState, mad_icp.cpp:43-117) are one call here — compute() — because
+// the whole loop runs on the device without host round trips (madicp_icp_register).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "linalg.h"
+#include "mad_tree.h"
+
+namespace madicp_host {
+
+class MADicp {
+ public:
+  MADicp(double min_ball, double rho_ker, double b_ratio, int num_threads);
+  ~MADicp();
+  MADicp(const MADicp&) = delete;
+  MADicp& operator=(const MADicp&) = delete;
+
+  // setMoving (mad_icp.cpp:53-55): the leaves of the current scan's tree, sensor frame
+  void setMoving(const MADtree& scan_tree);
+  void setMoving(const ContainerType& leaf_means);
+  void init(const Pose& moving_in_fixed) { X_ = moving_in_fixed; }  // mad_icp.cpp:57
+
+  // n_iters rounds of {resetAdders; update(tree) for every fixed tree; updateState} on the device.
+  // matched flags are those of the last round (cleared before it: pipeline.cpp:172-176).
+  void compute(const std::vector<MADtree*>& fixed, int n_iters);
+
+  int numMoving() const { return L_; }
+  int numMatched() const;
+
+  Pose X_;
+  double H_adder_[36];  // row-major
+  double b_adder_[6];
+  std::vector<uint8_t> matched_;
+  uint64_t visits_ = 0;  // internal nodes visited by the last compute() (instrumentation)
+
+  double rho_ker_;  // as given by the caller (the sqrt of mad_icp.cpp:32 is taken inside the library)
+  double min_ball_;
+  double b_ratio_;
+  int num_threads_;
+
+ private:
+  void releaseMoving();
+  int moving_id_ = -1;
+  int L_ = 0;
+};
+
+}  // namespace madicp_host

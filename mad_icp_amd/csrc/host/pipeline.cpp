@@ -1,0 +1,221 @@
+#include "pipeline.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <utility>
+
+namespace madicp_host {
+
+namespace {
+double now_ms() {
+  using clk = std::chrono::steady_clock;
+  return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+Pose motion_from_twist(const double* dx) {  // [t; omega] -> (expSO3(omega), t)
+  Pose p;
+  exp_so3(dx + 3, p.R);
+  p.t[0] = dx[0]; p.t[1] = dx[1]; p.t[2] = dx[2];
+  return p;
+}
+}  // namespace
+
+Matrix4d Pipeline::toMatrix(const Pose& p) {
+  Matrix4d M;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) M(r, c) = p.R[3 * r + c];
+    M(r, 3) = p.t[r];
+  }
+  M(3, 0) = M(3, 1) = M(3, 2) = 0.0;
+  M(3, 3) = 1.0;
+  return M;
+}
+
+Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, double p_th, double b_min,
+                   double b_ratio, int num_keyframes, int num_threads, bool realtime)
+  : icp_(b_max, rho_ker, b_ratio, num_threads),
+    vel_estimator_(sensor_hz),
+    deskew_(deskew),
+    realtime_(realtime),
+    num_keyframes_(num_keyframes),
+    num_threads_(num_threads),
+    sensor_hz_(sensor_hz),
+    b_max_(b_max),
+    p_th_(p_th),
+    b_min_(b_min) {
+  frame_to_map_ = Pose::identity();
+  keyframe_to_map_ = Pose::identity();
+  std::memset(current_velocity_, 0, sizeof(current_velocity_));
+  loop_time_ = (1. / sensor_hz_) * 1000;
+  max_parallel_levels_ = static_cast<int>(std::log2(num_threads));  // pipeline.cpp:64
+}
+
+Pipeline::~Pipeline() = default;  // Frames own their trees; trees release their HBM copies
+
+const std::vector<Matrix4d> Pipeline::trajectory() const {
+  std::vector<Matrix4d> out;
+  out.reserve(trajectory_.size());
+  for (const Pose& p : trajectory_) out.push_back(toMatrix(p));
+  return out;
+}
+
+// pipeline.cpp:79-123 — motion compensation in 1024 azimuth chunks (CPU; out of the GPU scope)
+void Pipeline::deskew(ContainerType& cloud, const Pose& T_prev, const Pose& T_now) {
+  const double ts = 1. / sensor_hz_;
+  const Pose rel = compose(inverse(T_prev), T_now);
+  double w[3], vel[6];
+  log_so3(rel.R, w);
+  for (int i = 0; i < 3; ++i) {
+    vel[i] = rel.t[i] / ts;
+    vel[3 + i] = w[i] / ts;
+  }
+  using AzimuthPair = std::pair<double, Vector3d>;
+  std::vector<AzimuthPair> sorted(cloud.size());
+  for (size_t i = 0; i < sorted.size(); ++i) sorted[i] = std::make_pair(std::atan2(cloud[i][1], cloud[i][0]), cloud[i]);
+  std::sort(sorted.begin(), sorted.end(),
+            [](const AzimuthPair& a, const AzimuthPair& b) -> bool { return a.first < b.first; });
+
+  const double resolution = 2 * M_PI / double(CHUNKS);
+  const double delta = ts / double(CHUNKS - 1);
+  double t = -ts;
+  auto pose_at = [&](double tt) {
+    const double dx[6] = {vel[0] * tt, vel[1] * tt, vel[2] * tt, vel[3] * tt, vel[4] * tt, vel[5] * tt};
+    return motion_from_twist(dx);
+  };
+  Pose m = pose_at(t);
+  double angle = M_PI - resolution;
+  for (int i = int(sorted.size()) - 1; i >= 0; --i) {
+    if (sorted[i].first < angle) {
+      angle -= resolution;
+      t += delta;
+      m = pose_at(t);
+    }
+    apply(m, sorted[i].second.data(), cloud[i].data());
+  }
+}
+
+// pipeline.cpp:267-284
+void Pipeline::initialize(const double& curr_stamp, ContainerType& cloud) {
+  auto frame = std::make_unique<Frame>();
+  frame->frame_ = int(seq_);
+  frame->frame_to_map_ = frame_to_map_;
+  frame->stamp_ = curr_stamp;
+  frame->tree_ = std::make_unique<MADtree>(std::move(cloud), b_max_, b_min_, max_parallel_levels_);
+  frame->tree_->deviceId();  // first keyframe: resident from now on
+  keyframes_.push_back(std::move(frame));
+  trajectory_.push_back(Pose::identity());
+  is_initialized_ = true;
+  is_map_updated_ = true;
+  seq_++;
+}
+
+// pipeline.cpp:125-265
+void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
+  is_map_updated_ = false;
+  if (!is_initialized_) {
+    initialize(curr_stamp, curr_cloud);
+    return;
+  }
+  const double t_pre = now_ms();
+
+  if (deskew_ && trajectory_.size() > 1)
+    deskew(curr_cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1]);
+
+  auto current_tree = std::make_unique<MADtree>(std::move(curr_cloud), b_max_, b_min_, max_parallel_levels_);
+  current_leaves_ = current_tree->leafMeans();
+  last_build_ms_ = now_ms() - t_pre;
+
+  // constant-velocity prediction (pipeline.cpp:146-152)
+  double dx[6];
+  for (int i = 0; i < 6; ++i) dx[i] = current_velocity_[i] * 1. / sensor_hz_;
+  const Pose prediction = compose(frame_to_map_, motion_from_twist(dx));
+
+  icp_.setMoving(current_leaves_);
+  icp_.init(prediction);
+
+  const float preprocessing_time = float(now_ms() - t_pre);
+  const double t_icp = now_ms();
+  // The reference re-checks its wall-clock budget before every round (pipeline.cpp:167-169).  The device
+  // loop is not interruptible — and at well under a millisecond it never needs to be — so the check is made
+  // once: either all MAX_ICP_ITS rounds run, or (budget already spent by preprocessing) none.
+  const float remaining_time = loop_time_ - 5.0f - preprocessing_time;
+  const bool run = !(realtime_ && remaining_time < 0);
+  int matched_leaves = 0;
+  if (run) {
+    std::vector<MADtree*> fixed;
+    fixed.reserve(keyframes_.size());
+    for (auto& f : keyframes_) fixed.push_back(f->tree_.get());
+    icp_.compute(fixed, MAX_ICP_ITS);
+    matched_leaves = icp_.numMatched();
+  }
+  last_icp_ms_ = now_ms() - t_icp;
+
+  frame_to_map_ = icp_.X_;
+  const double inliers_ratio = double(matched_leaves) / double(current_leaves_.size());
+  last_inliers_ratio_ = inliers_ratio;
+  trajectory_.push_back(frame_to_map_);
+
+  std::vector<Pose> odom_window;
+  for (int i = std::max(0, int(trajectory_.size()) - SMOOTHING_T); i < int(trajectory_.size()); ++i)
+    odom_window.push_back(trajectory_[i]);
+  vel_estimator_.init(current_velocity_);
+  vel_estimator_.setOdometry(odom_window);
+  vel_estimator_.oneRound();
+  std::memcpy(current_velocity_, vel_estimator_.X_, sizeof(current_velocity_));
+
+  auto current_frame = std::make_unique<Frame>();
+  current_frame->frame_ = int(seq_);
+  current_frame->frame_to_map_ = frame_to_map_;
+  current_frame->stamp_ = curr_stamp;
+  current_frame->weight_ = det_of_inverse6(icp_.H_adder_);  // pipeline.cpp:223
+  current_tree->applyTransform(frame_to_map_.R, frame_to_map_.t);
+  current_frame->tree_ = std::move(current_tree);
+  // the reference's current_leaves_ are pointers into the tree, so after applyTransform they read map-frame
+  // means (pipeline.cpp:290-297 is only ever called after compute())
+  current_leaves_ = current_frame->tree_->leafMeans();
+
+  frames_.push_back(std::move(current_frame));
+  if (frames_.size() > size_t(FRAME_WINDOW)) frames_.pop_front();
+
+  if (inliers_ratio < p_th_) {  // keyframe promotion (pipeline.cpp:234-262)
+    double best_weight = std::numeric_limits<double>::max();
+    int new_seq = 0;
+    size_t best = frames_.size();
+    for (size_t i = 0; i < frames_.size(); ++i) {
+      if (frames_[i]->weight_ < best_weight) {
+        best_weight = frames_[i]->weight_;
+        new_seq = frames_[i]->frame_;
+        best = i;
+      }
+    }
+    if (best < frames_.size()) {  // (all-NaN weights would dereference null in the reference; skip instead)
+      std::unique_ptr<Frame> best_frame;
+      while (!frames_.empty() && frames_.front()->frame_ <= new_seq) {
+        if (frames_.front()->frame_ == new_seq) best_frame = std::move(frames_.front());
+        frames_.pop_front();
+      }
+      best_frame->tree_->deviceId();  // promoted: the tree goes to HBM now
+      keyframe_to_map_ = best_frame->frame_to_map_;
+      keyframes_.push_back(std::move(best_frame));
+      if (keyframes_.size() > size_t(num_keyframes_)) keyframes_.pop_front();  // eviction frees the HBM copy
+      is_map_updated_ = true;
+      seq_keyframe_ = new_seq;
+    }
+  }
+  seq_++;
+}
+
+const ContainerType Pipeline::currentLeaves() { return current_leaves_; }
+
+const ContainerType Pipeline::modelLeaves() {  // pipeline.cpp:299-308
+  ContainerType leaves;
+  for (auto& frame : keyframes_) {
+    const ContainerType l = frame->tree_->leafMeans();
+    leaves.insert(leaves.end(), l.begin(), l.end());
+  }
+  return leaves;
+}
+
+}  // namespace madicp_host

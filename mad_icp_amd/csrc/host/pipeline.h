@@ -1,0 +1,90 @@
+// Pipeline — the odometry frame step.  Same constructor, same public methods and the same by-value
+// compute(stamp, cloud) as the reference class (mad_icp/src/odometry/pipeline.h:45-103), so
+// apps/cpp_runners/bin_runner.cpp:106-186 and the pybind module keep working unchanged.
+//
+// What moved: the data association + Gauss-Newton loop (pipeline.cpp:166-193) runs on the MI355X through
+// libmadicp_hip.so; keyframe trees live in HBM from the moment they are promoted (pipeline.cpp:253) until
+// they are evicted (pipeline.cpp:254-257).  What stayed on the CPU: tree construction of the incoming scan,
+// deskew, the constant-velocity predictor, the frame window and keyframe selection.
+#pragma once
+#include <cstddef>
+#include <deque>
+#include <memory>
+#include <vector>
+
+#include "linalg.h"
+#include "mad_icp.h"
+#include "mad_tree.h"
+#include "types.h"
+#include "vel_estimator.h"
+
+namespace madicp_host {
+
+// tools/constants.h:31-35
+static constexpr int CHUNKS = 1024;
+static constexpr int SMOOTHING_T = 10;
+static constexpr int MAX_ICP_ITS = 15;
+static constexpr int FRAME_WINDOW = 10;
+
+struct Frame {  // tools/frame.h:37-52; the tree is owned here
+  Pose frame_to_map_ = Pose::identity();
+  std::unique_ptr<MADtree> tree_;
+  double stamp_ = 0.;
+  double weight_ = 0.;
+  int frame_ = 0;
+};
+
+class Pipeline {
+ public:
+  Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, double p_th, double b_min, double b_ratio,
+           int num_keyframes, int num_threads, bool realtime);
+  ~Pipeline();
+
+  const Matrix4d currentPose() const { return toMatrix(frame_to_map_); }
+  const std::vector<Matrix4d> trajectory() const;
+  const Matrix4d keyframePose() const { return toMatrix(keyframe_to_map_); }
+  bool isInitialized() const { return is_initialized_; }
+  size_t currentID() const { return seq_; }
+  size_t keyframeID() const { return seq_keyframe_; }
+  bool isMapUpdated() { return is_map_updated_; }
+  const ContainerType currentLeaves();
+  const ContainerType modelLeaves();
+  void compute(const double& curr_stamp, ContainerType curr_cloud_mem);
+
+  // instrumentation (not in the reference)
+  double lastInliersRatio() const { return last_inliers_ratio_; }
+  double lastIcpMs() const { return last_icp_ms_; }
+  double lastBuildMs() const { return last_build_ms_; }
+  size_t numKeyframes() const { return keyframes_.size(); }
+
+  static Matrix4d toMatrix(const Pose& p);
+
+ protected:
+  void initialize(const double& curr_stamp, ContainerType& curr_cloud);
+  void deskew(ContainerType& curr_cloud, const Pose& T_prev, const Pose& T_now);
+
+  MADicp icp_;
+  VelEstimator vel_estimator_;
+  Pose frame_to_map_;
+  Pose keyframe_to_map_;
+  double current_velocity_[6];
+  std::deque<std::unique_ptr<Frame>> keyframes_;
+  std::deque<std::unique_ptr<Frame>> frames_;
+  std::vector<Pose> trajectory_;
+  ContainerType current_leaves_;  // sensor-frame leaf means of the last scan, then map frame after compute()
+  bool deskew_, realtime_;
+  int num_keyframes_, num_threads_, max_parallel_levels_;
+  double sensor_hz_, b_max_, p_th_, b_min_;
+  size_t seq_ = 0;
+  size_t seq_keyframe_ = 0;
+  bool is_initialized_ = false;
+  bool is_map_updated_ = false;
+  float loop_time_;
+  double last_inliers_ratio_ = 0., last_icp_ms_ = 0., last_build_ms_ = 0.;
+};
+
+}  // namespace madicp_host
+
+// the reference declares these names at global scope; keep them reachable the same way
+using madicp_host::ContainerType;
+using madicp_host::Pipeline;

@@ -1,0 +1,77 @@
+"""Keyframe-sharded multi-GPU registration (BASELINE configs[3]).
+
+The contribution of every keyframe tree to (H, b) is independent (the reference already runs them on different
+OpenMP threads, pipeline.cpp:180-183) and the join is a plain sum (mad_icp.cpp:106-109), so keyframe trees are
+sharded across ranks — round-robin by keyframe index — the moving leaves and the pose are replicated, and each GN
+round ends with ONE small all-reduce of [H, b]; the matched flags are OR-ed (MAX) once, after the last round.
+Every rank then solves the 6x6 redundantly and holds the same pose.
+
+Two transports:
+  * native  — `init_native_comm(ctx)`: the all-reduces are RCCL calls enqueued by libmadicp_hip.so on its own HIP
+              stream between the kernels of a round (no host round trip); torch.distributed only carries the
+              128-byte ncclUniqueId once.  This is what bench.py --gpus N uses.
+  * staged  — `StagedShardedRegistration`: one madicp_icp_linearize per round, (H,b) all-reduced through
+              torch.distributed (any backend: nccl on GPUs, gloo in the CPU tests), host-side updateState.  Slower
+              (host round trip per round) but backend-agnostic; the CPU tests drive it with an injected linearise
+              function to check the sharding and the collective logic with world_size 2.
+"""
+import numpy as np
+
+from . import capi
+
+
+def shard_keyframes(n_keyframes, world_size, rank):
+    """Keyframe indices owned by `rank`: round-robin by keyframe id (promotion order, pipeline.cpp:253)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return [k for k in range(n_keyframes) if k % world_size == rank]
+
+
+def init_native_comm(ctx, group=None, device=None):
+    """Create the RCCL communicator inside `ctx`: rank 0 makes the unique id, torch.distributed broadcasts it."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+    return rank, world
+
+
+class StagedShardedRegistration:
+    """GN loop with the (H,b) join done by torch.distributed.
+
+    linearize(X12) -> (H (6,6), b (6,), matched (L,) uint8) must return THIS rank's contribution at pose X12 —
+    normally `lambda X: ctx.icp_linearize(mid, local_tree_ids, X, params, L)` unpacked; the tests inject a CPU one.
+    """
+
+    def __init__(self, linearize, n_moving, group=None, device="cpu"):
+        self.linearize = linearize
+        self.L = n_moving
+        self.group = group
+        self.device = device
+
+    def register(self, X0, n_iters):
+        import torch
+        import torch.distributed as dist
+
+        X = capi.pose12(X0)
+        H = np.zeros((6, 6))
+        b = np.zeros(6)
+        matched = np.zeros(self.L, np.uint8)
+        for it in range(n_iters):
+            Hl, bl, ml = self.linearize(X)
+            buf = torch.from_numpy(np.concatenate([np.asarray(Hl, np.float64).reshape(-1), np.asarray(bl, np.float64)])).to(self.device)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            hb = buf.cpu().numpy()
+            H, b = hb[:36].reshape(6, 6).copy(), hb[36:].copy()
+            if it == n_iters - 1:  # flags of the last round only (pipeline.cpp:172-176), OR over ranks
+                m = torch.from_numpy(np.ascontiguousarray(ml, np.uint8)).to(self.device)
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+                matched = m.cpu().numpy()
+            X = capi.gn_update(H, b, X)
+        return dict(X=X, T=capi.pose44(X), H=H, b=b, matched=matched)

@@ -72,6 +72,45 @@ def test_nn_search_matches_oracle(ctx, b_max):
     ctx.tree_release(tid)
 
 
+def test_screening_fallback_is_exact(ctx):
+    """Queries placed ON split planes (and a hair off them) defeat the 16-byte screening test, so the lanes
+    must take the exact fp64 path — and still agree with the oracle bit for bit."""
+    pb = street_problem(2)
+    T = pb["keyframe_poses"][1]
+    ht, ot = build_pair(pb["keyframe_scans"][1], T=T)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    nodes = ht.nodes
+    internal = nodes[nodes["right"] != 0]
+    rng = np.random.default_rng(4)
+    pick = internal[rng.integers(0, len(internal), 6000)]
+    tang = np.cross(pick["dir"], rng.normal(size=(len(pick), 3)))
+    q = np.concatenate([
+        pick["mean"],                                             # s == 0 at that node
+        pick["mean"] + 1e-9 * pick["dir"],
+        pick["mean"] - 1e-9 * pick["dir"],
+        pick["mean"] + tang * rng.uniform(0, 0.2, (len(pick), 1)),  # slides inside the plane: |s| ~ 1e-17
+        pick["mean"] + tang + 3e-6 * pick["dir"] * rng.normal(size=(len(pick), 1)),
+    ])
+    g = ctx.nn_search(tid, q)
+    leaf, depth, dist = ot.search(q, want_dist=True)
+    assert np.array_equal(g["leaf"], leaf)
+    assert np.array_equal(g["depth"], depth)
+    assert np.array_equal(g["dist"], dist)
+    ctx.tree_release(tid)
+
+
+def test_nan_and_far_queries(ctx):
+    """NaN / huge queries: every comparison on NaN is false -> the descent keeps going right, as on the CPU."""
+    pb = street_problem(2)
+    ht, ot = build_pair(pb["keyframe_scans"][0])
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    q = np.array([[np.nan, 0, 0], [0, np.nan, 1], [1e300, -1e300, 1e300], [np.inf, 0, 0], [1e9, 1e9, -1e9], [0, 0, 0]])
+    g = ctx.nn_search(tid, q)
+    leaf, depth = ot.search(q)
+    assert np.array_equal(g["leaf"], leaf) and np.array_equal(g["depth"], depth)
+    ctx.tree_release(tid)
+
+
 def test_tree_transform_matches_host_and_oracle(ctx):
     pb = street_problem(2)
     T = pb["keyframe_poses"][1]

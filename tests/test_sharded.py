@@ -1,0 +1,138 @@
+"""Multi-rank path on CPU: world_size-2 gloo processes run the staged keyframe-sharded GN loop with the oracle as
+the per-rank lineariser (tests may use the oracle; the product never does) and must reproduce the single-process
+oracle registration.  Also: shard plan properties, host gn_update vs the oracle's updateState."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from fixtures import B_MAX, B_MIN, B_RATIO, RHO_KER, street_problem
+from mad_icp_amd import capi, sharded
+
+
+def test_shard_plan_partitions_keyframes():
+    for K in (1, 2, 7, 16, 64):
+        for W in (1, 2, 4, 8):
+            parts = [sharded.shard_keyframes(K, W, r) for r in range(W)]
+            flat = sorted(k for p in parts for k in p)
+            assert flat == list(range(K))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        sharded.shard_keyframes(4, 2, 2)
+
+
+def test_host_gn_update_matches_oracle_update_state(natives):
+    pb = street_problem(2)
+    trees = []
+    for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        t = O.Tree(s, B_MAX, B_MIN, 2)
+        t.transform(T[:3, :3], T[:3, 3])
+        trees.append(t)
+    q = O.Tree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+    T0 = pb["query_guess"][0]
+    H = np.zeros((6, 6))
+    b = np.zeros(6)
+    for t in trees:
+        Hk, bk, *_ = O.icp_linearize(q, t, T0, B_MAX, RHO_KER, B_RATIO)
+        H += Hk
+        b += bk
+    X1 = capi.gn_update(H, b, capi.pose12(T0))
+    r = O.icp_register(q, trees, T0, 2, B_MAX, RHO_KER, B_RATIO, num_threads=1)  # X_iters[1] = pose after round 0
+    assert np.allclose(X1, r["X_iters"][1], rtol=0, atol=1e-12)
+
+
+def _worker(rank, world, port, K, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pb = street_problem(K)
+        mine = sharded.shard_keyframes(K, world, rank)
+        trees = []
+        for k in mine:
+            T = pb["keyframe_poses"][k]
+            t = O.Tree(pb["keyframe_scans"][k], B_MAX, B_MIN, 2)
+            t.transform(T[:3, :3], T[:3, 3])
+            trees.append(t)
+        q = O.Tree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+
+        def linearize(X):
+            H = np.zeros((6, 6))
+            b = np.zeros(6)
+            m = np.zeros(q.num_leaves, np.uint8)
+            for t in trees:
+                Hk, bk, _, _, mk, _ = O.icp_linearize(q, t, capi.pose44(X), B_MAX, RHO_KER, B_RATIO)
+                H += Hk
+                b += bk
+                m |= mk
+            return H, b, m
+
+        reg = sharded.StagedShardedRegistration(linearize, q.num_leaves)
+        r = reg.register(pb["query_guess"][0], 15)
+        np.savez(out % rank, X=r["X"], H=r["H"], matched=r["matched"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K", [3])
+def test_staged_sharded_registration_world2_gloo(natives, tmp_path, K):
+    world = 2
+    out = str(tmp_path / "rank%d.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, K, out), nprocs=world, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    # every rank ends with the same pose, bit for bit (same all-reduced H,b, same solve)
+    assert np.array_equal(r0["X"], r1["X"]) and np.array_equal(r0["matched"], r1["matched"])
+    # and it is the single-process registration (summation order differs: tolerance, not bits)
+    pb = street_problem(K)
+    trees = []
+    for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        t = O.Tree(s, B_MAX, B_MIN, 2)
+        t.transform(T[:3, :3], T[:3, 3])
+        trees.append(t)
+    q = O.Tree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+    ref = O.icp_register(q, trees, pb["query_guess"][0], 15, B_MAX, RHO_KER, B_RATIO, num_threads=1)
+    d = np.linalg.inv(ref["T"]) @ capi.pose44(r0["X"])
+    assert np.linalg.norm(d[:3, 3]) <= 1e-9 and np.abs(d[:3, :3] - np.eye(3)).max() <= 1e-9
+    assert (r0["matched"] != ref["matched"]).sum() <= 1
+    assert np.allclose(r0["H"], ref["H"], rtol=1e-9, atol=1e-9 * np.abs(ref["H"]).max())
+
+
+@pytest.mark.gpu
+def test_native_rccl_path_single_rank(ctx):
+    """World size 1 on the one GPU of the test box: the reduce -> ncclAllReduce -> update launch sequence must give
+    exactly what the fused single-GPU sequence gives."""
+    from fixtures import PARAMS
+
+    pb = street_problem(2)
+    tids = []
+    for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        ht = capi.HostTree(s, B_MAX, B_MIN, 2)
+        ht.transform(T[:3, :3], T[:3, 3])
+        tids.append(ctx.upload(ht))
+    qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+    mid = ctx.moving_upload(qh.leaf_means())
+    L = qh.num_leaves
+    a = ctx.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, L)
+    c2 = capi.Context(0)
+    try:
+        t2 = []
+        for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+            ht = capi.HostTree(s, B_MAX, B_MIN, 2)
+            ht.transform(T[:3, :3], T[:3, 3])
+            t2.append(c2.upload(ht))
+        m2 = c2.moving_upload(qh.leaf_means())
+        c2.comm_init(capi.Context.comm_unique_id(), 1, 0)
+        b = c2.icp_register(m2, t2, pb["query_guess"][0], PARAMS, 15, L)
+        c2.comm_destroy()
+    finally:
+        c2.close()
+    assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["H"], b["H"]) and np.array_equal(a["matched"], b["matched"])
+    for t in tids:
+        ctx.tree_release(t)
+    ctx.moving_release(mid)

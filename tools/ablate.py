@@ -1,0 +1,33 @@
+"""Ablation timing of icp_linearize with the profiling build (tools/libmadicp_hip_ablate.so, -DMADICP_ABLATE):
+MADICP_ABLATE_FLAGS bit 1 (2) = skip the cross-lane reduction, bit 2 (4) = skip the descent.  Results are wrong
+by design; only the kernel time matters."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from mad_icp_amd import capi, synth
+capi._load_orig = capi._load
+capi._load = lambda name: ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmadicp_hip_ablate.so")) if "hip" in name else capi._load_orig(name)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pb = synth.make_problem(K, seed=1, n_queries=B)
+ctx = capi.Context(0)
+tids = []
+for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+    ht = capi.HostTree(s, 0.2, 0.1, 3); ht.transform(T[:3, :3], T[:3, 3]); tids.append(ctx.upload(ht))
+mids = []
+for s in pb["query_scans"]:
+    h = capi.HostTree(s, 0.2, 0.1, 3); mids.append(ctx.moving_upload(h.leaf_means()))
+X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
+P = (0.2, 0.1, 0.02)
+ctx.set_option("time_kernels", 1)
+for bpc in (1, 2, 3, 4, 8):
+    ctx.set_option("grid_blocks_per_cu", bpc)
+    for flags in (0, 2, 4, 6):
+        os.environ["MADICP_ABLATE_FLAGS"] = str(flags)
+        for _ in range(2):
+            ctx.icp_register_batch_enqueue(mids, tids, X0, P, 15)
+        ctx.kernel_time()
+        for _ in range(5):
+            ctx.icp_register_batch_enqueue(mids, tids, X0, P, 15)
+        nl, ms = ctx.kernel_time()
+        print("bpc %d flags %d (%s): linearize avg %.2f us" % (bpc, flags, {0: "full", 2: "no-reduce", 4: "no-descent", 6: "neither"}[flags], ms / nl * 1e3), flush=True)

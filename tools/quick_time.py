@@ -25,9 +25,7 @@ for s in pb["query_scans"]:
 print("L", Ls)
 X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
 P = (0.2, 0.1, 0.02)
-for opts in [dict(use_graph=1, grid_blocks_per_cu=4, queries_per_thread=1), dict(use_graph=0), dict(use_graph=1, grid_blocks_per_cu=8),
-             dict(grid_blocks_per_cu=2), dict(grid_blocks_per_cu=4, queries_per_thread=2), dict(grid_blocks_per_cu=2, queries_per_thread=2),
-             dict(grid_blocks_per_cu=2, queries_per_thread=4), dict(grid_blocks_per_cu=4, queries_per_thread=1)]:
+for opts in [dict(use_graph=1, grid_blocks_per_cu=4), dict(grid_blocks_per_cu=2), dict(grid_blocks_per_cu=1), dict(grid_blocks_per_cu=3), dict(grid_blocks_per_cu=8)]:
     for k, v in opts.items():
         ctx.set_option(k, v)
     for _ in range(3):
