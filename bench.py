@@ -18,7 +18,7 @@ N > 1 (one rank per GPU, RCCL over xGMI):
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (icp_linearize): algorithmic bytes per
 launch (24 + 64*d + 64 + 1 per (leaf, tree) pair, + 216 B of (H,b)) over its average duration,
-measured with HIP events around every launch on the library's stream.  `cpu_baseline` is the CPU restatement
+measured with HIP events around a captured graph of back-to-back launches on the library's stream.  `cpu_baseline` is the CPU restatement
 of the reference's OpenMP path (oracle/, kind "port") timed on this box's host cores on a bounded sample.
 """
 import argparse
@@ -145,18 +145,13 @@ def main():
     err = np.linalg.inv(pb["query_gt"][0]) @ capi.pose44(res["X"][0])
     terr = float(np.linalg.norm(err[:3, 3]))
 
-    # ---- roofline of the dominant kernel: HIP events around every icp_linearize launch ------------
-    ctx.set_option("time_kernels", 1)
-    n_timed = max(3, min(20, args.steps))
-    for _ in range(n_timed):
-        step()
-    n_launch, total_ms = ctx.kernel_time(reset=True)
-    ctx.set_option("time_kernels", 0)
-    res_t = ctx.icp_fetch(B)
+    # ---- roofline of the dominant kernel: HIP events around a graph of back-to-back icp_linearize launches ----
+    n_launch = 60
+    avg_us, visits = ctx.icp_time_linearize(mids, tids, X0, params, n_launch)
     pairs_per_launch = sum(Ls) * len(tids)
-    visits_per_launch = float(res_t["visits"].sum()) / N_ITERS
+    visits_per_launch = float(visits.sum())
     alg_bytes = pairs_per_launch * (24 + 64 + 1) + 64.0 * visits_per_launch + 216.0 * B
-    avg_s = total_ms * 1e-3 / n_launch
+    avg_s = avg_us * 1e-6
     achieved = alg_bytes / avg_s / 1e9
     roofline = {"bound": "hbm", "kernel": "icp_linearize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

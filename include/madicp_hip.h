@@ -69,12 +69,9 @@ int madicp_abi_version(void);
 int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out);
 int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
-/* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..8), "use_graph" (0/1), "time_kernels" (0/1)}. */
+/* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..8), "use_graph" (0/1), "queries_per_lane" (0=auto,1,2,4),
+ * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
-/* When option "time_kernels" is on, every icp_linearize launch carries start/stop hipEvents attached to the
- * dispatch (hipExtLaunchKernelGGL) on the ctx stream; this returns the number of launches timed since the last
- * reset and the sum of their execution times. */
-int madicp_ctx_kernel_time(madicp_ctx* ctx, int reset, int64_t* n_launches, double* total_ms);
 
 /* ---- MAD-tree (fixed side) ---------------------------------------------------------------------- */
 /* Upload a linearised tree.  Replaces keeping `MADtree*` alive in Frame::tree_ (frame.h:47). */
@@ -134,6 +131,14 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
                      int32_t* out_n_matched, uint64_t* out_visits);
 /* matched_ flags of scan `scan` of the last batch (L bytes). */
 int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, int32_t L);
+
+/* Measurement aid (bench.py's roofline): n_launches back-to-back launches of the dominant kernel (icp_linearize)
+ * for this batch at pose X0, no state update, replayed as one captured graph between two hipEvents on the context's
+ * stream.  out_avg_us = time per launch (a dependent dispatch's launch overhead included, as in a profiler trace of
+ * the registration graph); out_visits_per_launch (n_scans, optional) = internal nodes visited by one launch. */
+int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
+                              const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
+                              uint64_t* out_visits_per_launch);
 
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
 /* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte

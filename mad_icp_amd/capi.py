@@ -56,7 +56,6 @@ def hip_lib():
         L.madicp_ctx_destroy.argtypes = [C.c_void_p]
         L.madicp_ctx_synchronize.argtypes = [C.c_void_p]
         L.madicp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
-        L.madicp_ctx_kernel_time.argtypes = [C.c_void_p, C.c_int, _i64p, _dp]
         L.madicp_tree_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _ip]
         L.madicp_tree_release.argtypes = [C.c_void_p, C.c_int]
         L.madicp_tree_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
@@ -74,6 +73,8 @@ def hip_lib():
                                                 C.c_int, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_register_batch_enqueue.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp,
                                                         C.POINTER(IcpParams), C.c_int]
+        L.madicp_icp_time_linearize.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
+                                                _dp, _u64p]
         L.madicp_icp_fetch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_fetch_matched.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int32]
         L.madicp_comm_unique_id.argtypes = [_u8p]
@@ -208,11 +209,6 @@ class Context:
     def set_option(self, key, value):
         _check(hip_lib().madicp_ctx_set_option(self._h, key.encode(), int(value)))
 
-    def kernel_time(self, reset=True):
-        n, ms = C.c_int64(0), C.c_double(0.0)
-        _check(hip_lib().madicp_ctx_kernel_time(self._h, int(reset), C.byref(n), C.byref(ms)))
-        return n.value, ms.value
-
     # ---- trees ----
     def tree_upload(self, nodes, n_leaves):
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
@@ -305,6 +301,17 @@ class Context:
         p = IcpParams(*params)
         _check(hip_lib().madicp_icp_register_batch_enqueue(self._h, len(mids), self._ids(mids), self._ids(tree_ids),
                                                            len(tree_ids), X0.ctypes.data_as(_dp), C.byref(p), n_iters))
+
+    def icp_time_linearize(self, mids, tree_ids, X0, params, n_launches=50):
+        """(avg microseconds per icp_linearize launch, visits per launch per scan) — see madicp_icp_time_linearize."""
+        X0 = _f64(X0, (len(mids), 12))
+        p = IcpParams(*params)
+        us = C.c_double(0.0)
+        visits = np.zeros(len(mids), np.uint64)
+        _check(hip_lib().madicp_icp_time_linearize(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
+                                                   X0.ctypes.data_as(_dp), C.byref(p), n_launches, C.byref(us),
+                                                   visits.ctypes.data_as(_u64p)))
+        return us.value, visits
 
     def icp_fetch(self, n_scans):
         X, H, b = np.empty((n_scans, 12)), np.empty((n_scans, 6, 6)), np.empty((n_scans, 6))

@@ -55,14 +55,50 @@ constexpr int kSolveThreads = 1024;
 struct CNode {
   unsigned long long npack;  // n~: k0 | k1 << 21 | k2 << 42, k_i two's complement 21 bit, n~_i = k_i * 2^-20
   float c;                   // c~ ; +inf marks "always take the exact path" (non-finite node)
-  unsigned int right;        // same as madicp_node::right (0 = leaf)
+  unsigned int right;        // bits 0..29: madicp_node::right (DFS offset of the right child); bit 30: the left
+                             // child is a leaf; bit 31: the right child is a leaf
 };
+constexpr unsigned int kRightMask = 0x3fffffffu, kLeftLeaf = 0x40000000u, kRightLeaf = 0x80000000u;
 static_assert(sizeof(CNode) == 16, "screening record is 16 bytes");
+
+// Storage: record i belongs to node i (DFS preorder, like the exact array), so the records of a sub-tree are
+// contiguous and the spatially sorted queries of a wave touch a compact address range.  A parent's record says
+// which of its children are leaves, so leaf records are never read.  (A cache-line-blocked layout — 3-level
+// sub-trees per 128-byte line — was measured slower: it shortens one query's chain of dependent misses but
+// scatters the lines that NEIGHBOURING queries share, and that sharing is what the L1/L2 hit rate lives on.)
 
 constexpr double kScreenDelta = 9.6e-7;   // > 2^-20 + 32u, covers the rounding of |q-o|_1 and rho too
 constexpr double kScreenC = 6.0e-8;       // > 2^-24 (1 + 2^-23)
 
-// device-resident description of one uploaded tree
+// what a kernel needs to walk one tree; held by value in the Job / passed as a kernel argument so that no
+// dependent pointer chase precedes the first node load
+struct TreeDesc {
+  const madicp_node* nodes;
+  const CNode* cnodes;   // screening records, same indexing as nodes
+  double origin[3];      // o: mean of node 0
+  double rho;            // >= |m - o|_1 for every internal node (sqrt(3) * max |m - o|_2)
+  // the hot top of the tree, staged into LDS by icp_linearize (see "LDS-staged top levels" below)
+  const CNode* top;      // n_top records, breadth-first over the first kTopLevels levels (internal nodes only)
+  const int2* top_exit;  // per top entry: node index of its left / right child
+  const int* top_dfs;    // per top entry: its own node index (only the exact-path fallback reads it)
+  int32_t n_top;
+  int32_t pad_;
+};
+
+// LDS-staged top levels.  The descent is bound by the L1 address path: a 64-lane gather of 16-byte records costs
+// ~80 cycles of the CU's vector-memory pipe however hot the lines are (measured: a second, cache-warm pass over the
+// same queries costs as much as the first).  LDS serves the same gather in ~15 cycles.  Each workgroup works on ONE
+// tree, so it copies the first kTopLevels levels of that tree's screening records (<= 2047 x 16 B, plus 8 B of
+// child indices each = 48 KiB, three workgroups per CU) into LDS once and walks them there; only the last few
+// levels and the leaf record come from L1/L2.  A top entry's `right` word is re-purposed:
+//   bits 0..11 index of its first child that is itself in the top array | bit 12 left child in top |
+//   bit 13 right child in top | bit 14 left child is a leaf | bit 15 right child is a leaf
+constexpr int kTopLevels = 11;
+constexpr int kTopMax = 2048;
+constexpr unsigned int kTopFirst = 0xfffu, kTopLeftIn = 1u << 12, kTopRightIn = 1u << 13, kTopLeftLeaf = 1u << 14,
+                       kTopRightLeaf = 1u << 15;
+
+// device-resident record tree_compact fills (origin, radius); read back by the host after upload / transform
 struct TreeMeta {
   const madicp_node* nodes;
   const CNode* cnodes;
@@ -92,7 +128,9 @@ struct Job {
   double H[36];          // row-major, of the last round
   double b[6];
   double n_pairs;        // accepted (leaf,tree) pairs of the last round
-  const TreeMeta* trees[MADICP_MAX_TREES];
+  int32_t ranges_per_tree;  // launch geometry: every tree's moving leaves are cut into this many ranges
+  int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
+  TreeDesc trees[MADICP_MAX_TREES];
 };
 constexpr int kFlagNoUpdate = 1;
 
@@ -150,9 +188,9 @@ struct Screen {
   double r0, r1, r2;  // (q - o) * 2^-20
   double slack;       // kScreenDelta * (|q-o|_1 + rho)
 };
-__device__ __forceinline__ Screen make_screen(const TreeMeta* __restrict__ tm, double q0, double q1, double q2) {
-  const double e0 = q0 - tm->origin[0], e1 = q1 - tm->origin[1], e2 = q2 - tm->origin[2];
-  const double rho = 1.7320508075688774 * __longlong_as_double((long long)tm->rho2_bits);  // |.|_1 <= sqrt3 |.|_2
+__device__ __forceinline__ Screen make_screen(const TreeDesc& td, double q0, double q1, double q2) {
+  const double e0 = q0 - td.origin[0], e1 = q1 - td.origin[1], e2 = q2 - td.origin[2];
+  const double rho = td.rho;
   Screen s;
   s.r0 = e0 * 9.5367431640625e-07;  // 2^-20, exact scaling
   s.r1 = e1 * 9.5367431640625e-07;
@@ -161,34 +199,139 @@ __device__ __forceinline__ Screen make_screen(const TreeMeta* __restrict__ tm, d
   return s;
 }
 
-// greedy root->leaf descent, no backtracking (mad_tree.cpp:144-152), screened.  Returns the leaf's index.
-__device__ __forceinline__ int descend(const TreeMeta* __restrict__ tm, double q0, double q1, double q2, int& depth) {
-  const madicp_node* __restrict__ nodes = tm->nodes;
-  gptr_u4 cn = (gptr_u4)(uintptr_t)tm->cnodes;
-  const Screen sc = make_screen(tm, q0, q1, q2);
+// one screened side test: true = go left.  w = the node's 16-byte screening record
+__device__ __forceinline__ bool screened_goes_left(const vu4 w, const Screen& sc, const madicp_node* __restrict__ nodes, int idx,
+                                                   double q0, double q1, double q2) {
+  const int k0 = ((int)(w.x << 11)) >> 11;
+  const int k1 = ((int)(((w.y << 22) | (w.x >> 10)) & 0xfffff800u)) >> 11;
+  const int k2 = ((int)(w.y << 1)) >> 11;
+  const double c = (double)__uint_as_float(w.z);
+  const double sh = (sc.r0 * (double)k0 + sc.r1 * (double)k1) + sc.r2 * (double)k2 - c;
+  if (fabs(sh) > sc.slack + kScreenC * fabs(c)) return sh < 0.0;
+  return exact_goes_left(nodes, idx, q0, q1, q2);
+}
+
+// greedy root->leaf descent, no backtracking (mad_tree.cpp:144-152), screened.  Returns the leaf's index in the
+// node array; depth = internal nodes visited.
+__device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1, double q2, int& depth) {
+  gptr_u4 cn = (gptr_u4)(uintptr_t)td.cnodes;
+  const Screen sc = make_screen(td, q0, q1, q2);
   int idx = 0, d = 0;
   for (;;) {
     const vu4 w = cn[idx];
-    if (w.w == 0u) break;
-    const int k0 = ((int)(w.x << 11)) >> 11;
-    const int k1 = ((int)(((w.y << 22) | (w.x >> 10)) & 0xfffff800u)) >> 11;
-    const int k2 = ((int)(w.y << 1)) >> 11;
-    const double c = (double)__uint_as_float(w.z);
-    const double sh = (sc.r0 * (double)k0 + sc.r1 * (double)k1) + sc.r2 * (double)k2 - c;
-    bool left;
-    if (fabs(sh) > sc.slack + kScreenC * fabs(c)) {
-      left = sh < 0.0;
-    } else {
-      left = exact_goes_left(nodes, idx, q0, q1, q2);
-    }
-    idx = left ? idx + 1 : idx + (int)w.w;
+    const unsigned int roff = w.w & kRightMask;
+    if (roff == 0u) break;  // single-node tree: the root itself is the leaf
+    const bool left = screened_goes_left(w, sc, td.nodes, idx, q0, q1, q2);
+    idx = left ? idx + 1 : idx + (int)roff;
     ++d;
+    if (w.w & (left ? kLeftLeaf : kRightLeaf)) break;
   }
   depth = d;
   return idx;
 }
 
+// QPT independent descents per lane advanced in lock-step (their loads are issued together).  Phase 1 walks the
+// LDS copy of the tree's top levels (s_top / s_exit, n_top entries), phase 2 continues in global memory.
+template <int QPT>
+__device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_top, const int2* s_exit, int n_top,
+                                              const double (&q0)[QPT], const double (&q1)[QPT], const double (&q2)[QPT],
+                                              const bool (&valid)[QPT], int (&idx)[QPT], unsigned int& visits) {
+  gptr_u4 cn = (gptr_u4)(uintptr_t)td.cnodes;
+  Screen sc[QPT];
+  bool live[QPT];
+  vu4 w[QPT];
+#pragma unroll
+  for (int j = 0; j < QPT; ++j) {
+    sc[j] = make_screen(td, q0[j], q1[j], q2[j]);
+    idx[j] = 0;
+    live[j] = valid[j];
+  }
+  if (n_top > 0) {
+    int e[QPT];
+    bool intop[QPT];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) { e[j] = 0; intop[j] = valid[j]; }
+    for (;;) {
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < QPT; ++j)
+        if (intop[j]) w[j] = s_top[e[j]];
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        if (intop[j]) {
+          const int k0 = ((int)(w[j].x << 11)) >> 11;
+          const int k1 = ((int)(((w[j].y << 22) | (w[j].x >> 10)) & 0xfffff800u)) >> 11;
+          const int k2 = ((int)(w[j].y << 1)) >> 11;
+          const double c = (double)__uint_as_float(w[j].z);
+          const double sh = (sc[j].r0 * (double)k0 + sc[j].r1 * (double)k1) + sc[j].r2 * (double)k2 - c;
+          bool left;
+          if (fabs(sh) > sc[j].slack + kScreenC * fabs(c)) left = sh < 0.0;
+          else left = exact_goes_left(td.nodes, td.top_dfs[e[j]], q0[j], q1[j], q2[j]);
+          ++visits;
+          const unsigned int link = w[j].w;
+          if (link & (left ? kTopLeftIn : kTopRightIn)) {
+            e[j] = (int)(link & kTopFirst) + ((!left && (link & kTopLeftIn)) ? 1 : 0);
+            any = true;
+          } else {
+            const int2 ex = s_exit[e[j]];
+            idx[j] = left ? ex.x : ex.y;
+            intop[j] = false;
+            if (link & (left ? kTopLeftLeaf : kTopRightLeaf)) live[j] = false;  // arrived at a leaf
+          }
+        }
+      }
+      if (!any) break;
+    }
+  }
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j)
+      if (live[j]) w[j] = cn[idx[j]];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+      if (live[j]) {
+        const unsigned int roff = w[j].w & kRightMask;
+        if (roff == 0u) {
+          live[j] = false;
+        } else {
+          const bool left = screened_goes_left(w[j], sc[j], td.nodes, idx[j], q0[j], q1[j], q2[j]);
+          idx[j] = left ? idx[j] + 1 : idx[j] + (int)roff;
+          ++visits;
+          live[j] = !(w[j].w & (left ? kLeftLeaf : kRightLeaf));
+          any |= live[j];
+        }
+      }
+    }
+    if (!any) break;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
+// quantised normal + offset of one internal node (the first 12 bytes of its screening record); returns |m - o|_2
+__device__ __forceinline__ double make_record(const madicp_node& nd, double o0, double o1, double o2, CNode& c) {
+  const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
+  const bool finite = isfinite(e0) && isfinite(e1) && isfinite(e2) && fabs(nd.dir[0]) <= 1.0000001 &&
+                      fabs(nd.dir[1]) <= 1.0000001 && fabs(nd.dir[2]) <= 1.0000001;  // false on NaN
+  if (!finite) {
+    c.npack = 0ull;
+    c.c = __uint_as_float(0x7f800000u);  // +inf: the screening test can never pass -> exact path
+    return 0.0;
+  }
+  long long k[3];
+  double nt[3];
+  for (int a = 0; a < 3; ++a) {
+    double v = rint(nd.dir[a] * 1048576.0);
+    v = fmin(fmax(v, -1048575.0), 1048575.0);
+    k[a] = (long long)v;
+    nt[a] = v * 9.5367431640625e-07;
+  }
+  c.npack = ((unsigned long long)k[0] & 0x1fffffull) | (((unsigned long long)k[1] & 0x1fffffull) << 21) |
+            (((unsigned long long)k[2] & 0x1fffffull) << 42);
+  c.c = (float)((nt[0] * e0 + nt[1] * e1) + nt[2] * e2);
+  return sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+}
+
 // builds the screening records of a tree (after upload and after every transform); grid over nodes
 __global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnodes, int n) {
   const madicp_node* __restrict__ nodes = tm->nodes;
@@ -198,26 +341,13 @@ __global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnod
   if (i < n) {
     const madicp_node nd = nodes[i];
     CNode c;
-    c.right = (unsigned int)nd.right;
-    const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
-    const bool finite = isfinite(e0) && isfinite(e1) && isfinite(e2) && fabs(nd.dir[0]) <= 1.0000001 &&
-                        fabs(nd.dir[1]) <= 1.0000001 && fabs(nd.dir[2]) <= 1.0000001;  // false on NaN
-    if (nd.right != 0 && finite) {
-      long long k[3];
-      double nt[3];
-      for (int a = 0; a < 3; ++a) {
-        double v = rint(nd.dir[a] * 1048576.0);
-        v = fmin(fmax(v, -1048575.0), 1048575.0);
-        k[a] = (long long)v;
-        nt[a] = v * 9.5367431640625e-07;
-      }
-      c.npack = ((unsigned long long)k[0] & 0x1fffffull) | (((unsigned long long)k[1] & 0x1fffffull) << 21) |
-                (((unsigned long long)k[2] & 0x1fffffull) << 42);
-      c.c = (float)((nt[0] * e0 + nt[1] * e1) + nt[2] * e2);
-      r = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
-    } else {
-      c.npack = 0ull;
-      c.c = __uint_as_float(0x7f800000u);  // +inf: the screening test can never pass -> exact path
+    c.npack = 0ull;
+    c.c = 0.f;
+    c.right = 0u;  // leaf records are never read, except the root's in a single-node tree ("right == 0 -> leaf")
+    if (nd.right != 0) {
+      r = make_record(nd, o0, o1, o2, c);
+      c.right = (unsigned int)nd.right | (nodes[i + 1].right == 0 ? kLeftLeaf : 0u) |
+                (nodes[i + nd.right].right == 0 ? kRightLeaf : 0u);
     }
     cnodes[i] = c;
   }
@@ -231,6 +361,17 @@ __global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnod
   }
 }
 
+// the same records for the LDS-staged top array: entry e describes node top_dfs[e]; link[e] is its (static) link word
+__global__ void tree_compact_top(const madicp_node* __restrict__ nodes, CNode* __restrict__ top,
+                                 const int* __restrict__ top_dfs, const unsigned int* __restrict__ link, int n_top) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_top) return;
+  CNode c;
+  make_record(nodes[top_dfs[e]], nodes[0].mean[0], nodes[0].mean[1], nodes[0].mean[2], c);
+  c.right = link[e];
+  top[e] = c;
+}
+
 __global__ void moving_prep(const double* __restrict__ xyz, double* __restrict__ out, int L) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
@@ -241,14 +382,14 @@ __global__ void moving_prep(const double* __restrict__ xyz, double* __restrict__
   reinterpret_cast<double4*>(out)[i] = o;
 }
 
-__global__ void nn_descend(const TreeMeta* __restrict__ tm, const double* __restrict__ q, long long n,
+__global__ void nn_descend(const TreeDesc td, const double* __restrict__ q, long long n,
                            uint32_t* __restrict__ out_leaf, uint32_t* __restrict__ out_node,
                            double* __restrict__ out_dist, int32_t* __restrict__ out_depth) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
     int depth;
-    const int idx = descend(tm, q0, q1, q2, depth);
-    const NodeV leaf = load_node(tm->nodes, idx);
+    const int idx = descend(td, q0, q1, q2, depth);
+    const NodeV leaf = load_node(td.nodes, idx);
     if (out_leaf) out_leaf[i] = static_cast<uint32_t>(leaf.leaf_id);
     if (out_node) out_node[i] = static_cast<uint32_t>(idx);
     if (out_depth) out_depth[i] = depth;
@@ -281,52 +422,87 @@ __global__ void tree_transform(madicp_node* __restrict__ nodes, int n, const dou
 
 // ---------------------------------------------------------------------------------------------------
 // Sum of kAcc per-lane accumulators over the 64 lanes of a wave, as a reduce-scatter: at every step a
-// lane keeps one half of its slots, hands the other half to its partner (lane ^ 32, 16, 8, 4, 2) and adds
-// what it receives, so the slot count halves each time: 16+8+4+2+1 exchanges plus one final pair-wise add
-// instead of 6 per slot (32 cross-lane moves of a double instead of 174).  The tree is fixed, so the result
-// is bit-reproducible.  Afterwards lane l holds the wave total of slot l>>1; even lanes store it.
+// lane keeps one half of its slots, hands the other half to its partner and adds what it receives, so the
+// slot count halves each time (16+8+4+2+1 exchanges plus one final pair-wise add instead of 6 per slot).
+// All cross-lane traffic is VALU (no LDS): gfx950's v_permlane32_swap / v_permlane16_swap for the two
+// widest steps, DPP row_ror:8 / row_half_mirror with bank masks for the next two, quad_perm for the last.
+// With X = the slot a lower lane keeps and Y = the slot an upper lane keeps, one swap/masked-DPP turns
+// (X, Y) into (X', Y') such that X' + Y' is the pair total on BOTH lanes — no selects.  (An LDS-crossbar
+// version of the same tree, ds_bpermute, cost ~4 us of a 19 us kernel; this one is a few hundred cycles.)
+// The tree is fixed, so the result is bit-reproducible.  Afterwards lane l holds the wave total of slot
+// l>>1; even lanes store it.
 // ---------------------------------------------------------------------------------------------------
-template <int N, int MASK>
-__device__ __forceinline__ void butterfly_step(double* a, int lane) {
-  const bool upper = (lane & MASK) != 0;
-#pragma unroll
-  for (int j = 0; j < N / 2; ++j) {
-    const double keep = upper ? a[j + N / 2] : a[j];
-    const double give = upper ? a[j] : a[j + N / 2];
-    a[j] = keep + __shfl_xor(give, MASK, 64);
-  }
+__device__ __forceinline__ double pair_sum_swap32(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double pair_sum_swap16(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// CTRL: the DPP lane permutation (an involution pairing upper with lower lanes); UPPER_BANKS: the 4-lane
+// banks of a 16-lane row whose lanes are "upper" in this step
+template <int CTRL, int UPPER_BANKS>
+__device__ __forceinline__ double pair_sum_dpp(double x, double y) {
+  const int xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+  // upper lanes: X' = partner's Y ; lower lanes keep X.   lower lanes: Y' = partner's X ; upper lanes keep Y.
+  const int xl2 = __builtin_amdgcn_update_dpp(xl, yl, CTRL, 0xf, UPPER_BANKS, false);
+  const int xh2 = __builtin_amdgcn_update_dpp(xh, yh, CTRL, 0xf, UPPER_BANKS, false);
+  const int yl2 = __builtin_amdgcn_update_dpp(yl, xl, CTRL, 0xf, 0xf ^ UPPER_BANKS, false);
+  const int yh2 = __builtin_amdgcn_update_dpp(yh, xh, CTRL, 0xf, 0xf ^ UPPER_BANKS, false);
+  return __hiloint2double(xh2, xl2) + __hiloint2double(yh2, yl2);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_fetch(double v) {
+  return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false),
+                          __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false));
 }
 __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane, double* out32 /*LDS, 32 slots*/) {
   double a[32];
 #pragma unroll
   for (int v = 0; v < 32; ++v) a[v] = (v < kAcc) ? acc[v] : 0.0;
-  butterfly_step<32, 32>(a, lane);
-  butterfly_step<16, 16>(a, lane);
-  butterfly_step<8, 8>(a, lane);
-  butterfly_step<4, 4>(a, lane);
-  butterfly_step<2, 2>(a, lane);
-  const double tot = a[0] + __shfl_xor(a[0], 1, 64);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = pair_sum_swap32(a[j], a[j + 16]);   // partner lane ^ 32, upper = lane & 32
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = pair_sum_swap16(a[j], a[j + 8]);     // partner lane ^ 16, upper = lane & 16
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = pair_sum_dpp<0x128, 0xC>(a[j], a[j + 4]);  // row_ror:8 = lane ^ 8, upper = lane & 8
+#pragma unroll
+  for (int j = 0; j < 2; ++j) a[j] = pair_sum_dpp<0x141, 0xA>(a[j], a[j + 2]);  // row_half_mirror = lane ^ 7, upper = lane & 4
+  {                                                                        // quad_perm [2,3,0,1] = lane ^ 2, upper = lane & 2
+    const bool upper = (lane & 2) != 0;
+    const double keep = upper ? a[1] : a[0];
+    const double give = upper ? a[0] : a[1];
+    a[0] = keep + dpp_fetch<0x4E>(give);
+  }
+  const double tot = a[0] + dpp_fetch<0xB1>(a[0]);                         // quad_perm [1,0,3,2] = lane ^ 1
   if ((lane & 1) == 0) out32[lane >> 1] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // icp_linearize
 //
-// Work decomposition.  A *unit* is (tree k, chunk c): kBlock consecutive moving leaves against one
-// keyframe tree.  Units are ordered tree-major and cut into 8 contiguous ranges, one per XCD; workgroup
-// b runs on XCD b % 8 (observed dispatch rule — used for speed only, never for correctness), so every
-// XCD's private 4 MiB L2 only serves the nodes of its own ~K/8 trees.  Inside an XCD the workgroups
-// stride over the range.  Moving leaves arrive in the DFS order of the scan's own MAD-tree, i.e. spatially
-// sorted, so the 64 lanes of a wave walk the same upper path (one cache line per level for the whole
-// wave) and only diverge near the leaves.
+// Work decomposition.  The moving leaves of a scan are cut into `ranges_per_tree` equal ranges; a *unit* is
+// (tree k, range r).  The host picks ranges_per_tree so that there is about one unit per workgroup, i.e. the
+// work is balanced to the workgroup instead of quantised to 256-leaf chunks (with ~1.25 chunks per workgroup
+// the kernel used to run as long as its 2-chunk workgroups).  Units are ordered tree-major and cut into 8
+// contiguous ranges, one per XCD; workgroup b runs on XCD b % 8 (observed dispatch rule — used for speed only,
+// never for correctness), so every XCD's private 4 MiB L2 only serves the nodes of its own ~K/8 trees.  A lane
+// walks QPT leaves at once (their node loads are issued together).  Moving leaves arrive in the DFS order of
+// the scan's own MAD-tree, i.e. spatially sorted, so the 64 lanes of a wave walk the same upper path (one
+// request per level for the whole wave) and only diverge near the leaves.
 //
 // grid = (8 * slots, n_scans); blockIdx.y selects the registration (scans batched in flight).
 // partials: [scan][gridDim.x][kAcc]
 // ---------------------------------------------------------------------------------------------------
+template <int QPT>
 __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, double* __restrict__ partials) {
   Job* job = jobs + blockIdx.y;
   const int L = job->L;
   const int K = job->K;
+  const int RPT = job->ranges_per_tree;
   const bool last_round = (job->iter == job->n_iters - 1);
   const double* __restrict__ moving = job->moving;
   uint8_t* __restrict__ matched = job->matched;
@@ -344,84 +520,118 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
   for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
   unsigned int visits = 0;
 
-  const int C = (L + kBlock - 1) / kBlock;
-  const long long U = (long long)K * C;
+  __shared__ vu4 s_top[kTopMax];
+  __shared__ int2 s_exit[kTopMax];
+  int staged_tree = -1;
+
+  const int S = (L + RPT - 1) / RPT;  // leaves per range
+  const long long U = (long long)K * RPT;
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
   const int nslots = gridDim.x >> 3;
   const long long lo = (xcd * U) >> 3;
   const long long hi = ((xcd + 1) * U) >> 3;
 
-  for (long long u = lo + slot; u < hi; u += nslots) {
-    const int k = static_cast<int>(u / C);
-    const int c = static_cast<int>(u - (long long)k * C);
-    const int i = c * kBlock + threadIdx.x;
-    if (i >= L) continue;
-    const TreeMeta* __restrict__ tm = job->trees[k];
-
-    const vd4 p = ((gptr_d4)(uintptr_t)moving)[i];
-    // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
-    const double q0 = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
-    const double q1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
-    const double q2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
-
-    int depth;
 #ifdef MADICP_ABLATE
-    int idx = 0;
-    if (job->flags & 4) { depth = 0; idx = tm->n_nodes - 1; }  // profiling only: no descent (last node is a leaf)
-    else idx = descend(tm, q0, q1, q2, depth);
-#else
-    const int idx = descend(tm, q0, q1, q2, depth);
+  const int reps = (job->flags & 128) ? 2 : ((job->flags & 256) ? 3 : 1);  // profiling only: repeat the work (warm caches)
+  for (int rep = 0; rep < reps; ++rep)
 #endif
-    visits += depth;
-
-    // gate (mad_icp.cpp:81-83) needs only the leaf's surface point: fetch the rest when the pair survives
-    gptr_d2 lp = (gptr_d2)(uintptr_t)(tm->nodes + idx);
-    const vd2 la = lp[0], lb = lp[1];
-    const double g0 = q0 - la.x, g1 = q1 - la.y, g2 = q2 - lb.x;
-    const double src_ball = min_ball + b_ratio * p.w;
-    const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-    if (corr) {
-      const int leaf_id = (int)(__double_as_longlong(lp[3].x) >> 32);
-      corr[(long long)k * L + i] = static_cast<uint32_t>(leaf_id) | (rejected ? 0x80000000u : 0u);
+  for (long long u = lo + slot; u < hi; u += nslots) {
+    const int k = static_cast<int>(u / RPT);
+    const int r = static_cast<int>(u - (long long)k * RPT);
+    const int i_end = min(L, (r + 1) * S);
+    const TreeDesc& td = job->trees[k];
+    // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves
+    const int n_top = (i_end - r * S >= job->stage_min_leaves) ? min(td.n_top, kTopMax) : 0;
+    if (n_top > 0 && k != staged_tree) {  // (workgroup-uniform) copy this tree's top levels into LDS
+      if (staged_tree >= 0) __syncthreads();
+      gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
+      const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+      for (int e = threadIdx.x; e < n_top; e += kBlock) {
+        s_top[e] = gt[e];
+        reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+      }
+      __syncthreads();
+      staged_tree = k;
     }
-    if (rejected) continue;
-    if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 
-    const vd2 lc = lp[2];
-    const double bbox0 = lp[3].y;
-    const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
+    for (int base = r * S; base < i_end; base += QPT * kBlock) {
+      double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT];
+      bool valid[QPT];
+      int idx[QPT];
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const int i = base + j * kBlock + threadIdx.x;
+        valid[j] = i < i_end;
+        vd4 p = {0.0, 0.0, 0.0, 0.0};
+        if (valid[j]) p = ((gptr_d4)(uintptr_t)moving)[i];
+        px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
+        // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
+        q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
+        q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
+        q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+      }
+#ifdef MADICP_ABLATE
+      if (job->flags & 4) {  // profiling only: no descent (the last node of a preorder array is a leaf)
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) idx[j] = 0;
+      } else
+#endif
+      descend_multi<QPT>(td, s_top, s_exit, n_top, q0, q1, q2, valid, idx, visits);
 
-    // errorAndJacobian (mad_icp.cpp:59-72)
-    const double e = dotc(g0, g1, g2, n0, n1, n2);
-    double J[6];
-    J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
-    J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
-    J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
-    // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
-    const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
-    J[3] = dotc(a0, a1, a2, 0.0, p.z, -p.y);
-    J[4] = dotc(a0, a1, a2, -p.z, 0.0, p.x);
-    J[5] = dotc(a0, a1, a2, p.y, -p.x, 0.0);
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        if (!valid[j]) continue;
+        const int i = base + j * kBlock + threadIdx.x;
+        // gate (mad_icp.cpp:81-83) needs only the leaf's surface point: fetch the rest when the pair survives
+        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.nodes + idx[j]);
+        const vd2 la = lp[0], lb = lp[1];
+        const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
+        const double src_ball = min_ball + b_ratio * pn[j];
+        const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
+        if (corr) {
+          const int leaf_id = (int)(__double_as_longlong(lp[3].x) >> 32);
+          corr[(long long)k * L + i] = static_cast<uint32_t>(leaf_id) | (rejected ? 0x80000000u : 0u);
+        }
+        if (rejected) continue;
+        if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 
-    // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
-    double scale = 1.0;
-    const double chi = fabs(e);
-    if (chi > rho) scale = rho / chi;
-    const double w = 1.0 - bbox0 / min_ball;
-    scale *= w * w;
+        const vd2 lc = lp[2];
+        const double bbox0 = lp[3].y;
+        const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
 
-    double sJ[6];
+        // errorAndJacobian (mad_icp.cpp:59-72)
+        const double e = dotc(g0, g1, g2, n0, n1, n2);
+        double J[6];
+        J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
+        J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
+        J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
+        // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
+        const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
+        J[3] = dotc(a0, a1, a2, 0.0, pz[j], -py[j]);
+        J[4] = dotc(a0, a1, a2, -pz[j], 0.0, px[j]);
+        J[5] = dotc(a0, a1, a2, py[j], -px[j], 0.0);
+
+        // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
+        double scale = 1.0;
+        const double chi = fabs(e);
+        if (chi > rho) scale = rho / chi;
+        const double w = 1.0 - bbox0 / min_ball;
+        scale *= w * w;
+
+        double sJ[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) sJ[r] = scale * J[r];
-    int v = 0;
+        for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
+        int v = 0;
 #pragma unroll
-    for (int cc = 0; cc < 6; ++cc)
+        for (int cc = 0; cc < 6; ++cc)
 #pragma unroll
-      for (int r = cc; r < 6; ++r) acc[v++] += sJ[r] * J[cc];
+          for (int rr = cc; rr < 6; ++rr) acc[v++] += sJ[rr] * J[cc];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) acc[21 + r] += sJ[r] * e;
-    acc[27] += 1.0;
+        for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
+        acc[27] += 1.0;
+      }
+    }
   }
 
   // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
@@ -435,7 +645,18 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
     return;
   }
 #endif
+#ifdef MADICP_ABLATE
+  if (job->flags & 16) {  // profiling only: barrier + LDS join but no butterfly
+    if (lane < 32) red[wave][lane] = acc[lane < kAcc ? 0 : 1];
+  } else
+#endif
   wave_reduce_scatter(acc, lane, red[wave]);
+#ifdef MADICP_ABLATE
+  if (job->flags & 8) {  // profiling only: butterfly but no barrier / cross-wave join
+    if (lane < kAcc) partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * kAcc + lane] = red[wave][lane];
+    return;
+  }
+#endif
   __syncthreads();
   if (threadIdx.x < kAcc) {
     double s = red[0][threadIdx.x];
@@ -614,7 +835,9 @@ __device__ __forceinline__ void gn_update(Job* job, const double* total) {
   job->iter = it + 1;
 }
 
-// join of the per-workgroup partials in a fixed order: 32 segments summed in parallel, then in sequence
+// join of the per-workgroup partials in a fixed order: 32 segments summed in parallel (every lane issues all
+// of its loads before the first add, so the join costs one memory round trip), then the segments in sequence
+constexpr int kJoinMaxSeg = 32;  // partials per lane handled without looping: grids up to 32*32 = 1024 workgroups
 __device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
   __shared__ double seg[32][kAcc];
   const int j = threadIdx.x & 31;
@@ -624,8 +847,17 @@ __device__ __forceinline__ void join_partials(const double* __restrict__ partial
     double a = 0.0;
     const int b0 = s * seg_len;
     const int b1 = min(nblocks, b0 + seg_len);
+    if (seg_len <= kJoinMaxSeg) {
+      double v[kJoinMaxSeg];
+#pragma unroll
+      for (int i = 0; i < kJoinMaxSeg; ++i) v[i] = (b0 + i < b1) ? partials[(long long)(b0 + i) * kAcc + j] : 0.0;
+#pragma unroll
+      for (int i = 0; i < kJoinMaxSeg; ++i)
+        if (b0 + i < b1) a += v[i];  // same order as the loop below
+    } else {
 #pragma unroll 8
-    for (int b = b0; b < b1; ++b) a += partials[(long long)b * kAcc + j];
+      for (int b = b0; b < b1; ++b) a += partials[(long long)b * kAcc + j];
+    }
     seg[s][j] = a;
   }
   __syncthreads();
@@ -638,9 +870,10 @@ __device__ __forceinline__ void join_partials(const double* __restrict__ partial
   __syncthreads();
 }
 
-// before the last round the matched_ flags are cleared (pipeline.cpp:172-176)
-__device__ __forceinline__ void clear_matched_if_next_is_last(Job* job) {
-  if (job->iter + 1 == job->n_iters - 1) {
+// before the last round the matched_ flags are cleared (pipeline.cpp:172-176).  `iter` is the round that was
+// just linearised, read by every thread BEFORE the barriers of join_partials (thread 0 advances job->iter later).
+__device__ __forceinline__ void clear_matched_if_next_is_last(Job* job, int iter, int n_iters) {
+  if (iter + 1 == n_iters - 1) {
     const int L = job->L;
     uint4* m16 = reinterpret_cast<uint4*>(job->matched);  // hipMalloc'ed: 256-byte aligned
     for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) m16[i] = make_uint4(0, 0, 0, 0);
@@ -648,33 +881,8 @@ __device__ __forceinline__ void clear_matched_if_next_is_last(Job* job) {
   }
 }
 
-// single-GPU: join + solve + update in one launch; grid = n_scans, block = kSolveThreads
-__global__ __launch_bounds__(kSolveThreads) void icp_solve(Job* __restrict__ jobs, const double* __restrict__ partials,
-                                                          int nblocks) {
-  __shared__ double total[kAcc];
-  Job* job = jobs + blockIdx.x;
-  join_partials(partials + (long long)blockIdx.x * nblocks * kAcc, nblocks, total);
-  clear_matched_if_next_is_last(job);
-  if (threadIdx.x == 0) gn_update(job, total);
-}
-
-// multi-GPU: join -> totals[scan][kAcc] | ncclAllReduce(sum) | update
-__global__ __launch_bounds__(kSolveThreads) void icp_reduce(Job* __restrict__ jobs, const double* __restrict__ partials,
-                                                           int nblocks, double* __restrict__ totals) {
-  __shared__ double total[kAcc];
-  Job* job = jobs + blockIdx.x;
-  join_partials(partials + (long long)blockIdx.x * nblocks * kAcc, nblocks, total);
-  clear_matched_if_next_is_last(job);
-  if (threadIdx.x < kAcc) totals[blockIdx.x * kAcc + threadIdx.x] = total[threadIdx.x];
-}
-__global__ void icp_update(Job* __restrict__ jobs, const double* __restrict__ totals, int n_scans) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n_scans) gn_update(jobs + s, totals + s * kAcc);
-}
-
-// matched-leaf count (pipeline.cpp:197-204); grid = n_scans, block = kSolveThreads
-__global__ __launch_bounds__(kSolveThreads) void icp_finish(Job* __restrict__ jobs) {
-  Job* job = jobs + blockIdx.x;
+// matched-leaf count (pipeline.cpp:197-204), whole workgroup; valid once the last round's linearisation is done
+__device__ __forceinline__ void count_matched(Job* job) {
   __shared__ int cnt[kSolveThreads / 64];
   const int L = job->L;
   const uint4* m16 = reinterpret_cast<const uint4*>(job->matched);
@@ -688,10 +896,49 @@ __global__ __launch_bounds__(kSolveThreads) void icp_finish(Job* __restrict__ jo
   if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < kSolveThreads / 64; ++w) s += cnt[w];
-    job->n_matched = s;
+    int t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += cnt[w];
+    job->n_matched = t;
   }
 }
+
+// single-GPU: join + solve + update in one launch; grid = n_scans, block = kSolveThreads.  After the last round
+// the same launch also counts the matched leaves (their flags were written by the linearisation just before).
+__global__ __launch_bounds__(kSolveThreads) void icp_solve(Job* __restrict__ jobs, const double* __restrict__ partials,
+                                                          int nblocks) {
+  __shared__ double total[kAcc];
+  Job* job = jobs + blockIdx.x;
+  const int iter = job->iter, n_iters = job->n_iters;
+#ifdef MADICP_ABLATE
+  if (job->flags & 32) {  // profiling only: no join
+    if (threadIdx.x < kAcc) total[threadIdx.x] = partials[threadIdx.x];
+    __syncthreads();
+  } else
+#endif
+  join_partials(partials + (long long)blockIdx.x * nblocks * kAcc, nblocks, total);
+  clear_matched_if_next_is_last(job, iter, n_iters);
+  if (iter == n_iters - 1) count_matched(job);
+#ifdef MADICP_ABLATE
+  if (job->flags & 64) return;  // profiling only: no update at all
+#endif
+  if (threadIdx.x == 0) gn_update(job, total);
+}
+
+// multi-GPU: join -> totals[scan][kAcc] | ncclAllReduce(sum) | update | (last round) all-reduce(max) of the flags
+// | icp_finish
+__global__ __launch_bounds__(kSolveThreads) void icp_reduce(Job* __restrict__ jobs, const double* __restrict__ partials,
+                                                           int nblocks, double* __restrict__ totals) {
+  __shared__ double total[kAcc];
+  Job* job = jobs + blockIdx.x;
+  const int iter = job->iter, n_iters = job->n_iters;
+  join_partials(partials + (long long)blockIdx.x * nblocks * kAcc, nblocks, total);
+  clear_matched_if_next_is_last(job, iter, n_iters);
+  if (threadIdx.x < kAcc) totals[blockIdx.x * kAcc + threadIdx.x] = total[threadIdx.x];
+}
+__global__ void icp_update(Job* __restrict__ jobs, const double* __restrict__ totals, int n_scans) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n_scans) gn_update(jobs + s, totals + s * kAcc);
+}
+__global__ __launch_bounds__(kSolveThreads) void icp_finish(Job* __restrict__ jobs) { count_matched(jobs + blockIdx.x); }
 
 }  // namespace madicp

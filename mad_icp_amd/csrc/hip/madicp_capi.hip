@@ -44,7 +44,13 @@ int fail(int code, const std::string& msg) {
 struct DevTree {
   madicp_node* nodes = nullptr;
   CNode* cnodes = nullptr;    // 16-byte screening records, same indexing
-  TreeMeta* meta = nullptr;   // device-resident descriptor the kernels read
+  CNode* top = nullptr;       // top levels, breadth first (staged into LDS by icp_linearize)
+  int2* top_exit = nullptr;
+  int* top_dfs = nullptr;
+  unsigned int* top_link = nullptr;
+  int32_t n_top = 0;
+  TreeMeta* meta = nullptr;   // device-side scratch tree_compact writes origin / radius into
+  TreeDesc desc{};            // what the kernels get by value
   int32_t n_nodes = 0, n_leaves = 0;
 };
 struct DevMoving {
@@ -54,10 +60,15 @@ struct DevMoving {
 };
 
 struct GraphKey {
-  int grid, batch, iters, comm;
+  int grid, batch, iters, qpt, comm;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, comm) < std::tie(o.grid, o.batch, o.iters, o.comm);
+    return std::tie(grid, batch, iters, qpt, comm) < std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm);
   }
+};
+struct Geometry {
+  int grid;             // workgroups per scan (multiple of 8)
+  int ranges_per_tree;  // units per tree
+  int qpt;              // leaves a lane walks at once: 1, 2 or 4
 };
 
 }  // namespace
@@ -90,15 +101,13 @@ struct madicp_ctx {
   // options
   int blocks_per_cu = 4;
   int use_graph = 1;
-  int time_kernels = 0;
+  int qpt_override = 0;
+  int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
+  int occ_blocks[3] = {4, 3, 2};  // icp_linearize<1|2|4> workgroups resident per CU (queried at create)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
 
-  // kernel timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
-  std::vector<hipEvent_t> ev_pool;
-  int64_t timed_launches = 0;
-  double timed_ms = 0.0;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // madicp_icp_time_linearize
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -120,44 +129,34 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
   return MADICP_OK;
 }
 
-// launch geometry: 8 XCDs x slots; enough workgroups to cover the units once, capped by residency
-int pick_grid(const madicp_ctx* ctx, int max_L, int K) {
-  const long long chunk = kBlock;
-  const long long C = (max_L + chunk - 1) / chunk;
-  const long long U = std::max<long long>(1, C * K);
-  long long slots = (U + 7) / 8;
-  const long long cap = std::max(1, ctx->blocks_per_cu * ctx->n_cus / 8);
-  slots = std::min(slots, cap);
-  return static_cast<int>(8 * slots);
+// launch geometry: 8 XCDs x slots workgroups per scan, about blocks_per_cu * n_cus in total over the batch, and
+// one (tree, range) unit per workgroup so that every workgroup gets the same number of leaves
+Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
+  Geometry g;
+  // One leaf per lane and pass (QPT > 1 only costs registers: the kernel is bound by the L1 address path and by
+  // miss latency, not by the number of waves — measured).  Workgroups per scan: what is resident at once for a
+  // single scan; for a batch at least one workgroup per CU and scan.
+  g.qpt = ctx->qpt_override ? ctx->qpt_override : 1;
+  const int occ = ctx->occ_blocks[g.qpt == 1 ? 0 : (g.qpt == 2 ? 1 : 2)];
+  const long long per_cu = std::max(1, std::min(ctx->blocks_per_cu, occ));
+  long long grid = std::max<long long>(ctx->n_cus, per_cu * ctx->n_cus / std::max(1, batch));
+  const long long max_useful = (long long)K * ((max_L + 63) / 64);  // never below one wave of leaves per unit
+  grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
+  g.grid = static_cast<int>(grid);
+  g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / K));
+  return g;
 }
 
-hipEvent_t get_event(madicp_ctx* ctx) {
-  if (!ctx->ev_pool.empty()) {
-    hipEvent_t e = ctx->ev_pool.back();
-    ctx->ev_pool.pop_back();
-    return e;
-  }
-  hipEvent_t e = nullptr;
-  hipEventCreate(&e);
-  return e;
-}
-
-void launch_linearize(madicp_ctx* ctx, int grid, int batch) {
+void launch_linearize(madicp_ctx* ctx, int grid, int batch, int qpt) {
   dim3 g(grid, batch), b(kBlock);
-  if (ctx->time_kernels) {
-    // start/stop events attached to the dispatch itself: kernel execution time, like the profiler reports
-    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
-    hipExtLaunchKernelGGL(icp_linearize, g, b, 0, ctx->stream, e0, e1, 0, ctx->d_jobs, ctx->d_partials);
-    ctx->ev_pending.emplace_back(e0, e1);
-  } else {
-    hipLaunchKernelGGL(icp_linearize, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials);
-  }
+  void (*kern)(Job*, double*) = qpt == 1 ? icp_linearize<1> : (qpt == 2 ? icp_linearize<2> : icp_linearize<4>);
+  hipLaunchKernelGGL(kern, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials);
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
-int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters) {
+int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
   for (int it = 0; it < iters; ++it) {
-    launch_linearize(ctx, grid, batch);
+    launch_linearize(ctx, grid, batch, qpt);
     if (ctx->comm) {
       hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
                          grid, ctx->d_totals);
@@ -177,21 +176,22 @@ int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters) {
       NCCL_TRY(ncclAllReduce(mv.matched, mv.matched, (size_t)mv.L, ncclUint8, ncclMax, ctx->comm, ctx->stream));
     }
   }
-  hipLaunchKernelGGL(icp_finish, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs);
+  // single GPU: the last icp_solve already counted the matched leaves; with ranks the OR above had to come first
+  if (ctx->comm) hipLaunchKernelGGL(icp_finish, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
 
-int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters) {
-  // graphs: only without per-launch events, and (conservatively) only without a communicator
-  const bool graph_ok = ctx->use_graph && !ctx->time_kernels && !ctx->comm;
-  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters);
-  const GraphKey key{grid, batch, iters, ctx->comm ? 1 : 0};
+int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+  // graphs: (conservatively) only without a communicator
+  const bool graph_ok = ctx->use_graph && !ctx->comm;
+  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters, qpt);
+  const GraphKey key{grid, batch, iters, qpt, ctx->comm ? 1 : 0};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_rounds(ctx, grid, batch, iters);
+    const int rc = enqueue_rounds(ctx, grid, batch, iters, qpt);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != MADICP_OK) return rc;
     if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -215,6 +215,8 @@ struct RegArgs {
   int flags;
   uint32_t* d_corr;     // single-scan debug trace (device) or null
   double* d_x_iters;    // single-scan (device) or null
+  int time_launches = 0;    // > 0: measurement mode, see madicp_icp_time_linearize
+  double* out_avg_us = nullptr;
 };
 
 int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
@@ -249,6 +251,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     j.flags = a.flags;
 #ifdef MADICP_ABLATE
     if (const char* f = getenv("MADICP_ABLATE_FLAGS")) j.flags |= atoi(f);  // profiling builds only
+    if (const char* f = getenv("MADICP_ABLATE_CLEAR")) j.flags &= ~atoi(f);
 #endif
     std::memcpy(j.X, a.X0 + 12 * s, 12 * sizeof(double));
     j.min_ball = a.params->min_ball;
@@ -257,21 +260,59 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     for (int k = 0; k < a.K; ++k) {
       auto tit = ctx->trees.find(a.tree_ids[k]);
       if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
-      j.trees[k] = tit->second.meta;
+      j.trees[k] = tit->second.desc;
     }
     max_L = std::max(max_L, mv.L);
     // flags are cleared on the device before the last round; with a single round that is "now"
     if (a.n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
   }
-  const int grid = pick_grid(ctx, max_L, std::max(1, a.K));
+  const Geometry geo = pick_geometry(ctx, max_L, a.K, a.n_scans);
+  const int grid = geo.grid;
+  for (int s = 0; s < a.n_scans; ++s) {
+    h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
+    h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
+  }
   const int rc0 = ensure_partials(ctx, (size_t)a.n_scans * grid * kAcc);
   if (rc0 != MADICP_OK) return rc0;
-  const size_t job_bytes = offsetof(Job, trees) + sizeof(const TreeMeta*) * (size_t)std::max(1, a.K);
+  const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipEventRecord(ctx->stage_ev[slot], ctx->stream));
   ctx->last_batch = a.n_scans;
-  return run_rounds(ctx, grid, a.n_scans, a.n_iters);
+  if (a.time_launches > 0) {
+    // n back-to-back launches of the dominant kernel inside ONE captured graph, bracketed by two events: the
+    // per-launch time is defined exactly like a profiler trace of the registration graph defines it
+    if (!ctx->ev_t0) {
+      HIP_TRY(hipEventCreate(&ctx->ev_t0));
+      HIP_TRY(hipEventCreate(&ctx->ev_t1));
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+#ifdef MADICP_ABLATE
+    if (getenv("MADICP_TIME_SOLVE")) {  // profiling builds only: time the solve kernel instead
+      for (int i = 0; i < a.time_launches; ++i)
+        hipLaunchKernelGGL(icp_solve, dim3(a.n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, grid);
+    } else
+#endif
+    for (int i = 0; i < a.time_launches; ++i) launch_linearize(ctx, grid, a.n_scans, geo.qpt);
+    HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphLaunch(exec, ctx->stream));  // warm-up replay
+    HIP_TRY(hipEventRecord(ctx->ev_t0, ctx->stream));
+    HIP_TRY(hipGraphLaunch(exec, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
+    // fold the last launch's partials into job->visits / H / b (no pose update: kFlagNoUpdate is set)
+    hipLaunchKernelGGL(icp_solve, dim3(a.n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, grid);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+    hipGraphExecDestroy(exec);
+    hipGraphDestroy(graph);
+    if (a.out_avg_us) *a.out_avg_us = 1e3 * ms / a.time_launches;
+    return MADICP_OK;
+  }
+  return run_rounds(ctx, grid, a.n_scans, a.n_iters, geo.qpt);
 }
 
 }  // namespace
@@ -314,6 +355,12 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
     madicp_ctx_destroy(ctx);
     return fail(MADICP_ERR_DEVICE, std::string("context allocation: ") + hipGetErrorString(e));
   }
+  {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<1>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[0] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<2>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[1] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<4>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[2] = n;
+  }
   *out = ctx;
   return MADICP_OK;
 }
@@ -327,17 +374,18 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   for (auto& t : ctx->trees) {
     hipFree(t.second.nodes);
     hipFree(t.second.cnodes);
+    hipFree(t.second.top);
+    hipFree(t.second.top_exit);
+    hipFree(t.second.top_dfs);
+    hipFree(t.second.top_link);
     hipFree(t.second.meta);
   }
   for (auto& m : ctx->movings) {
     hipFree(m.second.xyzn);
     hipFree(m.second.matched);
   }
-  for (auto& p : ctx->ev_pending) {
-    hipEventDestroy(p.first);
-    hipEventDestroy(p.second);
-  }
-  for (auto e : ctx->ev_pool) hipEventDestroy(e);
+  if (ctx->ev_t0) hipEventDestroy(ctx->ev_t0);
+  if (ctx->ev_t1) hipEventDestroy(ctx->ev_t1);
   if (ctx->d_jobs) hipFree(ctx->d_jobs);
   for (int i = 0; i < madicp_ctx::kStageSlots; ++i) {
     if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
@@ -366,31 +414,14 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->blocks_per_cu = (int)value;
   } else if (k == "use_graph") {
     ctx->use_graph = value ? 1 : 0;
-  } else if (k == "time_kernels") {
-    ctx->time_kernels = value ? 1 : 0;
+  } else if (k == "lds_stage_min_leaves") {
+    if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
+    ctx->stage_min_leaves = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (k == "queries_per_lane") {
+    if (value != 0 && value != 1 && value != 2 && value != 4) return fail(MADICP_ERR_INVALID, "queries_per_lane must be 0 (auto), 1, 2 or 4");
+    ctx->qpt_override = (int)value;
   } else {
     return fail(MADICP_ERR_INVALID, "unknown option: " + k);
-  }
-  return MADICP_OK;
-}
-
-int madicp_ctx_kernel_time(madicp_ctx* ctx, int reset, int64_t* n_launches, double* total_ms) {
-  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (auto& p : ctx->ev_pending) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-    ctx->timed_ms += ms;
-    ctx->timed_launches += 1;
-    ctx->ev_pool.push_back(p.first);
-    ctx->ev_pool.push_back(p.second);
-  }
-  ctx->ev_pending.clear();
-  if (n_launches) *n_launches = ctx->timed_launches;
-  if (total_ms) *total_ms = ctx->timed_ms;
-  if (reset) {
-    ctx->timed_launches = 0;
-    ctx->timed_ms = 0.0;
   }
   return MADICP_OK;
 }
@@ -401,12 +432,59 @@ namespace {
 int compact_tree(madicp_ctx* ctx, DevTree& t) {
   HIP_TRY(hipMemsetAsync(&t.meta->rho2_bits, 0, sizeof(unsigned long long), ctx->stream));
   hipLaunchKernelGGL(tree_compact, dim3((t.n_nodes + 255) / 256), dim3(256), 0, ctx->stream, t.meta, t.cnodes, t.n_nodes);
+  if (t.n_top > 0)
+    hipLaunchKernelGGL(tree_compact_top, dim3((t.n_top + 255) / 256), dim3(256), 0, ctx->stream, t.nodes, t.top, t.top_dfs,
+                       t.top_link, t.n_top);
   HIP_TRY(hipGetLastError());
+  TreeMeta hm;
+  HIP_TRY(hipMemcpyAsync(&hm, t.meta, sizeof(hm), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  t.desc.nodes = t.nodes;
+  t.desc.cnodes = t.cnodes;
+  t.desc.top = t.top;
+  t.desc.top_exit = t.top_exit;
+  t.desc.top_dfs = t.top_dfs;
+  t.desc.n_top = t.n_top;
+  std::memcpy(t.desc.origin, hm.origin, sizeof(hm.origin));
+  double rho2;
+  std::memcpy(&rho2, &hm.rho2_bits, sizeof(double));
+  t.desc.rho = 1.7320508075688774 * rho2 * (1.0 + 1e-12);  // |v|_1 <= sqrt(3) |v|_2, rounded up
   return MADICP_OK;
 }
+
+// Breadth-first layout of the internal nodes of the first kTopLevels levels (structure only; depends on the tree's
+// topology, so it is made once at upload).  See "LDS-staged top levels" in kernels.hip.h for the link word.
+void layout_top(const madicp_node* nodes, std::vector<int>& dfs, std::vector<unsigned int>& link, std::vector<int2>& exits) {
+  dfs.clear();
+  link.clear();
+  exits.clear();
+  if (nodes[0].right == 0) return;
+  std::vector<int> level{0};
+  dfs.push_back(0);
+  for (size_t e = 0; e < dfs.size(); ++e) {
+    const int i = dfs[e];
+    const int l = i + 1, r = i + nodes[i].right;
+    const bool l_leaf = nodes[l].right == 0, r_leaf = nodes[r].right == 0;
+    const bool deeper = level[e] + 1 < kTopLevels;
+    const bool l_in = !l_leaf && deeper && dfs.size() + 1 <= (size_t)kTopMax - 1;
+    const bool r_in = !r_leaf && deeper && dfs.size() + (l_in ? 2 : 1) <= (size_t)kTopMax - 1;
+    unsigned int w = (unsigned int)dfs.size() & kTopFirst;
+    if (l_in) { dfs.push_back(l); level.push_back(level[e] + 1); w |= kTopLeftIn; }
+    if (r_in) { dfs.push_back(r); level.push_back(level[e] + 1); w |= kTopRightIn; }
+    if (l_leaf) w |= kTopLeftLeaf;
+    if (r_leaf) w |= kTopRightLeaf;
+    link.push_back(w);
+    exits.push_back(make_int2(l, r));
+  }
+}
+
 void free_tree(DevTree& t) {
   hipFree(t.nodes);
   hipFree(t.cnodes);
+  hipFree(t.top);
+  hipFree(t.top_exit);
+  hipFree(t.top_dfs);
+  hipFree(t.top_link);
   hipFree(t.meta);
   t = DevTree{};
 }
@@ -431,6 +509,20 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   if (e == hipSuccess) e = hipMemcpyAsync(t.meta, &hm, sizeof(hm), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess)
     e = hipMemcpyAsync(t.nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyHostToDevice, ctx->stream);
+  std::vector<int> top_dfs;
+  std::vector<unsigned int> top_link;
+  std::vector<int2> top_exit;
+  layout_top(nodes, top_dfs, top_link, top_exit);
+  t.n_top = static_cast<int32_t>(top_dfs.size());
+  if (t.n_top > 0) {
+    if (e == hipSuccess) e = hipMalloc(&t.top, sizeof(CNode) * top_dfs.size());
+    if (e == hipSuccess) e = hipMalloc(&t.top_exit, sizeof(int2) * top_dfs.size());
+    if (e == hipSuccess) e = hipMalloc(&t.top_dfs, sizeof(int) * top_dfs.size());
+    if (e == hipSuccess) e = hipMalloc(&t.top_link, sizeof(unsigned int) * top_dfs.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(t.top_exit, top_exit.data(), sizeof(int2) * top_dfs.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t.top_dfs, top_dfs.data(), sizeof(int) * top_dfs.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t.top_link, top_link.data(), sizeof(unsigned int) * top_dfs.size(), hipMemcpyHostToDevice, ctx->stream);
+  }
   int rc = MADICP_OK;
   if (e == hipSuccess) rc = compact_tree(ctx, t);
   if (e == hipSuccess && rc == MADICP_OK) e = hipStreamSynchronize(ctx->stream);  // hm / nodes are caller memory
@@ -496,7 +588,7 @@ int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* 
   if (!d_queries) return fail(MADICP_ERR_INVALID, "queries is null");
   HIP_TRY(hipSetDevice(ctx->device));
   const long long blocks = std::min<long long>((n + 255) / 256, (long long)ctx->n_cus * 8);
-  hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.meta, d_queries,
+  hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.desc, d_queries,
                      (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
@@ -678,6 +770,17 @@ int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, in
     hipStreamSynchronize(ctx->stream);
     hipFree(d_corr);
   }
+  return rc;
+}
+
+int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
+                              const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
+                              uint64_t* out_visits_per_launch) {
+  if (n_launches < 1) return fail(MADICP_ERR_INVALID, "n_launches must be >= 1");
+  // n_iters is set far above the round index so that no launch is "the last round" (no matched_ writes)
+  RegArgs a{n_scans, moving_ids, tree_ids, K, X0, params, 1 << 20, kFlagNoUpdate, nullptr, nullptr, n_launches, out_avg_us};
+  int rc = enqueue_registration(ctx, a);
+  if (rc == MADICP_OK && out_visits_per_launch) rc = madicp_icp_fetch(ctx, n_scans, nullptr, nullptr, nullptr, nullptr, out_visits_per_launch);
   return rc;
 }
 

@@ -211,16 +211,61 @@ def test_register_pose_and_per_iteration_correspondences(ctx, K):
 
 
 def test_register_batch_equals_single(ctx):
-    """Scans batched in flight advance exactly like the same scans registered one by one."""
+    """Scans batched in flight advance like the same scans registered one by one.  The launch geometry (hence the
+    order in which the per-workgroup partial sums are joined) depends on the batch size, so the two agree to
+    summation-order rounding, not bit for bit; each of them is bit-reproducible on its own."""
     pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 2, n_queries=3)
     X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
     gb = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+    gb2 = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+    assert np.array_equal(gb["X"], gb2["X"]) and np.array_equal(gb["H"], gb2["H"])
     for s in range(3):
         gs = ctx.icp_register(mids[s], tids, pb["query_guess"][s], PARAMS, 15, qh[s].num_leaves)
-        assert np.array_equal(gb["X"][s], gs["X"]), "batched and single registration must be bit-identical"
-        assert np.array_equal(gb["H"][s], gs["H"])
-        assert gb["n_matched"][s] == int(gs["matched"].sum())
+        assert np.allclose(gb["X"][s], gs["X"], rtol=0, atol=1e-10)
+        assert np.allclose(gb["H"][s], gs["H"], rtol=1e-9, atol=1e-9 * np.abs(gs["H"]).max())
+        assert abs(int(gb["n_matched"][s]) - int(gs["matched"].sum())) <= 1
+        assert gb["visits"][s] > 0
     _teardown(ctx, tids, mids)
+
+
+@pytest.mark.parametrize("stage_min", [0, 1 << 30])
+def test_lds_staged_and_unstaged_descent_agree_with_oracle(ctx, stage_min):
+    """The top levels of a tree walked from the LDS copy (threshold 0: always) or from global memory (never) give
+    the same correspondences as the oracle, bit for bit."""
+    ctx.set_option("lds_stage_min_leaves", stage_min)
+    try:
+        pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 3)
+        T = pb["query_guess"][0]
+        L = qh[0].num_leaves
+        g = ctx.icp_linearize(mids[0], tids, T, PARAMS, L)
+        for k in range(3):
+            _, _, corr, rej, _, _ = O.icp_linearize(qo[0], ots[k], T, B_MAX, RHO_KER, B_RATIO)
+            assert np.array_equal(g["corr"][k] & 0x7FFFFFFF, corr)
+            assert np.array_equal((g["corr"][k] >> 31).astype(np.uint8), rej)
+        _teardown(ctx, tids, mids)
+    finally:
+        ctx.set_option("lds_stage_min_leaves", 1024)
+
+
+def test_small_trees_fit_entirely_in_the_lds_top(ctx):
+    """A tree with fewer internal nodes than the LDS top array is walked entirely in LDS (four-walls tool cloud)."""
+    ctx.set_option("lds_stage_min_leaves", 0)
+    try:
+        np.random.seed(42)
+        ref = four_walls(400)
+        rt, ro = build_pair(ref)
+        qt = capi.HostTree(ref + 0.01, B_MAX, B_MIN, 0)
+        qo = O.Tree(ref + 0.01, B_MAX, B_MIN, 0)
+        assert rt.num_leaves < 2000
+        tid = ctx.tree_upload(rt.nodes, rt.num_leaves)
+        mid = ctx.moving_upload(qt.leaf_means())
+        g = ctx.icp_linearize(mid, [tid], np.eye(4), PARAMS, qt.num_leaves)
+        _, _, corr, rej, _, depth = O.icp_linearize(qo, ro, np.eye(4), B_MAX, RHO_KER, B_RATIO)
+        assert np.array_equal(g["corr"][0] & 0x7FFFFFFF, corr) and np.array_equal((g["corr"][0] >> 31).astype(np.uint8), rej)
+        assert g["visits"] == depth
+        _teardown(ctx, [tid], [mid])
+    finally:
+        ctx.set_option("lds_stage_min_leaves", 1024)
 
 
 def test_register_is_deterministic_and_graph_equals_eager(ctx):

@@ -19,15 +19,9 @@ for s in pb["query_scans"]:
     h = capi.HostTree(s, 0.2, 0.1, 3); mids.append(ctx.moving_upload(h.leaf_means()))
 X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
 P = (0.2, 0.1, 0.02)
-ctx.set_option("time_kernels", 1)
-for bpc in (1, 2, 3, 4, 8):
+for bpc in (2, 3):
     ctx.set_option("grid_blocks_per_cu", bpc)
-    for flags in (0, 2, 4, 6):
+    for flags in (0, 4, 128, 256, 128 + 4):
         os.environ["MADICP_ABLATE_FLAGS"] = str(flags)
-        for _ in range(2):
-            ctx.icp_register_batch_enqueue(mids, tids, X0, P, 15)
-        ctx.kernel_time()
-        for _ in range(5):
-            ctx.icp_register_batch_enqueue(mids, tids, X0, P, 15)
-        nl, ms = ctx.kernel_time()
-        print("bpc %d flags %d (%s): linearize avg %.2f us" % (bpc, flags, {0: "full", 2: "no-reduce", 4: "no-descent", 6: "neither"}[flags], ms / nl * 1e3), flush=True)
+        us, _ = ctx.icp_time_linearize(mids, tids, X0, P, 40)
+        print("bpc %d flags %d: linearize avg %.2f us" % (bpc, flags, us), flush=True)

@@ -25,7 +25,7 @@ for s in pb["query_scans"]:
 print("L", Ls)
 X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
 P = (0.2, 0.1, 0.02)
-for opts in [dict(use_graph=1, grid_blocks_per_cu=4), dict(grid_blocks_per_cu=2), dict(grid_blocks_per_cu=1), dict(grid_blocks_per_cu=3), dict(grid_blocks_per_cu=8)]:
+for opts in [dict(grid_blocks_per_cu=b, lds_stage_min_leaves=m) for b in (1, 3) for m in (0, 1 << 30)]:
     for k, v in opts.items():
         ctx.set_option(k, v)
     for _ in range(3):
@@ -41,8 +41,5 @@ for opts in [dict(use_graph=1, grid_blocks_per_cu=4), dict(grid_blocks_per_cu=2)
     err = np.linalg.inv(pb["query_gt"][0]) @ capi.pose44(r["X"][0])
     print(opts, "%.1f us/batch  %.0f reg/s  visits/round/pair %.2f  nmatched %s  terr %.4f" % (
         dt * 1e6, B / dt, r["visits"][0] / (15 * K * Ls[0]), r["n_matched"], np.linalg.norm(err[:3, 3])), flush=True)
-ctx.set_option("time_kernels", 1)
-for _ in range(5):
-    ctx.icp_register_batch_enqueue(mids, tids, X0, P, 15)
-nl, ms = ctx.kernel_time()
-print("linearize avg %.2f us over %d launches" % (ms / nl * 1e3, nl))
+us, v = ctx.icp_time_linearize(mids, tids, X0, P, 60)
+print("linearize avg %.2f us/launch, visits/launch %s" % (us, v))
