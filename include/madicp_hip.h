@@ -70,6 +70,7 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out);
 int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..8), "use_graph" (0/1), "queries_per_lane" (0=auto,1,2,4),
+ * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
  * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
 

@@ -70,11 +70,25 @@ static_assert(sizeof(CNode) == 16, "screening record is 16 bytes");
 constexpr double kScreenDelta = 9.6e-7;   // > 2^-20 + 32u, covers the rounding of |q-o|_1 and rho too
 constexpr double kScreenC = 6.0e-8;       // > 2^-24 (1 + 2^-23)
 
+// Dense per-leaf record, indexed by the leaf's getLeafs() ordinal: everything MADicp::update reads of the matched
+// leaf (mean_, eigenvectors_.col(0), bbox_(0): mad_icp.cpp:64-65,81,97).  The leaves are half of the nodes of the
+// exact array and are interleaved with internal nodes there, so fetching them from it touches twice the cache lines
+// and — measured — the scattered, L2-missing leaf fetch cost more than the whole descent.  The ordinal needs no
+// lookup: a sub-tree with s nodes has (s+1)/2 leaves, so going right at a node adds right/2 to the running ordinal.
+struct LeafRec {
+  double mean[3];
+  double normal[3];
+  double bbox0;
+  double pad_;
+};
+static_assert(sizeof(LeafRec) == 64, "leaf record is one 64-byte line");
+
 // what a kernel needs to walk one tree; held by value in the Job / passed as a kernel argument so that no
 // dependent pointer chase precedes the first node load
 struct TreeDesc {
   const madicp_node* nodes;
   const CNode* cnodes;   // screening records, same indexing as nodes
+  const LeafRec* leaves; // dense leaf records, indexed by leaf ordinal
   double origin[3];      // o: mean of node 0
   double rho;            // >= |m - o|_1 for every internal node (sqrt(3) * max |m - o|_2)
   // the hot top of the tree, staged into LDS by icp_linearize (see "LDS-staged top levels" below)
@@ -95,6 +109,7 @@ struct TreeDesc {
 //   bit 13 right child in top | bit 14 left child is a leaf | bit 15 right child is a leaf
 constexpr int kTopLevels = 11;
 constexpr int kTopMax = 2048;
+constexpr int kTopLdsBytes = kTopMax * (16 + 8);
 constexpr unsigned int kTopFirst = 0xfffu, kTopLeftIn = 1u << 12, kTopRightIn = 1u << 13, kTopLeftLeaf = 1u << 14,
                        kTopRightLeaf = 1u << 15;
 
@@ -116,6 +131,8 @@ struct Job {
   uint8_t* matched;      // (L) matched_ flags of the last round
   uint32_t* corr;        // optional (K,L) correspondence trace
   double* x_iters;       // optional (n_iters,12) pose before each round
+  uint32_t* cache_leaf;  // optional (K,L): leaf node index | depth << 26 found at an earlier round (see "Correspondence reuse")
+  float* cache_margin;   // optional (K,L): how far that leaf may still move before any side test on its path can flip
   int32_t L;
   int32_t K;
   int32_t n_iters;
@@ -124,15 +141,19 @@ struct Job {
   int32_t n_matched;
   unsigned long long visits;  // internal nodes visited (all rounds; exact: integer-valued doubles summed)
   double X[12];          // R row-major, t
+  double Xprev[12];      // pose the previous round linearised at (written by the solve)
   double min_ball, rho, b_ratio;
   double H[36];          // row-major, of the last round
   double b[6];
   double n_pairs;        // accepted (leaf,tree) pairs of the last round
   int32_t ranges_per_tree;  // launch geometry: every tree's moving leaves are cut into this many ranges
   int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
+  int32_t lds_top;          // 1 when the launch carries kTopLdsBytes of dynamic LDS
+  int32_t pad2_;
   TreeDesc trees[MADICP_MAX_TREES];
 };
 constexpr int kFlagNoUpdate = 1;
+constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (option cache_correspondences = 0)
 
 // ---------------------------------------------------------------------------------------------------
 // fp64 helpers with the reference's evaluation order (see oracle/linalg.h for the derivation).
@@ -183,10 +204,19 @@ __device__ __forceinline__ bool exact_goes_left(const madicp_node* __restrict__ 
   return dotc(q0 - a.x, q1 - a.y, q2 - b.x, b.y, c.x, c.y) < 0.0;
 }
 
+// the same test, returning the reference's computed fp64 value s = fl((q-m).n)
+__device__ __forceinline__ double exact_side_value(const madicp_node* __restrict__ nodes, int idx, double q0, double q1,
+                                                   double q2) {
+  gptr_d2 p = (gptr_d2)(uintptr_t)(nodes + idx);
+  const vd2 a = p[0], b = p[1], c = p[2];
+  return dotc(q0 - a.x, q1 - a.y, q2 - b.x, b.y, c.x, c.y);
+}
+
 // per (query, tree) constants of the screening test
 struct Screen {
   double r0, r1, r2;  // (q - o) * 2^-20
   double slack;       // kScreenDelta * (|q-o|_1 + rho)
+  double xslack;      // bound on |s_computed - S_real| of the exact expression: 4.1u * sum|q_i - m_i|, rounded far up
 };
 __device__ __forceinline__ Screen make_screen(const TreeDesc& td, double q0, double q1, double q2) {
   const double e0 = q0 - td.origin[0], e1 = q1 - td.origin[1], e2 = q2 - td.origin[2];
@@ -196,6 +226,7 @@ __device__ __forceinline__ Screen make_screen(const TreeDesc& td, double q0, dou
   s.r1 = e1 * 9.5367431640625e-07;
   s.r2 = e2 * 9.5367431640625e-07;
   s.slack = kScreenDelta * ((fabs(e0) + fabs(e1) + fabs(e2)) + rho);
+  s.xslack = 1e-14 * ((fabs(e0) + fabs(e1) + fabs(e2)) + rho) + 1e-300;
   return s;
 }
 
@@ -212,30 +243,53 @@ __device__ __forceinline__ bool screened_goes_left(const vu4 w, const Screen& sc
 }
 
 // greedy root->leaf descent, no backtracking (mad_tree.cpp:144-152), screened.  Returns the leaf's index in the
-// node array; depth = internal nodes visited.
-__device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1, double q2, int& depth) {
+// node array; leaf = its getLeafs() ordinal; depth = internal nodes visited.
+__device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1, double q2, int& leaf, int& depth) {
   gptr_u4 cn = (gptr_u4)(uintptr_t)td.cnodes;
   const Screen sc = make_screen(td, q0, q1, q2);
-  int idx = 0, d = 0;
+  int idx = 0, d = 0, lb = 0;
   for (;;) {
     const vu4 w = cn[idx];
     const unsigned int roff = w.w & kRightMask;
     if (roff == 0u) break;  // single-node tree: the root itself is the leaf
     const bool left = screened_goes_left(w, sc, td.nodes, idx, q0, q1, q2);
-    idx = left ? idx + 1 : idx + (int)roff;
+    if (left) {
+      idx += 1;
+    } else {
+      idx += (int)roff;
+      lb += (int)(roff >> 1);  // leaves of the left sub-tree
+    }
     ++d;
     if (w.w & (left ? kLeftLeaf : kRightLeaf)) break;
   }
   depth = d;
+  leaf = lb;
   return idx;
 }
 
+// Correspondence reuse across Gauss-Newton rounds (exact, not approximate).
+// While walking, a lane also keeps M = min over the visited levels of (|s^| - E): a proven lower bound of
+// |S_real| = |(q - m).n| at every node of its path (|s^ - S_real| <= E, section "Exact screening").  Moving the
+// query by d changes every S_real by at most d|n| <= d(1 + 2e-16).  So if, in a later round, the leaf has moved by
+// less than M in total (sum of the per-round displacements, each computed from the two poses), every side test on
+// the old path still has the sign it had — and |S_real| stays far above the fp64 rounding of the reference's own
+// evaluation — hence the reference's descent would end in the same leaf after the same number of steps.  The lane
+// then skips the walk and only refreshes the margin.  GN converges quadratically (leaf displacement per round at
+// config 3: 3e-1, 2e-2, 1e-3, 7e-5, 6e-6, ... m), so from the 4th round on almost every pair is reused.  The cache
+// is per (tree, leaf): leaf ordinal | depth << 26, and the margin as a float rounded DOWN.  Levels decided by the
+// exact fallback contribute |s| minus a generous bound on its rounding error (a lane that keeps walking keeps its
+// whole wave on the latency chain, so margins must not be thrown away).
+constexpr unsigned int kCacheIdxMask = 0x03ffffffu;
+constexpr int kCacheMaxDepth = 63;
+
 // QPT independent descents per lane advanced in lock-step (their loads are issued together).  Phase 1 walks the
 // LDS copy of the tree's top levels (s_top / s_exit, n_top entries), phase 2 continues in global memory.
+// margin[j] (in/out): running minimum of |s^| - E over the levels walked.
 template <int QPT>
 __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_top, const int2* s_exit, int n_top,
                                               const double (&q0)[QPT], const double (&q1)[QPT], const double (&q2)[QPT],
-                                              const bool (&valid)[QPT], int (&idx)[QPT], unsigned int& visits) {
+                                              const bool (&valid)[QPT], int (&idx)[QPT], int (&leaf)[QPT],
+                                              int (&depth)[QPT], double (&margin)[QPT]) {
   gptr_u4 cn = (gptr_u4)(uintptr_t)td.cnodes;
   Screen sc[QPT];
   bool live[QPT];
@@ -244,8 +298,27 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
   for (int j = 0; j < QPT; ++j) {
     sc[j] = make_screen(td, q0[j], q1[j], q2[j]);
     idx[j] = 0;
+    leaf[j] = 0;
+    depth[j] = 0;
     live[j] = valid[j];
   }
+  // one screened side test that also lowers the margin; exact fallback -> margin 0
+  auto side = [&](const vu4 ww, int j, int node_index) -> bool {
+    const int k0 = ((int)(ww.x << 11)) >> 11;
+    const int k1 = ((int)(((ww.y << 22) | (ww.x >> 10)) & 0xfffff800u)) >> 11;
+    const int k2 = ((int)(ww.y << 1)) >> 11;
+    const double c = (double)__uint_as_float(ww.z);
+    const double sh = (sc[j].r0 * (double)k0 + sc[j].r1 * (double)k1) + sc[j].r2 * (double)k2 - c;
+    const double slack = sc[j].slack + kScreenC * fabs(c);
+    const double m = fabs(sh) - slack;
+    if (m > 0.0) {
+      margin[j] = fmin(margin[j], m);
+      return sh < 0.0;
+    }
+    const double sx = exact_side_value(td.nodes, node_index, q0[j], q1[j], q2[j]);
+    margin[j] = fmin(margin[j], fmax(fabs(sx) - sc[j].xslack, 0.0));  // NaN -> 0 (fmax returns the non-NaN operand)
+    return sx < 0.0;
+  };
   if (n_top > 0) {
     int e[QPT];
     bool intop[QPT];
@@ -264,16 +337,24 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
           const int k2 = ((int)(w[j].y << 1)) >> 11;
           const double c = (double)__uint_as_float(w[j].z);
           const double sh = (sc[j].r0 * (double)k0 + sc[j].r1 * (double)k1) + sc[j].r2 * (double)k2 - c;
+          const double m = fabs(sh) - (sc[j].slack + kScreenC * fabs(c));
           bool left;
-          if (fabs(sh) > sc[j].slack + kScreenC * fabs(c)) left = sh < 0.0;
-          else left = exact_goes_left(td.nodes, td.top_dfs[e[j]], q0[j], q1[j], q2[j]);
-          ++visits;
+          if (m > 0.0) {
+            margin[j] = fmin(margin[j], m);
+            left = sh < 0.0;
+          } else {
+            const double sx = exact_side_value(td.nodes, td.top_dfs[e[j]], q0[j], q1[j], q2[j]);
+            margin[j] = fmin(margin[j], fmax(fabs(sx) - sc[j].xslack, 0.0));
+            left = sx < 0.0;
+          }
+          ++depth[j];
           const unsigned int link = w[j].w;
+          const int2 ex = s_exit[e[j]];                       // node indices of the two children
+          if (!left) leaf[j] += (ex.y - ex.x + 1) >> 1;         // leaves of the left sub-tree = (its node count + 1) / 2
           if (link & (left ? kTopLeftIn : kTopRightIn)) {
             e[j] = (int)(link & kTopFirst) + ((!left && (link & kTopLeftIn)) ? 1 : 0);
             any = true;
           } else {
-            const int2 ex = s_exit[e[j]];
             idx[j] = left ? ex.x : ex.y;
             intop[j] = false;
             if (link & (left ? kTopLeftLeaf : kTopRightLeaf)) live[j] = false;  // arrived at a leaf
@@ -295,9 +376,14 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
         if (roff == 0u) {
           live[j] = false;
         } else {
-          const bool left = screened_goes_left(w[j], sc[j], td.nodes, idx[j], q0[j], q1[j], q2[j]);
-          idx[j] = left ? idx[j] + 1 : idx[j] + (int)roff;
-          ++visits;
+          const bool left = side(w[j], j, idx[j]);
+          if (left) {
+            idx[j] += 1;
+          } else {
+            idx[j] += (int)roff;
+            leaf[j] += (int)(roff >> 1);
+          }
+          ++depth[j];
           live[j] = !(w[j].w & (left ? kLeftLeaf : kRightLeaf));
           any |= live[j];
         }
@@ -333,7 +419,7 @@ __device__ __forceinline__ double make_record(const madicp_node& nd, double o0, 
 }
 
 // builds the screening records of a tree (after upload and after every transform); grid over nodes
-__global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnodes, int n) {
+__global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnodes, LeafRec* __restrict__ leaves, int n) {
   const madicp_node* __restrict__ nodes = tm->nodes;
   const double o0 = nodes[0].mean[0], o1 = nodes[0].mean[1], o2 = nodes[0].mean[2];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,6 +434,15 @@ __global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnod
       r = make_record(nd, o0, o1, o2, c);
       c.right = (unsigned int)nd.right | (nodes[i + 1].right == 0 ? kLeftLeaf : 0u) |
                 (nodes[i + nd.right].right == 0 ? kRightLeaf : 0u);
+    } else {
+      LeafRec lr;
+      for (int a = 0; a < 3; ++a) {
+        lr.mean[a] = nd.mean[a];
+        lr.normal[a] = nd.dir[a];
+      }
+      lr.bbox0 = nd.bbox0;
+      lr.pad_ = 0.0;
+      leaves[nd.leaf_id] = lr;
     }
     cnodes[i] = c;
   }
@@ -387,14 +482,14 @@ __global__ void nn_descend(const TreeDesc td, const double* __restrict__ q, long
                            double* __restrict__ out_dist, int32_t* __restrict__ out_depth) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
-    int depth;
-    const int idx = descend(td, q0, q1, q2, depth);
-    const NodeV leaf = load_node(td.nodes, idx);
-    if (out_leaf) out_leaf[i] = static_cast<uint32_t>(leaf.leaf_id);
+    int depth, leaf;
+    const int idx = descend(td, q0, q1, q2, leaf, depth);
+    if (out_leaf) out_leaf[i] = static_cast<uint32_t>(leaf);
     if (out_node) out_node[i] = static_cast<uint32_t>(idx);
     if (out_depth) out_depth[i] = depth;
     if (out_dist) {
-      const double e0 = q0 - leaf.m0, e1 = q1 - leaf.m1, e2 = q2 - leaf.m2;
+      const LeafRec* lr = td.leaves + leaf;
+      const double e0 = q0 - lr->mean[0], e1 = q1 - lr->mean[1], e2 = q2 - lr->mean[2];
       out_dist[i] = sqrt(dotc(e0, e1, e2, e0, e1, e2));
     }
   }
@@ -514,14 +609,25 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = job->X[9 + k];
   const double min_ball = job->min_ball, rho = job->rho, b_ratio = job->b_ratio;
+  uint32_t* __restrict__ cache_leaf = job->cache_leaf;
+  float* __restrict__ cache_margin = job->cache_margin;
+  const bool reuse = cache_leaf != nullptr && job->iter > 0 && !(job->flags & kFlagNoReuse);
+  double Rp[9], tp[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rp[k] = job->Xprev[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tp[k] = job->Xprev[9 + k];
 
   double acc[kAcc];
 #pragma unroll
   for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
   unsigned int visits = 0;
 
-  __shared__ vu4 s_top[kTopMax];
-  __shared__ int2 s_exit[kTopMax];
+  // top-level copy: dynamic LDS, present only when the host launched with kTopLdsBytes (units big enough to pay
+  // for the copy); a launch without it is not limited to three workgroups per CU by LDS
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
+  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
   int staged_tree = -1;
 
   const int S = (L + RPT - 1) / RPT;  // leaves per range
@@ -541,24 +647,14 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
     const int r = static_cast<int>(u - (long long)k * RPT);
     const int i_end = min(L, (r + 1) * S);
     const TreeDesc& td = job->trees[k];
-    // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves
-    const int n_top = (i_end - r * S >= job->stage_min_leaves) ? min(td.n_top, kTopMax) : 0;
-    if (n_top > 0 && k != staged_tree) {  // (workgroup-uniform) copy this tree's top levels into LDS
-      if (staged_tree >= 0) __syncthreads();
-      gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-      const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
-      for (int e = threadIdx.x; e < n_top; e += kBlock) {
-        s_top[e] = gt[e];
-        reinterpret_cast<long long*>(s_exit)[e] = ge[e];
-      }
-      __syncthreads();
-      staged_tree = k;
-    }
+    // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
+    // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
+    const int n_top_avail = (job->lds_top && i_end - r * S >= job->stage_min_leaves) ? min(td.n_top, kTopMax) : 0;
 
     for (int base = r * S; base < i_end; base += QPT * kBlock) {
-      double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT];
-      bool valid[QPT];
-      int idx[QPT];
+      double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
+      bool valid[QPT], walk[QPT];
+      int leaf[QPT], depth[QPT];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         const int i = base + j * kBlock + threadIdx.x;
@@ -570,34 +666,96 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
         q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
         q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
         q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+        walk[j] = valid[j];
+        margin[j] = 3.0e38;
+        if (reuse && valid[j]) {
+          // how far has this leaf moved since the previous round?  (same expression as above at the previous pose,
+          // so it reproduces the previous round's query bit for bit)
+          const double o0 = tp[0] + dots(Rp[0], Rp[1], Rp[2], p.x, p.y, p.z);
+          const double o1 = tp[1] + dots(Rp[3], Rp[4], Rp[5], p.x, p.y, p.z);
+          const double o2 = tp[2] + dots(Rp[6], Rp[7], Rp[8], p.x, p.y, p.z);
+          const double d0 = q0[j] - o0, d1 = q1[j] - o1, d2 = q2[j] - o2;
+          const double moved = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+          const long long ci = (long long)k * L + i;
+          const double left_over = (double)cache_margin[ci] - moved * (1.0 + 1e-12) -
+                                   1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
+                                            fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
+          if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
+            const unsigned int cw = cache_leaf[ci];
+            leaf[j] = (int)(cw & kCacheIdxMask);
+            depth[j] = (int)(cw >> 26);
+            cache_margin[ci] = __double2float_rd(left_over);
+            walk[j] = false;
+          }
+        }
       }
 #ifdef MADICP_ABLATE
-      if (job->flags & 4) {  // profiling only: no descent (the last node of a preorder array is a leaf)
+      if (job->flags & 4) {  // profiling only: no descent
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) idx[j] = 0;
+        for (int j = 0; j < QPT; ++j) { if (walk[j]) { leaf[j] = 0; depth[j] = 0; } }
       } else
 #endif
-      descend_multi<QPT>(td, s_top, s_exit, n_top, q0, q1, q2, valid, idx, visits);
+      {
+        if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform condition) copy the top levels into LDS on demand
+          bool need = false;
+#pragma unroll
+          for (int j = 0; j < QPT; ++j) need |= walk[j];
+          if (__syncthreads_or(need ? 1 : 0)) {
+            gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
+            const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+            for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
+              s_top[e] = gt[e];
+              reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+            }
+            __syncthreads();
+            staged_tree = k;
+          }
+        }
+        const int n_top = (k == staged_tree) ? n_top_avail : 0;
+        int widx[QPT], wleaf[QPT], wdepth[QPT];
+        descend_multi<QPT>(td, s_top, s_exit, n_top, q0, q1, q2, walk, widx, wleaf, wdepth, margin);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+          if (walk[j]) {
+            leaf[j] = wleaf[j];
+            depth[j] = wdepth[j];
+            if (cache_leaf) {
+              const long long ci = (long long)k * L + (base + j * kBlock + threadIdx.x);
+              const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
+              cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
+              cache_margin[ci] = cacheable ? __double2float_rd(margin[j]) : 0.f;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < QPT; ++j)
+        if (valid[j]) visits += (unsigned int)depth[j];
 
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         if (!valid[j]) continue;
         const int i = base + j * kBlock + threadIdx.x;
-        // gate (mad_icp.cpp:81-83) needs only the leaf's surface point: fetch the rest when the pair survives
-        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.nodes + idx[j]);
-        const vd2 la = lp[0], lb = lp[1];
+        // the matched leaf's record: one 64-byte line, its four 16-byte loads issued together (one round trip)
+#ifdef MADICP_ABLATE
+        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + ((job->flags & 2048) ? (leaf[j] & 7) : leaf[j]));  // profiling: no random gather
+#else
+        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + leaf[j]);
+#endif
+        const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+        // gate (mad_icp.cpp:81-83)
         const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
         const double src_ball = min_ball + b_ratio * pn[j];
         const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-        if (corr) {
-          const int leaf_id = (int)(__double_as_longlong(lp[3].x) >> 32);
-          corr[(long long)k * L + i] = static_cast<uint32_t>(leaf_id) | (rejected ? 0x80000000u : 0u);
-        }
+        if (corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
+#ifdef MADICP_ABLATE
+        if (job->flags & 1024) { acc[0] += g0 + lc.x + ld.x; continue; }  // profiling: no J/H arithmetic
+        if (job->flags & 4096) { if (((i >> 6) & 1) == 0) continue; } else  // profiling: accept/reject per whole wave
+#endif
         if (rejected) continue;
         if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 
-        const vd2 lc = lp[2];
-        const double bbox0 = lp[3].y;
+        const double bbox0 = ld.x;
         const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
 
         // errorAndJacobian (mad_icp.cpp:59-72)
@@ -818,6 +976,8 @@ __device__ __forceinline__ void gn_update(Job* job, const double* total) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) job->x_iters[(long long)it * 12 + i] = X[i];
   }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) job->Xprev[i] = X[i];  // the pose this round linearised at
   if (!(job->flags & kFlagNoUpdate)) {
     double nb[6], dx[6], dR[9];
 #pragma unroll

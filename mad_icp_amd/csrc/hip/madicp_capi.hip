@@ -44,6 +44,7 @@ int fail(int code, const std::string& msg) {
 struct DevTree {
   madicp_node* nodes = nullptr;
   CNode* cnodes = nullptr;    // 16-byte screening records, same indexing
+  LeafRec* leaves = nullptr;  // dense 64-byte leaf records, by leaf ordinal
   CNode* top = nullptr;       // top levels, breadth first (staged into LDS by icp_linearize)
   int2* top_exit = nullptr;
   int* top_dfs = nullptr;
@@ -57,18 +58,23 @@ struct DevMoving {
   double* xyzn = nullptr;  // (L,4)
   uint8_t* matched = nullptr;
   int32_t L = 0;
+  // correspondence cache of the registration in flight for this scan: (K,L) each, grown on demand
+  uint32_t* cache_leaf = nullptr;
+  float* cache_margin = nullptr;
+  int32_t cache_K = 0;
 };
 
 struct GraphKey {
-  int grid, batch, iters, qpt, comm;
+  int grid, batch, iters, qpt, comm, lds;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, qpt, comm) < std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm);
+    return std::tie(grid, batch, iters, qpt, comm, lds) < std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds);
   }
 };
 struct Geometry {
   int grid;             // workgroups per scan (multiple of 8)
   int ranges_per_tree;  // units per tree
   int qpt;              // leaves a lane walks at once: 1, 2 or 4
+  int lds_bytes;        // dynamic LDS of the launch: kTopLdsBytes when units are big enough to stage a tree's top, else 0
 };
 
 }  // namespace
@@ -102,8 +108,10 @@ struct madicp_ctx {
   int blocks_per_cu = 4;
   int use_graph = 1;
   int qpt_override = 0;
+  int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
-  int occ_blocks[3] = {4, 3, 2};  // icp_linearize<1|2|4> workgroups resident per CU (queried at create)
+  int occ_blocks[3] = {4, 3, 2};      // icp_linearize<1|2|4> workgroups resident per CU without dynamic LDS (queried at create)
+  int occ_blocks_lds[3] = {3, 3, 2};  // ... with kTopLdsBytes
 
   std::map<GraphKey, hipGraphExec_t> graphs;
 
@@ -133,30 +141,37 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
 // one (tree, range) unit per workgroup so that every workgroup gets the same number of leaves
 Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   Geometry g;
-  // One leaf per lane and pass (QPT > 1 only costs registers: the kernel is bound by the L1 address path and by
-  // miss latency, not by the number of waves — measured).  Workgroups per scan: what is resident at once for a
-  // single scan; for a batch at least one workgroup per CU and scan.
+  // One leaf per lane and pass (QPT > 1 only costs registers: each step then waits for the slowest of 128 lanes —
+  // measured).  Workgroups per scan: what is resident at once for a single scan; for a batch at least one
+  // workgroup per CU and scan.
   g.qpt = ctx->qpt_override ? ctx->qpt_override : 1;
-  const int occ = ctx->occ_blocks[g.qpt == 1 ? 0 : (g.qpt == 2 ? 1 : 2)];
-  const long long per_cu = std::max(1, std::min(ctx->blocks_per_cu, occ));
-  long long grid = std::max<long long>(ctx->n_cus, per_cu * ctx->n_cus / std::max(1, batch));
-  const long long max_useful = (long long)K * ((max_L + 63) / 64);  // never below one wave of leaves per unit
-  grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
-  g.grid = static_cast<int>(grid);
-  g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / K));
+  const int v = g.qpt == 1 ? 0 : (g.qpt == 2 ? 1 : 2);
+  g.lds_bytes = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int occ = pass ? ctx->occ_blocks_lds[v] : ctx->occ_blocks[v];
+    const long long per_cu = std::max(1, std::min(ctx->blocks_per_cu, occ));
+    long long grid = std::max<long long>(ctx->n_cus, per_cu * ctx->n_cus / std::max(1, batch));
+    const long long max_useful = (long long)K * ((max_L + 63) / 64);  // never below one wave of leaves per unit
+    grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
+    g.grid = static_cast<int>(grid);
+    g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / K));
+    const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
+    if (pass == 1 || per_range < ctx->stage_min_leaves) break;  // units too small to stage: no LDS, more workgroups
+    g.lds_bytes = kTopLdsBytes;                                 // else redo the sizing with the LDS-limited occupancy
+  }
   return g;
 }
 
-void launch_linearize(madicp_ctx* ctx, int grid, int batch, int qpt) {
+void launch_linearize(madicp_ctx* ctx, int grid, int batch, int qpt, int lds_bytes) {
   dim3 g(grid, batch), b(kBlock);
   void (*kern)(Job*, double*) = qpt == 1 ? icp_linearize<1> : (qpt == 2 ? icp_linearize<2> : icp_linearize<4>);
-  hipLaunchKernelGGL(kern, g, b, 0, ctx->stream, ctx->d_jobs, ctx->d_partials);
+  hipLaunchKernelGGL(kern, g, b, lds_bytes, ctx->stream, ctx->d_jobs, ctx->d_partials);
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
-int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int lds) {
   for (int it = 0; it < iters; ++it) {
-    launch_linearize(ctx, grid, batch, qpt);
+    launch_linearize(ctx, grid, batch, qpt, lds);
     if (ctx->comm) {
       hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
                          grid, ctx->d_totals);
@@ -182,16 +197,16 @@ int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
   return MADICP_OK;
 }
 
-int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt) {
+int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int lds) {
   // graphs: (conservatively) only without a communicator
   const bool graph_ok = ctx->use_graph && !ctx->comm;
-  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters, qpt);
-  const GraphKey key{grid, batch, iters, qpt, ctx->comm ? 1 : 0};
+  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters, qpt, lds);
+  const GraphKey key{grid, batch, iters, qpt, ctx->comm ? 1 : 0, lds};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_rounds(ctx, grid, batch, iters, qpt);
+    const int rc = enqueue_rounds(ctx, grid, batch, iters, qpt, lds);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != MADICP_OK) return rc;
     if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -237,18 +252,31 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   for (int s = 0; s < a.n_scans; ++s) {
     auto mit = ctx->movings.find(a.moving_ids[s]);
     if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
-    const DevMoving& mv = mit->second;
+    DevMoving& mv = mit->second;
+    if (a.n_iters > 1 && !a.time_launches && mv.cache_K < a.K) {  // (re)size this scan's correspondence cache
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      hipFree(mv.cache_leaf);
+      hipFree(mv.cache_margin);
+      mv.cache_leaf = nullptr;
+      mv.cache_margin = nullptr;
+      mv.cache_K = 0;
+      HIP_TRY(hipMalloc(&mv.cache_leaf, sizeof(uint32_t) * (size_t)a.K * mv.L));
+      HIP_TRY(hipMalloc(&mv.cache_margin, sizeof(float) * (size_t)a.K * mv.L));
+      mv.cache_K = a.K;
+    }
     Job& j = h_jobs[s];
     std::memset(&j, 0, offsetof(Job, trees));
     j.moving = mv.xyzn;
     j.matched = mv.matched;
+    j.cache_leaf = (a.n_iters > 1 && !a.time_launches) ? mv.cache_leaf : nullptr;
+    j.cache_margin = j.cache_leaf ? mv.cache_margin : nullptr;
     j.corr = (s == 0) ? a.d_corr : nullptr;
     j.x_iters = (s == 0) ? a.d_x_iters : nullptr;
     j.L = mv.L;
     j.K = a.K;
     j.n_iters = a.n_iters;
     j.iter = 0;
-    j.flags = a.flags;
+    j.flags = a.flags | (ctx->cache_corr ? 0 : kFlagNoReuse);
 #ifdef MADICP_ABLATE
     if (const char* f = getenv("MADICP_ABLATE_FLAGS")) j.flags |= atoi(f);  // profiling builds only
     if (const char* f = getenv("MADICP_ABLATE_CLEAR")) j.flags &= ~atoi(f);
@@ -271,6 +299,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   for (int s = 0; s < a.n_scans; ++s) {
     h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
     h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
+    h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
   }
   const int rc0 = ensure_partials(ctx, (size_t)a.n_scans * grid * kAcc);
   if (rc0 != MADICP_OK) return rc0;
@@ -295,7 +324,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
         hipLaunchKernelGGL(icp_solve, dim3(a.n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, grid);
     } else
 #endif
-    for (int i = 0; i < a.time_launches; ++i) launch_linearize(ctx, grid, a.n_scans, geo.qpt);
+    for (int i = 0; i < a.time_launches; ++i) launch_linearize(ctx, grid, a.n_scans, geo.qpt, geo.lds_bytes);
     HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, ctx->stream));  // warm-up replay
@@ -312,7 +341,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     if (a.out_avg_us) *a.out_avg_us = 1e3 * ms / a.time_launches;
     return MADICP_OK;
   }
-  return run_rounds(ctx, grid, a.n_scans, a.n_iters, geo.qpt);
+  return run_rounds(ctx, grid, a.n_scans, a.n_iters, geo.qpt, geo.lds_bytes);
 }
 
 }  // namespace
@@ -360,6 +389,9 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<1>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[0] = n;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<2>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[1] = n;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<4>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[2] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<1>, kBlock, kTopLdsBytes) == hipSuccess && n > 0) ctx->occ_blocks_lds[0] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<2>, kBlock, kTopLdsBytes) == hipSuccess && n > 0) ctx->occ_blocks_lds[1] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<4>, kBlock, kTopLdsBytes) == hipSuccess && n > 0) ctx->occ_blocks_lds[2] = n;
   }
   *out = ctx;
   return MADICP_OK;
@@ -374,6 +406,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   for (auto& t : ctx->trees) {
     hipFree(t.second.nodes);
     hipFree(t.second.cnodes);
+    hipFree(t.second.leaves);
     hipFree(t.second.top);
     hipFree(t.second.top_exit);
     hipFree(t.second.top_dfs);
@@ -383,6 +416,8 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   for (auto& m : ctx->movings) {
     hipFree(m.second.xyzn);
     hipFree(m.second.matched);
+    hipFree(m.second.cache_leaf);
+    hipFree(m.second.cache_margin);
   }
   if (ctx->ev_t0) hipEventDestroy(ctx->ev_t0);
   if (ctx->ev_t1) hipEventDestroy(ctx->ev_t1);
@@ -414,6 +449,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->blocks_per_cu = (int)value;
   } else if (k == "use_graph") {
     ctx->use_graph = value ? 1 : 0;
+  } else if (k == "cache_correspondences") {
+    ctx->cache_corr = value ? 1 : 0;
   } else if (k == "lds_stage_min_leaves") {
     if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
     ctx->stage_min_leaves = (int)std::min<int64_t>(value, 1 << 30);
@@ -431,7 +468,7 @@ namespace {
 // (re)build the 16-byte screening records and the tree's origin / radius on the device
 int compact_tree(madicp_ctx* ctx, DevTree& t) {
   HIP_TRY(hipMemsetAsync(&t.meta->rho2_bits, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(tree_compact, dim3((t.n_nodes + 255) / 256), dim3(256), 0, ctx->stream, t.meta, t.cnodes, t.n_nodes);
+  hipLaunchKernelGGL(tree_compact, dim3((t.n_nodes + 255) / 256), dim3(256), 0, ctx->stream, t.meta, t.cnodes, t.leaves, t.n_nodes);
   if (t.n_top > 0)
     hipLaunchKernelGGL(tree_compact_top, dim3((t.n_top + 255) / 256), dim3(256), 0, ctx->stream, t.nodes, t.top, t.top_dfs,
                        t.top_link, t.n_top);
@@ -441,6 +478,7 @@ int compact_tree(madicp_ctx* ctx, DevTree& t) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   t.desc.nodes = t.nodes;
   t.desc.cnodes = t.cnodes;
+  t.desc.leaves = t.leaves;
   t.desc.top = t.top;
   t.desc.top_exit = t.top_exit;
   t.desc.top_dfs = t.top_dfs;
@@ -481,6 +519,7 @@ void layout_top(const madicp_node* nodes, std::vector<int>& dfs, std::vector<uns
 void free_tree(DevTree& t) {
   hipFree(t.nodes);
   hipFree(t.cnodes);
+  hipFree(t.leaves);
   hipFree(t.top);
   hipFree(t.top_exit);
   hipFree(t.top_dfs);
@@ -500,6 +539,7 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   t.n_leaves = n_leaves;
   hipError_t e = hipMalloc(&t.nodes, sizeof(madicp_node) * (size_t)n_nodes);
   if (e == hipSuccess) e = hipMalloc(&t.cnodes, sizeof(CNode) * (size_t)n_nodes);
+  if (e == hipSuccess) e = hipMalloc(&t.leaves, sizeof(LeafRec) * (size_t)n_leaves);
   if (e == hipSuccess) e = hipMalloc(&t.meta, sizeof(TreeMeta));
   TreeMeta hm{};
   hm.nodes = t.nodes;
@@ -673,6 +713,8 @@ int madicp_moving_release(madicp_ctx* ctx, int moving_id) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   hipFree(it->second.xyzn);
   hipFree(it->second.matched);
+  hipFree(it->second.cache_leaf);
+  hipFree(it->second.cache_margin);
   ctx->movings.erase(it);
   return MADICP_OK;
 }

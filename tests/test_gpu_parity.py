@@ -268,6 +268,30 @@ def test_small_trees_fit_entirely_in_the_lds_top(ctx):
         ctx.set_option("lds_stage_min_leaves", 1024)
 
 
+@pytest.mark.parametrize("K", [1, 4])
+def test_correspondence_reuse_is_exact(ctx, K):
+    """Reusing a correspondence in a later GN round when its margin proves it unchanged must not change a single
+    bit: same poses before every round, same H, b, flags and the same count of visited nodes as walking every time."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
+    L = qh[0].num_leaves
+    res = {}
+    for on in (1, 0):
+        ctx.set_option("cache_correspondences", on)
+        res[on] = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, 15, L)
+    ctx.set_option("cache_correspondences", 1)
+    for key in ("X", "X_iters", "H", "b", "matched"):
+        assert np.array_equal(res[1][key], res[0][key]), key
+    assert res[1]["visits"] == res[0]["visits"]
+    # a second registration of the same scan from a different start must not see stale cache entries
+    T2 = pb["query_gt"][0]
+    a = ctx.icp_register(mids[0], tids, T2, PARAMS, 15, L)
+    ctx.set_option("cache_correspondences", 0)
+    b = ctx.icp_register(mids[0], tids, T2, PARAMS, 15, L)
+    ctx.set_option("cache_correspondences", 1)
+    assert np.array_equal(a["X_iters"], b["X_iters"]) and a["visits"] == b["visits"]
+    _teardown(ctx, tids, mids)
+
+
 def test_register_is_deterministic_and_graph_equals_eager(ctx):
     pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 2)
     L = qh[0].num_leaves

@@ -19,9 +19,10 @@ for s in pb["query_scans"]:
     h = capi.HostTree(s, 0.2, 0.1, 3); mids.append(ctx.moving_upload(h.leaf_means()))
 X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
 P = (0.2, 0.1, 0.02)
-for bpc in (2, 3):
-    ctx.set_option("grid_blocks_per_cu", bpc)
-    for flags in (0, 4, 128, 256, 128 + 4):
-        os.environ["MADICP_ABLATE_FLAGS"] = str(flags)
-        us, _ = ctx.icp_time_linearize(mids, tids, X0, P, 40)
-        print("bpc %d flags %d: linearize avg %.2f us" % (bpc, flags, us), flush=True)
+ctx.set_option("grid_blocks_per_cu", 3)
+for flags, name in ((0, "full"), (4, "no walk (leaf 0 for all: coalesced fetch, ~all rejected)"), (1024, "walk + fetch, no J/H arithmetic"),
+                    (2048, "walk, fetch from 8 records only"), (2048 + 1024, "walk only"), (4096, "accept/reject decided per wave (no divergence in the arithmetic)"),
+                    (4 + 4096, "no walk, per-wave accept"), (2, "no reduction")):
+    os.environ["MADICP_ABLATE_FLAGS"] = str(flags)
+    us, _ = ctx.icp_time_linearize(mids, tids, X0, P, 40)
+    print("flags %5d: %6.2f us  %s" % (flags, us, name), flush=True)
