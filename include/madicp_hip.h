@@ -141,6 +141,15 @@ int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_id
                               const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
                               uint64_t* out_visits_per_launch);
 
+/* Measurement aid: the registration exactly as madicp_icp_register_batch_enqueue runs it (captured graph,
+ * correspondence reuse and all), `reps` times between two hipEvents, then the same number of icp_solve launches
+ * alone.  out_linearize_avg_us = (registration - solves) / n_iters = average icp_linearize launch over the rounds of a
+ * registration (what a profiler's kernel trace of the registration averages to); out_solve_avg_us likewise;
+ * out_visits_per_launch (n_scans) = internal nodes visited per round, averaged over the rounds. */
+int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
+                                 const double* X0, const madicp_icp_params* params, int n_iters, int reps,
+                                 double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch);
+
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
 /* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte
  * ncclUniqueId produced by madicp_comm_unique_id on rank 0 and distributed by the caller (e.g. a

@@ -75,6 +75,8 @@ def hip_lib():
                                                         C.POINTER(IcpParams), C.c_int]
         L.madicp_icp_time_linearize.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
                                                 _dp, _u64p]
+        L.madicp_icp_time_registration.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
+                                                   C.c_int, _dp, _dp, _u64p]
         L.madicp_icp_fetch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_fetch_matched.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int32]
         L.madicp_comm_unique_id.argtypes = [_u8p]
@@ -312,6 +314,17 @@ class Context:
                                                    X0.ctypes.data_as(_dp), C.byref(p), n_launches, C.byref(us),
                                                    visits.ctypes.data_as(_u64p)))
         return us.value, visits
+
+    def icp_time_registration(self, mids, tree_ids, X0, params, n_iters, reps=30):
+        """(avg us per icp_linearize launch over a registration's rounds, avg us per icp_solve, visits per round per scan)."""
+        X0 = _f64(X0, (len(mids), 12))
+        p = IcpParams(*params)
+        lin, sol = C.c_double(0.0), C.c_double(0.0)
+        visits = np.zeros(len(mids), np.uint64)
+        _check(hip_lib().madicp_icp_time_registration(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
+                                                      X0.ctypes.data_as(_dp), C.byref(p), n_iters, reps, C.byref(lin),
+                                                      C.byref(sol), visits.ctypes.data_as(_u64p)))
+        return lin.value, sol.value, visits
 
     def icp_fetch(self, n_scans):
         X, H, b = np.empty((n_scans, 12)), np.empty((n_scans, 6, 6)), np.empty((n_scans, 6))

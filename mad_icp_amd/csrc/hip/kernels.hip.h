@@ -947,7 +947,7 @@ __device__ __forceinline__ void exp_so3(const double* w, double* R) {
 }
 
 // total: kAcc sums of this round (already joined over workgroups / ranks).  One lane.
-__device__ __forceinline__ void gn_update(Job* job, const double* total) {
+__device__ __forceinline__ void gn_update(Job* job, const double* total, const double (&X)[12], int it, int flags) {
   double H[36], b[6];
   {
     int v = 0;
@@ -968,17 +968,13 @@ __device__ __forceinline__ void gn_update(Job* job, const double* total) {
   for (int i = 0; i < 6; ++i) job->b[i] = b[i];
   job->n_pairs = total[27];
   job->visits += static_cast<unsigned long long>(total[28]);
-  const int it = job->iter;
-  double X[12];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) X[i] = job->X[i];
   if (job->x_iters) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) job->x_iters[(long long)it * 12 + i] = X[i];
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) job->Xprev[i] = X[i];  // the pose this round linearised at
-  if (!(job->flags & kFlagNoUpdate)) {
+  if (!(flags & kFlagNoUpdate)) {
     double nb[6], dx[6], dR[9];
 #pragma unroll
     for (int r = 0; r < 6; ++r) nb[r] = -b[r];
@@ -1068,7 +1064,12 @@ __global__ __launch_bounds__(kSolveThreads) void icp_solve(Job* __restrict__ job
                                                           int nblocks) {
   __shared__ double total[kAcc];
   Job* job = jobs + blockIdx.x;
-  const int iter = job->iter, n_iters = job->n_iters;
+  const int iter = job->iter, n_iters = job->n_iters, flags = job->flags;
+  double X[12];  // the solving lane fetches the pose now, so the load overlaps the join instead of following it
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) X[i] = job->X[i];
+  }
 #ifdef MADICP_ABLATE
   if (job->flags & 32) {  // profiling only: no join
     if (threadIdx.x < kAcc) total[threadIdx.x] = partials[threadIdx.x];
@@ -1081,7 +1082,7 @@ __global__ __launch_bounds__(kSolveThreads) void icp_solve(Job* __restrict__ job
 #ifdef MADICP_ABLATE
   if (job->flags & 64) return;  // profiling only: no update at all
 #endif
-  if (threadIdx.x == 0) gn_update(job, total);
+  if (threadIdx.x == 0) gn_update(job, total, X, iter, flags);
 }
 
 // multi-GPU: join -> totals[scan][kAcc] | ncclAllReduce(sum) | update | (last round) all-reduce(max) of the flags
@@ -1097,7 +1098,13 @@ __global__ __launch_bounds__(kSolveThreads) void icp_reduce(Job* __restrict__ jo
 }
 __global__ void icp_update(Job* __restrict__ jobs, const double* __restrict__ totals, int n_scans) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n_scans) gn_update(jobs + s, totals + s * kAcc);
+  if (s < n_scans) {
+    Job* job = jobs + s;
+    double X[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) X[i] = job->X[i];
+    gn_update(job, totals + s * kAcc, X, job->iter, job->flags);
+  }
 }
 __global__ __launch_bounds__(kSolveThreads) void icp_finish(Job* __restrict__ jobs) { count_matched(jobs + blockIdx.x); }
 

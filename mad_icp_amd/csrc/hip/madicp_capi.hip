@@ -826,6 +826,67 @@ int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_id
   return rc;
 }
 
+int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
+                                 const double* X0, const madicp_icp_params* params, int n_iters, int reps,
+                                 double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch) {
+  if (!ctx || reps < 1 || n_iters < 1) return fail(MADICP_ERR_INVALID, "bad argument");
+  if (ctx->comm) return fail(MADICP_ERR_INVALID, "not available with a communicator");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->ev_t0) {
+    HIP_TRY(hipEventCreate(&ctx->ev_t0));
+    HIP_TRY(hipEventCreate(&ctx->ev_t1));
+  }
+  RegArgs a{n_scans, moving_ids, tree_ids, K, X0, params, n_iters, 0, nullptr, nullptr};
+  int rc = enqueue_registration(ctx, a);  // warm-up; also instantiates the graph
+  if (rc != MADICP_OK) return rc;
+  HIP_TRY(hipEventRecord(ctx->ev_t0, ctx->stream));
+  for (int r = 0; r < reps; ++r) {
+    rc = enqueue_registration(ctx, a);
+    if (rc != MADICP_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  float ms_reg = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms_reg, ctx->ev_t0, ctx->ev_t1));
+  if (out_visits_per_launch) {
+    rc = madicp_icp_fetch(ctx, n_scans, nullptr, nullptr, nullptr, nullptr, out_visits_per_launch);
+    if (rc != MADICP_OK) return rc;
+    for (int s = 0; s < n_scans; ++s) out_visits_per_launch[s] /= (uint64_t)n_iters;
+  }
+  // the same number of icp_solve launches alone (state frozen), replayed as a graph: what is left is icp_linearize
+  const Geometry geo = pick_geometry(ctx, [&] { int m = 0; for (int s = 0; s < n_scans; ++s) m = std::max(m, ctx->movings.at(moving_ids[s]).L); return m; }(), K, n_scans);
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < n_iters; ++i)
+    hipLaunchKernelGGL(icp_solve, dim3(n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, geo.grid);
+  HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+  HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  // freeze the jobs: no pose update, round counter far from the end
+  // one linearisation at X0 leaves valid partials behind; the solves then run in full (LDLT + pose update: the
+  // pose drifts, which is irrelevant here) with a round counter that never reaches "last"
+  RegArgs f{n_scans, moving_ids, tree_ids, K, X0, params, 1 << 20, 0, nullptr, nullptr, 1, nullptr};
+  rc = enqueue_registration(ctx, f);
+  if (rc == MADICP_OK) {
+    hipGraphLaunch(exec, ctx->stream);
+    hipEventRecord(ctx->ev_t0, ctx->stream);
+    for (int r = 0; r < reps; ++r) hipGraphLaunch(exec, ctx->stream);
+    hipEventRecord(ctx->ev_t1, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    float ms_solve = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_solve, ctx->ev_t0, ctx->ev_t1);
+    if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("solve timing: ") + hipGetErrorString(e));
+    if (rc == MADICP_OK) {
+      const double per_reg = 1e3 * ms_reg / reps, per_solves = 1e3 * ms_solve / reps;
+      if (out_solve_avg_us) *out_solve_avg_us = per_solves / n_iters;
+      if (out_linearize_avg_us) *out_linearize_avg_us = (per_reg - per_solves) / n_iters;
+    }
+  }
+  hipGraphExecDestroy(exec);
+  hipGraphDestroy(graph);
+  return rc;
+}
+
 // ---- multi-GPU --------------------------------------------------------------------------------------
 int madicp_comm_unique_id(uint8_t out_id[128]) {
   if (!out_id) return fail(MADICP_ERR_INVALID, "out_id is null");
