@@ -10,11 +10,15 @@ the whole device-resident GN loop and leaves (X, H, b, matched flags) on the dev
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (one rank per GPU, RCCL over xGMI):
-  --mode shard    (default) the 16 keyframe trees are sharded round-robin over the ranks and every GN round
-                  ends with one all-reduce of [H(21) b(6) n] — BASELINE configs[3].  Total work is fixed:
-                  "scaling": "strong".
-  --mode replica  every rank holds all 16 trees and registers its own scans; no collective ("weak").
+N > 1 (one rank per GPU):
+  --mode replica  (default) the unit of work is a registration and registrations are independent, so they are
+                  partitioned over the ranks: every rank holds the whole 16-keyframe map (43 MB) and registers its
+                  own scans; no data-path collective; per-GPU work fixed: "scaling": "weak".
+  --mode shard    BASELINE configs[3]: the 16 keyframe trees are sharded round-robin over the ranks and every GN
+                  round of every registration ends with one RCCL all-reduce of [H(21) b(6) n v] over xGMI, enqueued
+                  by the library between its kernels; the matched flags are OR-ed once.  Total work fixed: "strong".
+                  (A single registration is ~20 us of work per round per GPU: the all-reduce latency dominates, so
+                  this mode is about capacity/latency, not throughput — DESIGN.md section 7.)
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (icp_linearize): algorithmic bytes per
 launch (24 + 64*d + 64 + 1 per (leaf, tree) pair, + 216 B of (H,b)) over its average duration,
@@ -44,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--keyframes", type=int, default=16)
     ap.add_argument("--scans", type=int, default=1, help="scans registered in flight per step")
-    ap.add_argument("--mode", choices=["shard", "replica"], default="shard")
+    ap.add_argument("--mode", choices=["shard", "replica"], default="replica")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-baseline", choices=["auto", "off"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU time budget of the baseline sample")
@@ -83,7 +87,7 @@ def main():
 
     K, B = args.keyframes, args.scans
     sharded = world > 1 and args.mode == "shard"
-    pb = synth.make_problem(K, seed=args.seed, n_queries=B)
+    pb = synth.make_problem(K, seed=args.seed, n_queries=B, query_stream=(0 if sharded else rank))
 
     stream = torch.cuda.Stream()
     ctx = capi.Context(local_rank, stream.cuda_stream)
@@ -202,7 +206,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong" if (sharded or world == 1) else "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

@@ -116,12 +116,15 @@ def perturbation(seed, trans=0.3, rot_deg=1.0):
     return T
 
 
-def make_problem(n_keyframes, seed=0, spacing=3.0, query_offset=1.2, n_beams=N_BEAMS, n_azimuth=N_AZIMUTH, n_queries=1):
+def make_problem(n_keyframes, seed=0, spacing=3.0, query_offset=1.2, n_beams=N_BEAMS, n_azimuth=N_AZIMUTH, n_queries=1,
+                 query_stream=0):
     """Keyframe scans + query scans for a registration benchmark.
 
     Returns dict(keyframe_scans [K x (N,3) sensor frame], keyframe_poses [K x 4x4], query_scans [Q x (N,3)],
     query_gt [Q x 4x4], query_guess [Q x 4x4]).  Keyframes sit `spacing` metres apart; query q is rendered
     `query_offset` (+0.35 q) metres past the last keyframe; the guess is GT composed with a seeded perturbation.
+    `query_stream` selects an independent set of query scans (other noise, other perturbation, pose shifted by 5 cm
+    per stream) over the same keyframes — one stream per rank in bench.py's replica mode.
     """
     scene = Scene(seed)
     kf_scans, kf_poses = [], []
@@ -131,9 +134,9 @@ def make_problem(n_keyframes, seed=0, spacing=3.0, query_offset=1.2, n_beams=N_B
         kf_scans.append(render_scan(scene, T, seed * 1000 + k, n_beams=n_beams, n_azimuth=n_azimuth))
     q_scans, q_gt, q_guess = [], [], []
     for q in range(n_queries):
-        T = path_pose((n_keyframes - 1) * spacing + query_offset + 0.35 * q)
+        T = path_pose((n_keyframes - 1) * spacing + query_offset + 0.35 * q + 0.05 * query_stream)
         q_gt.append(T)
-        q_scans.append(render_scan(scene, T, seed * 1000 + 500 + q, n_beams=n_beams, n_azimuth=n_azimuth))
-        q_guess.append(T @ perturbation(seed * 1000 + 900 + q))
+        q_scans.append(render_scan(scene, T, seed * 1000 + 500 + q + 7919 * query_stream, n_beams=n_beams, n_azimuth=n_azimuth))
+        q_guess.append(T @ perturbation(seed * 1000 + 900 + q + 7919 * query_stream))
     return dict(keyframe_scans=kf_scans, keyframe_poses=kf_poses, query_scans=q_scans, query_gt=q_gt,
                 query_guess=q_guess)

@@ -37,11 +37,11 @@ def test_registration_onto_own_tree_recovers_identity(ctx, big):
     tid = ctx.upload(ht)
     mid = ctx.moving_upload(ht.leaf_means())
     g = ctx.icp_register(mid, [tid], synth.perturbation(5), PARAMS, 15, ht.num_leaves)
-    assert np.abs(g["T"] - np.eye(4)).max() < 1e-9
+    assert np.abs(g["T"] - np.eye(4)).max() < 1e-7
     assert g["matched"].all()
     # idempotence: starting from the answer stays at the answer
     g2 = ctx.icp_register(mid, [tid], g["T"], PARAMS, 15, ht.num_leaves)
-    assert np.abs(g2["T"] - np.eye(4)).max() < 1e-9
+    assert np.abs(g2["T"] - np.eye(4)).max() < 1e-7
     ctx.tree_release(tid)
     ctx.moving_release(mid)
 
