@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((11685.2 + 197.6) * 1024)  # FETCH_SIZE + WRITE_SIZE (KiB) per icp_linearize launch, config 3
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((9274.5 + 1533.9) * 1024)  # FETCH_SIZE + WRITE_SIZE (KiB) per icp_linearize launch, averaged over a registration, config 3
 
 
 def parse():
@@ -73,9 +73,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    # MADICP_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
+    # share devices; replica mode only — RCCL refuses two ranks on one GPU)
+    backend = os.environ.get("MADICP_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    small = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from mad_icp_amd import _build, capi, synth
 
@@ -90,7 +98,7 @@ def main():
     pb = synth.make_problem(K, seed=args.seed, n_queries=B, query_stream=(0 if sharded else rank))
 
     stream = torch.cuda.Stream()
-    ctx = capi.Context(local_rank, stream.cuda_stream)
+    ctx = capi.Context(device_index, stream.cuda_stream)
     for kv in args.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -115,7 +123,7 @@ def main():
     params = (B_MAX, RHO_KER, B_RATIO)
 
     if sharded:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        uid = torch.zeros(128, dtype=torch.uint8, device=small)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
@@ -138,7 +146,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=small)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,7 +175,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "icp_linearize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (B == 1 and K == 16) else None,
-                    "traffic_source": "profiles/r1_f_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                    "traffic_source": "profiles/r1_m_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                       "same workload; uncorrected, the gfx950 half-counting caveat would at most double it)",
                     "avg_launch_us": round(avg_us, 2), "first_round_launch_us": round(first_us, 2),
                     "solve_launch_us": None if solve_us is None else round(solve_us, 2), "rounds": N_ITERS,
