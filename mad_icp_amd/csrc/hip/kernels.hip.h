@@ -150,6 +150,9 @@ struct Job {
   int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
   int32_t lds_top;          // 1 when the launch carries kTopLdsBytes of dynamic LDS
   int32_t pad2_;
+#ifdef MADICP_ABLATE
+  unsigned long long* dbg;  // profiling builds: per-workgroup phase time stamps of the last launch
+#endif
   TreeDesc trees[MADICP_MAX_TREES];
 };
 constexpr int kFlagNoUpdate = 1;
@@ -593,7 +596,14 @@ __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane,
 // partials: [scan][gridDim.x][kAcc]
 // ---------------------------------------------------------------------------------------------------
 template <int QPT>
-__global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, double* __restrict__ partials) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_linearize(Job* __restrict__ jobs, double* __restrict__ partials) {
+#ifdef MADICP_ABLATE
+  const unsigned long long ts0 = wall_clock64();
+  unsigned long long ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+#define MADICP_STAMP(x) x = wall_clock64()
+#else
+#define MADICP_STAMP(x)
+#endif
   Job* job = jobs + blockIdx.y;
   const int L = job->L;
   const int K = job->K;
@@ -630,6 +640,7 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
   int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
   int staged_tree = -1;
 
+  MADICP_STAMP(ts1);  // prologue done (job fields requested)
   const int S = (L + RPT - 1) / RPT;  // leaves per range
   const long long U = (long long)K * RPT;
   const int xcd = blockIdx.x & 7;
@@ -655,12 +666,31 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
       double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
       bool valid[QPT], walk[QPT];
       int leaf[QPT], depth[QPT];
+      // every load of this pass that does not depend on another one is issued first — the leaf's coordinates and
+      // its cached correspondence — so a walk-free pass is two memory round trips (these, then the leaf record)
+      vd4 pv[QPT];
+      float cmar[QPT];
+      unsigned int cword[QPT];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         const int i = base + j * kBlock + threadIdx.x;
         valid[j] = i < i_end;
-        vd4 p = {0.0, 0.0, 0.0, 0.0};
-        if (valid[j]) p = ((gptr_d4)(uintptr_t)moving)[i];
+        pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
+        cmar[j] = 0.f;
+        cword[j] = 0u;
+        if (valid[j]) {
+          pv[j] = ((gptr_d4)(uintptr_t)moving)[i];
+          if (reuse) {
+            const long long ci = (long long)k * L + i;
+            cmar[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
+            cword[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const int i = base + j * kBlock + threadIdx.x;
+        const vd4 p = pv[j];
         px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
         // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
         q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
@@ -668,6 +698,8 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
         q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
         walk[j] = valid[j];
         margin[j] = 3.0e38;
+        leaf[j] = 0;
+        depth[j] = 0;
         if (reuse && valid[j]) {
           // how far has this leaf moved since the previous round?  (same expression as above at the previous pose,
           // so it reproduces the previous round's query bit for bit)
@@ -676,15 +708,13 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
           const double o2 = tp[2] + dots(Rp[6], Rp[7], Rp[8], p.x, p.y, p.z);
           const double d0 = q0[j] - o0, d1 = q1[j] - o1, d2 = q2[j] - o2;
           const double moved = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-          const long long ci = (long long)k * L + i;
-          const double left_over = (double)cache_margin[ci] - moved * (1.0 + 1e-12) -
+          const double left_over = (double)cmar[j] - moved * (1.0 + 1e-12) -
                                    1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
                                             fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
           if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
-            const unsigned int cw = cache_leaf[ci];
-            leaf[j] = (int)(cw & kCacheIdxMask);
-            depth[j] = (int)(cw >> 26);
-            cache_margin[ci] = __double2float_rd(left_over);
+            leaf[j] = (int)(cword[j] & kCacheIdxMask);
+            depth[j] = (int)(cword[j] >> 26);
+            cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
             walk[j] = false;
           }
         }
@@ -712,8 +742,25 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
           }
         }
         const int n_top = (k == staged_tree) ? n_top_avail : 0;
+        // The lane's QPT leaves share their LOADS (coordinates, cache, leaf record: issued together above and below),
+        // but they are WALKED one after the other: interleaved walks make every step wait for the slowest of
+        // 64*QPT lanes and were measured slower than back-to-back ones.
         int widx[QPT], wleaf[QPT], wdepth[QPT];
-        descend_multi<QPT>(td, s_top, s_exit, n_top, q0, q1, q2, walk, widx, wleaf, wdepth, margin);
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+          const double a0[1] = {q0[j]}, a1[1] = {q1[j]}, a2[1] = {q2[j]};
+          const bool wv[1] = {walk[j]};
+          int xi[1], xl[1], xd[1];
+          double xm[1] = {margin[j]};
+          bool any_walk = walk[j];
+          if (QPT > 1) any_walk = __any(walk[j]);  // skip the whole (wave-uniform) call when nobody in the wave walks
+          if (any_walk) {
+            descend_multi<1>(td, s_top, s_exit, n_top, a0, a1, a2, wv, xi, xl, xd, xm);
+            widx[j] = xi[0]; wleaf[j] = xl[0]; wdepth[j] = xd[0]; margin[j] = xm[0];
+          } else {
+            widx[j] = 0; wleaf[j] = 0; wdepth[j] = 0;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
           if (walk[j]) {
@@ -731,6 +778,9 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
 #pragma unroll
       for (int j = 0; j < QPT; ++j)
         if (valid[j]) visits += (unsigned int)depth[j];
+#ifdef MADICP_ABLATE
+      if (base == r * S) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MADICP_STAMP(ts2); }  // first pass: walk / reuse check done
+#endif
 
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
@@ -792,6 +842,7 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
     }
   }
 
+  MADICP_STAMP(ts3);  // all passes done (fetch + arithmetic included)
   // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
   acc[28] = static_cast<double>(visits);  // integer-valued: its sums are exact in any order
   __shared__ double red[kWaves][32];
@@ -815,13 +866,21 @@ __global__ __launch_bounds__(kBlock) void icp_linearize(Job* __restrict__ jobs, 
     return;
   }
 #endif
+  MADICP_STAMP(ts4);
   __syncthreads();
+  MADICP_STAMP(ts5);
   if (threadIdx.x < kAcc) {
     double s = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
     partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * kAcc + threadIdx.x] = s;
   }
+#ifdef MADICP_ABLATE
+  if (job->dbg && (threadIdx.x & 63) == 0) {
+    unsigned long long* d = job->dbg + ((long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
+    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = ts5; d[6] = wall_clock64(); d[7] = blockIdx.x;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------

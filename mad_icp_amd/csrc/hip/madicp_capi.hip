@@ -116,6 +116,9 @@ struct madicp_ctx {
   std::map<GraphKey, hipGraphExec_t> graphs;
 
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // madicp_icp_time_linearize
+#ifdef MADICP_ABLATE
+  unsigned long long* d_dbg = nullptr;
+#endif
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -278,6 +281,8 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     j.iter = 0;
     j.flags = a.flags | (ctx->cache_corr ? 0 : kFlagNoReuse);
 #ifdef MADICP_ABLATE
+    if (!ctx->d_dbg) hipMalloc(&ctx->d_dbg, sizeof(unsigned long long) * 8 * 4 * 4096);
+    j.dbg = ctx->d_dbg;
     if (const char* f = getenv("MADICP_ABLATE_FLAGS")) j.flags |= atoi(f);  // profiling builds only
     if (const char* f = getenv("MADICP_ABLATE_CLEAR")) j.flags &= ~atoi(f);
 #endif
@@ -886,6 +891,14 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
   hipGraphDestroy(graph);
   return rc;
 }
+
+#ifdef MADICP_ABLATE
+int madicp_debug_fetch(madicp_ctx* ctx, unsigned long long* out, int n_words) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpy(out, ctx->d_dbg, sizeof(unsigned long long) * (size_t)n_words, hipMemcpyDeviceToHost));
+  return MADICP_OK;
+}
+#endif
 
 // ---- multi-GPU --------------------------------------------------------------------------------------
 int madicp_comm_unique_id(uint8_t out_id[128]) {
