@@ -20,7 +20,7 @@ N > 1 (one rank per GPU):
                   (A single registration is ~20 us of work per round per GPU: the all-reduce latency dominates, so
                   this mode is about capacity/latency, not throughput — DESIGN.md section 7.)
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (icp_linearize): algorithmic bytes per
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (icp_round: one Gauss-Newton round): algorithmic bytes per
 launch (24 + 64*d + 64 + 1 per (leaf, tree) pair, + 216 B of (H,b)) over its average duration,
 measured with HIP events around a captured graph of back-to-back launches on the library's stream.  `cpu_baseline` is the CPU restatement
 of the reference's OpenMP path (oracle/, kind "port") timed on this box's host cores on a bounded sample.
@@ -158,10 +158,10 @@ def main():
     err = np.linalg.inv(pb["query_gt"][0]) @ capi.pose44(res["X"][0])
     terr = float(np.linalg.norm(err[:3, 3]))
 
-    # ---- roofline of the dominant kernel (icp_linearize), timed live with HIP events on the library's stream ----
+    # ---- roofline of the dominant kernel (icp_round), timed live with HIP events on the library's stream ----
     # (a) average launch over the 15 rounds of the registration exactly as timed above (graph, correspondence reuse):
-    #     (registration - the same number of icp_solve launches alone) / rounds — what a kernel trace averages to;
-    # (b) a first-round launch (every pair walked), as a graph of back-to-back launches.
+    #     (registration - icp_final alone) / rounds — what a kernel trace averages to;
+    # (b) a first-round launch (every pair walked, no solve prologue), as a graph of back-to-back launches.
     first_us, visits0 = ctx.icp_time_linearize(mids, tids, X0, params, 60)
     if sharded:  # with a communicator only (b) is available: use it for both
         avg_us, solve_us, visits = first_us, None, visits0
@@ -172,13 +172,13 @@ def main():
         visits_per_launch = float(visits.sum())
         alg_bytes = pairs_per_launch * (24 + 64 + 1) + 64.0 * visits_per_launch + 216.0 * B
         achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-        roofline = {"bound": "hbm", "kernel": "icp_linearize", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "icp_round", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (B == 1 and K == 16) else None,
                     "traffic_source": "profiles/r1_m_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                       "same workload; uncorrected, the gfx950 half-counting caveat would at most double it)",
                     "avg_launch_us": round(avg_us, 2), "first_round_launch_us": round(first_us, 2),
-                    "solve_launch_us": None if solve_us is None else round(solve_us, 2), "rounds": N_ITERS,
+                    "final_launch_us": None if solve_us is None else round(solve_us, 2), "rounds": N_ITERS,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "mean_descent_depth": round(visits_per_launch / pairs_per_launch, 3),
                     "note": "algorithmic bytes (SURVEY 8d: every visit = 64 B) are served by L1/L2/Infinity Cache and, in "

@@ -69,7 +69,7 @@ int madicp_abi_version(void);
 int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out);
 int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
-/* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..8), "use_graph" (0/1), "queries_per_lane" (0=auto,1,2,4),
+/* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
  * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
@@ -133,18 +133,18 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
 /* matched_ flags of scan `scan` of the last batch (L bytes). */
 int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, int32_t L);
 
-/* Measurement aid (bench.py's roofline): n_launches back-to-back launches of the dominant kernel (icp_linearize)
- * for this batch at pose X0, no state update, replayed as one captured graph between two hipEvents on the context's
- * stream.  out_avg_us = time per launch (a dependent dispatch's launch overhead included, as in a profiler trace of
- * the registration graph); out_visits_per_launch (n_scans, optional) = internal nodes visited by one launch. */
+/* Measurement aid (bench.py's roofline): n_launches back-to-back launches of the dominant kernel (icp_round, as
+ * round 0: every pair walked, no solve prologue) for this batch at pose X0, replayed as one captured graph between two
+ * hipEvents on the context's stream.  out_avg_us = time per launch (a dependent dispatch's launch overhead included, as
+ * in a profiler trace of the registration graph); out_visits_per_launch (n_scans, optional) = internal nodes visited. */
 int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
                               const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
                               uint64_t* out_visits_per_launch);
 
-/* Measurement aid: the registration exactly as madicp_icp_register_batch_enqueue runs it (captured graph,
- * correspondence reuse and all), `reps` times between two hipEvents, then the same number of icp_solve launches
- * alone.  out_linearize_avg_us = (registration - solves) / n_iters = average icp_linearize launch over the rounds of a
- * registration (what a profiler's kernel trace of the registration averages to); out_solve_avg_us likewise;
+/* Measurement aid: the registration exactly as madicp_icp_register_batch_enqueue runs it (captured graph of n_iters
+ * icp_round launches + icp_final, correspondence reuse and all), `reps` times between two hipEvents, then icp_final
+ * alone.  out_linearize_avg_us = (registration - icp_final) / n_iters = average icp_round launch over the rounds of a
+ * registration (what a profiler's kernel trace of the registration averages to); out_solve_avg_us = one icp_final;
  * out_visits_per_launch (n_scans) = internal nodes visited per round, averaged over the rounds. */
 int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
                                  const double* X0, const madicp_icp_params* params, int n_iters, int reps,

@@ -5,11 +5,12 @@
 //   moving_prep       : per moving leaf, cache |p| for the gate        (mad_icp.cpp:81, `moving->mean_.norm()`)
 //   nn_descend        : batched MADtree::bestMatchingLeafFast           (mad_tree.cpp:144-152, mad_tree_wrapper.h:48-67)
 //   tree_transform    : MADtree::applyTransform                         (mad_tree.cpp:165-172)
-//   icp_linearize     : MADicp::update over K trees, fused transform -> descent -> gate -> e,J -> weight ->
-//                       wave/block reduction of (H,b)                   (mad_icp.cpp:59-103 under pipeline.cpp:180-183)
-//   icp_solve         : adder join + LDLT + expSO3 + pose update        (mad_icp.cpp:105-117)
-//   icp_reduce/update : the same split in two around the RCCL all-reduce (multi-GPU)
-//   icp_finish        : matched-leaf count                              (pipeline.cpp:197-204)
+//   icp_round         : one Gauss-Newton round: [adder join + LDLT + expSO3 + pose update of the PREVIOUS round
+//                       (mad_icp.cpp:105-117), redundantly per workgroup] + MADicp::update over K trees at the new pose,
+//                       fused transform -> descent -> gate -> e,J -> weight -> wave/block reduction of (H,b)
+//                       (mad_icp.cpp:59-103 under pipeline.cpp:180-183)
+//   icp_final         : join + solve of the last round, matched-leaf count (pipeline.cpp:195-204)
+//   icp_reduce        : this rank's partials -> totals, in front of the RCCL all-reduce (multi-GPU)
 //
 // Numerics contract: IEEE fp64, the reference's (Eigen's) operation order, NO FMA contraction — every
 // branch decision (descent side test, gate) is bit-identical to the CPU path.  Enforced by the pragma
@@ -32,7 +33,7 @@
 
 namespace madicp {
 
-constexpr int kBlock = 256;          // threads per workgroup = 4 wave64
+constexpr int kBlock = 768;          // threads per icp_round workgroup = 12 wave64 = 3 per SIMD: ONE workgroup per CU
 constexpr int kWaves = kBlock / 64;
 constexpr int kAcc = 29;             // 21 (lower triangle of H, column by column) + 6 (b) + accepted pairs + nodes visited
 constexpr int kSolveThreads = 1024;
@@ -91,7 +92,7 @@ struct TreeDesc {
   const LeafRec* leaves; // dense leaf records, indexed by leaf ordinal
   double origin[3];      // o: mean of node 0
   double rho;            // >= |m - o|_1 for every internal node (sqrt(3) * max |m - o|_2)
-  // the hot top of the tree, staged into LDS by icp_linearize (see "LDS-staged top levels" below)
+  // the hot top of the tree, staged into LDS by icp_round (see "LDS-staged top levels" below)
   const CNode* top;      // n_top records, breadth-first over the first kTopLevels levels (internal nodes only)
   const int2* top_exit;  // per top entry: node index of its left / right child
   const int* top_dfs;    // per top entry: its own node index (only the exact-path fallback reads it)
@@ -124,7 +125,7 @@ struct TreeMeta {
 };
 
 // One registration in flight; lives in device memory, written by the host before each launch sequence
-// and advanced by icp_solve.  Keeping every per-registration quantity behind this one pointer is what lets
+// and advanced by workgroup 0 of every icp_round / by icp_final.  Keeping every per-registration quantity behind this one pointer is what lets
 // a single captured hipGraph serve every scan / keyframe set of the same launch geometry.
 struct Job {
   const double* moving;  // (L,4): x y z |p|  (sensor frame)
@@ -140,8 +141,8 @@ struct Job {
   int32_t flags;         // kFlagNoUpdate
   int32_t n_matched;
   unsigned long long visits;  // internal nodes visited (all rounds; exact: integer-valued doubles summed)
-  double X[12];          // R row-major, t
-  double Xprev[12];      // pose the previous round linearised at (written by the solve)
+  double X[12];          // final pose (R row-major, t), written by icp_final
+  double Xring[2][12];   // pose of round r lives in Xring[r & 1]; Xring[0] = initial guess (host)
   double min_ball, rho, b_ratio;
   double H[36];          // row-major, of the last round
   double b[6];
@@ -580,309 +581,30 @@ __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// icp_linearize
+// The Gauss-Newton round as ONE kernel.
 //
-// Work decomposition.  The moving leaves of a scan are cut into `ranges_per_tree` equal ranges; a *unit* is
-// (tree k, range r).  The host picks ranges_per_tree so that there is about one unit per workgroup, i.e. the
-// work is balanced to the workgroup instead of quantised to 256-leaf chunks (with ~1.25 chunks per workgroup
-// the kernel used to run as long as its 2-chunk workgroups).  Units are ordered tree-major and cut into 8
-// contiguous ranges, one per XCD; workgroup b runs on XCD b % 8 (observed dispatch rule — used for speed only,
-// never for correctness), so every XCD's private 4 MiB L2 only serves the nodes of its own ~K/8 trees.  A lane
-// walks QPT leaves at once (their node loads are issued together).  Moving leaves arrive in the DFS order of
-// the scan's own MAD-tree, i.e. spatially sorted, so the 64 lanes of a wave walk the same upper path (one
-// request per level for the whole wave) and only diverge near the leaves.
+// A registration is  n x { linearise at X_r ; join ; solve ; X_{r+1} = X_r dX }.  Run as two kernels per round the
+// solve (a single workgroup: join 2.8 us + a ~1000-instruction dependent fp64 chain on one lane 3.2 us + a
+// dependent dispatch 1.9 us) was 35 % of the registration, with 255 CUs idle.  Here round r's kernel STARTS with the
+// solve of round r-1, done redundantly by every workgroup: each joins the previous round's per-workgroup partials
+// (one per CU: 256 x 232 B, L2-resident after the first reader of an XCD) in the same fixed order and one of its lanes
+// runs the same LDLT, so all workgroups hold the bit-identical X_r without any inter-workgroup synchronisation; the
+// kernel boundary is the only barrier.  Workgroup 0 also does the bookkeeping (H, b, counters, X ring).  Partials and
+// poses are double-buffered by round parity because a fast workgroup may finish round r while a slow one is still
+// reading round r-1's.  After the last round a small icp_final joins/solves once more and counts the matched leaves.
+// Launches per registration: n + 1 instead of 2n.
+//
+// Work decomposition of the linearisation itself.  The moving leaves of a scan are cut into `ranges_per_tree` equal
+// ranges; a *unit* is (tree k, range r); the host picks the count so there is one unit per workgroup and one workgroup
+// (12 waves, 3 per SIMD — what the 140 VGPRs of the 29 fp64 accumulators + walk state allow) per CU.  Units are
+// ordered tree-major and cut into 8 contiguous pieces; workgroup b takes piece b % 8, i.e. (observed dispatch rule —
+// used for speed only, never for correctness) XCD b % 8 only walks its own K/8 trees, so each private 4 MiB L2 serves
+// 2 trees, not 16.  Moving leaves arrive in the DFS order of the scan's own MAD-tree, i.e. spatially sorted, so the
+// 64 lanes of a wave share the upper path and diverge only near the leaves.
 //
 // grid = (8 * slots, n_scans); blockIdx.y selects the registration (scans batched in flight).
-// partials: [scan][gridDim.x][kAcc]
+// partials: [2][n_scans][gridDim.x][kAcc] ; totals (multi-GPU): [n_scans][kAcc], already all-reduced
 // ---------------------------------------------------------------------------------------------------
-template <int QPT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_linearize(Job* __restrict__ jobs, double* __restrict__ partials) {
-#ifdef MADICP_ABLATE
-  const unsigned long long ts0 = wall_clock64();
-  unsigned long long ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
-#define MADICP_STAMP(x) x = wall_clock64()
-#else
-#define MADICP_STAMP(x)
-#endif
-  Job* job = jobs + blockIdx.y;
-  const int L = job->L;
-  const int K = job->K;
-  const int RPT = job->ranges_per_tree;
-  const bool last_round = (job->iter == job->n_iters - 1);
-  const double* __restrict__ moving = job->moving;
-  uint8_t* __restrict__ matched = job->matched;
-  uint32_t* __restrict__ corr = job->corr;
-
-  double R[9], t[3];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) R[k] = job->X[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) t[k] = job->X[9 + k];
-  const double min_ball = job->min_ball, rho = job->rho, b_ratio = job->b_ratio;
-  uint32_t* __restrict__ cache_leaf = job->cache_leaf;
-  float* __restrict__ cache_margin = job->cache_margin;
-  const bool reuse = cache_leaf != nullptr && job->iter > 0 && !(job->flags & kFlagNoReuse);
-  double Rp[9], tp[3];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) Rp[k] = job->Xprev[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) tp[k] = job->Xprev[9 + k];
-
-  double acc[kAcc];
-#pragma unroll
-  for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
-  unsigned int visits = 0;
-
-  // top-level copy: dynamic LDS, present only when the host launched with kTopLdsBytes (units big enough to pay
-  // for the copy); a launch without it is not limited to three workgroups per CU by LDS
-  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
-  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
-  int staged_tree = -1;
-
-  MADICP_STAMP(ts1);  // prologue done (job fields requested)
-  const int S = (L + RPT - 1) / RPT;  // leaves per range
-  const long long U = (long long)K * RPT;
-  const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int nslots = gridDim.x >> 3;
-  const long long lo = (xcd * U) >> 3;
-  const long long hi = ((xcd + 1) * U) >> 3;
-
-#ifdef MADICP_ABLATE
-  const int reps = (job->flags & 128) ? 2 : ((job->flags & 256) ? 3 : 1);  // profiling only: repeat the work (warm caches)
-  for (int rep = 0; rep < reps; ++rep)
-#endif
-  for (long long u = lo + slot; u < hi; u += nslots) {
-    const int k = static_cast<int>(u / RPT);
-    const int r = static_cast<int>(u - (long long)k * RPT);
-    const int i_end = min(L, (r + 1) * S);
-    const TreeDesc& td = job->trees[k];
-    // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
-    // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
-    const int n_top_avail = (job->lds_top && i_end - r * S >= job->stage_min_leaves) ? min(td.n_top, kTopMax) : 0;
-
-    for (int base = r * S; base < i_end; base += QPT * kBlock) {
-      double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
-      bool valid[QPT], walk[QPT];
-      int leaf[QPT], depth[QPT];
-      // every load of this pass that does not depend on another one is issued first — the leaf's coordinates and
-      // its cached correspondence — so a walk-free pass is two memory round trips (these, then the leaf record)
-      vd4 pv[QPT];
-      float cmar[QPT];
-      unsigned int cword[QPT];
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * kBlock + threadIdx.x;
-        valid[j] = i < i_end;
-        pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
-        cmar[j] = 0.f;
-        cword[j] = 0u;
-        if (valid[j]) {
-          pv[j] = ((gptr_d4)(uintptr_t)moving)[i];
-          if (reuse) {
-            const long long ci = (long long)k * L + i;
-            cmar[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
-            cword[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * kBlock + threadIdx.x;
-        const vd4 p = pv[j];
-        px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
-        // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
-        q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
-        q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
-        q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
-        walk[j] = valid[j];
-        margin[j] = 3.0e38;
-        leaf[j] = 0;
-        depth[j] = 0;
-        if (reuse && valid[j]) {
-          // how far has this leaf moved since the previous round?  (same expression as above at the previous pose,
-          // so it reproduces the previous round's query bit for bit)
-          const double o0 = tp[0] + dots(Rp[0], Rp[1], Rp[2], p.x, p.y, p.z);
-          const double o1 = tp[1] + dots(Rp[3], Rp[4], Rp[5], p.x, p.y, p.z);
-          const double o2 = tp[2] + dots(Rp[6], Rp[7], Rp[8], p.x, p.y, p.z);
-          const double d0 = q0[j] - o0, d1 = q1[j] - o1, d2 = q2[j] - o2;
-          const double moved = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-          const double left_over = (double)cmar[j] - moved * (1.0 + 1e-12) -
-                                   1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
-                                            fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
-          if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
-            leaf[j] = (int)(cword[j] & kCacheIdxMask);
-            depth[j] = (int)(cword[j] >> 26);
-            cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
-            walk[j] = false;
-          }
-        }
-      }
-#ifdef MADICP_ABLATE
-      if (job->flags & 4) {  // profiling only: no descent
-#pragma unroll
-        for (int j = 0; j < QPT; ++j) { if (walk[j]) { leaf[j] = 0; depth[j] = 0; } }
-      } else
-#endif
-      {
-        if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform condition) copy the top levels into LDS on demand
-          bool need = false;
-#pragma unroll
-          for (int j = 0; j < QPT; ++j) need |= walk[j];
-          if (__syncthreads_or(need ? 1 : 0)) {
-            gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-            const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
-            for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
-              s_top[e] = gt[e];
-              reinterpret_cast<long long*>(s_exit)[e] = ge[e];
-            }
-            __syncthreads();
-            staged_tree = k;
-          }
-        }
-        const int n_top = (k == staged_tree) ? n_top_avail : 0;
-        // The lane's QPT leaves share their LOADS (coordinates, cache, leaf record: issued together above and below),
-        // but they are WALKED one after the other: interleaved walks make every step wait for the slowest of
-        // 64*QPT lanes and were measured slower than back-to-back ones.
-        int widx[QPT], wleaf[QPT], wdepth[QPT];
-#pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-          const double a0[1] = {q0[j]}, a1[1] = {q1[j]}, a2[1] = {q2[j]};
-          const bool wv[1] = {walk[j]};
-          int xi[1], xl[1], xd[1];
-          double xm[1] = {margin[j]};
-          bool any_walk = walk[j];
-          if (QPT > 1) any_walk = __any(walk[j]);  // skip the whole (wave-uniform) call when nobody in the wave walks
-          if (any_walk) {
-            descend_multi<1>(td, s_top, s_exit, n_top, a0, a1, a2, wv, xi, xl, xd, xm);
-            widx[j] = xi[0]; wleaf[j] = xl[0]; wdepth[j] = xd[0]; margin[j] = xm[0];
-          } else {
-            widx[j] = 0; wleaf[j] = 0; wdepth[j] = 0;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-          if (walk[j]) {
-            leaf[j] = wleaf[j];
-            depth[j] = wdepth[j];
-            if (cache_leaf) {
-              const long long ci = (long long)k * L + (base + j * kBlock + threadIdx.x);
-              const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
-              cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
-              cache_margin[ci] = cacheable ? __double2float_rd(margin[j]) : 0.f;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < QPT; ++j)
-        if (valid[j]) visits += (unsigned int)depth[j];
-#ifdef MADICP_ABLATE
-      if (base == r * S) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MADICP_STAMP(ts2); }  // first pass: walk / reuse check done
-#endif
-
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        if (!valid[j]) continue;
-        const int i = base + j * kBlock + threadIdx.x;
-        // the matched leaf's record: one 64-byte line, its four 16-byte loads issued together (one round trip)
-#ifdef MADICP_ABLATE
-        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + ((job->flags & 2048) ? (leaf[j] & 7) : leaf[j]));  // profiling: no random gather
-#else
-        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + leaf[j]);
-#endif
-        const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
-        // gate (mad_icp.cpp:81-83)
-        const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
-        const double src_ball = min_ball + b_ratio * pn[j];
-        const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-        if (corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
-#ifdef MADICP_ABLATE
-        if (job->flags & 1024) { acc[0] += g0 + lc.x + ld.x; continue; }  // profiling: no J/H arithmetic
-        if (job->flags & 4096) { if (((i >> 6) & 1) == 0) continue; } else  // profiling: accept/reject per whole wave
-#endif
-        if (rejected) continue;
-        if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
-
-        const double bbox0 = ld.x;
-        const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
-
-        // errorAndJacobian (mad_icp.cpp:59-72)
-        const double e = dotc(g0, g1, g2, n0, n1, n2);
-        double J[6];
-        J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
-        J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
-        J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
-        // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
-        const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
-        J[3] = dotc(a0, a1, a2, 0.0, pz[j], -py[j]);
-        J[4] = dotc(a0, a1, a2, -pz[j], 0.0, px[j]);
-        J[5] = dotc(a0, a1, a2, py[j], -px[j], 0.0);
-
-        // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
-        double scale = 1.0;
-        const double chi = fabs(e);
-        if (chi > rho) scale = rho / chi;
-        const double w = 1.0 - bbox0 / min_ball;
-        scale *= w * w;
-
-        double sJ[6];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
-        int v = 0;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc)
-#pragma unroll
-          for (int rr = cc; rr < 6; ++rr) acc[v++] += sJ[rr] * J[cc];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
-        acc[27] += 1.0;
-      }
-    }
-  }
-
-  MADICP_STAMP(ts3);  // all passes done (fetch + arithmetic included)
-  // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
-  acc[28] = static_cast<double>(visits);  // integer-valued: its sums are exact in any order
-  __shared__ double red[kWaves][32];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-#ifdef MADICP_ABLATE
-  if (job->flags & 2) {  // profiling only: skip the cross-lane reduction
-    if (threadIdx.x < kAcc) partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * kAcc + threadIdx.x] = acc[0];
-    return;
-  }
-#endif
-#ifdef MADICP_ABLATE
-  if (job->flags & 16) {  // profiling only: barrier + LDS join but no butterfly
-    if (lane < 32) red[wave][lane] = acc[lane < kAcc ? 0 : 1];
-  } else
-#endif
-  wave_reduce_scatter(acc, lane, red[wave]);
-#ifdef MADICP_ABLATE
-  if (job->flags & 8) {  // profiling only: butterfly but no barrier / cross-wave join
-    if (lane < kAcc) partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * kAcc + lane] = red[wave][lane];
-    return;
-  }
-#endif
-  MADICP_STAMP(ts4);
-  __syncthreads();
-  MADICP_STAMP(ts5);
-  if (threadIdx.x < kAcc) {
-    double s = red[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
-    partials[((long long)blockIdx.y * gridDim.x + blockIdx.x) * kAcc + threadIdx.x] = s;
-  }
-#ifdef MADICP_ABLATE
-  if (job->dbg && (threadIdx.x & 63) == 0) {
-    unsigned long long* d = job->dbg + ((long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 8;
-    d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; d[4] = ts4; d[5] = ts5; d[6] = wall_clock64(); d[7] = blockIdx.x;
-  }
-#endif
-}
-
 // ---------------------------------------------------------------------------------------------------
 // 6x6 LDLT (lower, diagonal pivoting) factor + solve — the algorithm of Eigen::LDLT that
 // `H_adder_.ldlt().solve(-b_adder_)` runs (mad_icp.cpp:111).  A: row-major, only the lower triangle is
@@ -1005,9 +727,10 @@ __device__ __forceinline__ void exp_so3(const double* w, double* R) {
     }
 }
 
-// total: kAcc sums of this round (already joined over workgroups / ranks).  One lane.
-__device__ __forceinline__ void gn_update(Job* job, const double* total, const double (&X)[12], int it, int flags) {
-  double H[36], b[6];
+// one lane: X_next = X * [expSO3(dx[3:6]), dx[0:3]] with dx = LDLT(H) \\ (-b)   (mad_icp.cpp:111-116); also returns
+// H (mirrored from the 21 accumulated entries, see DESIGN.md "H symmetry") and b
+__device__ __forceinline__ void solve_pose(const double* total, const double (&X)[12], bool update, double (&Xn)[12],
+                                           double (&H)[36], double (&b)[6]) {
   {
     int v = 0;
 #pragma unroll
@@ -1015,25 +738,15 @@ __device__ __forceinline__ void gn_update(Job* job, const double* total, const d
 #pragma unroll
       for (int r = c; r < 6; ++r) {
         H[r * 6 + c] = total[v];
-        H[c * 6 + r] = total[v];  // mirror: see DESIGN.md "H symmetry"
+        H[c * 6 + r] = total[v];
         ++v;
       }
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r) b[r] = total[21 + r];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) job->H[i] = H[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) job->b[i] = b[i];
-  job->n_pairs = total[27];
-  job->visits += static_cast<unsigned long long>(total[28]);
-  if (job->x_iters) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) job->x_iters[(long long)it * 12 + i] = X[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 12; ++i) job->Xprev[i] = X[i];  // the pose this round linearised at
-  if (!(flags & kFlagNoUpdate)) {
+  for (int i = 0; i < 12; ++i) Xn[i] = X[i];
+  if (update) {
     double nb[6], dx[6], dR[9];
 #pragma unroll
     for (int r = 0; r < 6; ++r) nb[r] = -b[r];
@@ -1042,22 +755,22 @@ __device__ __forceinline__ void gn_update(Job* job, const double* total, const d
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        job->X[3 * r + c] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dR[c], dR[3 + c], dR[6 + c]);
-      job->X[9 + r] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dx[0], dx[1], dx[2]) + X[9 + r];
+      for (int c = 0; c < 3; ++c) Xn[3 * r + c] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dR[c], dR[3 + c], dR[6 + c]);
+      Xn[9 + r] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dx[0], dx[1], dx[2]) + X[9 + r];
     }
   }
-  job->iter = it + 1;
 }
 
-// join of the per-workgroup partials in a fixed order: 32 segments summed in parallel (every lane issues all
-// of its loads before the first add, so the join costs one memory round trip), then the segments in sequence
-constexpr int kJoinMaxSeg = 32;  // partials per lane handled without looping: grids up to 32*32 = 1024 workgroups
+// join of the per-workgroup partials in a fixed order: blockDim/32 segments summed in parallel (every lane issues
+// all of its loads before the first add: one memory round trip), then the segments in sequence.  The order depends
+// only on (nblocks, blockDim), so every workgroup of a launch computes the bit-identical total.
+constexpr int kJoinMaxSeg = 32;
 __device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
   __shared__ double seg[32][kAcc];
   const int j = threadIdx.x & 31;
   const int s = threadIdx.x >> 5;
-  const int seg_len = (nblocks + 31) / 32;
+  const int nseg = blockDim.x >> 5;  // <= 32
+  const int seg_len = (nblocks + nseg - 1) / nseg;
   if (j < kAcc) {
     double a = 0.0;
     const int b0 = s * seg_len;
@@ -1078,21 +791,332 @@ __device__ __forceinline__ void join_partials(const double* __restrict__ partial
   __syncthreads();
   if (threadIdx.x < kAcc) {
     double a = seg[0][threadIdx.x];
-#pragma unroll
-    for (int k = 1; k < 32; ++k) a += seg[k][threadIdx.x];
+    for (int k = 1; k < nseg; ++k) a += seg[k][threadIdx.x];
     total[threadIdx.x] = a;
   }
   __syncthreads();
 }
 
-// before the last round the matched_ flags are cleared (pipeline.cpp:172-176).  `iter` is the round that was
-// just linearised, read by every thread BEFORE the barriers of join_partials (thread 0 advances job->iter later).
-__device__ __forceinline__ void clear_matched_if_next_is_last(Job* job, int iter, int n_iters) {
-  if (iter + 1 == n_iters - 1) {
-    const int L = job->L;
-    uint4* m16 = reinterpret_cast<uint4*>(job->matched);  // hipMalloc'ed: 256-byte aligned
-    for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) m16[i] = make_uint4(0, 0, 0, 0);
-    for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) job->matched[i] = 0;
+__device__ __forceinline__ double wave_uniform(double v) {  // value known to be identical in all lanes -> SGPR pair
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int QPT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
+    Job* __restrict__ jobs, double* __restrict__ partials, const double* __restrict__ totals, int round) {
+  Job* job = jobs + blockIdx.y;
+  const int L = job->L;
+  const int K = job->K;
+  const int RPT = job->ranges_per_tree;
+  const int n_iters = job->n_iters;
+  const int flags = job->flags;
+  const bool last_round = (round == n_iters - 1);
+  const double* __restrict__ moving = job->moving;
+  uint8_t* __restrict__ matched = job->matched;
+  uint32_t* __restrict__ corr = job->corr;
+  const double min_ball = job->min_ball, rho = job->rho, b_ratio = job->b_ratio;
+  uint32_t* __restrict__ cache_leaf = job->cache_leaf;
+  float* __restrict__ cache_margin = job->cache_margin;
+  const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
+  const long long pstride = (long long)gridDim.y * gridDim.x * kAcc;  // one parity's worth of partials
+  double* __restrict__ my_partials = partials + (round & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc;
+
+  const int S = (L + RPT - 1) / RPT;  // leaves per range
+  const long long U = (long long)K * RPT;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int nslots = gridDim.x >> 3;
+  const long long lo = (xcd * U) >> 3;
+  const long long hi = ((xcd + 1) * U) >> 3;
+
+  // The first pass's loads that do not depend on the pose (leaf coordinates, cached correspondence) are issued NOW,
+  // so they are in flight while the workgroup joins and solves the previous round.
+  vd4 pv0[QPT];
+  float cmar0[QPT];
+  unsigned int cword0[QPT];
+  const long long u_first = lo + slot;
+  {
+    const int k = (u_first < hi) ? static_cast<int>(u_first / RPT) : 0;
+    const int r = (u_first < hi) ? static_cast<int>(u_first - (long long)k * RPT) : 0;
+    const int i_end = (u_first < hi) ? min(L, (r + 1) * S) : 0;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+      const int i = r * S + j * kBlock + threadIdx.x;
+      pv0[j] = vd4{0.0, 0.0, 0.0, 0.0};
+      cmar0[j] = 0.f;
+      cword0[j] = 0u;
+      if (i < i_end) {
+        pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
+        if (reuse) {
+          const long long ci = (long long)k * L + i;
+          cmar0[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
+          cword0[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
+        }
+      }
+    }
+  }
+
+  // ---- the solve of the previous round, by every workgroup -------------------------------------------------
+  __shared__ double s_total[kAcc];
+  __shared__ double s_X[24];  // X_round (12), X_{round-1} (12)
+  if (round > 0) {
+    if (totals) {
+      if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
+      __syncthreads();
+    } else {
+      join_partials(partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc, gridDim.x, s_total);
+    }
+  }
+  if (threadIdx.x == 0) {
+    double Xp[12], Xn[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(round > 0 ? round - 1 : 0) & 1][i];
+    if (round > 0) {
+      double H[36], b[6];
+      solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b);
+      if (blockIdx.x == 0) {  // bookkeeping of the finished round, once per scan
+#pragma unroll
+        for (int i = 0; i < 36; ++i) job->H[i] = H[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) job->b[i] = b[i];
+        job->n_pairs = s_total[27];
+        job->visits += static_cast<unsigned long long>(s_total[28]);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) job->Xring[round & 1][i] = Xn[i];
+        job->iter = round;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Xn[i] = Xp[i];
+    }
+    if (blockIdx.x == 0 && job->x_iters) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) job->x_iters[(long long)round * 12 + i] = Xn[i];  // the pose this round linearises at
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      s_X[i] = Xn[i];
+      s_X[12 + i] = Xp[i];
+    }
+  }
+  __syncthreads();
+  double R[9], t[3], Rp[9], tp[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { R[k] = wave_uniform(s_X[k]); Rp[k] = wave_uniform(s_X[12 + k]); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { t[k] = wave_uniform(s_X[9 + k]); tp[k] = wave_uniform(s_X[21 + k]); }
+
+  // the matched_ flags are cleared before the last round (pipeline.cpp:172-176); all workgroups share the work
+  if (round == n_iters - 2) {
+    uint4* m16 = reinterpret_cast<uint4*>(matched);  // hipMalloc'ed: 256-byte aligned
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (L >> 4); i += stride) m16[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0)
+      for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) matched[i] = 0;
+  }
+
+  double acc[kAcc];
+#pragma unroll
+  for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
+  unsigned int visits = 0;
+
+  // top-level copy: dynamic LDS, present only when the host launched with kTopLdsBytes (units big enough to pay
+  // for the copy)
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
+  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
+  int staged_tree = -1;
+
+
+  for (long long u = lo + slot; u < hi; u += nslots) {
+    const int k = static_cast<int>(u / RPT);
+    const int r = static_cast<int>(u - (long long)k * RPT);
+    const int i_end = min(L, (r + 1) * S);
+    const TreeDesc& td = job->trees[k];
+    // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
+    // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
+    const int n_top_avail = (job->lds_top && i_end - r * S >= job->stage_min_leaves) ? min(td.n_top, kTopMax) : 0;
+
+    for (int base = r * S; base < i_end; base += QPT * kBlock) {
+      double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
+      bool valid[QPT], walk[QPT];
+      int leaf[QPT], depth[QPT];
+      // every load of this pass that does not depend on another one is issued first — the leaf's coordinates and
+      // its cached correspondence — so a walk-free pass is two memory round trips (these, then the leaf record)
+      vd4 pv[QPT];
+      float cmar[QPT];
+      unsigned int cword[QPT];
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const int i = base + j * kBlock + threadIdx.x;
+        valid[j] = i < i_end;
+        pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
+        cmar[j] = 0.f;
+        cword[j] = 0u;
+        if (u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
+          pv[j] = pv0[j];
+          cmar[j] = cmar0[j];
+          cword[j] = cword0[j];
+        } else if (valid[j]) {
+          pv[j] = ((gptr_d4)(uintptr_t)moving)[i];
+          if (reuse) {
+            const long long ci = (long long)k * L + i;
+            cmar[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
+            cword[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const int i = base + j * kBlock + threadIdx.x;
+        const vd4 p = pv[j];
+        px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
+        // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
+        q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
+        q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
+        q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+        walk[j] = valid[j];
+        margin[j] = 3.0e38;
+        leaf[j] = 0;
+        depth[j] = 0;
+        if (reuse && valid[j]) {
+          // how far has this leaf moved since the previous round?  (same expression as above at the previous pose,
+          // so it reproduces the previous round's query bit for bit)
+          const double o0 = tp[0] + dots(Rp[0], Rp[1], Rp[2], p.x, p.y, p.z);
+          const double o1 = tp[1] + dots(Rp[3], Rp[4], Rp[5], p.x, p.y, p.z);
+          const double o2 = tp[2] + dots(Rp[6], Rp[7], Rp[8], p.x, p.y, p.z);
+          const double d0 = q0[j] - o0, d1 = q1[j] - o1, d2 = q2[j] - o2;
+          const double moved = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+          const double left_over = (double)cmar[j] - moved * (1.0 + 1e-12) -
+                                   1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
+                                            fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
+          if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
+            leaf[j] = (int)(cword[j] & kCacheIdxMask);
+            depth[j] = (int)(cword[j] >> 26);
+            cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
+            walk[j] = false;
+          }
+        }
+      }
+      {
+        if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform condition) copy the top levels into LDS on demand
+          bool need = false;
+#pragma unroll
+          for (int j = 0; j < QPT; ++j) need |= walk[j];
+          if (__syncthreads_or(need ? 1 : 0)) {
+            gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
+            const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+            for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
+              s_top[e] = gt[e];
+              reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+            }
+            __syncthreads();
+            staged_tree = k;
+          }
+        }
+        const int n_top = (k == staged_tree) ? n_top_avail : 0;
+        // The lane's QPT leaves share their LOADS (coordinates, cache, leaf record: issued together above and below),
+        // but they are WALKED one after the other: interleaved walks make every step wait for the slowest of
+        // 64*QPT lanes and were measured slower than back-to-back ones.
+        int widx[QPT], wleaf[QPT], wdepth[QPT];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+          const double a0[1] = {q0[j]}, a1[1] = {q1[j]}, a2[1] = {q2[j]};
+          const bool wv[1] = {walk[j]};
+          int xi[1], xl[1], xd[1];
+          double xm[1] = {margin[j]};
+          bool any_walk = walk[j];
+          if (QPT > 1) any_walk = __any(walk[j]);  // skip the whole (wave-uniform) call when nobody in the wave walks
+          if (any_walk) {
+            descend_multi<1>(td, s_top, s_exit, n_top, a0, a1, a2, wv, xi, xl, xd, xm);
+            widx[j] = xi[0]; wleaf[j] = xl[0]; wdepth[j] = xd[0]; margin[j] = xm[0];
+          } else {
+            widx[j] = 0; wleaf[j] = 0; wdepth[j] = 0;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+          if (walk[j]) {
+            leaf[j] = wleaf[j];
+            depth[j] = wdepth[j];
+            if (cache_leaf) {
+              const long long ci = (long long)k * L + (base + j * kBlock + threadIdx.x);
+              const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
+              cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
+              cache_margin[ci] = cacheable ? __double2float_rd(margin[j]) : 0.f;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < QPT; ++j)
+        if (valid[j]) visits += (unsigned int)depth[j];
+
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        if (!valid[j]) continue;
+        const int i = base + j * kBlock + threadIdx.x;
+        // the matched leaf's record: one 64-byte line, its four 16-byte loads issued together (one round trip)
+        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + leaf[j]);
+        const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+        // gate (mad_icp.cpp:81-83)
+        const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
+        const double src_ball = min_ball + b_ratio * pn[j];
+        const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
+        if (corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
+        if (rejected) continue;
+        if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
+
+        const double bbox0 = ld.x;
+        const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
+
+        // errorAndJacobian (mad_icp.cpp:59-72)
+        const double e = dotc(g0, g1, g2, n0, n1, n2);
+        double J[6];
+        J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
+        J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
+        J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
+        // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
+        const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
+        J[3] = dotc(a0, a1, a2, 0.0, pz[j], -py[j]);
+        J[4] = dotc(a0, a1, a2, -pz[j], 0.0, px[j]);
+        J[5] = dotc(a0, a1, a2, py[j], -px[j], 0.0);
+
+        // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
+        double scale = 1.0;
+        const double chi = fabs(e);
+        if (chi > rho) scale = rho / chi;
+        const double w = 1.0 - bbox0 / min_ball;
+        scale *= w * w;
+
+        double sJ[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
+        int v = 0;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+          for (int rr = cc; rr < 6; ++rr) acc[v++] += sJ[rr] * J[cc];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
+        acc[27] += 1.0;
+      }
+    }
+  }
+
+
+  // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
+  acc[28] = static_cast<double>(visits);  // integer-valued: its sums are exact in any order
+  __shared__ double red[kWaves][32];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  wave_reduce_scatter(acc, lane, red[wave]);
+  __syncthreads();
+  if (threadIdx.x < kAcc) {
+    double s = red[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
+    my_partials[(long long)blockIdx.x * kAcc + threadIdx.x] = s;
   }
 }
 
@@ -1117,54 +1141,45 @@ __device__ __forceinline__ void count_matched(Job* job) {
   }
 }
 
-// single-GPU: join + solve + update in one launch; grid = n_scans, block = kSolveThreads.  After the last round
-// the same launch also counts the matched leaves (their flags were written by the linearisation just before).
-__global__ __launch_bounds__(kSolveThreads) void icp_solve(Job* __restrict__ jobs, const double* __restrict__ partials,
-                                                          int nblocks) {
-  __shared__ double total[kAcc];
+// after the last round: join + solve once more -> final pose, H, b of the last round, counters, matched-leaf count
+// (pipeline.cpp:195-204,223).  grid = n_scans, block = kSolveThreads.  nblocks = workgroups per scan of icp_round.
+__global__ __launch_bounds__(kSolveThreads) void icp_final(Job* __restrict__ jobs, const double* __restrict__ partials,
+                                                          const double* __restrict__ totals, int nblocks, int n_scans) {
+  __shared__ double s_total[kAcc];
   Job* job = jobs + blockIdx.x;
-  const int iter = job->iter, n_iters = job->n_iters, flags = job->flags;
-  double X[12];  // the solving lane fetches the pose now, so the load overlaps the join instead of following it
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) X[i] = job->X[i];
-  }
-#ifdef MADICP_ABLATE
-  if (job->flags & 32) {  // profiling only: no join
-    if (threadIdx.x < kAcc) total[threadIdx.x] = partials[threadIdx.x];
+  const int n = job->n_iters;
+  if (totals) {
+    if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.x * kAcc + threadIdx.x];
     __syncthreads();
-  } else
-#endif
-  join_partials(partials + (long long)blockIdx.x * nblocks * kAcc, nblocks, total);
-  clear_matched_if_next_is_last(job, iter, n_iters);
-  if (iter == n_iters - 1) count_matched(job);
-#ifdef MADICP_ABLATE
-  if (job->flags & 64) return;  // profiling only: no update at all
-#endif
-  if (threadIdx.x == 0) gn_update(job, total, X, iter, flags);
+  } else {
+    const long long pstride = (long long)n_scans * nblocks * kAcc;
+    join_partials(partials + ((n - 1) & 1) * pstride + (long long)blockIdx.x * nblocks * kAcc, nblocks, s_total);
+  }
+  count_matched(job);
+  if (threadIdx.x == 0) {
+    double Xp[12], Xn[12], H[36], b[6];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(n - 1) & 1][i];
+    solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) job->H[i] = H[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) job->b[i] = b[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) job->X[i] = Xn[i];
+    job->n_pairs = s_total[27];
+    job->visits += static_cast<unsigned long long>(s_total[28]);
+    job->iter = n;
+  }
 }
 
-// multi-GPU: join -> totals[scan][kAcc] | ncclAllReduce(sum) | update | (last round) all-reduce(max) of the flags
-// | icp_finish
-__global__ __launch_bounds__(kSolveThreads) void icp_reduce(Job* __restrict__ jobs, const double* __restrict__ partials,
-                                                           int nblocks, double* __restrict__ totals) {
-  __shared__ double total[kAcc];
-  Job* job = jobs + blockIdx.x;
-  const int iter = job->iter, n_iters = job->n_iters;
-  join_partials(partials + (long long)blockIdx.x * nblocks * kAcc, nblocks, total);
-  clear_matched_if_next_is_last(job, iter, n_iters);
-  if (threadIdx.x < kAcc) totals[blockIdx.x * kAcc + threadIdx.x] = total[threadIdx.x];
+// multi-GPU: this rank's partials of the round just linearised -> totals[scan][kAcc], then ncclAllReduce(sum)
+__global__ __launch_bounds__(kSolveThreads) void icp_reduce(const double* __restrict__ partials, int nblocks, int n_scans,
+                                                           int round, double* __restrict__ totals) {
+  __shared__ double s_total[kAcc];
+  const long long pstride = (long long)n_scans * nblocks * kAcc;
+  join_partials(partials + (round & 1) * pstride + (long long)blockIdx.x * nblocks * kAcc, nblocks, s_total);
+  if (threadIdx.x < kAcc) totals[blockIdx.x * kAcc + threadIdx.x] = s_total[threadIdx.x];
 }
-__global__ void icp_update(Job* __restrict__ jobs, const double* __restrict__ totals, int n_scans) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < n_scans) {
-    Job* job = jobs + s;
-    double X[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) X[i] = job->X[i];
-    gn_update(job, totals + s * kAcc, X, job->iter, job->flags);
-  }
-}
-__global__ __launch_bounds__(kSolveThreads) void icp_finish(Job* __restrict__ jobs) { count_matched(jobs + blockIdx.x); }
 
 }  // namespace madicp

@@ -45,7 +45,7 @@ struct DevTree {
   madicp_node* nodes = nullptr;
   CNode* cnodes = nullptr;    // 16-byte screening records, same indexing
   LeafRec* leaves = nullptr;  // dense 64-byte leaf records, by leaf ordinal
-  CNode* top = nullptr;       // top levels, breadth first (staged into LDS by icp_linearize)
+  CNode* top = nullptr;       // top levels, breadth first (staged into LDS by icp_round)
   int2* top_exit = nullptr;
   int* top_dfs = nullptr;
   unsigned int* top_link = nullptr;
@@ -105,20 +105,15 @@ struct madicp_ctx {
   std::vector<int> last_moving;
 
   // options
-  int blocks_per_cu = 4;
+  int blocks_per_cu = 1;  // icp_round workgroups (768 threads) per CU
   int use_graph = 1;
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
-  int occ_blocks[3] = {4, 3, 2};      // icp_linearize<1|2|4> workgroups resident per CU without dynamic LDS (queried at create)
-  int occ_blocks_lds[3] = {3, 3, 2};  // ... with kTopLdsBytes
 
   std::map<GraphKey, hipGraphExec_t> graphs;
 
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // madicp_icp_time_linearize
-#ifdef MADICP_ABLATE
-  unsigned long long* d_dbg = nullptr;
-#endif
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -144,47 +139,35 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
 // one (tree, range) unit per workgroup so that every workgroup gets the same number of leaves
 Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   Geometry g;
-  // One leaf per lane and pass (QPT > 1 only costs registers: each step then waits for the slowest of 128 lanes —
-  // measured).  Workgroups per scan: what is resident at once for a single scan; for a batch at least one
-  // workgroup per CU and scan.
-  g.qpt = ctx->qpt_override ? ctx->qpt_override : 1;
-  const int v = g.qpt == 1 ? 0 : (g.qpt == 2 ? 1 : 2);
-  g.lds_bytes = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int occ = pass ? ctx->occ_blocks_lds[v] : ctx->occ_blocks[v];
-    const long long per_cu = std::max(1, std::min(ctx->blocks_per_cu, occ));
-    long long grid = std::max<long long>(ctx->n_cus, per_cu * ctx->n_cus / std::max(1, batch));
-    const long long max_useful = (long long)K * ((max_L + 63) / 64);  // never below one wave of leaves per unit
-    grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
-    g.grid = static_cast<int>(grid);
-    g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / K));
-    const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
-    if (pass == 1 || per_range < ctx->stage_min_leaves) break;  // units too small to stage: no LDS, more workgroups
-    g.lds_bytes = kTopLdsBytes;                                 // else redo the sizing with the LDS-limited occupancy
-  }
+  // One 768-thread workgroup per CU (3 waves per SIMD is what the kernel's registers allow), one (tree, range) unit
+  // per workgroup; a batch shares the CUs between its scans.  One leaf per lane and pass by default (two leaves per
+  // lane share their loads but were not measured faster).
+  g.qpt = ctx->qpt_override == 2 ? 2 : 1;
+  long long grid = std::max<long long>(8, (long long)ctx->blocks_per_cu * ctx->n_cus / std::max(1, batch));
+  const long long max_useful = (long long)K * ((max_L + 63) / 64);  // never below one wave of leaves per unit
+  grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
+  g.grid = static_cast<int>(grid);
+  g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / K));
+  const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
+  g.lds_bytes = per_range >= ctx->stage_min_leaves ? kTopLdsBytes : 0;
   return g;
 }
 
-void launch_linearize(madicp_ctx* ctx, int grid, int batch, int qpt, int lds_bytes) {
+void launch_round(madicp_ctx* ctx, int grid, int batch, int qpt, int lds_bytes, int round, const double* totals) {
   dim3 g(grid, batch), b(kBlock);
-  void (*kern)(Job*, double*) = qpt == 1 ? icp_linearize<1> : (qpt == 2 ? icp_linearize<2> : icp_linearize<4>);
-  hipLaunchKernelGGL(kern, g, b, lds_bytes, ctx->stream, ctx->d_jobs, ctx->d_partials);
+  void (*kern)(Job*, double*, const double*, int) = qpt == 2 ? icp_round<2> : icp_round<1>;
+  hipLaunchKernelGGL(kern, g, b, lds_bytes, ctx->stream, ctx->d_jobs, ctx->d_partials, totals, round);
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
 int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int lds) {
   for (int it = 0; it < iters; ++it) {
-    launch_linearize(ctx, grid, batch, qpt, lds);
+    launch_round(ctx, grid, batch, qpt, lds, it, (ctx->comm && it > 0) ? ctx->d_totals : nullptr);
     if (ctx->comm) {
-      hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                         grid, ctx->d_totals);
+      hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_partials, grid, batch, it,
+                         ctx->d_totals);
       NCCL_TRY(ncclAllReduce(ctx->d_totals, ctx->d_totals, (size_t)batch * kAcc, ncclDouble, ncclSum, ctx->comm,
                              ctx->stream));
-      hipLaunchKernelGGL(icp_update, dim3((batch + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_jobs, ctx->d_totals,
-                         batch);
-    } else {
-      hipLaunchKernelGGL(icp_solve, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                         grid);
     }
   }
   if (ctx->comm) {
@@ -194,8 +177,9 @@ int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int
       NCCL_TRY(ncclAllReduce(mv.matched, mv.matched, (size_t)mv.L, ncclUint8, ncclMax, ctx->comm, ctx->stream));
     }
   }
-  // single GPU: the last icp_solve already counted the matched leaves; with ranks the OR above had to come first
-  if (ctx->comm) hipLaunchKernelGGL(icp_finish, dim3(batch), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs);
+  // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
+  hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+                     ctx->comm ? ctx->d_totals : nullptr, grid, batch);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -280,13 +264,9 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     j.n_iters = a.n_iters;
     j.iter = 0;
     j.flags = a.flags | (ctx->cache_corr ? 0 : kFlagNoReuse);
-#ifdef MADICP_ABLATE
-    if (!ctx->d_dbg) hipMalloc(&ctx->d_dbg, sizeof(unsigned long long) * 8 * 4 * 4096);
-    j.dbg = ctx->d_dbg;
-    if (const char* f = getenv("MADICP_ABLATE_FLAGS")) j.flags |= atoi(f);  // profiling builds only
-    if (const char* f = getenv("MADICP_ABLATE_CLEAR")) j.flags &= ~atoi(f);
-#endif
     std::memcpy(j.X, a.X0 + 12 * s, 12 * sizeof(double));
+    std::memcpy(j.Xring[0], a.X0 + 12 * s, 12 * sizeof(double));
+    std::memcpy(j.Xring[1], a.X0 + 12 * s, 12 * sizeof(double));
     j.min_ball = a.params->min_ball;
     j.rho = std::sqrt(a.params->rho_ker);  // MADicp ctor, mad_icp.cpp:32
     j.b_ratio = a.params->b_ratio;
@@ -306,7 +286,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
     h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
   }
-  const int rc0 = ensure_partials(ctx, (size_t)a.n_scans * grid * kAcc);
+  const int rc0 = ensure_partials(ctx, (size_t)2 * a.n_scans * grid * kAcc);  // two round parities
   if (rc0 != MADICP_OK) return rc0;
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
@@ -323,21 +303,16 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-#ifdef MADICP_ABLATE
-    if (getenv("MADICP_TIME_SOLVE")) {  // profiling builds only: time the solve kernel instead
-      for (int i = 0; i < a.time_launches; ++i)
-        hipLaunchKernelGGL(icp_solve, dim3(a.n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, grid);
-    } else
-#endif
-    for (int i = 0; i < a.time_launches; ++i) launch_linearize(ctx, grid, a.n_scans, geo.qpt, geo.lds_bytes);
+    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, grid, a.n_scans, geo.qpt, geo.lds_bytes, 0, nullptr);
     HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, ctx->stream));  // warm-up replay
     HIP_TRY(hipEventRecord(ctx->ev_t0, ctx->stream));
     HIP_TRY(hipGraphLaunch(exec, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
-    // fold the last launch's partials into job->visits / H / b (no pose update: kFlagNoUpdate is set)
-    hipLaunchKernelGGL(icp_solve, dim3(a.n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, grid);
+    // fold the last launch's partials (round parity 0) into job->visits / H / b: icp_final with n_iters = 1 semantics
+    hipLaunchKernelGGL(icp_final, dim3(a.n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+                       (const double*)nullptr, grid, a.n_scans);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
@@ -388,15 +363,6 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   if (e != hipSuccess) {
     madicp_ctx_destroy(ctx);
     return fail(MADICP_ERR_DEVICE, std::string("context allocation: ") + hipGetErrorString(e));
-  }
-  {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<1>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[0] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<2>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[1] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<4>, kBlock, 0) == hipSuccess && n > 0) ctx->occ_blocks[2] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<1>, kBlock, kTopLdsBytes) == hipSuccess && n > 0) ctx->occ_blocks_lds[0] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<2>, kBlock, kTopLdsBytes) == hipSuccess && n > 0) ctx->occ_blocks_lds[1] = n;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, icp_linearize<4>, kBlock, kTopLdsBytes) == hipSuccess && n > 0) ctx->occ_blocks_lds[2] = n;
   }
   *out = ctx;
   return MADICP_OK;
@@ -450,7 +416,7 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   if (!ctx || !key) return fail(MADICP_ERR_INVALID, "null argument");
   const std::string k(key);
   if (k == "grid_blocks_per_cu") {
-    if (value < 1 || value > 8) return fail(MADICP_ERR_INVALID, "grid_blocks_per_cu must be in 1..8");
+    if (value < 1 || value > 4) return fail(MADICP_ERR_INVALID, "grid_blocks_per_cu must be in 1..4");
     ctx->blocks_per_cu = (int)value;
   } else if (k == "use_graph") {
     ctx->use_graph = value ? 1 : 0;
@@ -460,7 +426,7 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
     ctx->stage_min_leaves = (int)std::min<int64_t>(value, 1 << 30);
   } else if (k == "queries_per_lane") {
-    if (value != 0 && value != 1 && value != 2 && value != 4) return fail(MADICP_ERR_INVALID, "queries_per_lane must be 0 (auto), 1, 2 or 4");
+    if (value != 0 && value != 1 && value != 2) return fail(MADICP_ERR_INVALID, "queries_per_lane must be 0 (default), 1 or 2");
     ctx->qpt_override = (int)value;
   } else {
     return fail(MADICP_ERR_INVALID, "unknown option: " + k);
@@ -824,8 +790,8 @@ int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_id
                               const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
                               uint64_t* out_visits_per_launch) {
   if (n_launches < 1) return fail(MADICP_ERR_INVALID, "n_launches must be >= 1");
-  // n_iters is set far above the round index so that no launch is "the last round" (no matched_ writes)
-  RegArgs a{n_scans, moving_ids, tree_ids, K, X0, params, 1 << 20, kFlagNoUpdate, nullptr, nullptr, n_launches, out_avg_us};
+  // a one-round registration without pose update, its round-0 kernel launched n_launches times
+  RegArgs a{n_scans, moving_ids, tree_ids, K, X0, params, 1, kFlagNoUpdate, nullptr, nullptr, n_launches, out_avg_us};
   int rc = enqueue_registration(ctx, a);
   if (rc == MADICP_OK && out_visits_per_launch) rc = madicp_icp_fetch(ctx, n_scans, nullptr, nullptr, nullptr, nullptr, out_visits_per_launch);
   return rc;
@@ -858,33 +824,28 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
     if (rc != MADICP_OK) return rc;
     for (int s = 0; s < n_scans; ++s) out_visits_per_launch[s] /= (uint64_t)n_iters;
   }
-  // the same number of icp_solve launches alone (state frozen), replayed as a graph: what is left is icp_linearize
+  // icp_final alone, replayed `reps` times as a graph: what is left of a registration is its n_iters icp_round launches
   const Geometry geo = pick_geometry(ctx, [&] { int m = 0; for (int s = 0; s < n_scans; ++s) m = std::max(m, ctx->movings.at(moving_ids[s]).L); return m; }(), K, n_scans);
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  for (int i = 0; i < n_iters; ++i)
-    hipLaunchKernelGGL(icp_solve, dim3(n_scans), dim3(kSolveThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_partials, geo.grid);
+  hipLaunchKernelGGL(icp_final, dim3(n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+                     (const double*)nullptr, geo.grid, n_scans);
   HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
   HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  // freeze the jobs: no pose update, round counter far from the end
-  // one linearisation at X0 leaves valid partials behind; the solves then run in full (LDLT + pose update: the
-  // pose drifts, which is irrelevant here) with a round counter that never reaches "last"
-  RegArgs f{n_scans, moving_ids, tree_ids, K, X0, params, 1 << 20, 0, nullptr, nullptr, 1, nullptr};
-  rc = enqueue_registration(ctx, f);
-  if (rc == MADICP_OK) {
+  {
     hipGraphLaunch(exec, ctx->stream);
     hipEventRecord(ctx->ev_t0, ctx->stream);
     for (int r = 0; r < reps; ++r) hipGraphLaunch(exec, ctx->stream);
     hipEventRecord(ctx->ev_t1, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    float ms_solve = 0.f;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms_solve, ctx->ev_t0, ctx->ev_t1);
-    if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("solve timing: ") + hipGetErrorString(e));
+    float ms_final = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_final, ctx->ev_t0, ctx->ev_t1);
+    if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("final timing: ") + hipGetErrorString(e));
     if (rc == MADICP_OK) {
-      const double per_reg = 1e3 * ms_reg / reps, per_solves = 1e3 * ms_solve / reps;
-      if (out_solve_avg_us) *out_solve_avg_us = per_solves / n_iters;
-      if (out_linearize_avg_us) *out_linearize_avg_us = (per_reg - per_solves) / n_iters;
+      const double per_reg = 1e3 * ms_reg / reps, per_final = 1e3 * ms_final / reps;
+      if (out_solve_avg_us) *out_solve_avg_us = per_final;
+      if (out_linearize_avg_us) *out_linearize_avg_us = (per_reg - per_final) / n_iters;
     }
   }
   hipGraphExecDestroy(exec);
@@ -892,13 +853,6 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
   return rc;
 }
 
-#ifdef MADICP_ABLATE
-int madicp_debug_fetch(madicp_ctx* ctx, unsigned long long* out, int n_words) {
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  HIP_TRY(hipMemcpy(out, ctx->d_dbg, sizeof(unsigned long long) * (size_t)n_words, hipMemcpyDeviceToHost));
-  return MADICP_OK;
-}
-#endif
 
 // ---- multi-GPU --------------------------------------------------------------------------------------
 int madicp_comm_unique_id(uint8_t out_id[128]) {

@@ -12,7 +12,7 @@ mids = [ctx.moving_upload(h.leaf_means())]
 P = (0.2, 0.1, 0.02)
 X0 = capi.pose12(pb["query_guess"][0])[None, :]
 for q in (1, 2):
-    for bpc in (2, 3, 4):
+    for bpc in (1,):
         ctx.set_option("queries_per_lane", q); ctx.set_option("grid_blocks_per_cu", bpc)
         lin, sol, v = ctx.icp_time_registration(mids, tids, X0, P, 15, 30)
         first, _ = ctx.icp_time_linearize(mids, tids, X0, P, 40)

@@ -25,7 +25,7 @@ for s in pb["query_scans"]:
 print("L", Ls)
 X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
 P = (0.2, 0.1, 0.02)
-for opts in [dict(grid_blocks_per_cu=b, lds_stage_min_leaves=m) for b in (1, 3) for m in (0, 1 << 30)]:
+for opts in [dict(grid_blocks_per_cu=1, lds_stage_min_leaves=m) for m in (1024, 0, 1 << 30)]:
     for k, v in opts.items():
         ctx.set_option(k, v)
     for _ in range(3):
