@@ -42,6 +42,8 @@ _host = None
 
 def _load(name):
     path = os.path.join(_PKG, name)
+    if name == "libmadicp_hip.so" and os.environ.get("MADICP_HIP_LIB"):
+        path = os.environ["MADICP_HIP_LIB"]  # an instrumented build of the same library (tools/stamps.py)
     if not os.path.exists(path):
         raise MadIcpError(f"{name} is not built (run `python -m mad_icp_amd._build`); there is no fallback path")
     return C.CDLL(path)

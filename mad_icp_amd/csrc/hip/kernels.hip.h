@@ -36,7 +36,7 @@ namespace madicp {
 constexpr int kBlock = 768;          // threads per icp_round workgroup = 12 wave64 = 3 per SIMD: ONE workgroup per CU
 constexpr int kWaves = kBlock / 64;
 constexpr int kAcc = 29;             // 21 (lower triangle of H, column by column) + 6 (b) + accepted pairs + nodes visited
-constexpr int kSolveThreads = 1024;
+
 
 // 16-byte screening record of one node, same index as the exact 64-byte madicp_node.
 //
@@ -761,27 +761,39 @@ __device__ __forceinline__ void solve_pose(const double* total, const double (&X
   }
 }
 
-// join of the per-workgroup partials in a fixed order: blockDim/32 segments summed in parallel (every lane issues
-// all of its loads before the first add: one memory round trip), then the segments in sequence.  The order depends
-// only on (nblocks, blockDim), so every workgroup of a launch computes the bit-identical total.
-constexpr int kJoinMaxSeg = 32;
-__device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
-  __shared__ double seg[32][kAcc];
+// join of the per-workgroup partials in a fixed order: kJoinSeg segments summed in parallel, then the segments in
+// sequence.  The order depends only on nblocks (every caller runs kBlock threads), so every workgroup of a launch —
+// and icp_reduce / icp_final — computes the bit-identical total.  Split in two so that a caller can put the loads in
+// flight first (join_issue: every lane issues all of its loads, one memory round trip) and consume them later.
+constexpr int kJoinSeg = kBlock / 32;  // 24 segments x 32 lanes (29 used)
+constexpr int kJoinMaxSeg = 16;        // segment length held in registers (nblocks <= 384); longer ones stream
+struct JoinLoads {
+  double v[kJoinMaxSeg];
+};
+__device__ __forceinline__ void join_issue(const double* __restrict__ partials, int nblocks, JoinLoads& jl) {
   const int j = threadIdx.x & 31;
   const int s = threadIdx.x >> 5;
-  const int nseg = blockDim.x >> 5;  // <= 32
-  const int seg_len = (nblocks + nseg - 1) / nseg;
+  const int seg_len = (nblocks + kJoinSeg - 1) / kJoinSeg;
+  const int b0 = s * seg_len;
+  const int b1 = min(nblocks, b0 + seg_len);
+  const __attribute__((address_space(1))) double* gp = (const __attribute__((address_space(1))) double*)(uintptr_t)partials;
+#pragma unroll
+  for (int i = 0; i < kJoinMaxSeg; ++i) jl.v[i] = (j < kAcc && seg_len <= kJoinMaxSeg && b0 + i < b1) ? gp[(long long)(b0 + i) * kAcc + j] : 0.0;
+}
+__device__ __forceinline__ void join_finish(const double* __restrict__ partials, int nblocks, const JoinLoads& jl,
+                                            double* total /*LDS kAcc*/) {
+  __shared__ double seg[kJoinSeg][kAcc];
+  const int j = threadIdx.x & 31;
+  const int s = threadIdx.x >> 5;
+  const int seg_len = (nblocks + kJoinSeg - 1) / kJoinSeg;
   if (j < kAcc) {
     double a = 0.0;
     const int b0 = s * seg_len;
     const int b1 = min(nblocks, b0 + seg_len);
     if (seg_len <= kJoinMaxSeg) {
-      double v[kJoinMaxSeg];
-#pragma unroll
-      for (int i = 0; i < kJoinMaxSeg; ++i) v[i] = (b0 + i < b1) ? partials[(long long)(b0 + i) * kAcc + j] : 0.0;
 #pragma unroll
       for (int i = 0; i < kJoinMaxSeg; ++i)
-        if (b0 + i < b1) a += v[i];  // same order as the loop below
+        if (b0 + i < b1) a += jl.v[i];  // same order as the loop below
     } else {
 #pragma unroll 8
       for (int b = b0; b < b1; ++b) a += partials[(long long)b * kAcc + j];
@@ -790,25 +802,74 @@ __device__ __forceinline__ void join_partials(const double* __restrict__ partial
   }
   __syncthreads();
   if (threadIdx.x < kAcc) {
-    double a = seg[0][threadIdx.x];
-    for (int k = 1; k < nseg; ++k) a += seg[k][threadIdx.x];
+    double r[kJoinSeg];
+#pragma unroll
+    for (int k = 0; k < kJoinSeg; ++k) r[k] = seg[k][threadIdx.x];  // all LDS reads in flight before the first add
+    double a = r[0];
+#pragma unroll
+    for (int k = 1; k < kJoinSeg; ++k) a += r[k];
     total[threadIdx.x] = a;
   }
   __syncthreads();
+}
+__device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
+  JoinLoads jl;
+  join_issue(partials, nblocks, jl);
+  join_finish(partials, nblocks, jl, total);
 }
 
 __device__ __forceinline__ double wave_uniform(double v) {  // value known to be identical in all lanes -> SGPR pair
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// development instrumentation (tools/stamps.py builds a separate library with -DMADICP_STAMPS): wave 0 of every
+// workgroup of scan 0 records the 100 MHz wall clock at a few points of icp_round
+#ifdef MADICP_STAMPS
+__device__ unsigned long long g_stamps[16 * 256 * 8];
+#define MADICP_STAMP(n)                                                                                  \
+  if (threadIdx.x == 0 && blockIdx.y == 0 && round < 16 && blockIdx.x < 256)                             \
+  g_stamps[(round * 256 + blockIdx.x) * 8 + (n)] = wall_clock64()
+#else
+#define MADICP_STAMP(n)
+#endif
+
 template <int QPT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
-    Job* __restrict__ jobs, double* __restrict__ partials, const double* __restrict__ totals, int round) {
+    Job* __restrict__ jobs, double* __restrict__ partials, const double* __restrict__ totals, int round, int n_iters,
+    int K, int RPT) {
+  // (n_iters, K and ranges_per_tree are the same for every scan of the launch: as kernel arguments they are known
+  // one memory round trip before anything read through `job`)
   Job* job = jobs + blockIdx.y;
+  MADICP_STAMP(0);
+  typedef const __attribute__((address_space(1))) unsigned int* gptr_u1;
+  typedef const __attribute__((address_space(1))) float* gptr_f1;
+  typedef const __attribute__((address_space(1))) double* gptr_d1;
+  // Loads whose addresses need nothing but the launch geometry go first: the previous round's partials (joined by
+  // every workgroup below) and — lane 0 only, it is the one that solves — the pose that round linearised at.
+  // (Measured alternatives, all slower: every lane loading the pose, which turns it into scalar loads that the rest
+  // of the scalar traffic then queues behind; requesting all of the Job's scalars in one pinned batch.)
+  const long long pstride = (long long)gridDim.y * gridDim.x * kAcc;  // one parity's worth of partials
+  const double* __restrict__ prev_partials = partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc;
+  JoinLoads jl;
+  double Xp[12];
+  if (round > 0 && !totals) join_issue(prev_partials, gridDim.x, jl);
+  if (threadIdx.x == 0) {
+    gptr_d1 xr = (gptr_d1)(uintptr_t)job->Xring[(round > 0 ? round - 1 : 0) & 1];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Xp[i] = xr[i];
+  }
+  const long long U = (long long)K * RPT;
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int nslots = gridDim.x >> 3;
+  const long long lo = (xcd * U) >> 3;
+  const long long hi = ((xcd + 1) * U) >> 3;
+  const long long u_first = lo + slot;
+  const bool have_first = u_first < hi;
+  const int k_first = have_first ? static_cast<int>(u_first / RPT) : 0;
+  const int r_first = have_first ? static_cast<int>(u_first - (long long)k_first * RPT) : 0;
+
   const int L = job->L;
-  const int K = job->K;
-  const int RPT = job->ranges_per_tree;
-  const int n_iters = job->n_iters;
   const int flags = job->flags;
   const bool last_round = (round == n_iters - 1);
   const double* __restrict__ moving = job->moving;
@@ -818,40 +879,29 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   uint32_t* __restrict__ cache_leaf = job->cache_leaf;
   float* __restrict__ cache_margin = job->cache_margin;
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
-  const long long pstride = (long long)gridDim.y * gridDim.x * kAcc;  // one parity's worth of partials
   double* __restrict__ my_partials = partials + (round & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc;
-
   const int S = (L + RPT - 1) / RPT;  // leaves per range
-  const long long U = (long long)K * RPT;
-  const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int nslots = gridDim.x >> 3;
-  const long long lo = (xcd * U) >> 3;
-  const long long hi = ((xcd + 1) * U) >> 3;
 
   // The first pass's loads that do not depend on the pose (leaf coordinates, cached correspondence) are issued NOW,
-  // so they are in flight while the workgroup joins and solves the previous round.
+  // so they are in flight while the workgroup joins and solves the previous round.  Branch-free (clamped index): a
+  // divergent region would wait for its loads where it ends.  (Also touching the second pass's lines and the cached
+  // leaf records here was measured: no gain.)
   vd4 pv0[QPT];
   float cmar0[QPT];
   unsigned int cword0[QPT];
-  const long long u_first = lo + slot;
   {
-    const int k = (u_first < hi) ? static_cast<int>(u_first / RPT) : 0;
-    const int r = (u_first < hi) ? static_cast<int>(u_first - (long long)k * RPT) : 0;
-    const int i_end = (u_first < hi) ? min(L, (r + 1) * S) : 0;
+    const int i_end = have_first ? min(L, (r_first + 1) * S) : 0;
+    const int i_last = max(i_end - 1, 0);
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
-      const int i = r * S + j * kBlock + threadIdx.x;
-      pv0[j] = vd4{0.0, 0.0, 0.0, 0.0};
+      const int i = min(r_first * S + j * kBlock + threadIdx.x, i_last);
+      pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
       cmar0[j] = 0.f;
       cword0[j] = 0u;
-      if (i < i_end) {
-        pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
-        if (reuse) {
-          const long long ci = (long long)k * L + i;
-          cmar0[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
-          cword0[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
-        }
+      if (reuse) {  // (uniform)
+        const long long ci = (long long)k_first * L + i;
+        cmar0[j] = ((gptr_f1)(uintptr_t)cache_margin)[ci];
+        cword0[j] = ((gptr_u1)(uintptr_t)cache_leaf)[ci];
       }
     }
   }
@@ -864,13 +914,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
       __syncthreads();
     } else {
-      join_partials(partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc, gridDim.x, s_total);
+      join_finish(prev_partials, gridDim.x, jl, s_total);
     }
   }
+  MADICP_STAMP(1);
   if (threadIdx.x == 0) {
-    double Xp[12], Xn[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(round > 0 ? round - 1 : 0) & 1][i];
+    double Xn[12];
     if (round > 0) {
       double H[36], b[6];
       solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b);
@@ -900,6 +949,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
   }
   __syncthreads();
+  MADICP_STAMP(2);
   double R[9], t[3], Rp[9], tp[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) { R[k] = wave_uniform(s_X[k]); Rp[k] = wave_uniform(s_X[12 + k]); }
@@ -998,6 +1048,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
           }
         }
       }
+      if (u == u_first && base == r * S) { MADICP_STAMP(3); }
       {
         if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform condition) copy the top levels into LDS on demand
           bool need = false;
@@ -1051,6 +1102,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 #pragma unroll
       for (int j = 0; j < QPT; ++j)
         if (valid[j]) visits += (unsigned int)depth[j];
+      if (u == u_first && base == r * S) { MADICP_STAMP(4); }
 
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
@@ -1105,6 +1157,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   }
 
 
+  MADICP_STAMP(5);
   // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
   acc[28] = static_cast<double>(visits);  // integer-valued: its sums are exact in any order
   __shared__ double red[kWaves][32];
@@ -1118,11 +1171,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
     my_partials[(long long)blockIdx.x * kAcc + threadIdx.x] = s;
   }
+  MADICP_STAMP(6);
 }
 
 // matched-leaf count (pipeline.cpp:197-204), whole workgroup; valid once the last round's linearisation is done
 __device__ __forceinline__ void count_matched(Job* job) {
-  __shared__ int cnt[kSolveThreads / 64];
+  __shared__ int cnt[kBlock / 64];
   const int L = job->L;
   const uint4* m16 = reinterpret_cast<const uint4*>(job->matched);
   int c = 0;
@@ -1142,8 +1196,8 @@ __device__ __forceinline__ void count_matched(Job* job) {
 }
 
 // after the last round: join + solve once more -> final pose, H, b of the last round, counters, matched-leaf count
-// (pipeline.cpp:195-204,223).  grid = n_scans, block = kSolveThreads.  nblocks = workgroups per scan of icp_round.
-__global__ __launch_bounds__(kSolveThreads) void icp_final(Job* __restrict__ jobs, const double* __restrict__ partials,
+// (pipeline.cpp:195-204,223).  grid = n_scans, block = kBlock (the join order depends on it).  nblocks = workgroups per scan of icp_round.
+__global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, const double* __restrict__ partials,
                                                           const double* __restrict__ totals, int nblocks, int n_scans) {
   __shared__ double s_total[kAcc];
   Job* job = jobs + blockIdx.x;
@@ -1174,7 +1228,7 @@ __global__ __launch_bounds__(kSolveThreads) void icp_final(Job* __restrict__ job
 }
 
 // multi-GPU: this rank's partials of the round just linearised -> totals[scan][kAcc], then ncclAllReduce(sum)
-__global__ __launch_bounds__(kSolveThreads) void icp_reduce(const double* __restrict__ partials, int nblocks, int n_scans,
+__global__ __launch_bounds__(kBlock) void icp_reduce(const double* __restrict__ partials, int nblocks, int n_scans,
                                                            int round, double* __restrict__ totals) {
   __shared__ double s_total[kAcc];
   const long long pstride = (long long)n_scans * nblocks * kAcc;

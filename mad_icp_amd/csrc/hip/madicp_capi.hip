@@ -64,10 +64,11 @@ struct DevMoving {
   int32_t cache_K = 0;
 };
 
-struct GraphKey {
-  int grid, batch, iters, qpt, comm, lds;
+struct GraphKey {  // everything a captured launch sequence bakes in
+  int grid, batch, iters, qpt, comm, lds, K, rpt;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, qpt, comm, lds) < std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds);
+    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt) <
+           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt);
   }
 };
 struct Geometry {
@@ -153,16 +154,21 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   return g;
 }
 
-void launch_round(madicp_ctx* ctx, int grid, int batch, int qpt, int lds_bytes, int round, const double* totals) {
-  dim3 g(grid, batch), b(kBlock);
-  void (*kern)(Job*, double*, const double*, int) = qpt == 2 ? icp_round<2> : icp_round<1>;
-  hipLaunchKernelGGL(kern, g, b, lds_bytes, ctx->stream, ctx->d_jobs, ctx->d_partials, totals, round);
+struct Launch {  // one registration's launch shape
+  int grid, batch, iters, qpt, lds, K, rpt;
+};
+
+void launch_round(madicp_ctx* ctx, const Launch& l, int round, const double* totals) {
+  dim3 g(l.grid, l.batch), b(kBlock);
+  void (*kern)(Job*, double*, const double*, int, int, int, int) = l.qpt == 2 ? icp_round<2> : icp_round<1>;
+  hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, ctx->d_jobs, ctx->d_partials, totals, round, l.iters, l.K, l.rpt);
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
-int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int lds) {
+int enqueue_rounds(madicp_ctx* ctx, const Launch& l) {
+  const int grid = l.grid, batch = l.batch, iters = l.iters;
   for (int it = 0; it < iters; ++it) {
-    launch_round(ctx, grid, batch, qpt, lds, it, (ctx->comm && it > 0) ? ctx->d_totals : nullptr);
+    launch_round(ctx, l, it, (ctx->comm && it > 0) ? ctx->d_totals : nullptr);
     if (ctx->comm) {
       hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_partials, grid, batch, it,
                          ctx->d_totals);
@@ -184,16 +190,16 @@ int enqueue_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int
   return MADICP_OK;
 }
 
-int run_rounds(madicp_ctx* ctx, int grid, int batch, int iters, int qpt, int lds) {
+int run_rounds(madicp_ctx* ctx, const Launch& l) {
   // graphs: (conservatively) only without a communicator
   const bool graph_ok = ctx->use_graph && !ctx->comm;
-  if (!graph_ok) return enqueue_rounds(ctx, grid, batch, iters, qpt, lds);
-  const GraphKey key{grid, batch, iters, qpt, ctx->comm ? 1 : 0, lds};
+  if (!graph_ok) return enqueue_rounds(ctx, l);
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_rounds(ctx, grid, batch, iters, qpt, lds);
+    const int rc = enqueue_rounds(ctx, l);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != MADICP_OK) return rc;
     if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -281,6 +287,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   }
   const Geometry geo = pick_geometry(ctx, max_L, a.K, a.n_scans);
   const int grid = geo.grid;
+  const Launch launch{grid, a.n_scans, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree};
   for (int s = 0; s < a.n_scans; ++s) {
     h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
     h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
@@ -303,7 +310,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, grid, a.n_scans, geo.qpt, geo.lds_bytes, 0, nullptr);
+    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, launch, 0, nullptr);
     HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, ctx->stream));  // warm-up replay
@@ -321,7 +328,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     if (a.out_avg_us) *a.out_avg_us = 1e3 * ms / a.time_launches;
     return MADICP_OK;
   }
-  return run_rounds(ctx, grid, a.n_scans, a.n_iters, geo.qpt, geo.lds_bytes);
+  return run_rounds(ctx, launch);
 }
 
 }  // namespace
@@ -890,3 +897,13 @@ int madicp_comm_destroy(madicp_ctx* ctx) {
 }
 
 }  // extern "C"
+
+#ifdef MADICP_STAMPS
+// development only (tools/stamps.py): copies the icp_round wall-clock stamps of scan 0, [16 rounds][256 wg][8]
+extern "C" int madicp_debug_stamps(madicp_ctx* ctx, unsigned long long* out) {
+  if (!ctx || !out) return MADICP_ERR_INVALID;
+  hipStreamSynchronize(ctx->stream);
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(madicp::g_stamps), sizeof(unsigned long long) * 16 * 256 * 8) == hipSuccess
+             ? 0 : MADICP_ERR_DEVICE;
+}
+#endif
