@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((9274.5 + 1533.9) * 1024)  # FETCH_SIZE + WRITE_SIZE (KiB) per icp_linearize launch, averaged over a registration, config 3
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((9702.0 + 1416.9) * 1024)  # FETCH_SIZE + WRITE_SIZE (KiB) per icp_round launch, averaged over a registration, config 3
 
 
 def parse():
@@ -175,7 +175,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "icp_round", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (B == 1 and K == 16) else None,
-                    "traffic_source": "profiles/r1_m_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                    "traffic_source": "profiles/r1_p_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                       "same workload; uncorrected, the gfx950 half-counting caveat would at most double it)",
                     "avg_launch_us": round(avg_us, 2), "first_round_launch_us": round(first_us, 2),
                     "final_launch_us": None if solve_us is None else round(solve_us, 2), "rounds": N_ITERS,
@@ -183,7 +183,7 @@ def main():
                     "mean_descent_depth": round(visits_per_launch / pairs_per_launch, 3),
                     "note": "algorithmic bytes (SURVEY 8d: every visit = 64 B) are served by L1/L2/Infinity Cache and, in "
                             "later rounds, not re-walked at all when a margin proves the correspondence unchanged, so "
-                            "frac exceeds 1; HBM is not the limiter of this kernel (map ~%d MB < 256 MB): DESIGN.md 3.1"
+                            "frac exceeds 1; HBM is not the limiter of this kernel (exact-node map %d MB vs 256 MB Infinity Cache): DESIGN.md 3.1"
                             % (n_nodes * 64 // 2**20)}
 
     # PCIe-inclusive single registration (upload leaves, register, read back) — reported, never `value`

@@ -307,7 +307,7 @@ class Context:
                                                            len(tree_ids), X0.ctypes.data_as(_dp), C.byref(p), n_iters))
 
     def icp_time_linearize(self, mids, tree_ids, X0, params, n_launches=50):
-        """(avg microseconds per icp_linearize launch, visits per launch per scan) — see madicp_icp_time_linearize."""
+        """(avg microseconds per first-round icp_round launch, visits per launch per scan) — see madicp_icp_time_linearize."""
         X0 = _f64(X0, (len(mids), 12))
         p = IcpParams(*params)
         us = C.c_double(0.0)
@@ -318,7 +318,7 @@ class Context:
         return us.value, visits
 
     def icp_time_registration(self, mids, tree_ids, X0, params, n_iters, reps=30):
-        """(avg us per icp_linearize launch over a registration's rounds, avg us per icp_solve, visits per round per scan)."""
+        """(avg us per icp_round launch over a registration's rounds, us of icp_final, visits per round per scan)."""
         X0 = _f64(X0, (len(mids), 12))
         p = IcpParams(*params)
         lin, sol = C.c_double(0.0), C.c_double(0.0)

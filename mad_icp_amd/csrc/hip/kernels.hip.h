@@ -825,12 +825,14 @@ __device__ __forceinline__ double wave_uniform(double v) {  // value known to be
 // development instrumentation (tools/stamps.py builds a separate library with -DMADICP_STAMPS): wave 0 of every
 // workgroup of scan 0 records the 100 MHz wall clock at a few points of icp_round
 #ifdef MADICP_STAMPS
-__device__ unsigned long long g_stamps[16 * 256 * 8];
+__device__ unsigned long long g_stamps[16 * 256 * 16];
 #define MADICP_STAMP(n)                                                                                  \
   if (threadIdx.x == 0 && blockIdx.y == 0 && round < 16 && blockIdx.x < 256)                             \
-  g_stamps[(round * 256 + blockIdx.x) * 8 + (n)] = wall_clock64()
+  g_stamps[(round * 256 + blockIdx.x) * 16 + (n)] = wall_clock64()
+#define MADICP_STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #else
 #define MADICP_STAMP(n)
+#define MADICP_STAMP_WAIT()
 #endif
 
 template <int QPT>
@@ -1016,6 +1018,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
           }
         }
       }
+#ifdef MADICP_STAMPS
+      if (u == u_first && base == r * S) { MADICP_STAMP(7); }
+      if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP_WAIT(); MADICP_STAMP(10); }
+#endif
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         const int i = base + j * kBlock + threadIdx.x;
@@ -1049,6 +1055,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         }
       }
       if (u == u_first && base == r * S) { MADICP_STAMP(3); }
+      if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP(11); }
       {
         if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform condition) copy the top levels into LDS on demand
           bool need = false;
@@ -1111,6 +1118,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         // the matched leaf's record: one 64-byte line, its four 16-byte loads issued together (one round trip)
         gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + leaf[j]);
         const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+#ifdef MADICP_STAMPS
+        if (u == u_first && base == r * S) { MADICP_STAMP_WAIT(); MADICP_STAMP(8); }
+        if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP_WAIT(); MADICP_STAMP(12); }
+#endif
         // gate (mad_icp.cpp:81-83)
         const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
         const double src_ball = min_ball + b_ratio * pn[j];
@@ -1153,6 +1164,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
         acc[27] += 1.0;
       }
+      if (u == u_first && base == r * S) { MADICP_STAMP(9); }
     }
   }
 

@@ -899,11 +899,11 @@ int madicp_comm_destroy(madicp_ctx* ctx) {
 }  // extern "C"
 
 #ifdef MADICP_STAMPS
-// development only (tools/stamps.py): copies the icp_round wall-clock stamps of scan 0, [16 rounds][256 wg][8]
+// development only (tools/stamps.py): copies the icp_round wall-clock stamps of scan 0, [16 rounds][256 wg][16]
 extern "C" int madicp_debug_stamps(madicp_ctx* ctx, unsigned long long* out) {
   if (!ctx || !out) return MADICP_ERR_INVALID;
   hipStreamSynchronize(ctx->stream);
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(madicp::g_stamps), sizeof(unsigned long long) * 16 * 256 * 8) == hipSuccess
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(madicp::g_stamps), sizeof(unsigned long long) * 16 * 256 * 16) == hipSuccess
              ? 0 : MADICP_ERR_DEVICE;
 }
 #endif

@@ -41,17 +41,21 @@ mid = ctx.moving_upload(qt.leaf_means())
 params = (0.2, 0.1, 0.02)
 for _ in range(3):
     ctx.icp_register(mid, tids, prob["query_guess"][0], params, 15, qt.num_leaves)
-buf = np.zeros(16 * 256 * 8, dtype=np.uint64)
+buf = np.zeros(16 * 256 * 16, dtype=np.uint64)
 lib = capi.hip_lib()
 lib.madicp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.madicp_debug_stamps(ctx._h, buf.ctypes.data) == 0
-s = buf.reshape(16, 256, 8).astype(np.int64)
-print("| round | join | solve | reuse decided | walks | rest of passes | reduce+store | total | entry spread |")
-print("|---|---|---|---|---|---|---|---|---|")
+s = buf.reshape(16, 256, 16).astype(np.int64)
+# stamp order along a workgroup's time line (wave 0): see kernels.hip.h MADICP_STAMP
+ORDER = [0, 1, 2, 7, 3, 4, 8, 9, 10, 11, 12, 5, 6]
+NAMES = ["join", "solve", "bcast+init", "p0 reuse", "p0 walk", "p0 record", "p0 math", "p1 loads", "p1 reuse", "p1 record",
+         "p1 math", "reduce+store"]
+print("| round | " + " | ".join(NAMES) + " | total | whole |")
+print("|" + "---|" * (len(NAMES) + 3))
 for r in range(15):
-    d = np.diff(s[r, :, :7], axis=1) / 100.0  # us
+    t = s[r][:, ORDER]
+    d = np.diff(t, axis=1) / 100.0  # us
     med = np.median(d, axis=0)
     tot = np.median(s[r, :, 6] - s[r, :, 0]) / 100.0
-    spread = (s[r, :, 0].max() - s[r, :, 0].min()) / 100.0
     whole = (s[r, :, 6].max() - s[r, :, 0].min()) / 100.0
-    print("| %d | " % r + " | ".join("%.2f" % x for x in med) + " | %.2f | %.2f (whole %.2f) |" % (tot, spread, whole))
+    print("| %d | " % r + " | ".join("%.2f" % x for x in med) + " | %.2f | %.2f |" % (tot, whole))
