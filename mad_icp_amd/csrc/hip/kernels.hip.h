@@ -603,7 +603,7 @@ __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane,
 // 64 lanes of a wave share the upper path and diverge only near the leaves.
 //
 // grid = (8 * slots, n_scans); blockIdx.y selects the registration (scans batched in flight).
-// partials: [2][n_scans][gridDim.x][kAcc] ; totals (multi-GPU): [n_scans][kAcc], already all-reduced
+// partials: [2][n_scans][gridDim.x][kAcc], then walk hints [2][n_scans][gridDim.x] ; totals (multi-GPU): [n_scans][kAcc], already all-reduced
 // ---------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------
 // 6x6 LDLT (lower, diagonal pivoting) factor + solve — the algorithm of Eigen::LDLT that
@@ -855,10 +855,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   JoinLoads jl;
   double Xp[12];
   if (round > 0 && !totals) join_issue(prev_partials, gridDim.x, jl);
+  // walk hint: how many lanes of THIS workgroup had to walk in the previous round (written at the end of that round,
+  // behind the two partial buffers); decides — without a vote, i.e. without a barrier per pass — whether the tree's
+  // top levels are worth staging into LDS.  Speed only: the descent gives the same result from LDS or from global.
+  double* __restrict__ hints = partials + 2 * pstride;
+  const long long hint_slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+  const long long hint_stride = (long long)gridDim.y * gridDim.x;
+  double prev_hint = 1.0;
   if (threadIdx.x == 0) {
     gptr_d1 xr = (gptr_d1)(uintptr_t)job->Xring[(round > 0 ? round - 1 : 0) & 1];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Xp[i] = xr[i];
+    if (round > 0) prev_hint = ((gptr_d1)(uintptr_t)hints)[((round - 1) & 1) * hint_stride + hint_slot];
   }
   const long long U = (long long)K * RPT;
   const int xcd = blockIdx.x & 7;
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 
   // ---- the solve of the previous round, by every workgroup -------------------------------------------------
   __shared__ double s_total[kAcc];
-  __shared__ double s_X[24];  // X_round (12), X_{round-1} (12)
+  __shared__ double s_X[25];  // X_round (12), X_{round-1} (12), walk hint
   if (round > 0) {
     if (totals) {
       if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
@@ -949,6 +957,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       s_X[i] = Xn[i];
       s_X[12 + i] = Xp[i];
     }
+    s_X[24] = prev_hint;
   }
   __syncthreads();
   MADICP_STAMP(2);
@@ -957,6 +966,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   for (int k = 0; k < 9; ++k) { R[k] = wave_uniform(s_X[k]); Rp[k] = wave_uniform(s_X[12 + k]); }
 #pragma unroll
   for (int k = 0; k < 3; ++k) { t[k] = wave_uniform(s_X[9 + k]); tp[k] = wave_uniform(s_X[21 + k]); }
+  const bool stage_hint = round == 0 || wave_uniform(s_X[24]) > 0.0;
+  bool walked = false;
 
   // the matched_ flags are cleared before the last round (pipeline.cpp:172-176); all workgroups share the work
   if (round == n_iters - 2) {
@@ -1057,20 +1068,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       if (u == u_first && base == r * S) { MADICP_STAMP(3); }
       if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP(11); }
       {
-        if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform condition) copy the top levels into LDS on demand
-          bool need = false;
 #pragma unroll
-          for (int j = 0; j < QPT; ++j) need |= walk[j];
-          if (__syncthreads_or(need ? 1 : 0)) {
-            gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-            const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
-            for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
-              s_top[e] = gt[e];
-              reinterpret_cast<long long*>(s_exit)[e] = ge[e];
-            }
-            __syncthreads();
-            staged_tree = k;
+        for (int j = 0; j < QPT; ++j) walked |= walk[j];
+        if (n_top_avail > 0 && k != staged_tree && stage_hint) {  // (workgroup-uniform condition) copy the top levels into LDS
+          if (staged_tree >= 0) __syncthreads();  // nobody may still be walking the previous tree's copy
+          gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
+          const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+          for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
+            s_top[e] = gt[e];
+            reinterpret_cast<long long*>(s_exit)[e] = ge[e];
           }
+          __syncthreads();
+          staged_tree = k;
         }
         const int n_top = (k == staged_tree) ? n_top_avail : 0;
         // The lane's QPT leaves share their LOADS (coordinates, cache, leaf record: issued together above and below),
@@ -1176,13 +1185,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   wave_reduce_scatter(acc, lane, red[wave]);
-  __syncthreads();
+  const int n_walked = __syncthreads_count(walked ? 1 : 0);
   if (threadIdx.x < kAcc) {
     double s = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
     my_partials[(long long)blockIdx.x * kAcc + threadIdx.x] = s;
   }
+  if (threadIdx.x == 0) hints[(round & 1) * hint_stride + hint_slot] = static_cast<double>(n_walked);
   MADICP_STAMP(6);
 }
 
