@@ -275,7 +275,8 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 // While walking, a lane also keeps M = min over the visited levels of (|s^| - E): a proven lower bound of
 // |S_real| = |(q - m).n| at every node of its path (|s^ - S_real| <= E, section "Exact screening").  Moving the
 // query by d changes every S_real by at most d|n| <= d(1 + 2e-16).  So if, in a later round, the leaf has moved by
-// less than M in total (sum of the per-round displacements, each computed from the two poses), every side test on
+// less than M in total (sum of per-round displacement BOUNDS, each from the update itself: rotation angle x |p| +
+// translation length, see solve_pose — two multiply-adds per pair instead of a second transform), every side test on
 // the old path still has the sign it had — and |S_real| stays far above the fp64 rounding of the reference's own
 // evaluation — hence the reference's descent would end in the same leaf after the same number of steps.  The lane
 // then skips the walk and only refreshes the margin.  GN converges quadratically (leaf displacement per round at
@@ -729,8 +730,13 @@ __device__ __forceinline__ void exp_so3(const double* w, double* R) {
 
 // one lane: X_next = X * [expSO3(dx[3:6]), dx[0:3]] with dx = LDLT(H) \\ (-b)   (mad_icp.cpp:111-116); also returns
 // H (mirrored from the 21 accumulated entries, see DESIGN.md "H symmetry") and b
+// `moved[2]`: upper bounds of the update's rotation angle and translation length — what the correspondence reuse needs
+// to bound how far any leaf moves: |X_next p - X p| <= |R|_2 (|dR - I|_2 |p| + |dt|) <= (1+1e-6)(moved[0] |p| + moved[1])
+// (|expSO3(w) - I|_2 = 2 sin(|w|/2) <= |w|, and = |w| for the first-order branch; |R|_2 <= 1 + 1e-7 after 15 updates).
 __device__ __forceinline__ void solve_pose(const double* total, const double (&X)[12], bool update, double (&Xn)[12],
-                                           double (&H)[36], double (&b)[6]) {
+                                           double (&H)[36], double (&b)[6], double (&moved)[2]) {
+  moved[0] = 0.0;
+  moved[1] = 0.0;
   {
     int v = 0;
 #pragma unroll
@@ -752,6 +758,8 @@ __device__ __forceinline__ void solve_pose(const double* total, const double (&X
     for (int r = 0; r < 6; ++r) nb[r] = -b[r];
     ldlt6_solve(H, nb, dx);
     exp_so3(dx + 3, dR);
+    moved[0] = sqrt(dotc(dx[3], dx[4], dx[5], dx[3], dx[4], dx[5])) * (1.0 + 1e-6);
+    moved[1] = sqrt(dotc(dx[0], dx[1], dx[2], dx[0], dx[1], dx[2])) * (1.0 + 1e-6);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -918,7 +926,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 
   // ---- the solve of the previous round, by every workgroup -------------------------------------------------
   __shared__ double s_total[kAcc];
-  __shared__ double s_X[25];  // X_round (12), X_{round-1} (12), walk hint
+  __shared__ double s_X[15];  // X_round (12), bounds of the last update's rotation angle and translation, walk hint
   if (round > 0) {
     if (totals) {
       if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
@@ -930,9 +938,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   MADICP_STAMP(1);
   if (threadIdx.x == 0) {
     double Xn[12];
+    double moved[2] = {0.0, 0.0};
     if (round > 0) {
       double H[36], b[6];
-      solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b);
+      solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved);
       if (blockIdx.x == 0) {  // bookkeeping of the finished round, once per scan
 #pragma unroll
         for (int i = 0; i < 36; ++i) job->H[i] = H[i];
@@ -953,20 +962,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       for (int i = 0; i < 12; ++i) job->x_iters[(long long)round * 12 + i] = Xn[i];  // the pose this round linearises at
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      s_X[i] = Xn[i];
-      s_X[12 + i] = Xp[i];
-    }
-    s_X[24] = prev_hint;
+    for (int i = 0; i < 12; ++i) s_X[i] = Xn[i];
+    s_X[12] = moved[0];
+    s_X[13] = moved[1];
+    s_X[14] = prev_hint;
   }
   __syncthreads();
   MADICP_STAMP(2);
-  double R[9], t[3], Rp[9], tp[3];
+  double R[9], t[3];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { R[k] = wave_uniform(s_X[k]); Rp[k] = wave_uniform(s_X[12 + k]); }
+  for (int k = 0; k < 9; ++k) R[k] = wave_uniform(s_X[k]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { t[k] = wave_uniform(s_X[9 + k]); tp[k] = wave_uniform(s_X[21 + k]); }
-  const bool stage_hint = round == 0 || wave_uniform(s_X[24]) > 0.0;
+  for (int k = 0; k < 3; ++k) t[k] = wave_uniform(s_X[9 + k]);
+  const double moved_rot = wave_uniform(s_X[12]), moved_trans = wave_uniform(s_X[13]);
+  const bool stage_hint = round == 0 || wave_uniform(s_X[14]) > 0.0;
   bool walked = false;
 
   // the matched_ flags are cleared before the last round (pipeline.cpp:172-176); all workgroups share the work
@@ -1047,13 +1056,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         leaf[j] = 0;
         depth[j] = 0;
         if (reuse && valid[j]) {
-          // how far has this leaf moved since the previous round?  (same expression as above at the previous pose,
-          // so it reproduces the previous round's query bit for bit)
-          const double o0 = tp[0] + dots(Rp[0], Rp[1], Rp[2], p.x, p.y, p.z);
-          const double o1 = tp[1] + dots(Rp[3], Rp[4], Rp[5], p.x, p.y, p.z);
-          const double o2 = tp[2] + dots(Rp[6], Rp[7], Rp[8], p.x, p.y, p.z);
-          const double d0 = q0[j] - o0, d1 = q1[j] - o1, d2 = q2[j] - o2;
-          const double moved = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+          // how far can this leaf have moved since the previous round?  (bound from the update itself, see solve_pose;
+          // the 1e-11 term covers the rounding of the two computed queries)
+          const double moved = moved_rot * p.w + moved_trans;
           const double left_over = (double)cmar[j] - moved * (1.0 + 1e-12) -
                                    1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
                                             fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
@@ -1236,7 +1241,8 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     double Xp[12], Xn[12], H[36], b[6];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(n - 1) & 1][i];
-    solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b);
+    double moved[2];
+    solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b, moved);
 #pragma unroll
     for (int i = 0; i < 36; ++i) job->H[i] = H[i];
 #pragma unroll
