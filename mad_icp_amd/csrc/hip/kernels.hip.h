@@ -609,10 +609,54 @@ __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane,
 // ---------------------------------------------------------------------------------------------------
 // 6x6 LDLT (lower, diagonal pivoting) factor + solve — the algorithm of Eigen::LDLT that
 // `H_adder_.ldlt().solve(-b_adder_)` runs (mad_icp.cpp:111).  A: row-major, only the lower triangle is
-// read.  One lane, everything unrolled so the matrix lives in registers (a scratch-memory version of the
-// same code cost ~15 us per GN round; this one ~1 us).
+// read.  Everything unrolled so the matrix lives in registers (a scratch-memory version of the same code
+// cost ~15 us per GN round).  WAVE-UNIFORM: called by all 64 lanes of one wave with identical arguments;
+// every lane runs the same serial algorithm, except that the independent divisions of a step (the column
+// scaling by the pivot, the division by D) are spread over the lanes — lane i divides element i — and
+// read back with v_readlane, so a step costs one division sequence (~15 dependent instructions) instead
+// of up to five.  Each quotient is still one correctly rounded fp64 division of the same operands.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_get(double v, int lane /* compile-time constant */) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// num[i] /= den[i], i < N (lane-uniform operands; N <= 64)
+template <int N>
+__device__ __forceinline__ void div_spread(double (&num)[N], const double (&den)[N]) {
+  const int lane = threadIdx.x & 63;
+  double a = num[0], d = den[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) {
+    a = (lane == i) ? num[i] : a;
+    d = (lane == i) ? den[i] : d;
+  }
+  const double q = a / d;
+#pragma unroll
+  for (int i = 0; i < N; ++i) num[i] = lane_get(q, i);
+}
 #define MADICP_SWAP(a, b) do { const double t_ = (a); (a) = (b); (b) = t_; } while (0)
+template <int K>
+__device__ __forceinline__ void scale_column_k(double (&m)[6][6], double akk) {  // m[i][K] /= akk for i > K
+  constexpr int N = 5 - K;
+  if constexpr (N > 0) {
+    double num[N], den[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { num[i] = m[K + 1 + i][K]; den[i] = akk; }
+    div_spread<N>(num, den);
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[K + 1 + i][K] = num[i];
+  }
+}
+__device__ __forceinline__ void scale_column(double (&m)[6][6], int k /* unrolled loop index */, double akk) {
+  switch (k) {
+    case 0: scale_column_k<0>(m, akk); break;
+    case 1: scale_column_k<1>(m, akk); break;
+    case 2: scale_column_k<2>(m, akk); break;
+    case 3: scale_column_k<3>(m, akk); break;
+    case 4: scale_column_k<4>(m, akk); break;
+    default: break;
+  }
+}
 __device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, double* x) {
   double m[6][6];
   int tr[6];
@@ -664,8 +708,7 @@ __device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, 
     const bool ok = fabs(akk) > 0.0;
     if (k == 0 && !ok) zero_matrix = true;  // whole diagonal is zero: identity transpositions, no scaling
     if (ok && !zero_matrix) {
-#pragma unroll
-      for (int i = k + 1; i < 6; ++i) m[i][k] /= akk;
+      scale_column(m, k, akk);
     }
   }
   double y[6];
@@ -685,8 +728,14 @@ __device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, 
     y[i] -= a;
   }
   const double tol = 2.2250738585072014e-308;  // numeric_limits<double>::min()
+  {
+    double num[6], den[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] = (fabs(m[i][i]) > tol) ? y[i] / m[i][i] : 0.0;
+    for (int i = 0; i < 6; ++i) { num[i] = y[i]; den[i] = m[i][i]; }
+    div_spread<6>(num, den);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = (fabs(m[i][i]) > tol) ? num[i] : 0.0;
+  }
 #pragma unroll
   for (int i = 4; i >= 0; --i) {
     double a = m[i + 1][i] * y[i + 1];
@@ -704,21 +753,26 @@ __device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, 
   for (int i = 0; i < 6; ++i) x[i] = y[i];
 }
 
-// lie_algebra.h:39-52, R row-major
+// lie_algebra.h:39-52, R row-major.  Wave-uniform like ldlt6_solve.  K = skew(w)/theta has six non-zero entries
+// +-w_i/theta: three divisions (spread over three lanes), the rest by negation — -(a/b) and (-a)/b are the same double.
 __device__ __forceinline__ void exp_so3(const double* w, double* R) {
   const double th2 = dotc(w[0], w[1], w[2], w[0], w[1], w[2]);
   const double th = sqrt(th2);
-  const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
   if (th2 < 1e-8) {
+    const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + W[i];
     return;
   }
-  double Kx[9], cK[9];
+  double k[3] = {w[0], w[1], w[2]};
+  const double den[3] = {th, th, th};
+  div_spread<3>(k, den);
+  const double Kx[9] = {0.0, -k[2], k[1], k[2], 0.0, -k[0], -k[1], k[0], 0.0};
+  double cK[9];
   const double omc = 2.0 * sin(th / 2.0) * sin(th / 2.0);
   const double s = sin(th);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { Kx[i] = W[i] / th; cK[i] = omc * Kx[i]; }
+  for (int i = 0; i < 9; ++i) cK[i] = omc * Kx[i];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -728,8 +782,6 @@ __device__ __forceinline__ void exp_so3(const double* w, double* R) {
     }
 }
 
-// one lane: X_next = X * [expSO3(dx[3:6]), dx[0:3]] with dx = LDLT(H) \\ (-b)   (mad_icp.cpp:111-116); also returns
-// H (mirrored from the 21 accumulated entries, see DESIGN.md "H symmetry") and b
 // `moved[2]`: upper bounds of the update's rotation angle and translation length — what the correspondence reuse needs
 // to bound how far any leaf moves: |X_next p - X p| <= |R|_2 (|dR - I|_2 |p| + |dt|) <= (1+1e-6)(moved[0] |p| + moved[1])
 // (|expSO3(w) - I|_2 = 2 sin(|w|/2) <= |w|, and = |w| for the first-order branch; |R|_2 <= 1 + 1e-7 after 15 updates).
@@ -788,9 +840,17 @@ __device__ __forceinline__ void join_issue(const double* __restrict__ partials, 
 #pragma unroll
   for (int i = 0; i < kJoinMaxSeg; ++i) jl.v[i] = (j < kAcc && seg_len <= kJoinMaxSeg && b0 + i < b1) ? gp[(long long)(b0 + i) * kAcc + j] : 0.0;
 }
-__device__ __forceinline__ void join_finish(const double* __restrict__ partials, int nblocks, const JoinLoads& jl,
-                                            double* total /*LDS kAcc*/) {
-  __shared__ double seg[kJoinSeg][kAcc];
+// LDS written by some lanes of a wave, read by other lanes of the SAME wave: the hardware keeps a wave's LDS
+// operations in order; this only stops the compiler from reordering them
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+typedef double JoinSeg[kJoinSeg][kAcc];
+// stage 1 (whole workgroup): the segment sums, into LDS; ends with the workgroup barrier that publishes them
+__device__ __forceinline__ void join_stage1(const double* __restrict__ partials, int nblocks, const JoinLoads& jl,
+                                            JoinSeg& seg /*LDS*/) {
   const int j = threadIdx.x & 31;
   const int s = threadIdx.x >> 5;
   const int seg_len = (nblocks + kJoinSeg - 1) / kJoinSeg;
@@ -809,6 +869,9 @@ __device__ __forceinline__ void join_finish(const double* __restrict__ partials,
     seg[s][j] = a;
   }
   __syncthreads();
+}
+// stage 2 (wave 0 only): the segments in sequence -> total[kAcc] in LDS, visible to wave 0
+__device__ __forceinline__ void join_stage2_wave0(const JoinSeg& seg, double* total /*LDS kAcc*/) {
   if (threadIdx.x < kAcc) {
     double r[kJoinSeg];
 #pragma unroll
@@ -818,12 +881,15 @@ __device__ __forceinline__ void join_finish(const double* __restrict__ partials,
     for (int k = 1; k < kJoinSeg; ++k) a += r[k];
     total[threadIdx.x] = a;
   }
-  __syncthreads();
+  wave_lds_order();
 }
+// whole workgroup in, total[] valid for WAVE 0 out (icp_reduce / icp_final)
 __device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
+  __shared__ JoinSeg seg;
   JoinLoads jl;
   join_issue(partials, nblocks, jl);
-  join_finish(partials, nblocks, jl, total);
+  join_stage1(partials, nblocks, jl, seg);
+  if (threadIdx.x < 64) join_stage2_wave0(seg, total);
 }
 
 __device__ __forceinline__ double wave_uniform(double v) {  // value known to be identical in all lanes -> SGPR pair
@@ -855,7 +921,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   typedef const __attribute__((address_space(1))) float* gptr_f1;
   typedef const __attribute__((address_space(1))) double* gptr_d1;
   // Loads whose addresses need nothing but the launch geometry go first: the previous round's partials (joined by
-  // every workgroup below) and — lane 0 only, it is the one that solves — the pose that round linearised at.
+  // every workgroup below) and — wave 0 only, it is the one that solves — the pose that round linearised at.
   // (Measured alternatives, all slower: every lane loading the pose, which turns it into scalar loads that the rest
   // of the scalar traffic then queues behind; requesting all of the Job's scalars in one pinned batch.)
   const long long pstride = (long long)gridDim.y * gridDim.x * kAcc;  // one parity's worth of partials
@@ -870,7 +936,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const long long hint_slot = (long long)blockIdx.y * gridDim.x + blockIdx.x;
   const long long hint_stride = (long long)gridDim.y * gridDim.x;
   double prev_hint = 1.0;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // wave 0 solves (every lane the same values)
     gptr_d1 xr = (gptr_d1)(uintptr_t)job->Xring[(round > 0 ? round - 1 : 0) & 1];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Xp[i] = xr[i];
@@ -924,25 +990,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     }
   }
 
-  // ---- the solve of the previous round, by every workgroup -------------------------------------------------
+  // ---- the solve of the previous round, by every workgroup (its wave 0) ------------------------------------
   __shared__ double s_total[kAcc];
   __shared__ double s_X[15];  // X_round (12), bounds of the last update's rotation angle and translation, walk hint
-  if (round > 0) {
-    if (totals) {
-      if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
-      __syncthreads();
-    } else {
-      join_finish(prev_partials, gridDim.x, jl, s_total);
-    }
-  }
-  MADICP_STAMP(1);
-  if (threadIdx.x == 0) {
+  __shared__ JoinSeg s_seg;
+  if (round > 0 && !totals) join_stage1(prev_partials, gridDim.x, jl, s_seg);
+  if (threadIdx.x < 64) {
     double Xn[12];
     double moved[2] = {0.0, 0.0};
     if (round > 0) {
+      if (totals) {
+        if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
+        wave_lds_order();
+      } else {
+        join_stage2_wave0(s_seg, s_total);
+      }
+      MADICP_STAMP(1);
       double H[36], b[6];
       solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved);
-      if (blockIdx.x == 0) {  // bookkeeping of the finished round, once per scan
+      if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping of the finished round, once per scan
 #pragma unroll
         for (int i = 0; i < 36; ++i) job->H[i] = H[i];
 #pragma unroll
@@ -954,18 +1020,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         job->iter = round;
       }
     } else {
+      MADICP_STAMP(1);
 #pragma unroll
       for (int i = 0; i < 12; ++i) Xn[i] = Xp[i];
     }
-    if (blockIdx.x == 0 && job->x_iters) {
+    if (threadIdx.x == 0) {
+      if (blockIdx.x == 0 && job->x_iters) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) job->x_iters[(long long)round * 12 + i] = Xn[i];  // the pose this round linearises at
+        for (int i = 0; i < 12; ++i) job->x_iters[(long long)round * 12 + i] = Xn[i];  // the pose this round linearises at
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s_X[i] = Xn[i];
+      s_X[12] = moved[0];
+      s_X[13] = moved[1];
+      s_X[14] = prev_hint;
     }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) s_X[i] = Xn[i];
-    s_X[12] = moved[0];
-    s_X[13] = moved[1];
-    s_X[14] = prev_hint;
   }
   __syncthreads();
   MADICP_STAMP(2);
@@ -1237,21 +1306,23 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     join_partials(partials + ((n - 1) & 1) * pstride + (long long)blockIdx.x * nblocks * kAcc, nblocks, s_total);
   }
   count_matched(job);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {  // wave 0, every lane the same values (solve_pose is wave-uniform)
     double Xp[12], Xn[12], H[36], b[6];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(n - 1) & 1][i];
     double moved[2];
     solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b, moved);
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) job->H[i] = H[i];
+      for (int i = 0; i < 36; ++i) job->H[i] = H[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) job->b[i] = b[i];
+      for (int i = 0; i < 6; ++i) job->b[i] = b[i];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) job->X[i] = Xn[i];
-    job->n_pairs = s_total[27];
-    job->visits += static_cast<unsigned long long>(s_total[28]);
-    job->iter = n;
+      for (int i = 0; i < 12; ++i) job->X[i] = Xn[i];
+      job->n_pairs = s_total[27];
+      job->visits += static_cast<unsigned long long>(s_total[28]);
+      job->iter = n;
+    }
   }
 }
 
