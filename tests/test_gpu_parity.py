@@ -229,6 +229,33 @@ def test_register_batch_equals_single(ctx):
 
 
 @pytest.mark.parametrize("stage_min", [0, 1 << 30])
+def test_more_keyframes_than_workgroups_per_scan(ctx, stage_min):
+    """16 scans in flight against 20 keyframes: 16 workgroups per scan, 20 (tree, range) units — some workgroups walk
+    two different trees one after the other (with threshold 0 they re-stage the LDS top between them).  Every scan
+    must end where the oracle's registration of that scan ends, and like the same scan registered alone."""
+    ctx.set_option("lds_stage_min_leaves", stage_min)
+    try:
+        pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 20, n_queries=2)
+        B = 16
+        # each moving cloud may be in flight only once per batch: upload copies
+        extra = [ctx.moving_upload(qh[s % 2].leaf_means()) for s in range(2, B)]
+        mids16 = mids[:2] + extra
+        X0 = np.stack([capi.pose12(pb["query_guess"][s % 2]) for s in range(B)])
+        gb = ctx.icp_register_batch(mids16, tids, X0, PARAMS, 15)
+        for s in range(2):
+            o = O.icp_register(qo[s], ots, pb["query_guess"][s], 15, B_MAX, RHO_KER, B_RATIO, num_threads=4)
+            gs = ctx.icp_register(mids[s], tids, pb["query_guess"][s], PARAMS, 15, qh[s].num_leaves)
+            dt, da = pose_err(o["T"], gs["T"])
+            assert dt < 1e-5 and da < 1e-5
+            for r in range(s, B, 2):
+                assert np.allclose(gb["X"][r], gs["X"], rtol=0, atol=1e-10)
+                assert np.allclose(gb["H"][r], gs["H"], rtol=1e-9, atol=1e-9 * np.abs(gs["H"]).max())
+        _teardown(ctx, tids, mids + extra)
+    finally:
+        ctx.set_option("lds_stage_min_leaves", 1024)
+
+
+@pytest.mark.parametrize("stage_min", [0, 1 << 30])
 def test_lds_staged_and_unstaged_descent_agree_with_oracle(ctx, stage_min):
     """The top levels of a tree walked from the LDS copy (threshold 0: always) or from global memory (never) give
     the same correspondences as the oracle, bit for bit."""

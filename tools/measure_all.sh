@@ -6,7 +6,7 @@ TAG=$1
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-(python -m pytest tests -m gpu -q 2>&1 | tail -3) > $OUT/tests.log 2>&1
+(python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|rror" | tail -5) > $OUT/tests.log 2>&1
 python bench.py > $OUT/bench_n1.json 2> $OUT/bench.err
 python bench.py --scans 8 --cpu-baseline off > $OUT/bench_n1_scans8.json 2>> $OUT/bench.err
 python bench.py --keyframes 64 --scans 8 --steps 30 --warmup 5 --cpu-baseline off > $OUT/bench_n1_k64_scans8.json 2>> $OUT/bench.err
