@@ -1,9 +1,12 @@
 #include "tree_builder.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <future>
 #include <limits>
+#include <memory>
+#include <thread>
 
 #include "linalg.h"
 
@@ -13,8 +16,17 @@ namespace {
 struct Ctx {
   double* pts;  // xyz triples
   double b_max, b_min;
-  int max_parallel_level;
+  int max_parallel_level;  // levels above this depth run as tasks (0: everything on the calling thread)
 };
+
+// Task policy.  The reference forks two std::async tasks per node above `max_parallel_level` and the parent waits
+// (mad_tree.cpp:99-117): 2^level leaf tasks, badly balanced because MAD-trees split at the mean, not the median.
+// Here the same argument buys 4x as many, smaller tasks (two more levels), the parent builds one child itself, a
+// range below kTaskMinPoints is never forked, and the order-independent pass of a big node (the bounding box) is cut
+// over idle threads.  None of this can change a bit of the result: every sum keeps its sequential order.
+constexpr int kExtraTaskLevels = 2;
+constexpr int64_t kTaskMinPoints = 4096;
+constexpr int64_t kBboxSliceMinPoints = 16384;
 
 // what a leaf may need from its ancestors (reference mad_tree.cpp:64-74)
 struct Inherited {
@@ -27,14 +39,17 @@ inline double* P(const Ctx& c, int64_t i) { return c.pts + 3 * i; }
 // utils.h:54-73: one pass, mean and sample covariance (full 3x3 accumulated, symmetric by construction)
 void mean_cov(const Ctx& c, int64_t b, int64_t e, double* mean, double* cov /*row-major 9*/) {
   double m[3] = {0, 0, 0};
-  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // the reference accumulates all nine products; v_r*v_q and v_q*v_r are the same double, so six sums give the same
+  // nine values
+  double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
   for (int64_t i = b; i < e; ++i) {
     const double* v = P(c, i);
     m[0] += v[0]; m[1] += v[1]; m[2] += v[2];
-    s[0] += v[0] * v[0]; s[1] += v[0] * v[1]; s[2] += v[0] * v[2];
-    s[3] += v[1] * v[0]; s[4] += v[1] * v[1]; s[5] += v[1] * v[2];
-    s[6] += v[2] * v[0]; s[7] += v[2] * v[1]; s[8] += v[2] * v[2];
+    s00 += v[0] * v[0]; s01 += v[0] * v[1]; s02 += v[0] * v[2];
+    s11 += v[1] * v[1]; s12 += v[1] * v[2];
+    s22 += v[2] * v[2];
   }
+  const double s[9] = {s00, s01, s02, s01, s11, s12, s02, s12, s22};
   const int k = static_cast<int>(e - b);
   const double inv_k = 1. / k;
   for (int i = 0; i < 3; ++i) mean[i] = m[i] * inv_k;
@@ -47,10 +62,9 @@ void mean_cov(const Ctx& c, int64_t b, int64_t e, double* mean, double* cov /*ro
     }
 }
 
-// utils.h:75-97: extents of the points in the eigen frame, 0 included; min/max keep the running value on NaN
-void bbox_extents(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V /*row-major, cols = eigvecs*/,
-                  double* ext) {
-  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+// utils.h:75-97: extents of the points in the eigen frame, 0 included; min/max keep the running value on NaN.
+// min and max do not depend on the order of the points, so a big range is cut into slices.
+void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V, double* lo, double* hi) {
   const double c0[3] = {V[0], V[3], V[6]}, c1[3] = {V[1], V[4], V[7]}, c2[3] = {V[2], V[5], V[8]};
   for (int64_t i = b; i < e; ++i) {
     const double* p = P(c, i);
@@ -61,40 +75,65 @@ void bbox_extents(const Ctx& c, int64_t b, int64_t e, const double* mean, const 
       if (hi[a] < v[a]) hi[a] = v[a];
     }
   }
+}
+
+void bbox_extents(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V /*row-major, cols = eigvecs*/,
+                  double* ext, int slices) {
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  if (slices <= 1 || e - b < kBboxSliceMinPoints) {
+    bbox_lohi(c, b, e, mean, V, lo, hi);
+  } else {
+    struct LoHi { double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; };
+    std::vector<LoHi> part(static_cast<size_t>(slices));
+    std::vector<std::future<void>> fut;
+    const int64_t step = (e - b + slices - 1) / slices;
+    for (int s = 1; s < slices; ++s) {
+      const int64_t sb = b + s * step, se = std::min(e, sb + step);
+      if (sb >= se) break;
+      fut.push_back(std::async(std::launch::async, [&c, sb, se, mean, V, &part, s] {
+        bbox_lohi(c, sb, se, mean, V, part[s].lo, part[s].hi);
+      }));
+    }
+    bbox_lohi(c, b, std::min(e, b + step), mean, V, part[0].lo, part[0].hi);
+    for (auto& f : fut) f.get();
+    for (const LoHi& q : part)
+      for (int a = 0; a < 3; ++a) {
+        if (q.lo[a] < lo[a]) lo[a] = q.lo[a];
+        if (hi[a] < q.hi[a]) hi[a] = q.hi[a];
+      }
+  }
   for (int a = 0; a < 3; ++a) ext[a] = hi[a] - lo[a];
 }
 
 // utils.h:37-52: partition; the non-matching element is swapped with the one just below the upper cursor
 int64_t partition_by_plane(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* normal) {
+  // same sequence of swaps as the reference's loop, written without a data-dependent branch (the side test is a coin
+  // flip to the branch predictor): both elements are rewritten every step, swapped or not
   int64_t lo = b, hi = e;
   while (lo != hi) {
     double* p = P(c, lo);
-    const double d[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
-    if (dot3c(d, normal) < 0.0) {
-      ++lo;
-    } else {
-      double* q = P(c, hi - 1);
-      for (int a = 0; a < 3; ++a) {
-        const double t = p[a];
-        p[a] = q[a];
-        q[a] = t;
-      }
-      --hi;
-    }
+    double* q = P(c, hi - 1);
+    const double p0 = p[0], p1 = p[1], p2 = p[2];
+    const double q0 = q[0], q1 = q[1], q2 = q[2];
+    const double d[3] = {p0 - mean[0], p1 - mean[1], p2 - mean[2]};
+    const bool keep = dot3c(d, normal) < 0.0;
+    p[0] = keep ? p0 : q0; p[1] = keep ? p1 : q1; p[2] = keep ? p2 : q2;
+    q[0] = keep ? q0 : p0; q[1] = keep ? q1 : p1; q[2] = keep ? q2 : p2;
+    lo += keep ? 1 : 0;
+    hi -= keep ? 0 : 1;
   }
   return hi;
 }
 
-void build_range(const Ctx& c, int64_t b, int64_t e, int level, Inherited inh, std::vector<madicp_node>& out) {
+// one node: statistics, leaf test, and — for an internal node — the partition.  Returns true for a leaf.
+// `col0` / `mid` are only set for internal nodes; `col0` must outlive the children (they may inherit it).
+bool make_node(const Ctx& c, int64_t b, int64_t e, Inherited& inh, madicp_node& nd, double* col0, int64_t& mid,
+               int bbox_slices) {
   const int n_pts = static_cast<int>(e - b);
   double mean[3], cov[9], w[3], V[9], ext[3];
   mean_cov(c, b, e, mean, cov);
   eig3_sym(cov, w, V);
-  bbox_extents(c, b, e, mean, V, ext);
-
-  const size_t self = out.size();
-  out.emplace_back();
-  madicp_node nd;
+  bbox_extents(c, b, e, mean, V, ext, bbox_slices);
   nd.bbox0 = ext[0];
 
   if (ext[2] < c.b_max) {  // leaf: mad_tree.cpp:64-88
@@ -121,42 +160,85 @@ void build_range(const Ctx& c, int64_t b, int64_t e, int level, Inherited inh, s
     std::memcpy(nd.mean, first, sizeof(nd.mean));
     std::memcpy(nd.dir, normal, sizeof(nd.dir));
     nd.right = 0;
-    nd.leaf_id = 0;  // assigned after the splice
-    out[self] = nd;
-    return;
+    nd.leaf_id = 0;  // assigned after the flattening
+    return true;
   }
 
-  const double col0[3] = {V[0], V[3], V[6]};
+  col0[0] = V[0]; col0[1] = V[3]; col0[2] = V[6];
   const double col2[3] = {V[2], V[5], V[8]};
   if (!inh.plane_normal && ext[0] < c.b_min) inh.plane_normal = col0;  // mad_tree.cpp:90-93
   if (n_pts >= 3 || !inh.small_normal) inh.small_normal = col0;         // mad_tree.cpp:68-72, walked top-down
 
-  const int64_t mid = partition_by_plane(c, b, e, mean, col2);
+  mid = partition_by_plane(c, b, e, mean, col2);
 
   std::memcpy(nd.mean, mean, sizeof(nd.mean));
   std::memcpy(nd.dir, col2, sizeof(nd.dir));
   nd.leaf_id = -1;
+  return false;
+}
 
-  if (level >= c.max_parallel_level) {
-    build_range(c, b, mid, level + 1, inh, out);
-    nd.right = static_cast<int32_t>(out.size() - self);
-    build_range(c, mid, e, level + 1, inh, out);
-  } else {
-    auto task = [&c, level, inh](int64_t tb, int64_t te) {
-      std::vector<madicp_node> sub;
-      sub.reserve(static_cast<size_t>(2 * (te - tb)));
-      build_range(c, tb, te, level + 1, inh, sub);
-      return sub;
-    };
-    std::future<std::vector<madicp_node>> fl = std::async(std::launch::async, task, b, mid);
-    std::future<std::vector<madicp_node>> fr = std::async(std::launch::async, task, mid, e);
-    const std::vector<madicp_node> l = fl.get();
-    const std::vector<madicp_node> r = fr.get();
-    out.insert(out.end(), l.begin(), l.end());
-    nd.right = static_cast<int32_t>(out.size() - self);
-    out.insert(out.end(), r.begin(), r.end());
+// a whole sub-tree on the calling thread, appended to `out` in preorder
+void build_sequential(const Ctx& c, int64_t b, int64_t e, Inherited inh, std::vector<madicp_node>& out) {
+  const size_t self = out.size();
+  out.emplace_back();
+  madicp_node nd;
+  double col0[3];
+  int64_t mid = 0;
+  if (make_node(c, b, e, inh, nd, col0, mid, 1)) {
+    out[self] = nd;
+    return;
   }
+  build_sequential(c, b, mid, inh, out);
+  nd.right = static_cast<int32_t>(out.size() - self);
+  build_sequential(c, mid, e, inh, out);
   out[self] = nd;
+}
+
+// The forked top of the tree: a node of it is either one record with two children, or a chunk (a sub-tree that one
+// thread built, already in preorder with relative offsets — position independent).
+struct Piece {
+  std::vector<madicp_node> chunk;  // non-empty: a finished sub-tree
+  madicp_node nd;                  // else: this node ...
+  std::unique_ptr<Piece> left, right;  // ... and its sub-trees
+  size_t size = 0;                 // nodes in this piece
+};
+
+std::unique_ptr<Piece> build_forked(const Ctx& c, int64_t b, int64_t e, int level, Inherited inh, int bbox_slices) {
+  auto piece = std::make_unique<Piece>();
+  if (level >= c.max_parallel_level || e - b < kTaskMinPoints) {
+    piece->chunk.reserve(static_cast<size_t>(std::min<int64_t>(2 * (e - b), 1 << 16)));
+    build_sequential(c, b, e, inh, piece->chunk);
+    piece->size = piece->chunk.size();
+    return piece;
+  }
+  double col0[3];  // lives until both children are done (they may point at it through `inh`)
+  int64_t mid = 0;
+  if (make_node(c, b, e, inh, piece->nd, col0, mid, bbox_slices)) {
+    piece->chunk.push_back(piece->nd);
+    piece->size = 1;
+    return piece;
+  }
+  // left child on another thread, right child here; a level down there are twice as many busy threads, so the
+  // bounding-box pass gets half the slices
+  const int child_slices = std::max(1, bbox_slices / 2);
+  std::future<std::unique_ptr<Piece>> fl = std::async(std::launch::async, [&c, b, mid, level, inh, child_slices] {
+    return build_forked(c, b, mid, level + 1, inh, child_slices);
+  });
+  piece->right = build_forked(c, mid, e, level + 1, inh, child_slices);
+  piece->left = fl.get();
+  piece->size = 1 + piece->left->size + piece->right->size;
+  piece->nd.right = static_cast<int32_t>(1 + piece->left->size);
+  return piece;
+}
+
+void flatten(const Piece& p, madicp_node* out) {
+  if (!p.chunk.empty()) {
+    std::memcpy(out, p.chunk.data(), p.chunk.size() * sizeof(madicp_node));
+    return;
+  }
+  out[0] = p.nd;
+  flatten(*p.left, out + 1);
+  flatten(*p.right, out + 1 + p.left->size);
 }
 
 }  // namespace
@@ -164,11 +246,22 @@ void build_range(const Ctx& c, int64_t b, int64_t e, int level, Inherited inh, s
 LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int max_parallel_level) {
   LinearTree t;
   if (n <= 0) return t;
-  Ctx c{points, b_max, b_min, max_parallel_level};
-  t.nodes.reserve(static_cast<size_t>(2 * n));
-  build_range(c, 0, n, 0, Inherited{nullptr, nullptr}, t.nodes);
-  t.nodes.shrink_to_fit();
+  const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
+  int levels = max_parallel_level > 0 ? max_parallel_level + kExtraTaskLevels : 0;
+  while (levels > 0 && (1 << (levels - 1)) > 2 * hw) --levels;  // never far more leaf tasks than cores
+  Ctx c{points, b_max, b_min, levels};
+  if (levels == 0) {
+    t.nodes.reserve(static_cast<size_t>(2 * n));
+    build_sequential(c, 0, n, Inherited{nullptr, nullptr}, t.nodes);
+    t.nodes.shrink_to_fit();
+  } else {
+    const int slices = std::min(hw, 1 << std::min(levels, 4));
+    const std::unique_ptr<Piece> top = build_forked(c, 0, n, 0, Inherited{nullptr, nullptr}, slices);
+    t.nodes.resize(top->size);
+    flatten(*top, t.nodes.data());
+  }
   // getLeafs() order == order of appearance in the preorder array (mad_tree.cpp:154-163)
+  t.leaf_nodes.reserve((t.nodes.size() + 1) / 2);
   for (size_t i = 0; i < t.nodes.size(); ++i)
     if (t.nodes[i].right == 0) {
       t.nodes[i].leaf_id = static_cast<int32_t>(t.leaf_nodes.size());

@@ -19,8 +19,9 @@ struct LinearTree {
 };
 
 // points: n x 3 doubles, permuted in place exactly like the reference permutes its private copy.
-// max_parallel_level: sub-trees above this depth are built by std::async tasks (reference: the
-// `level >= max_parallel_level` test at mad_tree.cpp:99).
+// max_parallel_level: 0 = build on the calling thread; > 0 = fork tasks for the top of the tree (reference: the
+// `level >= max_parallel_level` test at mad_tree.cpp:99; here the same argument forks two levels deeper, smaller
+// tasks, see tree_builder.cpp "Task policy").  The result does not depend on it.
 LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int max_parallel_level);
 
 // MADtree::applyTransform (mad_tree.cpp:165-172) on the linear form; R row-major.
