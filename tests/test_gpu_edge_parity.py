@@ -1,0 +1,122 @@
+"""GPU parity on inputs that stress the exactness arguments rather than the common case: scenes far from the
+origin (the screening certificate's error bound grows with |q - o|), clouds with no planar structure, duplicated
+points (zero-extent leaves, rank-deficient covariances), and the largest keyframe count the ABI accepts.
+Same bar as tests/test_gpu_parity.py: correspondences and gate decisions bit-exact, pose within 1e-5 m / 1e-5 rad."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fixtures import B_MAX, B_MIN, B_RATIO, PARAMS, RHO_KER, street_problem
+from mad_icp_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_err(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    ang = np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1))
+    return np.linalg.norm(d[:3, 3]), ang
+
+
+def _check_registration(ctx, fixed_clouds, fixed_poses, moving_cloud, T0, tol=(1e-5, 1e-5), b_max=B_MAX):
+    hts, ots, tids = [], [], []
+    for s, T in zip(fixed_clouds, fixed_poses):
+        ht = capi.HostTree(s, b_max, B_MIN, 2)
+        ot = O.Tree(s, b_max, B_MIN, 2)
+        if T is not None:
+            ht.transform(T[:3, :3], T[:3, 3])
+            ot.transform(T[:3, :3], T[:3, 3])
+        assert np.array_equal(ht.nodes["mean"], ot.export()["mean"])  # identical trees, or the bar below is meaningless
+        hts.append(ht)
+        ots.append(ot)
+        tids.append(ctx.tree_upload(ht.nodes, ht.num_leaves))
+    qh = capi.HostTree(moving_cloud, b_max, B_MIN, 2)
+    qo = O.Tree(moving_cloud, b_max, B_MIN, 2)
+    mid = ctx.moving_upload(qh.leaf_means())
+    L = qh.num_leaves
+    params = (b_max, RHO_KER, B_RATIO)
+    # correspondences + gate at the initial pose, bit for bit, and the node-visit count
+    g = ctx.icp_linearize(mid, tids, T0, params, L)
+    visits = 0
+    for k, ot in enumerate(ots):
+        _, _, corr, rej, _, depth = O.icp_linearize(qo, ot, T0, b_max, RHO_KER, B_RATIO)
+        assert np.array_equal(g["corr"][k] & 0x7FFFFFFF, corr), k
+        assert np.array_equal((g["corr"][k] >> 31).astype(np.uint8), rej), k
+        visits += depth
+    assert g["visits"] == visits
+    # the whole registration
+    o = O.icp_register(qo, ots, T0, 15, b_max, RHO_KER, B_RATIO, num_threads=4)
+    r = ctx.icp_register(mid, tids, T0, params, 15, L)
+    dt, da = pose_err(o["T"], r["T"])
+    assert dt <= tol[0] and da <= tol[1], (dt, da)
+    assert np.array_equal(r["matched"], o["matched"])
+    assert r["visits"] == o["depth_sum"]
+    for t in tids:
+        ctx.tree_release(t)
+    ctx.moving_release(mid)
+    return r, o
+
+
+@pytest.mark.parametrize("offset", [1.0e3, 1.0e5])
+def test_scene_far_from_the_origin(ctx, offset):
+    """The same street, translated by kilometres (UTM-like map frames).  |q - o| stays small because the screening
+    origin is the tree's own centroid, but every coordinate now carries 1e3..1e5 times less absolute precision, and the
+    exact fallback must still decide like the reference."""
+    pb = street_problem(2)
+    shift = np.eye(4)
+    shift[:3, 3] = [offset, -0.7 * offset, 0.01 * offset]
+    poses = [shift @ T for T in pb["keyframe_poses"]]
+    T0 = shift @ pb["query_guess"][0]
+    r, o = _check_registration(ctx, pb["keyframe_scans"], poses, pb["query_scans"][0], T0)
+    gt = shift @ pb["query_gt"][0]
+    assert np.linalg.norm(r["T"][:3, 3] - gt[:3, 3]) < 0.1
+
+
+def test_unstructured_cloud(ctx):
+    """A Gaussian blob has no planes: leaves are small balls with arbitrary normals, most pairs fail the gate, H is
+    poorly conditioned.  Nothing about the GPU path assumes structure."""
+    rng = np.random.default_rng(11)
+    ref = rng.normal(0.0, 3.0, (6000, 3))
+    mov = ref[rng.permutation(6000)[:4000]] + rng.normal(0.0, 0.003, (4000, 3))
+    T0 = synth.perturbation(5, trans=0.05, rot_deg=0.3)
+    _check_registration(ctx, [ref], [None], mov, T0)
+
+
+def test_duplicated_points_and_tiny_leaves(ctx):
+    """Every point four times (zero-extent leaves, singular covariances), b_max small enough that most leaves hold a
+    single distinct location."""
+    rng = np.random.default_rng(12)
+    base = np.concatenate([rng.uniform(-2, 2, (1500, 3)) * [1, 1, 0.0], rng.uniform(-2, 2, (1500, 3)) * [1, 0.0, 1]])
+    ref = np.repeat(base, 4, axis=0)
+    mov = base + rng.normal(0.0, 0.001, base.shape)
+    T0 = synth.perturbation(6, trans=0.02, rot_deg=0.2)
+    _check_registration(ctx, [ref], [None], mov, T0, b_max=0.05)
+
+
+def test_maximum_number_of_keyframes(ctx):
+    """MADICP_MAX_TREES keyframes in one registration (the device Job holds the descriptors by value)."""
+    pb = street_problem(4, n_beams=16, n_azimuth=300)
+    K = capi.MAX_TREES
+    clouds = [pb["keyframe_scans"][k % 4][(k // 4)::3] for k in range(K)]  # 128 different sub-samplings
+    poses = [pb["keyframe_poses"][k % 4] for k in range(K)]
+    hts, ots, tids = [], [], []
+    for s, T in zip(clouds, poses):
+        ht = capi.HostTree(s, B_MAX, B_MIN, 0)
+        ot = O.Tree(s, B_MAX, B_MIN, 0)
+        ht.transform(T[:3, :3], T[:3, 3])
+        ot.transform(T[:3, :3], T[:3, 3])
+        hts.append(ht)
+        ots.append(ot)
+        tids.append(ctx.tree_upload(ht.nodes, ht.num_leaves))
+    qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 0)
+    qo = O.Tree(pb["query_scans"][0], B_MAX, B_MIN, 0)
+    mid = ctx.moving_upload(qh.leaf_means())
+    T0 = pb["query_guess"][0]
+    o = O.icp_register(qo, ots, T0, 15, B_MAX, RHO_KER, B_RATIO, num_threads=8)
+    r = ctx.icp_register(mid, tids, T0, PARAMS, 15, qh.num_leaves)
+    dt, da = pose_err(o["T"], r["T"])
+    assert dt <= 1e-5 and da <= 1e-5, (dt, da)
+    assert np.array_equal(r["matched"], o["matched"]) and r["visits"] == o["depth_sum"]
+    for t in tids:
+        ctx.tree_release(t)
+    ctx.moving_release(mid)
