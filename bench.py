@@ -177,6 +177,8 @@ def main():
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (B == 1 and K == 16) else None,
                     "traffic_source": "profiles/r1_q_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                       "same workload; uncorrected, the gfx950 half-counting caveat would at most double it)",
+                    "measured_traffic_frac_of_peak": (round(PMC_TRAFFIC_BYTES_PER_LAUNCH / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                                      if (B == 1 and K == 16) else None),
                     "avg_launch_us": round(avg_us, 2), "first_round_launch_us": round(first_us, 2),
                     "final_launch_us": None if solve_us is None else round(solve_us, 2), "rounds": N_ITERS,
                     "algorithmic_bytes_per_launch": int(alg_bytes),

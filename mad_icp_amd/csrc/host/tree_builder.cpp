@@ -3,12 +3,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <future>
 #include <limits>
 #include <memory>
 #include <thread>
 
 #include "linalg.h"
+#include "task_pool.h"
 
 namespace madicp_host {
 namespace {
@@ -19,7 +19,7 @@ struct Ctx {
   int max_parallel_level;  // levels above this depth run as tasks (0: everything on the calling thread)
 };
 
-// Task policy.  The reference forks two std::async tasks per node above `max_parallel_level` and the parent waits
+// Task policy.  The reference forks two std::async threads per node above `max_parallel_level` and the parent waits
 // (mad_tree.cpp:99-117): 2^level leaf tasks, badly balanced because MAD-trees split at the mean, not the median.
 // Here the same argument buys 4x as many, smaller tasks (two more levels), the parent builds one child itself, a
 // range below kTaskMinPoints is never forked, and the order-independent pass of a big node (the bounding box) is cut
@@ -85,17 +85,16 @@ void bbox_extents(const Ctx& c, int64_t b, int64_t e, const double* mean, const 
   } else {
     struct LoHi { double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; };
     std::vector<LoHi> part(static_cast<size_t>(slices));
-    std::vector<std::future<void>> fut;
+    std::vector<TaskPool::Handle> jobs;
+    TaskPool& pool = TaskPool::instance();
     const int64_t step = (e - b + slices - 1) / slices;
     for (int s = 1; s < slices; ++s) {
       const int64_t sb = b + s * step, se = std::min(e, sb + step);
       if (sb >= se) break;
-      fut.push_back(std::async(std::launch::async, [&c, sb, se, mean, V, &part, s] {
-        bbox_lohi(c, sb, se, mean, V, part[s].lo, part[s].hi);
-      }));
+      jobs.push_back(pool.submit([&c, sb, se, mean, V, &part, s] { bbox_lohi(c, sb, se, mean, V, part[s].lo, part[s].hi); }));
     }
     bbox_lohi(c, b, std::min(e, b + step), mean, V, part[0].lo, part[0].hi);
-    for (auto& f : fut) f.get();
+    for (const TaskPool::Handle& j : jobs) pool.wait(j);
     for (const LoHi& q : part)
       for (int a = 0; a < 3; ++a) {
         if (q.lo[a] < lo[a]) lo[a] = q.lo[a];
@@ -218,14 +217,16 @@ std::unique_ptr<Piece> build_forked(const Ctx& c, int64_t b, int64_t e, int leve
     piece->size = 1;
     return piece;
   }
-  // left child on another thread, right child here; a level down there are twice as many busy threads, so the
+  // left child as a pool task, right child here; a level down there are twice as many busy threads, so the
   // bounding-box pass gets half the slices
   const int child_slices = std::max(1, bbox_slices / 2);
-  std::future<std::unique_ptr<Piece>> fl = std::async(std::launch::async, [&c, b, mid, level, inh, child_slices] {
-    return build_forked(c, b, mid, level + 1, inh, child_slices);
+  TaskPool& pool = TaskPool::instance();
+  Piece* self = piece.get();
+  const TaskPool::Handle jl = pool.submit([&c, self, b, mid, level, inh, child_slices] {
+    self->left = build_forked(c, b, mid, level + 1, inh, child_slices);
   });
   piece->right = build_forked(c, mid, e, level + 1, inh, child_slices);
-  piece->left = fl.get();
+  pool.wait(jl);
   piece->size = 1 + piece->left->size + piece->right->size;
   piece->nd.right = static_cast<int32_t>(1 + piece->left->size);
   return piece;
