@@ -16,13 +16,16 @@
 // branch decision (descent side test, gate) is bit-identical to the CPU path.  Enforced by the pragma
 // below and by -ffp-contract=off on the command line.
 //
-// Why no MFMA: nothing here is a dense contraction.  Per (leaf, tree) pair the work is a ~16-step
-// dependent pointer chase (56 useful bytes of a 64 B node per step) followed by ~150 flops; the 6x6
-// accumulation is a reduction over pairs.  The kernel is bound by the memory system (L2 / Infinity
-// Cache gather latency and bandwidth), so the levers are the ones used here: 64 B node records so one
-// visit is one cache line, DFS-preorder storage so spatially coherent queries walk contiguous memory,
-// an XCD-aware unit -> workgroup map so each XCD's private L2 only ever sees its own trees, many
-// queries in flight per CU, and a deterministic register -> wave shuffle -> LDS -> partial reduction.
+// Why no MFMA: nothing here is a dense contraction.  Per (leaf, tree) pair the work is a ~14-step
+// dependent pointer chase followed by ~150 flops; the 6x6 accumulation is a reduction over pairs.
+// What bounds it (measured: DESIGN.md 3.1) is the chain of dependent steps at the 3 waves/SIMD the
+// accumulators allow — the L1 address path of 64-lane gathers while walking, instruction issue and
+// barriers otherwise — not HBM.  So the levers are: a 16-byte screening record per visit (one gather
+// instead of four, exactness certified per decision), the top of the tree in LDS, dense 64 B leaf
+// records, DFS-preorder storage so spatially coherent queries walk contiguous memory, an XCD-aware
+// unit -> workgroup map so each XCD's private L2 only sees its own trees, correspondences reused across
+// rounds when a margin proves them unchanged, the solve of a round fused into the next round's kernel,
+// and a deterministic register -> wave shuffle -> LDS -> partial reduction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
