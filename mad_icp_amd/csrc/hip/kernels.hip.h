@@ -824,25 +824,6 @@ __device__ __forceinline__ void solve_pose(const double* total, const double (&X
   }
 }
 
-// join of the per-workgroup partials in a fixed order: kJoinSeg segments summed in parallel, then the segments in
-// sequence.  The order depends only on nblocks (every caller runs kBlock threads), so every workgroup of a launch —
-// and icp_reduce / icp_final — computes the bit-identical total.  Split in two so that a caller can put the loads in
-// flight first (join_issue: every lane issues all of its loads, one memory round trip) and consume them later.
-constexpr int kJoinSeg = kBlock / 32;  // 24 segments x 32 lanes (29 used)
-constexpr int kJoinMaxSeg = 16;        // segment length held in registers (nblocks <= 384); longer ones stream
-struct JoinLoads {
-  double v[kJoinMaxSeg];
-};
-__device__ __forceinline__ void join_issue(const double* __restrict__ partials, int nblocks, JoinLoads& jl) {
-  const int j = threadIdx.x & 31;
-  const int s = threadIdx.x >> 5;
-  const int seg_len = (nblocks + kJoinSeg - 1) / kJoinSeg;
-  const int b0 = s * seg_len;
-  const int b1 = min(nblocks, b0 + seg_len);
-  const __attribute__((address_space(1))) double* gp = (const __attribute__((address_space(1))) double*)(uintptr_t)partials;
-#pragma unroll
-  for (int i = 0; i < kJoinMaxSeg; ++i) jl.v[i] = (j < kAcc && seg_len <= kJoinMaxSeg && b0 + i < b1) ? gp[(long long)(b0 + i) * kAcc + j] : 0.0;
-}
 // LDS written by some lanes of a wave, read by other lanes of the SAME wave: the hardware keeps a wave's LDS
 // operations in order; this only stops the compiler from reordering them
 __device__ __forceinline__ void wave_lds_order() {
@@ -850,38 +831,66 @@ __device__ __forceinline__ void wave_lds_order() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-typedef double JoinSeg[kJoinSeg][kAcc];
-// stage 1 (whole workgroup): the segment sums, into LDS; ends with the workgroup barrier that publishes them
+
+// Join of the per-workgroup partials [nblocks][kAcc] in a fixed order.  Whole workgroup (kBlock threads): lane =
+// (row group g = 0..3, column pair c = 0..14) of wave w; one 16-byte load covers columns 2c, 2c+1 of a row, so one
+// wave instruction covers four whole rows = 928 contiguous bytes (an earlier version used 16 strided 8-byte loads
+// per lane: 2.7x the instructions for the same bytes, and it was the vector-memory pipe's time that the prologue
+// waited for).  Row group G = 4w + g sums rows G, G + 48, G + 96, ... in sequence; wave 0 then adds the 48 group sums
+// in order.  The order depends only on nblocks, so every workgroup of a launch — and icp_reduce / icp_final —
+// computes the bit-identical total.  Split in issue (loads in flight) / stage 1 (ends with the workgroup barrier) /
+// stage 2 (wave 0), so that the caller can overlap the memory round trip with other work.
+// The buffer must be readable one double past the last row (c = 14 loads columns 28 and "29"): the host pads.
+constexpr int kJoinGroups = 4 * kWaves;  // 48
+constexpr int kJoinRows = 8;             // rows per lane held in registers (nblocks <= 384); longer ones stream
+typedef double vd2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef const __attribute__((address_space(1))) vd2u* gptr_d2u;
+typedef double JoinSeg[kJoinGroups][30];
+struct JoinLoads {
+  vd2u x[kJoinRows];
+};
+__device__ __forceinline__ void join_issue(const double* __restrict__ partials, int nblocks, JoinLoads& jl) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane / 15;      // 0..3 (4 for lanes 60..63: no rows)
+  const int c = lane - 15 * g;  // 0..14
+  const int G = 4 * (threadIdx.x >> 6) + g;
+  const double* col = partials + 2 * c;
+#pragma unroll
+  for (int i = 0; i < kJoinRows; ++i) {
+    const int row = G + kJoinGroups * i;
+    jl.x[i] = vd2u{0.0, 0.0};  // (adding +0.0 later is exact)
+    if (g < 4 && row < nblocks) jl.x[i] = *(gptr_d2u)(uintptr_t)(col + (long long)row * kAcc);
+  }
+}
 __device__ __forceinline__ void join_stage1(const double* __restrict__ partials, int nblocks, const JoinLoads& jl,
                                             JoinSeg& seg /*LDS*/) {
-  const int j = threadIdx.x & 31;
-  const int s = threadIdx.x >> 5;
-  const int seg_len = (nblocks + kJoinSeg - 1) / kJoinSeg;
-  if (j < kAcc) {
-    double a = 0.0;
-    const int b0 = s * seg_len;
-    const int b1 = min(nblocks, b0 + seg_len);
-    if (seg_len <= kJoinMaxSeg) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane / 15;
+  const int c = lane - 15 * g;
+  const int G = 4 * (threadIdx.x >> 6) + g;
+  double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-      for (int i = 0; i < kJoinMaxSeg; ++i)
-        if (b0 + i < b1) a += jl.v[i];  // same order as the loop below
-    } else {
-#pragma unroll 8
-      for (int b = b0; b < b1; ++b) a += partials[(long long)b * kAcc + j];
+  for (int i = 0; i < kJoinRows; ++i) { a0 += jl.x[i].x; a1 += jl.x[i].y; }
+  if (g < 4) {
+    for (int row = G + kJoinGroups * kJoinRows; row < nblocks; row += kJoinGroups) {
+      const vd2u x = *(gptr_d2u)(uintptr_t)(partials + 2 * c + (long long)row * kAcc);
+      a0 += x.x;
+      a1 += x.y;
     }
-    seg[s][j] = a;
+    seg[G][2 * c] = a0;
+    seg[G][2 * c + 1] = a1;
   }
   __syncthreads();
 }
-// stage 2 (wave 0 only): the segments in sequence -> total[kAcc] in LDS, visible to wave 0
+// stage 2 (wave 0 only): the group sums in sequence -> total[kAcc] in LDS, visible to wave 0
 __device__ __forceinline__ void join_stage2_wave0(const JoinSeg& seg, double* total /*LDS kAcc*/) {
   if (threadIdx.x < kAcc) {
-    double r[kJoinSeg];
+    double r[kJoinGroups];
 #pragma unroll
-    for (int k = 0; k < kJoinSeg; ++k) r[k] = seg[k][threadIdx.x];  // all LDS reads in flight before the first add
+    for (int k = 0; k < kJoinGroups; ++k) r[k] = seg[k][threadIdx.x];  // all LDS reads in flight before the first add
     double a = r[0];
 #pragma unroll
-    for (int k = 1; k < kJoinSeg; ++k) a += r[k];
+    for (int k = 1; k < kJoinGroups; ++k) a += r[k];
     total[threadIdx.x] = a;
   }
   wave_lds_order();
@@ -929,9 +938,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // of the scalar traffic then queues behind; requesting all of the Job's scalars in one pinned batch.)
   const long long pstride = (long long)gridDim.y * gridDim.x * kAcc;  // one parity's worth of partials
   const double* __restrict__ prev_partials = partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc;
-  JoinLoads jl;
   double Xp[12];
+  JoinLoads jl;
   if (round > 0 && !totals) join_issue(prev_partials, gridDim.x, jl);
+  MADICP_STAMP(14);
   // walk hint: how many lanes of THIS workgroup had to walk in the previous round (written at the end of that round,
   // behind the two partial buffers); decides — without a vote, i.e. without a barrier per pass — whether the tree's
   // top levels are worth staging into LDS.  Speed only: the descent gives the same result from LDS or from global.
@@ -945,16 +955,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     for (int i = 0; i < 12; ++i) Xp[i] = xr[i];
     if (round > 0) prev_hint = ((gptr_d1)(uintptr_t)hints)[((round - 1) & 1) * hint_stride + hint_slot];
   }
-  const long long U = (long long)K * RPT;
+  MADICP_STAMP(15);
+  const int U = K * RPT;  // <= MADICP_MAX_TREES x workgroups: 32-bit arithmetic (a 64-bit division is ~100 instructions)
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
   const int nslots = gridDim.x >> 3;
-  const long long lo = (xcd * U) >> 3;
-  const long long hi = ((xcd + 1) * U) >> 3;
-  const long long u_first = lo + slot;
+  const int lo = (xcd * U) >> 3;
+  const int hi = ((xcd + 1) * U) >> 3;
+  const int u_first = lo + slot;
   const bool have_first = u_first < hi;
-  const int k_first = have_first ? static_cast<int>(u_first / RPT) : 0;
-  const int r_first = have_first ? static_cast<int>(u_first - (long long)k_first * RPT) : 0;
+  const int k_first = have_first ? u_first / RPT : 0;
+  const int r_first = have_first ? u_first - k_first * RPT : 0;
 
   const int L = job->L;
   const int flags = job->flags;
@@ -997,6 +1008,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   __shared__ double s_total[kAcc];
   __shared__ double s_X[15];  // X_round (12), bounds of the last update's rotation angle and translation, walk hint
   __shared__ JoinSeg s_seg;
+  MADICP_STAMP(13);
   if (round > 0 && !totals) join_stage1(prev_partials, gridDim.x, jl, s_seg);
   if (threadIdx.x < 64) {
     double Xn[12];
@@ -1072,9 +1084,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   int staged_tree = -1;
 
 
-  for (long long u = lo + slot; u < hi; u += nslots) {
-    const int k = static_cast<int>(u / RPT);
-    const int r = static_cast<int>(u - (long long)k * RPT);
+  for (int u = lo + slot; u < hi; u += nslots) {
+    const int k = u / RPT;
+    const int r = u - k * RPT;
     const int i_end = min(L, (r + 1) * S);
     const TreeDesc& td = job->trees[k];
     // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only

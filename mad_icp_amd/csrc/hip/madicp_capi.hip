@@ -294,7 +294,8 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
   }
   // two round parities of partials, then two parities of per-workgroup walk hints
-  const int rc0 = ensure_partials(ctx, (size_t)2 * a.n_scans * grid * kAcc + (size_t)2 * a.n_scans * grid);
+  // (+ one padding row: the join's 16-byte loads read one double past a row, see join_wave0)
+  const int rc0 = ensure_partials(ctx, (size_t)2 * a.n_scans * grid * kAcc + (size_t)2 * a.n_scans * grid + kAcc);
   if (rc0 != MADICP_OK) return rc0;
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)

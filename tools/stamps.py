@@ -47,8 +47,8 @@ lib.madicp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.madicp_debug_stamps(ctx._h, buf.ctypes.data) == 0
 s = buf.reshape(16, 256, 16).astype(np.int64)
 # stamp order along a workgroup's time line (wave 0): see kernels.hip.h MADICP_STAMP
-ORDER = [0, 1, 2, 7, 3, 4, 8, 9, 10, 11, 12, 5, 6]
-NAMES = ["join", "solve", "bcast+init", "p0 reuse", "p0 walk", "p0 record", "p0 math", "p1 loads", "p1 reuse", "p1 record",
+ORDER = [0, 14, 15, 13, 1, 2, 7, 3, 4, 8, 9, 10, 11, 12, 5, 6]
+NAMES = ["join issue", "pose issue", "scalars+prefetch", "stage1+2", "solve", "bcast+init", "p0 reuse", "p0 walk", "p0 record", "p0 math", "p1 loads", "p1 reuse", "p1 record",
          "p1 math", "reduce+store"]
 print("| round | " + " | ".join(NAMES) + " | total | whole |")
 print("|" + "---|" * (len(NAMES) + 3))
