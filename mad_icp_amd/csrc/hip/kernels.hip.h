@@ -607,7 +607,7 @@ __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane,
 // 64 lanes of a wave share the upper path and diverge only near the leaves.
 //
 // grid = (8 * slots, n_scans); blockIdx.y selects the registration (scans batched in flight).
-// partials: [2][n_scans][gridDim.x][kAcc], then walk hints [2][n_scans][gridDim.x] ; totals (multi-GPU): [n_scans][kAcc], already all-reduced
+// partials: [2][n_scans][join_rows(gridDim.x)][kAcc] (rows >= gridDim.x stay zero), then walk hints [2][n_scans][gridDim.x] ; totals (multi-GPU): [n_scans][kAcc], already all-reduced
 // ---------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------
 // 6x6 LDLT (lower, diagonal pivoting) factor + solve — the algorithm of Eigen::LDLT that
@@ -832,47 +832,51 @@ __device__ __forceinline__ void wave_lds_order() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Join of the per-workgroup partials [nblocks][kAcc] in a fixed order.  Whole workgroup (kBlock threads): lane =
-// (row group g = 0..3, column pair c = 0..14) of wave w; one 16-byte load covers columns 2c, 2c+1 of a row, so one
-// wave instruction covers four whole rows = 928 contiguous bytes (an earlier version used 16 strided 8-byte loads
-// per lane: 2.7x the instructions for the same bytes, and it was the vector-memory pipe's time that the prologue
-// waited for).  Row group G = 4w + g sums rows G, G + 48, G + 96, ... in sequence; wave 0 then adds the 48 group sums
-// in order.  The order depends only on nblocks, so every workgroup of a launch — and icp_reduce / icp_final —
-// computes the bit-identical total.  Split in issue (loads in flight) / stage 1 (ends with the workgroup barrier) /
-// stage 2 (wave 0), so that the caller can overlap the memory round trip with other work.
-// The buffer must be readable one double past the last row (c = 14 loads columns 28 and "29"): the host pads.
+// Join of the per-workgroup partials in a fixed order.  Whole workgroup (kBlock threads): lane = (row group g = 0..3,
+// column pair c = 0..14) of wave w; one 16-byte load covers columns 2c, 2c+1 of a row, so one wave instruction covers
+// four whole rows = 928 contiguous bytes (an earlier version used 16 strided 8-byte loads per lane: 2.7x the
+// instructions for the same bytes, and it was the vector-memory pipe's time that the prologue waited for).  Row group
+// G = 4w + g sums rows G, G + 48, G + 96, ... in sequence; wave 0 then adds the 48 group sums in order.  The order
+// depends only on the row count, so every workgroup of a launch — and icp_reduce / icp_final — computes the
+// bit-identical total.
+// No predicates: a scan's partials are stored as join_rows(nblocks) >= nblocks rows, a multiple of 48 and at least
+// 48 * kJoinRows; the rows no workgroup writes are kept zero by the host (adding +0.0 is exact), so every lane issues
+// the same kJoinRows unconditional loads off one base address.  (Per-load predicates compiled to ~25 instructions of
+// control flow each — executed by all 12 waves before anything else could be issued.)
+// Split in issue (loads in flight) / stage 1 (ends with the workgroup barrier) / stage 2 (wave 0), so that the
+// caller can overlap the memory round trip with other work.  Readable one double past the last row (c = 14 loads
+// columns 28 and "29"): the host pads.
 constexpr int kJoinGroups = 4 * kWaves;  // 48
-constexpr int kJoinRows = 8;             // rows per lane held in registers (nblocks <= 384); longer ones stream
+constexpr int kJoinRows = 6;             // rows per lane held in registers (nblocks <= 288); longer ones stream
+__host__ __device__ constexpr int join_rows(int nblocks) {
+  return (nblocks <= kJoinGroups * kJoinRows) ? kJoinGroups * kJoinRows : (nblocks + kJoinGroups - 1) / kJoinGroups * kJoinGroups;
+}
 typedef double vd2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef const __attribute__((address_space(1))) vd2u* gptr_d2u;
 typedef double JoinSeg[kJoinGroups][30];
 struct JoinLoads {
   vd2u x[kJoinRows];
 };
-__device__ __forceinline__ void join_issue(const double* __restrict__ partials, int nblocks, JoinLoads& jl) {
-  const int lane = threadIdx.x & 63;
-  const int g = lane / 15;      // 0..3 (4 for lanes 60..63: no rows)
-  const int c = lane - 15 * g;  // 0..14
-  const int G = 4 * (threadIdx.x >> 6) + g;
-  const double* col = partials + 2 * c;
+__device__ __forceinline__ void join_issue(const double* __restrict__ partials, JoinLoads& jl) {
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned g = min((lane * 274u) >> 12, 3u);  // lane / 15, lanes 60..63 duplicate group 3 (never stored)
+  const unsigned c = min(lane - 15u * g, 14u);
+  const unsigned G = 4u * (threadIdx.x >> 6) + g;
+  gptr_d2u p = (gptr_d2u)(uintptr_t)(partials + (G * kAcc + 2u * c));
 #pragma unroll
-  for (int i = 0; i < kJoinRows; ++i) {
-    const int row = G + kJoinGroups * i;
-    jl.x[i] = vd2u{0.0, 0.0};  // (adding +0.0 later is exact)
-    if (g < 4 && row < nblocks) jl.x[i] = *(gptr_d2u)(uintptr_t)(col + (long long)row * kAcc);
-  }
+  for (int i = 0; i < kJoinRows; ++i) jl.x[i] = *(gptr_d2u)((const __attribute__((address_space(1))) double*)p + i * (kJoinGroups * kAcc));
 }
-__device__ __forceinline__ void join_stage1(const double* __restrict__ partials, int nblocks, const JoinLoads& jl,
+__device__ __forceinline__ void join_stage1(const double* __restrict__ partials, int rows, const JoinLoads& jl,
                                             JoinSeg& seg /*LDS*/) {
-  const int lane = threadIdx.x & 63;
-  const int g = lane / 15;
-  const int c = lane - 15 * g;
-  const int G = 4 * (threadIdx.x >> 6) + g;
+  const unsigned lane = threadIdx.x & 63;
+  const unsigned g = (lane * 274u) >> 12;
+  const unsigned c = lane - 15u * g;
+  const unsigned G = 4u * (threadIdx.x >> 6) + g;
   double a0 = 0.0, a1 = 0.0;
 #pragma unroll
   for (int i = 0; i < kJoinRows; ++i) { a0 += jl.x[i].x; a1 += jl.x[i].y; }
   if (g < 4) {
-    for (int row = G + kJoinGroups * kJoinRows; row < nblocks; row += kJoinGroups) {
+    for (int row = G + kJoinGroups * kJoinRows; row < rows; row += kJoinGroups) {  // (rows > 288 only)
       const vd2u x = *(gptr_d2u)(uintptr_t)(partials + 2 * c + (long long)row * kAcc);
       a0 += x.x;
       a1 += x.y;
@@ -895,12 +899,12 @@ __device__ __forceinline__ void join_stage2_wave0(const JoinSeg& seg, double* to
   }
   wave_lds_order();
 }
-// whole workgroup in, total[] valid for WAVE 0 out (icp_reduce / icp_final)
-__device__ __forceinline__ void join_partials(const double* __restrict__ partials, int nblocks, double* total /*LDS kAcc*/) {
+// whole workgroup in, total[] valid for WAVE 0 out (icp_reduce / icp_final); rows = join_rows(nblocks)
+__device__ __forceinline__ void join_partials(const double* __restrict__ partials, int rows, double* total /*LDS kAcc*/) {
   __shared__ JoinSeg seg;
   JoinLoads jl;
-  join_issue(partials, nblocks, jl);
-  join_stage1(partials, nblocks, jl, seg);
+  join_issue(partials, jl);
+  join_stage1(partials, rows, jl, seg);
   if (threadIdx.x < 64) join_stage2_wave0(seg, total);
 }
 
@@ -936,11 +940,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // every workgroup below) and — wave 0 only, it is the one that solves — the pose that round linearised at.
   // (Measured alternatives, all slower: every lane loading the pose, which turns it into scalar loads that the rest
   // of the scalar traffic then queues behind; requesting all of the Job's scalars in one pinned batch.)
-  const long long pstride = (long long)gridDim.y * gridDim.x * kAcc;  // one parity's worth of partials
-  const double* __restrict__ prev_partials = partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc;
+  const int prows = join_rows(gridDim.x);                          // rows stored per scan (>= gridDim.x, zero padded)
+  const long long pstride = (long long)gridDim.y * prows * kAcc;  // one parity's worth of partials
+  const double* __restrict__ prev_partials = partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * prows * kAcc;
   double Xp[12];
   JoinLoads jl;
-  if (round > 0 && !totals) join_issue(prev_partials, gridDim.x, jl);
+  if (round > 0 && !totals) join_issue(prev_partials, jl);
   MADICP_STAMP(14);
   // walk hint: how many lanes of THIS workgroup had to walk in the previous round (written at the end of that round,
   // behind the two partial buffers); decides — without a vote, i.e. without a barrier per pass — whether the tree's
@@ -977,7 +982,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   uint32_t* __restrict__ cache_leaf = job->cache_leaf;
   float* __restrict__ cache_margin = job->cache_margin;
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
-  double* __restrict__ my_partials = partials + (round & 1) * pstride + (long long)blockIdx.y * gridDim.x * kAcc;
+  double* __restrict__ my_partials = partials + (round & 1) * pstride + (long long)blockIdx.y * prows * kAcc;
   const int S = (L + RPT - 1) / RPT;  // leaves per range
 
   // The first pass's loads that do not depend on the pose (leaf coordinates, cached correspondence) are issued NOW,
@@ -1009,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   __shared__ double s_X[15];  // X_round (12), bounds of the last update's rotation angle and translation, walk hint
   __shared__ JoinSeg s_seg;
   MADICP_STAMP(13);
-  if (round > 0 && !totals) join_stage1(prev_partials, gridDim.x, jl, s_seg);
+  if (round > 0 && !totals) join_stage1(prev_partials, prows, jl, s_seg);
   if (threadIdx.x < 64) {
     double Xn[12];
     double moved[2] = {0.0, 0.0};
@@ -1084,9 +1089,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   int staged_tree = -1;
 
 
-  for (int u = lo + slot; u < hi; u += nslots) {
-    const int k = u / RPT;
-    const int r = u - k * RPT;
+  int k = k_first, r = r_first;
+  for (int u = u_first; u < hi; u += nslots, r += nslots) {
+    while (r >= RPT) {  // (k, r) follow u without a division
+      r -= RPT;
+      ++k;
+    }
     const int i_end = min(L, (r + 1) * S);
     const TreeDesc& td = job->trees[k];
     // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
@@ -1317,8 +1325,9 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.x * kAcc + threadIdx.x];
     __syncthreads();
   } else {
-    const long long pstride = (long long)n_scans * nblocks * kAcc;
-    join_partials(partials + ((n - 1) & 1) * pstride + (long long)blockIdx.x * nblocks * kAcc, nblocks, s_total);
+    const int prows = join_rows(nblocks);
+    const long long pstride = (long long)n_scans * prows * kAcc;
+    join_partials(partials + ((n - 1) & 1) * pstride + (long long)blockIdx.x * prows * kAcc, prows, s_total);
   }
   count_matched(job);
   if (threadIdx.x < 64) {  // wave 0, every lane the same values (solve_pose is wave-uniform)
@@ -1345,8 +1354,9 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
 __global__ __launch_bounds__(kBlock) void icp_reduce(const double* __restrict__ partials, int nblocks, int n_scans,
                                                            int round, double* __restrict__ totals) {
   __shared__ double s_total[kAcc];
-  const long long pstride = (long long)n_scans * nblocks * kAcc;
-  join_partials(partials + (round & 1) * pstride + (long long)blockIdx.x * nblocks * kAcc, nblocks, s_total);
+  const int prows = join_rows(nblocks);
+  const long long pstride = (long long)n_scans * prows * kAcc;
+  join_partials(partials + (round & 1) * pstride + (long long)blockIdx.x * prows * kAcc, prows, s_total);
   if (threadIdx.x < kAcc) totals[blockIdx.x * kAcc + threadIdx.x] = s_total[threadIdx.x];
 }
 

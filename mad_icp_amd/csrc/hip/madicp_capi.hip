@@ -100,6 +100,7 @@ struct madicp_ctx {
   Job* h_fetch = nullptr;      // pinned read-back block
   double* d_partials = nullptr;
   size_t partials_cap = 0;     // doubles
+  int partials_grid = -1, partials_batch = -1;  // geometry the zero padding rows of d_partials are valid for
   double* d_totals = nullptr;  // [MADICP_MAX_BATCH][kAcc]
   double* d_scratch = nullptr; // 12 doubles (R,t for tree_transform)
   int last_batch = 0;
@@ -130,6 +131,7 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
   ctx->partials_cap = 0;
   HIP_TRY(hipMalloc(&ctx->d_partials, doubles * sizeof(double)));
   ctx->partials_cap = doubles;
+  ctx->partials_grid = ctx->partials_batch = -1;
   // cached graphs hold the old pointer
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
   ctx->graphs.clear();
@@ -294,9 +296,18 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
   }
   // two round parities of partials, then two parities of per-workgroup walk hints
-  // (+ one padding row: the join's 16-byte loads read one double past a row, see join_wave0)
-  const int rc0 = ensure_partials(ctx, (size_t)2 * a.n_scans * grid * kAcc + (size_t)2 * a.n_scans * grid + kAcc);
+  // two round parities of partials — join_rows(grid) rows per scan, the rows beyond `grid` are zero and stay zero —
+  // then two parities of per-workgroup walk hints, + one padding row (the join's 16-byte loads read one double past)
+  const size_t prows = (size_t)madicp::join_rows(grid);
+  const size_t partial_doubles = (size_t)2 * a.n_scans * prows * kAcc + (size_t)2 * a.n_scans * grid + kAcc;
+  const int rc0 = ensure_partials(ctx, partial_doubles);
   if (rc0 != MADICP_OK) return rc0;
+  if (ctx->partials_grid != grid || ctx->partials_batch != a.n_scans) {
+    // a row that is padding in this geometry may have been a real row in the previous one
+    HIP_TRY(hipMemsetAsync(ctx->d_partials, 0, partial_doubles * sizeof(double), ctx->stream));
+    ctx->partials_grid = grid;
+    ctx->partials_batch = a.n_scans;
+  }
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
