@@ -927,11 +927,17 @@ __device__ unsigned long long g_stamps[16 * 256 * 16];
 
 template <int QPT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
-    Job* __restrict__ jobs, double* __restrict__ partials, const double* __restrict__ totals, int round, int n_iters,
-    int K, int RPT) {
+    const Job* __restrict__ jobs, Job* __restrict__ jobs_out, double* __restrict__ partials,
+    const double* __restrict__ totals, int round, int n_iters, int K, int RPT) {
   // (n_iters, K and ranges_per_tree are the same for every scan of the launch: as kernel arguments they are known
   // one memory round trip before anything read through `job`)
-  Job* job = jobs + blockIdx.y;
+  // `jobs` and `jobs_out` are the SAME array: everything this kernel reads goes through the const restrict view, the
+  // few fields workgroup 0 records (H, b, counters, the other pose slot) through the other — never the same element
+  // through both.  With one pointer the first store made every later read of the Job (tree descriptors, options) a
+  // vector load + wait + readfirstlane instead of a scalar load: three serialized round trips at the top of the unit
+  // loop alone.
+  const Job* job = jobs + blockIdx.y;
+  Job* jout = jobs_out + blockIdx.y;
   MADICP_STAMP(0);
   typedef const __attribute__((address_space(1))) unsigned int* gptr_u1;
   typedef const __attribute__((address_space(1))) float* gptr_f1;
@@ -972,6 +978,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int k_first = have_first ? u_first / RPT : 0;
   const int r_first = have_first ? u_first - k_first * RPT : 0;
 
+  // The descriptor of the first unit's tree goes to LDS (11 lanes x 8 bytes, stored before the barrier that ends the
+  // prologue), the two staging options to registers — all read BEFORE the first barrier: after one, the compiler
+  // must treat global memory as clobbered and turns every uniform read of the Job into a vector load + full
+  // vmcnt wait + readfirstlane, which is what the pass used to do for every field of the descriptor it touched.
+  __shared__ __attribute__((aligned(16))) TreeDesc s_td;
+  static_assert(sizeof(TreeDesc) == 88, "descriptor copy below moves 11 x 8 bytes");
+  long long td_word = 0;
+  if (threadIdx.x < 11)
+    td_word = ((const __attribute__((address_space(1))) long long*)(uintptr_t)&job->trees[k_first])[threadIdx.x];
+  const int opt_lds_top = job->lds_top;
+  const int opt_stage_min = job->stage_min_leaves;
   const int L = job->L;
   const int flags = job->flags;
   const bool last_round = (round == n_iters - 1);
@@ -1013,6 +1030,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   __shared__ double s_total[kAcc];
   __shared__ double s_X[15];  // X_round (12), bounds of the last update's rotation angle and translation, walk hint
   __shared__ JoinSeg s_seg;
+  if (threadIdx.x < 11) reinterpret_cast<long long*>(&s_td)[threadIdx.x] = td_word;
+  int desc_tree = k_first;
   MADICP_STAMP(13);
   if (round > 0 && !totals) join_stage1(prev_partials, prows, jl, s_seg);
   if (threadIdx.x < 64) {
@@ -1030,14 +1049,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved);
       if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping of the finished round, once per scan
 #pragma unroll
-        for (int i = 0; i < 36; ++i) job->H[i] = H[i];
+        for (int i = 0; i < 36; ++i) jout->H[i] = H[i];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) job->b[i] = b[i];
-        job->n_pairs = s_total[27];
-        job->visits += static_cast<unsigned long long>(s_total[28]);
+        for (int i = 0; i < 6; ++i) jout->b[i] = b[i];
+        jout->n_pairs = s_total[27];
+        jout->visits += static_cast<unsigned long long>(s_total[28]);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) job->Xring[round & 1][i] = Xn[i];
-        job->iter = round;
+        for (int i = 0; i < 12; ++i) jout->Xring[round & 1][i] = Xn[i];
+        jout->iter = round;
       }
     } else {
       MADICP_STAMP(1);
@@ -1096,10 +1115,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       ++k;
     }
     const int i_end = min(L, (r + 1) * S);
-    const TreeDesc& td = job->trees[k];
+    if (k != desc_tree) {  // (workgroup-uniform; only workgroups with several units get here)
+      __syncthreads();     // nobody still reads the previous descriptor
+      if (threadIdx.x < 11)
+        reinterpret_cast<long long*>(&s_td)[threadIdx.x] =
+            ((const __attribute__((address_space(1))) long long*)(uintptr_t)&job->trees[k])[threadIdx.x];
+      __syncthreads();
+      desc_tree = k;
+    }
+    const TreeDesc& td = s_td;
     // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
     // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
-    const int n_top_avail = (job->lds_top && i_end - r * S >= job->stage_min_leaves) ? min(td.n_top, kTopMax) : 0;
+    const int n_top_avail = (opt_lds_top && i_end - r * S >= opt_stage_min) ? min(td.n_top, kTopMax) : 0;
 
     for (int base = r * S; base < i_end; base += QPT * kBlock) {
       double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];

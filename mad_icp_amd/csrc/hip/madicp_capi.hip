@@ -162,8 +162,9 @@ struct Launch {  // one registration's launch shape
 
 void launch_round(madicp_ctx* ctx, const Launch& l, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
-  void (*kern)(Job*, double*, const double*, int, int, int, int) = l.qpt == 2 ? icp_round<2> : icp_round<1>;
-  hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, ctx->d_jobs, ctx->d_partials, totals, round, l.iters, l.K, l.rpt);
+  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int) = l.qpt == 2 ? icp_round<2> : icp_round<1>;
+  hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)ctx->d_jobs, ctx->d_jobs, ctx->d_partials, totals, round,
+                     l.iters, l.K, l.rpt);
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
