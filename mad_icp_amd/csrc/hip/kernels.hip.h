@@ -925,7 +925,8 @@ __device__ unsigned long long g_stamps[16 * 256 * 16];
 #define MADICP_STAMP_WAIT()
 #endif
 
-template <int QPT>
+// TRACE: also write the per-pair correspondence trace (Job::corr) — the single-round debugging entry point only
+template <int QPT, bool TRACE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
     const Job* __restrict__ jobs, Job* __restrict__ jobs_out, double* __restrict__ partials,
     const double* __restrict__ totals, int round, int n_iters, int K, int RPT) {
@@ -994,12 +995,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const bool last_round = (round == n_iters - 1);
   const double* __restrict__ moving = job->moving;
   uint8_t* __restrict__ matched = job->matched;
-  uint32_t* __restrict__ corr = job->corr;
+  uint32_t* __restrict__ corr = TRACE ? job->corr : nullptr;
   const double min_ball = job->min_ball, rho = job->rho, b_ratio = job->b_ratio;
   uint32_t* __restrict__ cache_leaf = job->cache_leaf;
   float* __restrict__ cache_margin = job->cache_margin;
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
-  double* __restrict__ my_partials = partials + (round & 1) * pstride + (long long)blockIdx.y * prows * kAcc;
   const int S = (L + RPT - 1) / RPT;  // leaves per range
 
   // The first pass's loads that do not depend on the pose (leaf coordinates, cached correspondence) are issued NOW,
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
         const double src_ball = min_ball + b_ratio * pn[j];
         const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-        if (corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
+        if (TRACE && corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
         if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 
@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     double s = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
-    my_partials[(long long)blockIdx.x * kAcc + threadIdx.x] = s;
+    partials[(round & 1) * pstride + ((long long)blockIdx.y * prows + blockIdx.x) * kAcc + threadIdx.x] = s;
   }
   if (threadIdx.x == 0) hints[(round & 1) * hint_stride + hint_slot] = static_cast<double>(n_walked);
   MADICP_STAMP(6);

@@ -65,10 +65,10 @@ struct DevMoving {
 };
 
 struct GraphKey {  // everything a captured launch sequence bakes in
-  int grid, batch, iters, qpt, comm, lds, K, rpt;
+  int grid, batch, iters, qpt, comm, lds, K, rpt, trace;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt) <
-           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt);
+    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt, trace) <
+           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt, o.trace);
   }
 };
 struct Geometry {
@@ -157,12 +157,13 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
 }
 
 struct Launch {  // one registration's launch shape
-  int grid, batch, iters, qpt, lds, K, rpt;
+  int grid, batch, iters, qpt, lds, K, rpt, trace;
 };
 
 void launch_round(madicp_ctx* ctx, const Launch& l, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
-  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int) = l.qpt == 2 ? icp_round<2> : icp_round<1>;
+  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int) =
+      l.trace ? (l.qpt == 2 ? icp_round<2, true> : icp_round<1, true>) : (l.qpt == 2 ? icp_round<2, false> : icp_round<1, false>);
   hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)ctx->d_jobs, ctx->d_jobs, ctx->d_partials, totals, round,
                      l.iters, l.K, l.rpt);
 }
@@ -197,7 +198,7 @@ int run_rounds(madicp_ctx* ctx, const Launch& l) {
   // graphs: (conservatively) only without a communicator
   const bool graph_ok = ctx->use_graph && !ctx->comm;
   if (!graph_ok) return enqueue_rounds(ctx, l);
-  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt};
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t graph = nullptr;
@@ -290,7 +291,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   }
   const Geometry geo = pick_geometry(ctx, max_L, a.K, a.n_scans);
   const int grid = geo.grid;
-  const Launch launch{grid, a.n_scans, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree};
+  const Launch launch{grid, a.n_scans, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree, a.d_corr ? 1 : 0};
   for (int s = 0; s < a.n_scans; ++s) {
     h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
     h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
