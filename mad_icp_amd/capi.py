@@ -168,15 +168,17 @@ class HostTree:
 
     @property
     def nodes(self):
-        """numpy view (NODE_DTYPE) of the library-owned node array; valid while this object lives."""
+        """numpy view (NODE_DTYPE) of the library-owned node array (the view keeps this object alive)."""
         ptr = host_lib().madicp_host_tree_nodes(self._h)
         buf = (C.c_char * (64 * self.num_nodes)).from_address(ptr)
+        buf._owner = self  # the array's base keeps the tree (and so the memory) alive
         return np.frombuffer(buf, dtype=NODE_DTYPE)
 
     @property
     def leaf_nodes(self):
         ptr = host_lib().madicp_host_tree_leaf_nodes(self._h)
         buf = (C.c_char * (4 * self.num_leaves)).from_address(ptr)
+        buf._owner = self
         return np.frombuffer(buf, dtype=np.int32)
 
     def leaf_means(self):

@@ -84,3 +84,29 @@ def test_input_cloud_is_not_modified():
 def test_empty_cloud_raises():
     with pytest.raises(ValueError):
         capi.HostTree(np.zeros((0, 3)), 0.2, 0.1, 0)
+
+
+def test_concurrent_builds_share_the_task_pool():
+    """Several host threads building different trees at once (the ctypes call releases the GIL; all of them fork onto
+    the one persistent task pool, whose waiters help each other): every tree must equal the one built alone on the
+    calling thread."""
+    import threading
+
+    from mad_icp_amd import synth
+
+    scene = synth.Scene(9)
+    clouds = [synth.render_scan(scene, synth.path_pose(0.7 * i), 300 + i, n_beams=16, n_azimuth=400) for i in range(6)]
+    want = [capi.HostTree(c, 0.2, 0.1, 0).nodes.copy() for c in clouds]
+    got = [None] * len(clouds)
+
+    def work(i):
+        for _ in range(3):
+            got[i] = capi.HostTree(clouds[i], 0.2, 0.1, 4).nodes.copy()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(clouds))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for a, b in zip(want, got):
+        assert a.tobytes() == b.tobytes()
