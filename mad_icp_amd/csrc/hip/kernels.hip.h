@@ -1033,7 +1033,34 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   if (threadIdx.x < 11) reinterpret_cast<long long*>(&s_td)[threadIdx.x] = td_word;
   int desc_tree = k_first;
   MADICP_STAMP(13);
-  if (round > 0 && !totals) join_stage1(prev_partials, prows, jl, s_seg);
+  // top-level copy: dynamic LDS, present only when the host launched with kTopLdsBytes (units big enough to pay
+  // for the copy)
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
+  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
+  int staged_tree = -1;
+  __shared__ double s_hint;
+  if (round > 0 && !totals) {
+    if (threadIdx.x == 0) s_hint = prev_hint;
+    join_stage1(prev_partials, prows, jl, s_seg);
+    // The barrier above also published the first unit's descriptor and the walk hint.  While wave 0 solves (2-3 us),
+    // the other eleven waves have nothing to do: if lanes of this workgroup had to walk last round they copy the
+    // tree's top levels into LDS NOW instead of after the prologue (~1 us of every walking round).
+    const int unit_len = have_first ? min(L, (r_first + 1) * S) - r_first * S : 0;
+    const int n_top_first = (opt_lds_top && unit_len >= opt_stage_min) ? min(s_td.n_top, kTopMax) : 0;
+    if (s_hint > 0.0 && n_top_first > 0) {  // (workgroup-uniform)
+      if (threadIdx.x >= 64) {
+        gptr_u4 gt = (gptr_u4)(uintptr_t)s_td.top;
+        const __attribute__((address_space(1))) long long* ge =
+            (const __attribute__((address_space(1))) long long*)(uintptr_t)s_td.top_exit;
+        for (int e = threadIdx.x - 64; e < n_top_first; e += kBlock - 64) {
+          s_top[e] = gt[e];
+          reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+        }
+      }
+      staged_tree = k_first;  // visible to everybody after the barrier that ends the prologue
+    }
+  }
   if (threadIdx.x < 64) {
     double Xn[12];
     double moved[2] = {0.0, 0.0};
@@ -1099,13 +1126,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 #pragma unroll
   for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
   unsigned int visits = 0;
-
-  // top-level copy: dynamic LDS, present only when the host launched with kTopLdsBytes (units big enough to pay
-  // for the copy)
-  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
-  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
-  int staged_tree = -1;
 
 
   int k = k_first, r = r_first;
