@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PMC_TRAFFIC_BYTES_PER_LAUNCH = int((9835.4 + 1456.4) * 1024)  # FETCH_SIZE + WRITE_SIZE (KiB) per icp_round launch, averaged over a registration, config 3
+PMC_TRAFFIC_BYTES_PER_LAUNCH = int((9844.5 + 1456.0) * 1024)  # FETCH_SIZE + WRITE_SIZE (KiB) per icp_round launch, averaged over a registration, config 3
 
 
 def parse():
@@ -175,7 +175,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "icp_round", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH if (B == 1 and K == 16) else None,
-                    "traffic_source": "profiles/r1_s_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                    "traffic_source": "profiles/r1_t_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                       "same workload; uncorrected, the gfx950 half-counting caveat would at most double it)",
                     "measured_traffic_frac_of_peak": (round(PMC_TRAFFIC_BYTES_PER_LAUNCH / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                                       if (B == 1 and K == 16) else None),
