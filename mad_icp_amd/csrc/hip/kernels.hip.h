@@ -1102,6 +1102,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       s_X[14] = prev_hint;
     }
   }
+  // Pose-independent set-up goes here, BEFORE the barrier that ends the prologue: eleven of the twelve waves reach this
+  // point ~2 us before wave 0 has solved, and whatever they do now they do for free.
+  // the matched_ flags are cleared before the last round (pipeline.cpp:172-176); all workgroups share the work
+  if (round == n_iters - 2) {
+    uint4* m16 = reinterpret_cast<uint4*>(matched);  // hipMalloc'ed: 256-byte aligned
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (L >> 4); i += stride) m16[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0)
+      for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) matched[i] = 0;
+  }
+  double acc[kAcc];
+#pragma unroll
+  for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
+  unsigned int visits = 0;
+  bool walked = false;
   __syncthreads();
   MADICP_STAMP(2);
   double R[9], t[3];
@@ -1111,21 +1126,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   for (int k = 0; k < 3; ++k) t[k] = wave_uniform(s_X[9 + k]);
   const double moved_rot = wave_uniform(s_X[12]), moved_trans = wave_uniform(s_X[13]);
   const bool stage_hint = round == 0 || wave_uniform(s_X[14]) > 0.0;
-  bool walked = false;
-
-  // the matched_ flags are cleared before the last round (pipeline.cpp:172-176); all workgroups share the work
-  if (round == n_iters - 2) {
-    uint4* m16 = reinterpret_cast<uint4*>(matched);  // hipMalloc'ed: 256-byte aligned
-    const int stride = gridDim.x * blockDim.x;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (L >> 4); i += stride) m16[i] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0)
-      for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) matched[i] = 0;
-  }
-
-  double acc[kAcc];
-#pragma unroll
-  for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
-  unsigned int visits = 0;
 
 
   int k = k_first, r = r_first;
