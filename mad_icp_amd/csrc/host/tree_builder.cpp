@@ -7,6 +7,10 @@
 #include <memory>
 #include <thread>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
 #include "linalg.h"
 #include "task_pool.h"
 
@@ -65,6 +69,32 @@ void mean_cov(const Ctx& c, int64_t b, int64_t e, double* mean, double* cov /*ro
 // utils.h:75-97: extents of the points in the eigen frame, 0 included; min/max keep the running value on NaN.
 // min and max do not depend on the order of the points, so a big range is cut into slices.
 void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V, double* lo, double* hi) {
+#if defined(__SSE2__)
+  // two of the three projections per instruction; every lane does exactly the scalar sequence
+  // (c_a0 d0 + c_a1 d1) + c_a2 d2, and min_pd/max_pd keep their SECOND operand on NaN or equality — the running value,
+  // like the `if (v < lo) lo = v` of the scalar loop below
+  const __m128d A0 = _mm_set_pd(V[1], V[0]), A1 = _mm_set_pd(V[4], V[3]), A2 = _mm_set_pd(V[7], V[6]);
+  const double c20 = V[2], c21 = V[5], c22 = V[8];
+  __m128d lo01 = _mm_set_pd(lo[1], lo[0]), hi01 = _mm_set_pd(hi[1], hi[0]);
+  __m128d lo2 = _mm_set_sd(lo[2]), hi2 = _mm_set_sd(hi[2]);
+  const double m0 = mean[0], m1 = mean[1], m2 = mean[2];
+  for (int64_t i = b; i < e; ++i) {
+    const double* p = P(c, i);
+    const double d0 = p[0] - m0, d1 = p[1] - m1, d2 = p[2] - m2;
+    const __m128d v01 = _mm_add_pd(_mm_add_pd(_mm_mul_pd(A0, _mm_set1_pd(d0)), _mm_mul_pd(A1, _mm_set1_pd(d1))),
+                                   _mm_mul_pd(A2, _mm_set1_pd(d2)));
+    const __m128d v2 = _mm_set_sd((c20 * d0 + c21 * d1) + c22 * d2);
+    lo01 = _mm_min_pd(v01, lo01);
+    hi01 = _mm_max_pd(v01, hi01);
+    lo2 = _mm_min_sd(v2, lo2);
+    hi2 = _mm_max_sd(v2, hi2);
+  }
+  double t[2];
+  _mm_storeu_pd(t, lo01); lo[0] = t[0]; lo[1] = t[1];
+  _mm_storeu_pd(t, hi01); hi[0] = t[0]; hi[1] = t[1];
+  lo[2] = _mm_cvtsd_f64(lo2);
+  hi[2] = _mm_cvtsd_f64(hi2);
+#else
   const double c0[3] = {V[0], V[3], V[6]}, c1[3] = {V[1], V[4], V[7]}, c2[3] = {V[2], V[5], V[8]};
   for (int64_t i = b; i < e; ++i) {
     const double* p = P(c, i);
@@ -75,6 +105,7 @@ void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const dou
       if (hi[a] < v[a]) hi[a] = v[a];
     }
   }
+#endif
 }
 
 void bbox_extents(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V /*row-major, cols = eigvecs*/,
