@@ -46,6 +46,30 @@ void mean_cov(const Ctx& c, int64_t b, int64_t e, double* mean, double* cov /*ro
   // the reference accumulates all nine products; v_r*v_q and v_q*v_r are the same double, so six sums give the same
   // nine values
   double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0;
+#if defined(__SSE2__)
+  {  // the same nine running sums, two per register: every lane is its own sequential chain, as in the scalar loop
+    __m128d m01 = _mm_setzero_pd(), m2_ = _mm_setzero_pd();
+    __m128d a = _mm_setzero_pd(), bb = _mm_setzero_pd(), cc = _mm_setzero_pd();  // (s00,s01) (s02,s11) (s12,s22)
+    for (int64_t i = b; i < e; ++i) {
+      const double* v = P(c, i);
+      const __m128d xy = _mm_loadu_pd(v);          // (x, y)
+      const __m128d zz = _mm_set1_pd(v[2]);        // (z, z)
+      const __m128d xx = _mm_unpacklo_pd(xy, xy);  // (x, x)
+      const __m128d yy = _mm_unpackhi_pd(xy, xy);  // (y, y)
+      m01 = _mm_add_pd(m01, xy);
+      m2_ = _mm_add_sd(m2_, zz);
+      a = _mm_add_pd(a, _mm_mul_pd(xx, xy));                         // x*x, x*y
+      bb = _mm_add_pd(bb, _mm_mul_pd(xy, _mm_shuffle_pd(zz, xy, 2)));  // x*z, y*y
+      cc = _mm_add_pd(cc, _mm_mul_pd(_mm_shuffle_pd(yy, zz, 0), zz));  // y*z, z*z
+    }
+    double t[2];
+    _mm_storeu_pd(t, m01); m[0] = t[0]; m[1] = t[1];
+    m[2] = _mm_cvtsd_f64(m2_);
+    _mm_storeu_pd(t, a); s00 = t[0]; s01 = t[1];
+    _mm_storeu_pd(t, bb); s02 = t[0]; s11 = t[1];
+    _mm_storeu_pd(t, cc); s12 = t[0]; s22 = t[1];
+  }
+#else
   for (int64_t i = b; i < e; ++i) {
     const double* v = P(c, i);
     m[0] += v[0]; m[1] += v[1]; m[2] += v[2];
@@ -53,6 +77,7 @@ void mean_cov(const Ctx& c, int64_t b, int64_t e, double* mean, double* cov /*ro
     s11 += v[1] * v[1]; s12 += v[1] * v[2];
     s22 += v[2] * v[2];
   }
+#endif
   const double s[9] = {s00, s01, s02, s01, s11, s12, s02, s12, s22};
   const int k = static_cast<int>(e - b);
   const double inv_k = 1. / k;
@@ -208,7 +233,7 @@ bool make_node(const Ctx& c, int64_t b, int64_t e, Inherited& inh, madicp_node& 
 }
 
 // a whole sub-tree on the calling thread, appended to `out` in preorder
-void build_sequential(const Ctx& c, int64_t b, int64_t e, Inherited inh, std::vector<madicp_node>& out) {
+void build_sequential(const Ctx& c, int64_t b, int64_t e, Inherited inh, NodeVec& out) {
   const size_t self = out.size();
   out.emplace_back();
   madicp_node nd;
@@ -227,7 +252,7 @@ void build_sequential(const Ctx& c, int64_t b, int64_t e, Inherited inh, std::ve
 // The forked top of the tree: a node of it is either one record with two children, or a chunk (a sub-tree that one
 // thread built, already in preorder with relative offsets — position independent).
 struct Piece {
-  std::vector<madicp_node> chunk;  // non-empty: a finished sub-tree
+  NodeVec chunk;                   // non-empty: a finished sub-tree
   madicp_node nd;                  // else: this node ...
   std::unique_ptr<Piece> left, right;  // ... and its sub-trees
   size_t size = 0;                 // nodes in this piece
@@ -263,15 +288,33 @@ std::unique_ptr<Piece> build_forked(const Ctx& c, int64_t b, int64_t e, int leve
   return piece;
 }
 
-// preorder = this node, the left piece, the right piece: plain appends (no zero-filled resize first)
-void flatten(const Piece& p, std::vector<madicp_node>& out) {
+// preorder = this node, the left piece, the right piece.  The forked nodes are written here; the chunks (whole
+// sub-trees, each with (size + 1) / 2 leaves) are only listed, with their node and leaf offsets, and copied by tasks.
+struct ChunkRef {
+  const Piece* piece;
+  size_t node_off, leaf_off;
+};
+void layout(const Piece& p, size_t node_off, size_t& leaf_off, madicp_node* out, std::vector<ChunkRef>& chunks) {
   if (!p.chunk.empty()) {
-    out.insert(out.end(), p.chunk.begin(), p.chunk.end());
+    chunks.push_back(ChunkRef{&p, node_off, leaf_off});
+    leaf_off += (p.chunk.size() + 1) / 2;
     return;
   }
-  out.push_back(p.nd);
-  flatten(*p.left, out);
-  flatten(*p.right, out);
+  out[node_off] = p.nd;
+  layout(*p.left, node_off + 1, leaf_off, out, chunks);
+  layout(*p.right, node_off + 1 + p.left->size, leaf_off, out, chunks);
+}
+
+// copy one chunk into place and number its leaves (getLeafs() order == order of appearance in preorder)
+void place_chunk(const ChunkRef& r, madicp_node* out, int32_t* leaf_nodes) {
+  const NodeVec& ch = r.piece->chunk;
+  std::memcpy(out + r.node_off, ch.data(), ch.size() * sizeof(madicp_node));
+  size_t leaf = r.leaf_off;
+  for (size_t i = 0; i < ch.size(); ++i)
+    if (ch[i].right == 0) {
+      out[r.node_off + i].leaf_id = static_cast<int32_t>(leaf);
+      leaf_nodes[leaf++] = static_cast<int32_t>(r.node_off + i);
+    }
 }
 
 }  // namespace
@@ -287,19 +330,43 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
     t.nodes.reserve(static_cast<size_t>(2 * n));
     build_sequential(c, 0, n, Inherited{nullptr, nullptr}, t.nodes);
     t.nodes.shrink_to_fit();
-  } else {
-    const int slices = std::min(hw, 1 << std::min(levels, 4));
-    const std::unique_ptr<Piece> top = build_forked(c, 0, n, 0, Inherited{nullptr, nullptr}, slices);
-    t.nodes.reserve(top->size);
-    flatten(*top, t.nodes);
+    // getLeafs() order == order of appearance in the preorder array (mad_tree.cpp:154-163)
+    t.leaf_nodes.reserve((t.nodes.size() + 1) / 2);
+    for (size_t i = 0; i < t.nodes.size(); ++i)
+      if (t.nodes[i].right == 0) {
+        t.nodes[i].leaf_id = static_cast<int32_t>(t.leaf_nodes.size());
+        t.leaf_nodes.push_back(static_cast<int32_t>(i));
+      }
+    return t;
   }
-  // getLeafs() order == order of appearance in the preorder array (mad_tree.cpp:154-163)
-  t.leaf_nodes.reserve((t.nodes.size() + 1) / 2);
-  for (size_t i = 0; i < t.nodes.size(); ++i)
-    if (t.nodes[i].right == 0) {
-      t.nodes[i].leaf_id = static_cast<int32_t>(t.leaf_nodes.size());
-      t.leaf_nodes.push_back(static_cast<int32_t>(i));
-    }
+  const int slices = std::min(hw, 1 << std::min(levels, 4));
+  const std::unique_ptr<Piece> top = build_forked(c, 0, n, 0, Inherited{nullptr, nullptr}, slices);
+  t.nodes.resize(top->size);  // (uninitialised: every element is written below)
+  t.leaf_nodes.resize((top->size + 1) / 2);
+  std::vector<ChunkRef> chunks;
+  size_t n_leaves = 0;
+  layout(*top, 0, n_leaves, t.nodes.data(), chunks);
+  // a handful of copy tasks, each a contiguous run of chunks of about the same number of nodes
+  TaskPool& pool = TaskPool::instance();
+  const size_t n_tasks = std::min<size_t>(8, chunks.size());
+  std::vector<TaskPool::Handle> jobs;
+  madicp_node* out = t.nodes.data();
+  int32_t* leaf_nodes = t.leaf_nodes.data();
+  size_t first = 0;
+  for (size_t k = 0; k < n_tasks; ++k) {
+    const size_t want = top->size * (k + 1) / n_tasks;  // nodes up to which this task copies
+    size_t last = first;
+    while (last < chunks.size() && (k + 1 == n_tasks || chunks[last].node_off < want)) ++last;
+    if (last == first) continue;
+    const ChunkRef* cb = chunks.data() + first;
+    const ChunkRef* ce = chunks.data() + last;
+    auto run = [cb, ce, out, leaf_nodes] {
+      for (const ChunkRef* r = cb; r != ce; ++r) place_chunk(*r, out, leaf_nodes);
+    };
+    if (k + 1 == n_tasks) run(); else jobs.push_back(pool.submit(run));
+    first = last;
+  }
+  for (const TaskPool::Handle& j : jobs) pool.wait(j);
   return t;
 }
 

@@ -5,15 +5,39 @@
 // offsets, so sub-trees built by different threads are position independent and are spliced by memcpy.
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <new>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "madicp_hip.h"
 
 namespace madicp_host {
 
+// std::vector that leaves trivially-constructible elements uninitialised on resize (the builder overwrites every one;
+// zero-filling 3 MB first is a tenth of a whole build)
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = DefaultInitAllocator<U>;
+  };
+  template <class U>
+  void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+    ::new (static_cast<void*>(p)) U;
+  }
+  template <class U, class... Args>
+  void construct(U* p, Args&&... args) {
+    ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+  }
+};
+using NodeVec = std::vector<madicp_node, DefaultInitAllocator<madicp_node>>;
+using IndexVec = std::vector<int32_t, DefaultInitAllocator<int32_t>>;
+
 struct LinearTree {
-  std::vector<madicp_node> nodes;   // DFS preorder; left child = i + 1, right child = i + nodes[i].right
-  std::vector<int32_t> leaf_nodes;  // node index of leaf `leaf_id`, i.e. getLeafs() order
+  NodeVec nodes;        // DFS preorder; left child = i + 1, right child = i + nodes[i].right
+  IndexVec leaf_nodes;  // node index of leaf `leaf_id`, i.e. getLeafs() order
   int32_t num_leaves() const { return static_cast<int32_t>(leaf_nodes.size()); }
   int32_t num_nodes() const { return static_cast<int32_t>(nodes.size()); }
 };
