@@ -371,15 +371,29 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
 }
 
 void transform_tree(LinearTree& tree, const double* R, const double* t) {
-  for (madicp_node& nd : tree.nodes) {
-    double m[3], d[3];
-    matvec3(R, nd.mean, m);
-    matvec3(R, nd.dir, d);
-    for (int i = 0; i < 3; ++i) {
-      nd.mean[i] = m[i] + t[i];
-      nd.dir[i] = d[i];
+  auto run = [&tree, R, t](size_t b, size_t e) {
+    for (size_t k = b; k < e; ++k) {
+      madicp_node& nd = tree.nodes[k];
+      double m[3], d[3];
+      matvec3(R, nd.mean, m);
+      matvec3(R, nd.dir, d);
+      for (int i = 0; i < 3; ++i) {
+        nd.mean[i] = m[i] + t[i];
+        nd.dir[i] = d[i];
+      }
     }
+  };
+  const size_t n = tree.nodes.size();
+  constexpr size_t kSlice = 8192;  // nodes per task: per-node work is independent
+  if (n < 2 * kSlice) {
+    run(0, n);
+    return;
   }
+  TaskPool& pool = TaskPool::instance();
+  std::vector<TaskPool::Handle> jobs;
+  for (size_t b = kSlice; b < n; b += kSlice) jobs.push_back(pool.submit([run, b, n] { run(b, std::min(n, b + kSlice)); }));
+  run(0, kSlice);
+  for (const TaskPool::Handle& j : jobs) pool.wait(j);
 }
 
 }  // namespace madicp_host
