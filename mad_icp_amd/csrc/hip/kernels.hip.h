@@ -591,16 +591,17 @@ __device__ __forceinline__ void wave_reduce_scatter(const double* acc, int lane,
 // solve (a single workgroup: join 2.8 us + a ~1000-instruction dependent fp64 chain on one lane 3.2 us + a
 // dependent dispatch 1.9 us) was 35 % of the registration, with 255 CUs idle.  Here round r's kernel STARTS with the
 // solve of round r-1, done redundantly by every workgroup: each joins the previous round's per-workgroup partials
-// (one per CU: 256 x 232 B, L2-resident after the first reader of an XCD) in the same fixed order and one of its lanes
-// runs the same LDLT, so all workgroups hold the bit-identical X_r without any inter-workgroup synchronisation; the
-// kernel boundary is the only barrier.  Workgroup 0 also does the bookkeeping (H, b, counters, X ring).  Partials and
-// poses are double-buffered by round parity because a fast workgroup may finish round r while a slow one is still
-// reading round r-1's.  After the last round a small icp_final joins/solves once more and counts the matched leaves.
-// Launches per registration: n + 1 instead of 2n.
+// (one per CU: 256 x 232 B, L2-resident after the first reader of an XCD) in the same fixed order and its wave 0
+// runs the same LDLT (wave-uniform, divisions spread over lanes), so all workgroups hold the bit-identical X_r without
+// any inter-workgroup synchronisation; the kernel boundary is the only barrier.  While wave 0 solves, the other waves
+// do what does not need the pose (copy the tree's top levels into LDS, zero their accumulators).  Workgroup 0 also
+// does the bookkeeping (H, b, counters, X ring).  Partials and poses are double-buffered by round parity because a
+// fast workgroup may finish round r while a slow one is still reading round r-1's.  After the last round a small
+// icp_final joins/solves once more and counts the matched leaves.  Launches per registration: n + 1 instead of 2n.
 //
 // Work decomposition of the linearisation itself.  The moving leaves of a scan are cut into `ranges_per_tree` equal
 // ranges; a *unit* is (tree k, range r); the host picks the count so there is one unit per workgroup and one workgroup
-// (12 waves, 3 per SIMD — what the 140 VGPRs of the 29 fp64 accumulators + walk state allow) per CU.  Units are
+// (12 waves, 3 per SIMD — what the ~150 VGPRs of the 29 fp64 accumulators + walk state allow) per CU.  Units are
 // ordered tree-major and cut into 8 contiguous pieces; workgroup b takes piece b % 8, i.e. (observed dispatch rule —
 // used for speed only, never for correctness) XCD b % 8 only walks its own K/8 trees, so each private 4 MiB L2 serves
 // 2 trees, not 16.  Moving leaves arrive in the DFS order of the scan's own MAD-tree, i.e. spatially sorted, so the
