@@ -20,6 +20,11 @@ PYBIND11_MODULE(pypeline, m) {
     .def("modelLeaves", &Pipeline::modelLeaves)
     .def("currentLeaves", &Pipeline::currentLeaves)
     .def("compute", &Pipeline::compute)
+    // additive: an (N,3) float64 array directly — one copy instead of the two of VectorEigen3d(points) + by-value call
+    .def("compute",
+         [](Pipeline& self, double stamp, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {
+           self.compute(stamp, container_from_array(std::move(cloud)));
+         })
     // instrumentation, not in the reference
     .def("lastInliersRatio", &Pipeline::lastInliersRatio)
     .def("lastIcpMs", &Pipeline::lastIcpMs)

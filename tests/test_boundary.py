@@ -171,6 +171,11 @@ def test_pipeline_matches_oracle_pipeline(mods):
             assert np.allclose(np.asarray(gp.currentLeaves()), op.currentLeaves(), atol=1e-4)
     assert gp.isInitialized() and len(gp.trajectory()) == n_frames
     assert np.asarray(gp.modelLeaves()).shape == op.modelLeaves().shape
+    # additive overload: the same drive fed as plain (N,3) arrays ends in the same pose, bit for bit
+    ga = pypeline.Pipeline(**args)
+    for i, s in enumerate(scans):
+        ga.compute(0.1 * i, s)
+    assert np.array_equal(ga.currentPose(), gp.currentPose())
     # the drive really moved and tracked it
     gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(0.9 * (n_frames - 1))
     assert np.linalg.norm(gp.currentPose()[:3, 3] - gt[:3, 3]) < 0.1
