@@ -297,7 +297,6 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
     h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
   }
-  // two round parities of partials, then two parities of per-workgroup walk hints
   // two round parities of partials — join_rows(grid) rows per scan, the rows beyond `grid` are zero and stay zero —
   // then two parities of per-workgroup walk hints, + one padding row (the join's 16-byte loads read one double past)
   const size_t prows = (size_t)madicp::join_rows(grid);
