@@ -1,5 +1,6 @@
 """End-to-end Pipeline.compute rate on full-size synthetic scans: the product (pybind pypeline, GPU hot path) next to
-the CPU oracle pipeline (the restated reference).  GPU box only.  usage: python tools/pipeline_rate.py [frames=24]
+the CPU oracle pipeline (the restated reference).  GPU box only.  usage: python tests/pipeline_rate.py [frames=24]
+(Lives under tests/ because it runs the oracle, which only tests and bench.py's cpu_baseline leg may do.)
 
 Every frame: MAD-tree build of the incoming 120k-point scan on the host (both sides), then the 15-round registration
 against up to 16 keyframes (GPU: one device call; CPU: the reference's OpenMP loop), keyframe bookkeeping.
@@ -12,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle_lib as O  # noqa: E402  (checker/baseline only)
 from mad_icp_amd import synth  # noqa: E402
 from mad_icp.src.pybind import pypeline  # noqa: E402
