@@ -15,8 +15,13 @@
  *     (mad_icp/src/tools/mad_tree.h:42, mad_icp/src/pybind/eigen_stl_bindings.h:73-81).
  *   - all arithmetic on the path is IEEE fp64 with the reference's operation order and no FMA contraction,
  *     so descent/gate decisions are bit-identical to the CPU path.
- *   - a context is bound to one device and one stream; calls on one context are not re-entrant.
- *     Calls without the `_enqueue` suffix are synchronous on return.
+ *   - a context is bound to one device and owns two streams: the compute stream (the caller's, or its own) carries the
+ *     registrations, an internal copy stream feeds them (tree uploads, the next scan's leaves).  Calls on one context
+ *     are not re-entrant and must come from one host thread at a time.
+ *   - "synchronous on return" below means: the caller's HOST buffers are no longer referenced and every output
+ *     argument is filled.  Uploads, transforms and releases return as soon as the host buffer has been staged; the
+ *     device work behind them is ordered by events, never by a device-wide synchronisation, and nothing on the
+ *     registration path allocates or frees device memory (pooled buffers, grow-only staging).
  */
 #ifndef MADICP_HIP_H
 #define MADICP_HIP_H
@@ -71,15 +76,21 @@ int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
- * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves)}. */
+ * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves),
+ * "comm_graph" (0/1: with a communicator, capture the per-round RCCL all-reduces into the registration's hipGraph
+ * instead of launching the rounds eagerly)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
 
 /* ---- MAD-tree (fixed side) ---------------------------------------------------------------------- */
-/* Upload a linearised tree.  Replaces keeping `MADtree*` alive in Frame::tree_ (frame.h:47). */
+/* Upload a linearised tree.  Replaces keeping `MADtree*` alive in Frame::tree_ (frame.h:47).  The node array is
+ * validated first (DFS-preorder structure, child links inside their parent's extent, leaf ordinals unique and in
+ * range): a malformed array is MADICP_ERR_INVALID, never an out-of-bounds access.  Returns once `nodes` has been
+ * staged; the copy and the build of the screening records run on the context's copy stream. */
 int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id);
 int madicp_tree_release(madicp_ctx* ctx, int tree_id);
 int madicp_tree_download(madicp_ctx* ctx, int tree_id, madicp_node* out_nodes, int32_t n_nodes);
-/* MADtree::applyTransform (mad_tree.cpp:165-172): mean <- R mean + t, dir <- R dir on every node. */
+/* MADtree::applyTransform (mad_tree.cpp:165-172): mean <- R mean + t, dir <- R dir on every node.  Stream-ordered
+ * behind every registration enqueued so far; no host synchronisation. */
 int madicp_tree_transform(madicp_ctx* ctx, int tree_id, const double R[9], const double t[3]);
 /* Batched MADtree::bestMatchingLeafFast (mad_tree.cpp:144-152) as used by MADtreeWrapper::search /
  * searchCloud / searchCloudDist (mad_tree_wrapper.h:42-67).  queries: host (n,3).  Any output may be NULL.
@@ -95,6 +106,8 @@ int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* 
 /* ---- moving side -------------------------------------------------------------------------------- */
 /* MADicp::setMoving (mad_icp.cpp:53-55): the sensor-frame means of the current scan's leaves, (L,3). */
 int madicp_moving_upload(madicp_ctx* ctx, const double* leaf_means, int32_t L, int* out_moving_id);
+/* The next scan into the SAME buffers (grow-only: no allocation, free or synchronisation in steady state). */
+int madicp_moving_update(madicp_ctx* ctx, int moving_id, const double* leaf_means, int32_t L);
 int madicp_moving_release(madicp_ctx* ctx, int moving_id);
 
 /* ---- registration ------------------------------------------------------------------------------- */
@@ -133,6 +146,23 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
 /* matched_ flags of scan `scan` of the last batch (L bytes). */
 int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, int32_t L);
 
+/* ---- streamed registrations: new scan in -> X / H / b / matched flags out --------------------------- */
+/* What Pipeline::compute does per frame (pipeline.cpp:154-204), as one asynchronous submission: setMoving(leaf_means),
+ * init(X0), n_iters rounds against K resident trees, and the read-out of X_, H_adder_, b_adder_, the matched_ flags and
+ * their count.  The leaves and the job description are fed on the copy stream (they overlap the registration in
+ * flight), the results are written by the registration's last kernel straight into pinned host memory, and
+ * madicp_stream_collect waits for ONE event.  Up to 4 tickets may be outstanding; collect them in any order before
+ * their slot is needed again (MADICP_ERR_CAPACITY otherwise).  Bit-identical to madicp_icp_register on the same inputs. */
+int madicp_stream_submit(madicp_ctx* ctx, const double* leaf_means, int32_t L, const int* tree_ids, int K,
+                         const double X0[12], const madicp_icp_params* params, int n_iters, int* out_ticket);
+/* The same with the moving set taken from a tree that is already resident: the scan's own MAD-tree, uploaded for the
+ * frame window (pipeline.cpp:140-144: current_leaves_ ARE its leaves, in getLeafs() order, sensor frame). */
+int madicp_stream_submit_tree(madicp_ctx* ctx, int moving_tree_id, const int* tree_ids, int K, const double X0[12],
+                              const madicp_icp_params* params, int n_iters, int* out_ticket);
+/* Any output may be NULL; out_matched holds L bytes. */
+int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double out_H[36], double out_b[6],
+                          uint8_t* out_matched, int32_t* out_n_matched, uint64_t* out_visits);
+
 /* Measurement aid (bench.py's roofline): n_launches back-to-back launches of the dominant kernel (icp_round, as
  * round 0: every pair walked, no solve prologue) for this batch at pose X0, replayed as one captured graph between two
  * hipEvents on the context's stream.  out_avg_us = time per launch (a dependent dispatch's launch overhead included, as
@@ -145,16 +175,31 @@ int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_id
  * icp_round launches + icp_final, correspondence reuse and all), `reps` times between two hipEvents, then icp_final
  * alone.  out_linearize_avg_us = (registration - icp_final) / n_iters = average icp_round launch over the rounds of a
  * registration (what a profiler's kernel trace of the registration averages to); out_solve_avg_us = one icp_final;
- * out_visits_per_launch (n_scans) = internal nodes visited per round, averaged over the rounds. */
+ * out_visits_per_launch (n_scans) = internal nodes visited per round, averaged over the rounds, counted like the
+ * reference's descent would (a reused correspondence counts its cached depth); out_walked_per_launch (n_scans, optional)
+ * = the nodes the kernel really walked per round (correspondence reuse excluded). */
 int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
                                  const double* X0, const madicp_icp_params* params, int n_iters, int reps,
-                                 double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch);
+                                 double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch,
+                                 uint64_t* out_walked_per_launch);
+
+/* Measurement aid: `reps` launches of nn_descend (batched bestMatchingLeafFast, mad_tree.cpp:144-152 as
+ * mad_tree_wrapper.h:48-67 loops it) over n host queries already copied to the device, between two hipEvents.
+ * out_avg_us per launch; out_depth_sum = internal nodes visited by one launch. */
+int madicp_nn_time_descend(madicp_ctx* ctx, int tree_id, const double* queries, int64_t n, int reps, double* out_avg_us,
+                           uint64_t* out_depth_sum);
+/* Measurement aid: a plain 16-byte-per-lane device-to-device copy of `bytes` bytes, `reps` times; out_gbs = read +
+ * written bytes per second / 1e9.  The measured HBM rate of this box, and the known byte count on which bench.py
+ * calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE. */
+int madicp_debug_stream_copy(madicp_ctx* ctx, int64_t bytes, int reps, double* out_gbs);
 
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
 /* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte
  * ncclUniqueId produced by madicp_comm_unique_id on rank 0 and distributed by the caller (e.g. a
  * torch.distributed broadcast).  After this call every registration on the context all-reduces
- * [H(21) b(6) n] over the communicator after each round and ORs the matched flags after the last. */
+ * [H(21) b(6) n] over the communicator after each round and ORs the matched flags after the last.  With a
+ * communicator a registration may be given K = 0 trees (a rank that owns no keyframe still joins every collective,
+ * contributing zeros). */
 int madicp_comm_unique_id(uint8_t out_id[128]);
 int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks, int rank);
 int madicp_comm_destroy(madicp_ctx* ctx);

@@ -6,6 +6,7 @@
 
 No CPU fallback is ever built for the HIP entry points.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -22,13 +23,40 @@ CXX = os.environ.get("CXX", "g++")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
              "-Wno-unused-value"]
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wextra", "-fopenmp"]
+# MADICP_EXTRA_DEFINES="-DMADICP_REDUX_SCALAR_ONLY": the Eigen-3.3 evaluation order of 3-vector reductions, in the
+# product AND (oracle/Makefile reads the same variable) in the oracle — tests/test_redux_variant.py builds both that way
+_EXTRA = os.environ.get("MADICP_EXTRA_DEFINES", "").split()
+EXTRA_HIP_FLAGS = list(_EXTRA)
+EXTRA_HOST_FLAGS = list(_EXTRA)
 
 
-def _newer(target, sources):
+def source_hash(sources, flags=()):
+    """sha-256 over the build command's flags and the CONTENT of every source / header it depends on."""
+    h = hashlib.sha256()
+    for f in flags:
+        h.update(str(f).encode() + b"\0")
+    for s in sorted(sources):
+        h.update(os.path.relpath(s, ROOT).encode() + b"\0")
+        with open(s, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stale(target, sources, flags=()):
+    """A target is up to date iff it exists and was built from exactly these sources with these flags (content hash
+    kept beside it in <target>.srchash) — modification times say nothing once a snapshot has been copied to another box."""
     if not os.path.exists(target):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    try:
+        with open(target + ".srchash") as fh:
+            return fh.read().strip() != source_hash(sources, flags)
+    except OSError:
+        return True
+
+
+def _stamp(target, sources, flags=()):
+    with open(target + ".srchash", "w") as fh:
+        fh.write(source_hash(sources, flags) + "\n")
 
 
 def _run(cmd):
@@ -49,9 +77,17 @@ def build_hip(force=False):
     out = os.path.join(PKG, "libmadicp_hip.so")
     srcs = [os.path.join(CSRC, "hip", "madicp_capi.hip")]
     deps = srcs + _glob(os.path.join(CSRC, "hip"), (".h",)) + _glob(INC, (".h",))
-    if force or _newer(out, deps):
-        _run([HIPCC] + HIP_FLAGS + ["-I" + INC, "-I" + os.path.join(CSRC, "hip")] + srcs + ["-o", out, "-lrccl"])
+    flags = HIP_FLAGS + EXTRA_HIP_FLAGS
+    if force or _stale(out, deps, flags):
+        _run([HIPCC] + flags + ["-I" + INC, "-I" + os.path.join(CSRC, "hip")] + srcs + ["-o", out, "-lrccl"])
+        _stamp(out, deps, flags)
     return out
+
+
+def hip_source_hash():
+    srcs = [os.path.join(CSRC, "hip", "madicp_capi.hip")]
+    deps = srcs + _glob(os.path.join(CSRC, "hip"), (".h",)) + _glob(INC, (".h",))
+    return source_hash(deps, HIP_FLAGS + EXTRA_HIP_FLAGS)
 
 
 HOST_SRCS = ("tree_builder.cpp", "host_capi.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp", "pipeline.cpp")
@@ -63,10 +99,12 @@ def build_host(force=False):
     out = os.path.join(PKG, "libmadicp_host.so")
     hdir = os.path.join(CSRC, "host")
     srcs = [os.path.join(hdir, f) for f in HOST_SRCS]
-    deps = srcs + _glob(hdir, (".h",)) + _glob(INC, (".h",)) + [os.path.join(PKG, "libmadicp_hip.so")]
-    if force or _newer(out, deps):
-        _run([CXX] + HOST_FLAGS + ["-shared", "-I" + INC, "-I" + hdir] + srcs +
+    deps = srcs + _glob(hdir, (".h",)) + _glob(INC, (".h",))
+    flags = HOST_FLAGS + EXTRA_HOST_FLAGS
+    if force or _stale(out, deps, flags):
+        _run([CXX] + flags + ["-shared", "-I" + INC, "-I" + hdir] + srcs +
              ["-o", out, "-L" + PKG, "-lmadicp_hip", "-Wl,-rpath,$ORIGIN", "-pthread"])
+        _stamp(out, deps, flags)
     return out
 
 
@@ -78,16 +116,18 @@ def build_pybind(force=False):
     outdir = os.path.join(PKG, "pybind")
     os.makedirs(outdir, exist_ok=True)
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
-    deps_h = _glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(INC, (".h",)) + [os.path.join(PKG, "libmadicp_host.so")]
+    deps_h = _glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(INC, (".h",))
+    flags = HOST_FLAGS + EXTRA_HOST_FLAGS
     built = []
     for mod in ("pyvector", "pymadtree", "pymadicp", "pypeline"):
         src = os.path.join(pdir, mod + ".cpp")
         out = os.path.join(outdir, mod + suffix)
-        if force or _newer(out, [src] + deps_h):
-            _run([CXX] + HOST_FLAGS + ["-shared", "-fvisibility=hidden", "-I" + INC, "-I" + hdir, "-I" + pdir,
-                                       "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src,
-                                       "-o", out, "-L" + PKG, "-lmadicp_host", "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..",
-                                       "-pthread"])
+        if force or _stale(out, [src] + deps_h, flags):
+            _run([CXX] + flags + ["-shared", "-fvisibility=hidden", "-I" + INC, "-I" + hdir, "-I" + pdir,
+                                  "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src,
+                                  "-o", out, "-L" + PKG, "-lmadicp_host", "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..",
+                                  "-pthread"])
+            _stamp(out, [src] + deps_h, flags)
         built.append(out)
     return built
 

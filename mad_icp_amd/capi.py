@@ -66,7 +66,13 @@ def hip_lib():
         L.madicp_nn_search_device_enqueue.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
                                                       C.c_void_p, C.c_void_p, C.c_void_p]
         L.madicp_moving_upload.argtypes = [C.c_void_p, _dp, C.c_int32, _ip]
+        L.madicp_moving_update.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int32]
         L.madicp_moving_release.argtypes = [C.c_void_p, C.c_int]
+        L.madicp_stream_submit.argtypes = [C.c_void_p, _dp, C.c_int32, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip]
+        L.madicp_stream_submit_tree.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip]
+        L.madicp_stream_collect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _u8p, _i32p, _u64p]
+        L.madicp_nn_time_descend.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, _dp, _u64p]
+        L.madicp_debug_stream_copy.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp]
         L.madicp_icp_linearize.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), _dp, _dp,
                                            _u32p, _u8p, _u64p]
         L.madicp_icp_register.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _dp,
@@ -78,7 +84,7 @@ def hip_lib():
         L.madicp_icp_time_linearize.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
                                                 _dp, _u64p]
         L.madicp_icp_time_registration.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
-                                                   C.c_int, _dp, _dp, _u64p]
+                                                   C.c_int, _dp, _dp, _u64p, _u64p]
         L.madicp_icp_fetch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_fetch_matched.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int32]
         L.madicp_comm_unique_id.argtypes = [_u8p]
@@ -265,6 +271,10 @@ class Context:
         _check(hip_lib().madicp_moving_upload(self._h, m.ctypes.data_as(_dp), m.shape[0], C.byref(mid)))
         return mid.value
 
+    def moving_update(self, mid, leaf_means):
+        m = _f64(leaf_means)
+        _check(hip_lib().madicp_moving_update(self._h, mid, m.ctypes.data_as(_dp), m.shape[0]))
+
     def moving_release(self, mid):
         _check(hip_lib().madicp_moving_release(self._h, mid))
 
@@ -302,6 +312,49 @@ class Context:
                                              C.byref(visits)))
         return dict(T=pose44(X), X=X, H=H, b=b, matched=matched, X_iters=X_iters, visits=visits.value)
 
+    # ---- streamed registrations (new scan in -> X / H / b / flags out) ----
+    def stream_submit(self, leaf_means, tree_ids, T, params, n_iters):
+        m = _f64(leaf_means)
+        X = pose12(T)
+        p = IcpParams(*params)
+        tk = C.c_int(-1)
+        _check(hip_lib().madicp_stream_submit(self._h, m.ctypes.data_as(_dp), m.shape[0], self._ids(tree_ids), len(tree_ids),
+                                              X.ctypes.data_as(_dp), C.byref(p), n_iters, C.byref(tk)))
+        return tk.value
+
+    def stream_submit_tree(self, moving_tid, tree_ids, T, params, n_iters):
+        X = pose12(T)
+        p = IcpParams(*params)
+        tk = C.c_int(-1)
+        _check(hip_lib().madicp_stream_submit_tree(self._h, moving_tid, self._ids(tree_ids), len(tree_ids),
+                                                   X.ctypes.data_as(_dp), C.byref(p), n_iters, C.byref(tk)))
+        return tk.value
+
+    def stream_collect(self, ticket, L=0):
+        X, H, b = np.empty(12), np.empty((6, 6)), np.empty(6)
+        matched = np.empty(L, np.uint8) if L else None
+        nm = C.c_int32(0)
+        visits = C.c_uint64(0)
+        _check(hip_lib().madicp_stream_collect(self._h, ticket, X.ctypes.data_as(_dp), H.ctypes.data_as(_dp),
+                                               b.ctypes.data_as(_dp), matched.ctypes.data_as(_u8p) if L else None,
+                                               C.byref(nm), C.byref(visits)))
+        return dict(T=pose44(X), X=X, H=H, b=b, matched=matched, n_matched=nm.value, visits=visits.value)
+
+    # ---- measurement aids ----
+    def nn_time_descend(self, tid, queries, reps=20):
+        """(avg microseconds per nn_descend launch over the queries, internal nodes visited per launch)."""
+        q = _f64(queries)
+        us = C.c_double(0.0)
+        depth = C.c_uint64(0)
+        _check(hip_lib().madicp_nn_time_descend(self._h, tid, q.ctypes.data_as(_dp), q.shape[0], reps, C.byref(us),
+                                                C.byref(depth)))
+        return us.value, depth.value
+
+    def stream_copy_gbs(self, nbytes=1 << 30, reps=10):
+        g = C.c_double(0.0)
+        _check(hip_lib().madicp_debug_stream_copy(self._h, nbytes, reps, C.byref(g)))
+        return g.value
+
     def icp_register_batch_enqueue(self, mids, tree_ids, X0, params, n_iters):
         X0 = _f64(X0, (len(mids), 12))
         p = IcpParams(*params)
@@ -320,15 +373,17 @@ class Context:
         return us.value, visits
 
     def icp_time_registration(self, mids, tree_ids, X0, params, n_iters, reps=30):
-        """(avg us per icp_round launch over a registration's rounds, us of icp_final, visits per round per scan)."""
+        """(avg us per icp_round launch over a registration's rounds, us of icp_final, visits per round per scan,
+        nodes really walked per round per scan)."""
         X0 = _f64(X0, (len(mids), 12))
         p = IcpParams(*params)
         lin, sol = C.c_double(0.0), C.c_double(0.0)
         visits = np.zeros(len(mids), np.uint64)
+        walked = np.zeros(len(mids), np.uint64)
         _check(hip_lib().madicp_icp_time_registration(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
                                                       X0.ctypes.data_as(_dp), C.byref(p), n_iters, reps, C.byref(lin),
-                                                      C.byref(sol), visits.ctypes.data_as(_u64p)))
-        return lin.value, sol.value, visits
+                                                      C.byref(sol), visits.ctypes.data_as(_u64p), walked.ctypes.data_as(_u64p)))
+        return lin.value, sol.value, visits, walked
 
     def icp_fetch(self, n_scans):
         X, H, b = np.empty((n_scans, 12)), np.empty((n_scans, 6, 6)), np.empty((n_scans, 6))

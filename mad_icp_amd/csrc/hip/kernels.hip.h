@@ -38,7 +38,9 @@ namespace madicp {
 
 constexpr int kBlock = 768;          // threads per icp_round workgroup = 12 wave64 = 3 per SIMD: ONE workgroup per CU
 constexpr int kWaves = kBlock / 64;
-constexpr int kAcc = 29;             // 21 (lower triangle of H, column by column) + 6 (b) + accepted pairs + nodes visited
+constexpr int kAcc = 30;             // 21 (lower triangle of H, column by column) + 6 (b) + accepted pairs + nodes visited
+                                     // (the reference's count: cached depths included) + nodes actually walked this round;
+                                     // 30 doubles = 240 B: partial rows are 16-byte aligned
 
 
 // 16-byte screening record of one node, same index as the exact 64-byte madicp_node.
@@ -117,14 +119,17 @@ constexpr int kTopLdsBytes = kTopMax * (16 + 8);
 constexpr unsigned int kTopFirst = 0xfffu, kTopLeftIn = 1u << 12, kTopRightIn = 1u << 13, kTopLeftLeaf = 1u << 14,
                        kTopRightLeaf = 1u << 15;
 
-// device-resident record tree_compact fills (origin, radius); read back by the host after upload / transform
-struct TreeMeta {
-  const madicp_node* nodes;
-  const CNode* cnodes;
-  int32_t n_nodes;
-  int32_t n_leaves;
-  double origin[3];              // o: mean of node 0
-  unsigned long long rho2_bits;  // bits of max_i |m_i - o|_2 (non-negative doubles order like integers)
+// What one registration hands back, written by icp_final straight into a pinned host block (no D2H copy operation
+// on any stream): the caller waits for the event behind the registration's last kernel and reads it.
+struct HostResult {
+  double X[12];   // final pose (R row-major, t)
+  double H[36];   // H_adder_ of the last round (pipeline.cpp:223 reads it)
+  double b[6];
+  double n_pairs;
+  unsigned long long visits;
+  unsigned long long walked;
+  int32_t n_matched;
+  int32_t iter;
 };
 
 // One registration in flight; lives in device memory, written by the host before each launch sequence
@@ -144,6 +149,7 @@ struct Job {
   int32_t flags;         // kFlagNoUpdate
   int32_t n_matched;
   unsigned long long visits;  // internal nodes visited (all rounds; exact: integer-valued doubles summed)
+  unsigned long long walked;  // of those, the ones this registration really walked (the rest: correspondence reuse)
   double X[12];          // final pose (R row-major, t), written by icp_final
   double Xring[2][12];   // pose of round r lives in Xring[r & 1]; Xring[0] = initial guess (host)
   double min_ball, rho, b_ratio;
@@ -157,6 +163,8 @@ struct Job {
 #ifdef MADICP_ABLATE
   unsigned long long* dbg;  // profiling builds: per-workgroup phase time stamps of the last launch
 #endif
+  HostResult* host_out;     // optional: pinned host block icp_final also writes the results to
+  uint8_t* host_matched;    // optional: pinned host copy of the matched_ flags (L bytes, 16-byte aligned)
   TreeDesc trees[MADICP_MAX_TREES];
 };
 constexpr int kFlagNoUpdate = 1;
@@ -426,51 +434,42 @@ __device__ __forceinline__ double make_record(const madicp_node& nd, double o0, 
   return sqrt((e0 * e0 + e1 * e1) + e2 * e2);
 }
 
-// builds the screening records of a tree (after upload and after every transform); grid over nodes
-__global__ void tree_compact(TreeMeta* __restrict__ tm, CNode* __restrict__ cnodes, LeafRec* __restrict__ leaves, int n) {
-  const madicp_node* __restrict__ nodes = tm->nodes;
-  const double o0 = nodes[0].mean[0], o1 = nodes[0].mean[1], o2 = nodes[0].mean[2];
+// builds the screening records and the dense leaf records of a tree (after upload and after every transform); grid over
+// nodes.  o = the tree's origin (mean of node 0), handed over by the host, which tracks it (no read-back, no sync).
+__global__ void tree_compact(const madicp_node* __restrict__ nodes, CNode* __restrict__ cnodes, LeafRec* __restrict__ leaves,
+                             int n, double o0, double o1, double o2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  double r = 0.0;
-  if (i < n) {
-    const madicp_node nd = nodes[i];
-    CNode c;
-    c.npack = 0ull;
-    c.c = 0.f;
-    c.right = 0u;  // leaf records are never read, except the root's in a single-node tree ("right == 0 -> leaf")
-    if (nd.right != 0) {
-      r = make_record(nd, o0, o1, o2, c);
-      c.right = (unsigned int)nd.right | (nodes[i + 1].right == 0 ? kLeftLeaf : 0u) |
-                (nodes[i + nd.right].right == 0 ? kRightLeaf : 0u);
-    } else {
-      LeafRec lr;
-      for (int a = 0; a < 3; ++a) {
-        lr.mean[a] = nd.mean[a];
-        lr.normal[a] = nd.dir[a];
-      }
-      lr.bbox0 = nd.bbox0;
-      lr.pad_ = 0.0;
-      leaves[nd.leaf_id] = lr;
+  if (i >= n) return;
+  const madicp_node nd = nodes[i];
+  CNode c;
+  c.npack = 0ull;
+  c.c = 0.f;
+  c.right = 0u;  // leaf records are never read, except the root's in a single-node tree ("right == 0 -> leaf")
+  if (nd.right != 0) {
+    make_record(nd, o0, o1, o2, c);
+    c.right = (unsigned int)nd.right | (nodes[i + 1].right == 0 ? kLeftLeaf : 0u) |
+              (nodes[i + nd.right].right == 0 ? kRightLeaf : 0u);
+  } else {
+    LeafRec lr;
+    for (int a = 0; a < 3; ++a) {
+      lr.mean[a] = nd.mean[a];
+      lr.normal[a] = nd.dir[a];
     }
-    cnodes[i] = c;
+    lr.bbox0 = nd.bbox0;
+    lr.pad_ = 0.0;
+    leaves[nd.leaf_id] = lr;
   }
-  // rho2 = max |m - o|_2 over the internal nodes; max is order independent -> deterministic
-  for (int off = 32; off > 0; off >>= 1) r = fmax(r, __shfl_down(r, off, 64));
-  if ((threadIdx.x & 63) == 0 && r > 0.0) atomicMax(&tm->rho2_bits, (unsigned long long)__double_as_longlong(r));
-  if (i == 0) {
-    tm->origin[0] = o0;
-    tm->origin[1] = o1;
-    tm->origin[2] = o2;
-  }
+  cnodes[i] = c;
 }
 
 // the same records for the LDS-staged top array: entry e describes node top_dfs[e]; link[e] is its (static) link word
 __global__ void tree_compact_top(const madicp_node* __restrict__ nodes, CNode* __restrict__ top,
-                                 const int* __restrict__ top_dfs, const unsigned int* __restrict__ link, int n_top) {
+                                 const int* __restrict__ top_dfs, const unsigned int* __restrict__ link, int n_top,
+                                 double o0, double o1, double o2) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_top) return;
   CNode c;
-  make_record(nodes[top_dfs[e]], nodes[0].mean[0], nodes[0].mean[1], nodes[0].mean[2], c);
+  make_record(nodes[top_dfs[e]], o0, o1, o2, c);
   c.right = link[e];
   top[e] = c;
 }
@@ -479,6 +478,18 @@ __global__ void moving_prep(const double* __restrict__ xyz, double* __restrict__
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L) return;
   const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  double4 o;
+  o.x = x; o.y = y; o.z = z;
+  o.w = sqrt(dotc(x, y, z, x, y, z));
+  reinterpret_cast<double4*>(out)[i] = o;
+}
+
+// MADicp::setMoving fed from a tree that is already resident (the current scan's tree, uploaded for the frame window):
+// the moving set IS that tree's leaves in getLeafs() order (pipeline.cpp:143-144,154), so nothing crosses PCIe twice
+__global__ void moving_from_leaves(const LeafRec* __restrict__ leaves, double* __restrict__ out, int L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  const double x = leaves[i].mean[0], y = leaves[i].mean[1], z = leaves[i].mean[2];
   double4 o;
   o.x = x; o.y = y; o.z = z;
   o.w = sqrt(dotc(x, y, z, x, y, z));
@@ -504,14 +515,17 @@ __global__ void nn_descend(const TreeDesc td, const double* __restrict__ q, long
 }
 
 // mean <- R mean + t ; dir <- R dir   (R row-major)
-__global__ void tree_transform(madicp_node* __restrict__ nodes, int n, const double* __restrict__ Rt) {
+struct Pose12 {
+  double v[12];  // R row-major, t
+};
+__global__ void tree_transform(madicp_node* __restrict__ nodes, int n, const Pose12 Rt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double R[9], t[3];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) R[k] = Rt[k];
+  for (int k = 0; k < 9; ++k) R[k] = Rt.v[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) t[k] = Rt[9 + k];
+  for (int k = 0; k < 3; ++k) t[k] = Rt.v[9 + k];
   madicp_node nd = nodes[i];
   const double m0 = nd.mean[0], m1 = nd.mean[1], m2 = nd.mean[2];
   const double d0 = nd.dir[0], d1 = nd.dir[1], d2 = nd.dir[2];
@@ -1082,6 +1096,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         for (int i = 0; i < 6; ++i) jout->b[i] = b[i];
         jout->n_pairs = s_total[27];
         jout->visits += static_cast<unsigned long long>(s_total[28]);
+        jout->walked += static_cast<unsigned long long>(s_total[29]);
 #pragma unroll
         for (int i = 0; i < 12; ++i) jout->Xring[round & 1][i] = Xn[i];
         jout->iter = round;
@@ -1116,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   double acc[kAcc];
 #pragma unroll
   for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
-  unsigned int visits = 0;
+  unsigned int visits = 0, walked_visits = 0;
   bool walked = false;
   __syncthreads();
   MADICP_STAMP(2);
@@ -1251,6 +1266,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
           if (walk[j]) {
             leaf[j] = wleaf[j];
             depth[j] = wdepth[j];
+            walked_visits += (unsigned int)wdepth[j];
             if (cache_leaf) {
               const long long ci = (long long)k * L + (base + j * kBlock + threadIdx.x);
               const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
@@ -1326,6 +1342,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   MADICP_STAMP(5);
   // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
   acc[28] = static_cast<double>(visits);  // integer-valued: its sums are exact in any order
+  acc[29] = static_cast<double>(walked_visits);
   __shared__ double red[kWaves][32];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -1346,12 +1363,18 @@ __device__ __forceinline__ void count_matched(Job* job) {
   __shared__ int cnt[kBlock / 64];
   const int L = job->L;
   const uint4* m16 = reinterpret_cast<const uint4*>(job->matched);
+  uint8_t* hm = job->host_matched;  // pinned host copy of the flags (posted PCIe writes, 16 bytes per lane)
   int c = 0;
   for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) {
     const uint4 v = m16[i];  // flags are 0/1 bytes: popcount counts them
     c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    if (hm) reinterpret_cast<uint4*>(hm)[i] = v;
   }
-  for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) c += job->matched[i] ? 1 : 0;
+  for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) {
+    const uint8_t f = job->matched[i];
+    c += f ? 1 : 0;
+    if (hm) hm[i] = f;
+  }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -1393,9 +1416,32 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
       for (int i = 0; i < 12; ++i) job->X[i] = Xn[i];
       job->n_pairs = s_total[27];
       job->visits += static_cast<unsigned long long>(s_total[28]);
+      job->walked += static_cast<unsigned long long>(s_total[29]);
       job->iter = n;
     }
+    // the same results straight to the caller's pinned block: lanes 0..35 write H, 0..11 X, 0..5 b
+    if (HostResult* ho = job->host_out) {
+      const int l = threadIdx.x;
+      double h = H[0], x = Xn[0], bb = b[0];
+#pragma unroll
+      for (int i = 1; i < 36; ++i) h = (l == i) ? H[i] : h;
+#pragma unroll
+      for (int i = 1; i < 12; ++i) x = (l == i) ? Xn[i] : x;
+#pragma unroll
+      for (int i = 1; i < 6; ++i) bb = (l == i) ? b[i] : bb;
+      if (l < 36) ho->H[l] = h;
+      if (l < 12) ho->X[l] = x;
+      if (l < 6) ho->b[l] = bb;
+      if (l == 0) {
+        ho->n_pairs = s_total[27];
+        ho->visits = job->visits;
+        ho->walked = job->walked;
+        ho->iter = n;
+      }
+    }
   }
+  __syncthreads();  // count_matched's n_matched (thread 0) is final
+  if (threadIdx.x == 0 && job->host_out) job->host_out->n_matched = job->n_matched;
 }
 
 // multi-GPU: this rank's partials of the round just linearised -> totals[scan][kAcc], then ncclAllReduce(sum)

@@ -1,5 +1,12 @@
 // libmadicp_hip.so — implementation of the C ABI declared in include/madicp_hip.h.
 // Context / buffer management, launch sequencing (eager or captured hipGraph), optional RCCL all-reduce.
+//
+// Streams.  `stream` (compute) carries every registration; `copy` carries what feeds them — tree uploads + their
+// screening-record builds, the moving leaves of the NEXT scan, its Job — so those overlap the registration in flight.
+// Hand-over is by events only; nothing on the registration path allocates, frees or synchronises the device:
+// device memory comes from a small in-context pool (a released buffer is reused once the event recorded at its
+// release has passed), pinned staging is grow-only, results are written by the last kernel of a registration straight
+// into a pinned host block (Job::host_out) that the caller reads after one event wait.
 #include "kernels.hip.h"
 
 #include <hip/hip_ext.h>
@@ -11,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -34,6 +42,12 @@ int fail(int code, const std::string& msg) {
       return fail(MADICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
   } while (0)
 
+#define RC_TRY(expr)              \
+  do {                            \
+    const int rc_ = (expr);       \
+    if (rc_ != MADICP_OK) return rc_; \
+  } while (0)
+
 #define NCCL_TRY(expr)                                                                            \
   do {                                                                                            \
     ncclResult_t r_ = (expr);                                                                     \
@@ -41,7 +55,24 @@ int fail(int code, const std::string& msg) {
       return fail(MADICP_ERR_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_));          \
   } while (0)
 
+// a pair of events (one per stream) shared by the buffers released together; destroyed with the last of them
+struct EventHolder {
+  hipEvent_t ev = nullptr;       // behind everything enqueued on the compute stream
+  hipEvent_t ev_copy = nullptr;  // behind everything enqueued on the copy stream
+  ~EventHolder() {
+    if (ev) hipEventDestroy(ev);
+    if (ev_copy) hipEventDestroy(ev_copy);
+  }
+};
+using EventRef = std::shared_ptr<EventHolder>;
+
+struct PoolEntry {
+  void* ptr;
+  EventRef after;  // work that may still touch the buffer (null: none)
+};
+
 struct DevTree {
+  char* block = nullptr;       // one device allocation: [nodes | top_exit | top_dfs | top_link] (uploaded) [cnodes | leaves | top]
   madicp_node* nodes = nullptr;
   CNode* cnodes = nullptr;    // 16-byte screening records, same indexing
   LeafRec* leaves = nullptr;  // dense 64-byte leaf records, by leaf ordinal
@@ -50,25 +81,34 @@ struct DevTree {
   int* top_dfs = nullptr;
   unsigned int* top_link = nullptr;
   int32_t n_top = 0;
-  TreeMeta* meta = nullptr;   // device-side scratch tree_compact writes origin / radius into
   TreeDesc desc{};            // what the kernels get by value
   int32_t n_nodes = 0, n_leaves = 0;
+  double rho2 = 0.0;          // max |m - o|_2 over the internal nodes (host computed; rotation invariant)
+  hipEvent_t ready = nullptr; // recorded on the copy stream behind the upload + record build
+  bool compute_waited = false;  // the compute stream is already ordered behind `ready`
 };
 struct DevMoving {
   double* xyzn = nullptr;  // (L,4)
   uint8_t* matched = nullptr;
   int32_t L = 0;
-  // correspondence cache of the registration in flight for this scan: (K,L) each, grown on demand
+  int32_t cap_L = 0;
+  // correspondence cache of the registration in flight for this scan: (K,L) each, grow-only
   uint32_t* cache_leaf = nullptr;
   float* cache_margin = nullptr;
-  int32_t cache_K = 0;
+  size_t cache_cap = 0;  // elements
+  // pinned staging of the leaf means (moving_prep reads it over PCIe: no separate H2D operation, no device scratch)
+  double* h_in = nullptr;
+  size_t h_in_cap = 0;        // doubles
+  hipEvent_t h_in_read = nullptr;  // the kernel that reads h_in has run
+  hipEvent_t ready = nullptr;      // xyzn valid (recorded on whichever stream prepared it)
+  bool on_copy = false;            // `ready` was recorded on the copy stream and the compute stream has not waited yet
 };
 
 struct GraphKey {  // everything a captured launch sequence bakes in
-  int grid, batch, iters, qpt, comm, lds, K, rpt, trace;
+  int grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt, trace) <
-           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt, o.trace);
+    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot) <
+           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt, o.trace, o.slot);
   }
 };
 struct Geometry {
@@ -78,17 +118,38 @@ struct Geometry {
   int lds_bytes;        // dynamic LDS of the launch: kTopLdsBytes when units are big enough to stage a tree's top, else 0
 };
 
+// one streamed registration in flight (madicp_stream_submit .. madicp_stream_collect)
+struct StreamSlot {
+  int moving_id = -1;       // a DevMoving owned by this slot
+  Job* d_job = nullptr;     // this slot's Job on the device (its graphs bake the pointer)
+  Job* h_job = nullptr;     // pinned staging of it
+  HostResult* h_out = nullptr;   // pinned: icp_final writes the results here
+  uint8_t* h_matched = nullptr;  // pinned: and the matched_ flags here
+  size_t h_matched_cap = 0;
+  hipEvent_t ev_up = nullptr;    // copy stream: Job + moving leaves are on the device
+  hipEvent_t ev_done = nullptr;  // compute stream: the registration has finished
+  bool pending = false;
+  int ticket = -1;
+  int L = 0;
+};
+
 }  // namespace
 
 struct madicp_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // compute
+  hipStream_t copy = nullptr;    // feeds: uploads, record builds, next scan's leaves
   bool own_stream = false;
   int n_cus = 256;
 
   std::unordered_map<int, DevTree> trees;
   std::unordered_map<int, DevMoving> movings;
   int next_id = 1;
+
+  // device memory pool
+  std::multimap<size_t, PoolEntry> pool;            // free buffers by capacity
+  std::unordered_map<void*, size_t> alloc_bytes;    // capacity of every buffer handed out
+  size_t pool_bytes = 0;
 
   // registration state
   Job* d_jobs = nullptr;       // [MADICP_MAX_BATCH]
@@ -102,20 +163,31 @@ struct madicp_ctx {
   size_t partials_cap = 0;     // doubles
   int partials_grid = -1, partials_batch = -1;  // geometry the zero padding rows of d_partials are valid for
   double* d_totals = nullptr;  // [MADICP_MAX_BATCH][kAcc]
-  double* d_scratch = nullptr; // 12 doubles (R,t for tree_transform)
   int last_batch = 0;
   std::vector<int> last_moving;
+
+  // pinned staging for tree uploads (two buffers, alternating)
+  char* h_tree[2] = {nullptr, nullptr};
+  size_t h_tree_cap[2] = {0, 0};
+  hipEvent_t h_tree_ev[2] = {nullptr, nullptr};
+  int h_tree_next = 0;
+
+  // streamed registrations
+  static constexpr int kStreamSlots = 4;
+  StreamSlot slots[kStreamSlots];
+  int next_ticket = 0;
 
   // options
   int blocks_per_cu = 1;  // icp_round workgroups (768 threads) per CU
   int use_graph = 1;
+  int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
 
-  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // madicp_icp_time_linearize
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // measurement entry points
 
   // multi-GPU
   ncclComm_t comm = nullptr;
@@ -124,11 +196,80 @@ struct madicp_ctx {
 
 namespace {
 
+constexpr size_t kAlign = 256;
+size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+// ---- device memory pool -----------------------------------------------------------------------------
+// alloc: a pooled buffer of capacity in [bytes, 2*bytes] if there is one (ordering `user` behind the work recorded at
+// its release), else hipMalloc.  Trees of consecutive scans have nearly the same size, so the steady state of an
+// odometry run allocates nothing.
+int pool_alloc(madicp_ctx* ctx, size_t bytes, hipStream_t user, void** out) {
+  bytes = std::max<size_t>(align_up(bytes), kAlign);
+  auto it = ctx->pool.lower_bound(bytes);
+  if (it != ctx->pool.end() && it->first <= 2 * bytes) {
+    if (it->second.after) {
+      if (it->second.after->ev) HIP_TRY(hipStreamWaitEvent(user, it->second.after->ev, 0));
+      if (it->second.after->ev_copy) HIP_TRY(hipStreamWaitEvent(user, it->second.after->ev_copy, 0));
+    }
+    *out = it->second.ptr;
+    ctx->pool_bytes -= it->first;
+    ctx->pool.erase(it);
+    return MADICP_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {  // out of memory: give the pool back and retry once
+    (void)hipGetLastError();
+    hipDeviceSynchronize();
+    for (auto& pe : ctx->pool) {
+      ctx->alloc_bytes.erase(pe.second.ptr);
+      hipFree(pe.second.ptr);
+    }
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+  ctx->alloc_bytes[p] = bytes;
+  *out = p;
+  return MADICP_OK;
+}
+
+// events behind everything enqueued so far on the two streams (neither stream is made to wait for the other)
+int fence_event(madicp_ctx* ctx, EventRef* out) {
+  auto h = std::make_shared<EventHolder>();
+  HIP_TRY(hipEventCreateWithFlags(&h->ev, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->ev, ctx->stream));
+  HIP_TRY(hipEventRecord(h->ev_copy, ctx->copy));
+  *out = h;
+  return MADICP_OK;
+}
+
+void pool_free(madicp_ctx* ctx, void* p, const EventRef& after) {
+  if (!p) return;
+  auto it = ctx->alloc_bytes.find(p);
+  if (it == ctx->alloc_bytes.end()) return;
+  const size_t cap = it->second;
+  constexpr size_t kPoolMax = size_t(1) << 30;  // keep at most 1 GiB parked
+  if (ctx->pool_bytes + cap > kPoolMax) {
+    if (after && after->ev) hipEventSynchronize(after->ev);
+    if (after && after->ev_copy) hipEventSynchronize(after->ev_copy);
+    ctx->alloc_bytes.erase(it);
+    hipFree(p);
+    return;
+  }
+  ctx->pool.emplace(cap, PoolEntry{p, after});
+  ctx->pool_bytes += cap;
+}
+
 int ensure_partials(madicp_ctx* ctx, size_t doubles) {
   if (doubles <= ctx->partials_cap) return MADICP_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->d_partials) HIP_TRY(hipFree(ctx->d_partials));
   ctx->d_partials = nullptr;
   ctx->partials_cap = 0;
+  doubles = std::max(doubles, (size_t)2 * 288 * kAcc * 8);  // room for the common geometries: grows once
   HIP_TRY(hipMalloc(&ctx->d_partials, doubles * sizeof(double)));
   ctx->partials_cap = doubles;
   ctx->partials_grid = ctx->partials_batch = -1;
@@ -147,12 +288,12 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   // lane share their loads but were not measured faster).
   g.qpt = ctx->qpt_override == 2 ? 2 : 1;
   long long grid = std::max<long long>(8, (long long)ctx->blocks_per_cu * ctx->n_cus / std::max(1, batch));
-  const long long max_useful = (long long)K * ((max_L + 63) / 64);  // never below one wave of leaves per unit
+  const long long max_useful = (long long)std::max(1, K) * ((max_L + 63) / 64);  // never below one wave of leaves per unit
   grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
   g.grid = static_cast<int>(grid);
-  g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / K));
+  g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / std::max(1, K)));
   const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
-  g.lds_bytes = per_range >= ctx->stage_min_leaves ? kTopLdsBytes : 0;
+  g.lds_bytes = (K > 0 && per_range >= ctx->stage_min_leaves) ? kTopLdsBytes : 0;
   return g;
 }
 
@@ -160,20 +301,22 @@ struct Launch {  // one registration's launch shape
   int grid, batch, iters, qpt, lds, K, rpt, trace;
 };
 
-void launch_round(madicp_ctx* ctx, const Launch& l, int round, const double* totals) {
+void launch_round(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
   void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int) =
       l.trace ? (l.qpt == 2 ? icp_round<2, true> : icp_round<1, true>) : (l.qpt == 2 ? icp_round<2, false> : icp_round<1, false>);
-  hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)ctx->d_jobs, ctx->d_jobs, ctx->d_partials, totals, round,
-                     l.iters, l.K, l.rpt);
+  hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)d_jobs, d_jobs, ctx->d_partials, totals, round, l.iters, l.K,
+                     l.rpt);
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
-int enqueue_rounds(madicp_ctx* ctx, const Launch& l) {
+int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vector<int>& moving_ids) {
   const int grid = l.grid, batch = l.batch, iters = l.iters;
   for (int it = 0; it < iters; ++it) {
-    launch_round(ctx, l, it, (ctx->comm && it > 0) ? ctx->d_totals : nullptr);
+    launch_round(ctx, l, d_jobs, it, (ctx->comm && it > 0) ? ctx->d_totals : nullptr);
     if (ctx->comm) {
+      // this rank's share of the adders (a rank that owns no tree contributes zeros) -> one all-reduce of
+      // [H(21) b(6) n v] per scan over xGMI: the serial sum of mad_icp.cpp:106-109
       hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_partials, grid, batch, it,
                          ctx->d_totals);
       NCCL_TRY(ncclAllReduce(ctx->d_totals, ctx->d_totals, (size_t)batch * kAcc, ncclDouble, ncclSum, ctx->comm,
@@ -183,27 +326,31 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l) {
   if (ctx->comm) {
     // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204)
     for (int s = 0; s < batch; ++s) {
-      const DevMoving& mv = ctx->movings.at(ctx->last_moving[s]);
+      const DevMoving& mv = ctx->movings.at(moving_ids[s]);
       NCCL_TRY(ncclAllReduce(mv.matched, mv.matched, (size_t)mv.L, ncclUint8, ncclMax, ctx->comm, ctx->stream));
     }
   }
   // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
-  hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+  hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials,
                      ctx->comm ? ctx->d_totals : nullptr, grid, batch);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
 
-int run_rounds(madicp_ctx* ctx, const Launch& l) {
-  // graphs: (conservatively) only without a communicator
-  const bool graph_ok = ctx->use_graph && !ctx->comm;
-  if (!graph_ok) return enqueue_rounds(ctx, l);
-  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace};
+// slot: which device Job array the sequence works on (-1: ctx->d_jobs; >= 0: that stream slot's) — part of the graph key
+int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const std::vector<int>& moving_ids) {
+  // with a communicator the RCCL calls are captured only on request (option "comm_graph"): it could not be
+  // exercised on more than one rank where this was developed
+  const bool graph_ok = ctx->use_graph && (!ctx->comm || ctx->comm_graph);
+  if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
+  // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
+  // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     hipGraph_t graph = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_rounds(ctx, l);
+    const int rc = enqueue_rounds(ctx, l, d_jobs, moving_ids);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc != MADICP_OK) return rc;
     if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -214,6 +361,112 @@ int run_rounds(madicp_ctx* ctx, const Launch& l) {
   }
   HIP_TRY(hipGraphLaunch(it->second, ctx->stream));
   return MADICP_OK;
+}
+
+// the compute stream must see a tree's upload / record build (copy stream) before it reads the tree
+int wait_tree(madicp_ctx* ctx, DevTree& t) {
+  if (!t.compute_waited) {
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, t.ready, 0));
+    t.compute_waited = true;
+  }
+  return MADICP_OK;
+}
+int wait_moving(madicp_ctx* ctx, DevMoving& m) {
+  if (m.on_copy) {
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, m.ready, 0));
+    m.on_copy = false;
+  }
+  return MADICP_OK;
+}
+
+// grow-only device buffers of a moving set
+int reserve_moving(madicp_ctx* ctx, DevMoving& m, int L, hipStream_t user) {
+  if (L <= m.cap_L) return MADICP_OK;
+  EventRef after;
+  if (m.xyzn) RC_TRY(fence_event(ctx, &after));
+  pool_free(ctx, m.xyzn, after);
+  pool_free(ctx, m.matched, after);
+  pool_free(ctx, m.cache_leaf, after);
+  pool_free(ctx, m.cache_margin, after);
+  m.xyzn = nullptr; m.matched = nullptr; m.cache_leaf = nullptr; m.cache_margin = nullptr;
+  m.cache_cap = 0;
+  m.cap_L = 0;
+  if (ctx->comm) {  // a captured sequence with collectives bakes the matched-flag buffer's address
+    for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+    ctx->graphs.clear();
+  }
+  const int cap = (L + L / 8 + 255) / 256 * 256;  // head-room: consecutive scans differ by a few per cent
+  void* p = nullptr;
+  RC_TRY(pool_alloc(ctx, sizeof(double) * 4 * (size_t)cap, user, &p));
+  m.xyzn = static_cast<double*>(p);
+  RC_TRY(pool_alloc(ctx, (size_t)cap + 16, user, &p));
+  m.matched = static_cast<uint8_t*>(p);
+  m.cap_L = cap;
+  return MADICP_OK;
+}
+int reserve_cache(madicp_ctx* ctx, DevMoving& m, int K) {
+  const size_t need = (size_t)K * (size_t)m.cap_L;
+  if (need <= m.cache_cap) return MADICP_OK;
+  EventRef after;
+  if (m.cache_leaf) RC_TRY(fence_event(ctx, &after));
+  pool_free(ctx, m.cache_leaf, after);
+  pool_free(ctx, m.cache_margin, after);
+  m.cache_leaf = nullptr; m.cache_margin = nullptr;
+  m.cache_cap = 0;
+  void* p = nullptr;
+  RC_TRY(pool_alloc(ctx, sizeof(uint32_t) * need, ctx->stream, &p));
+  m.cache_leaf = static_cast<uint32_t*>(p);
+  RC_TRY(pool_alloc(ctx, sizeof(float) * need, ctx->stream, &p));
+  m.cache_margin = static_cast<float*>(p);
+  m.cache_cap = need;
+  return MADICP_OK;
+}
+int reserve_pinned_in(DevMoving& m, int L) {
+  const size_t need = 3 * (size_t)L;
+  if (need <= m.h_in_cap) return MADICP_OK;
+  if (m.h_in) {
+    if (m.h_in_read) HIP_TRY(hipEventSynchronize(m.h_in_read));
+    HIP_TRY(hipHostFree(m.h_in));
+    m.h_in = nullptr;
+    m.h_in_cap = 0;
+  }
+  const size_t cap = need + need / 8 + 768;
+  HIP_TRY(hipHostMalloc(&m.h_in, cap * sizeof(double), hipHostMallocDefault));
+  m.h_in_cap = cap;
+  if (!m.h_in_read) HIP_TRY(hipEventCreateWithFlags(&m.h_in_read, hipEventDisableTiming));
+  return MADICP_OK;
+}
+
+// leaf means (host, pageable) -> pinned staging -> moving_prep on `s` reads them over PCIe and writes (x,y,z,|p|)
+int load_moving(madicp_ctx* ctx, DevMoving& m, const double* leaf_means, int L, hipStream_t s) {
+  RC_TRY(reserve_moving(ctx, m, L, s));
+  RC_TRY(reserve_pinned_in(m, L));
+  HIP_TRY(hipEventSynchronize(m.h_in_read));  // (never recorded: returns at once)
+  std::memcpy(m.h_in, leaf_means, sizeof(double) * 3 * (size_t)L);
+  m.L = L;
+  double* d_in = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_in), m.h_in, 0));
+  hipLaunchKernelGGL(moving_prep, dim3((L + 255) / 256), dim3(256), 0, s, (const double*)d_in, m.xyzn, L);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(m.h_in_read, s));
+  if (!m.ready) HIP_TRY(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(m.ready, s));
+  m.on_copy = (s != ctx->stream);
+  return MADICP_OK;
+}
+
+void free_moving(madicp_ctx* ctx, DevMoving& m, const EventRef& after) {
+  pool_free(ctx, m.xyzn, after);
+  pool_free(ctx, m.matched, after);
+  pool_free(ctx, m.cache_leaf, after);
+  pool_free(ctx, m.cache_margin, after);
+  if (m.h_in) {
+    if (m.h_in_read) hipEventSynchronize(m.h_in_read);
+    hipHostFree(m.h_in);
+  }
+  if (m.h_in_read) hipEventDestroy(m.h_in_read);
+  if (m.ready) hipEventDestroy(m.ready);
+  m = DevMoving{};
 }
 
 struct RegArgs {
@@ -231,12 +484,76 @@ struct RegArgs {
   double* out_avg_us = nullptr;
 };
 
+// A start pose that is not a rigid motion breaks the displacement bound of the correspondence reuse (it assumes
+// |R|_2 <= 1 + 1e-7): such a registration re-walks every round, like the reference.
+bool is_rigid(const double* X) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double d = 0.0;
+      for (int k = 0; k < 3; ++k) d += X[3 * k + i] * X[3 * k + j];
+      if (!(std::fabs(d - (i == j ? 1.0 : 0.0)) <= 1e-9)) return false;
+    }
+  return true;
+}
+
+// everything of a Job but the launch geometry
+int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K, const double* X0,
+             const madicp_icp_params* params, int n_iters, int flags, bool use_cache) {
+  std::memset(&j, 0, offsetof(Job, trees));
+  j.moving = mv.xyzn;
+  j.matched = mv.matched;
+  j.cache_leaf = use_cache ? mv.cache_leaf : nullptr;
+  j.cache_margin = use_cache ? mv.cache_margin : nullptr;
+  j.L = mv.L;
+  j.K = K;
+  j.n_iters = n_iters;
+  j.iter = 0;
+  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse);
+  std::memcpy(j.X, X0, 12 * sizeof(double));
+  std::memcpy(j.Xring[0], X0, 12 * sizeof(double));
+  std::memcpy(j.Xring[1], X0, 12 * sizeof(double));
+  j.min_ball = params->min_ball;
+  j.rho = std::sqrt(params->rho_ker);  // MADicp ctor, mad_icp.cpp:32
+  j.b_ratio = params->b_ratio;
+  if (K == 0) std::memset(&j.trees[0], 0, sizeof(TreeDesc));
+  for (int k = 0; k < K; ++k) {
+    auto tit = ctx->trees.find(tree_ids[k]);
+    if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+    RC_TRY(wait_tree(ctx, tit->second));
+    j.trees[k] = tit->second.desc;
+  }
+  return MADICP_OK;
+}
+
+int check_reg_args(madicp_ctx* ctx, const void* a, const void* b, const void* c, int K, int n_iters) {
+  if (!ctx || !a || !b || !c) return fail(MADICP_ERR_INVALID, "null argument");
+  // a rank that owns no keyframe tree still has to join the collectives (with zero adders): K == 0 is legal there
+  if (K < (ctx->comm ? 0 : 1)) return fail(MADICP_ERR_INVALID, "K must be >= 1");
+  if (K > MADICP_MAX_TREES) return fail(MADICP_ERR_CAPACITY, "K exceeds MADICP_MAX_TREES");
+  if (n_iters < 1) return fail(MADICP_ERR_INVALID, "n_iters must be >= 1");
+  return MADICP_OK;
+}
+
+// partials for this launch shape: two round parities of join_rows(grid) rows per scan — the rows beyond `grid` are
+// zero and stay zero — then two parities of per-workgroup walk hints, + one padding row (the join's 16-byte loads
+// read one double past)
+int prepare_partials(madicp_ctx* ctx, int grid, int n_scans) {
+  const size_t prows = (size_t)madicp::join_rows(grid);
+  const size_t partial_doubles = (size_t)2 * n_scans * prows * kAcc + (size_t)2 * n_scans * grid + kAcc;
+  RC_TRY(ensure_partials(ctx, partial_doubles));
+  if (ctx->partials_grid != grid || ctx->partials_batch != n_scans) {
+    // a row that is padding in this geometry may have been a real row in the previous one
+    HIP_TRY(hipMemsetAsync(ctx->d_partials, 0, partial_doubles * sizeof(double), ctx->stream));
+    ctx->partials_grid = grid;
+    ctx->partials_batch = n_scans;
+  }
+  return MADICP_OK;
+}
+
 int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
-  if (!ctx || !a.moving_ids || !a.tree_ids || !a.X0 || !a.params) return fail(MADICP_ERR_INVALID, "null argument");
+  RC_TRY(check_reg_args(ctx, a.moving_ids, a.X0, a.params, a.K, a.n_iters));
+  if (a.K > 0 && !a.tree_ids) return fail(MADICP_ERR_INVALID, "null argument");
   if (a.n_scans < 1 || a.n_scans > MADICP_MAX_BATCH) return fail(MADICP_ERR_CAPACITY, "n_scans out of range");
-  if (a.K < 1) return fail(MADICP_ERR_INVALID, "K must be >= 1");
-  if (a.K > MADICP_MAX_TREES) return fail(MADICP_ERR_CAPACITY, "K exceeds MADICP_MAX_TREES");
-  if (a.n_iters < 1) return fail(MADICP_ERR_INVALID, "n_iters must be >= 1");
   HIP_TRY(hipSetDevice(ctx->device));
   // next slot of the pinned staging ring; wait until the H2D copy that last used it has executed
   const int slot = ctx->stage_next;
@@ -246,45 +563,17 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
 
   int max_L = 0;
   ctx->last_moving.assign(a.moving_ids, a.moving_ids + a.n_scans);
+  const bool use_cache = a.n_iters > 1 && !a.time_launches;
   for (int s = 0; s < a.n_scans; ++s) {
     auto mit = ctx->movings.find(a.moving_ids[s]);
     if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
     DevMoving& mv = mit->second;
-    if (a.n_iters > 1 && !a.time_launches && mv.cache_K < a.K) {  // (re)size this scan's correspondence cache
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      hipFree(mv.cache_leaf);
-      hipFree(mv.cache_margin);
-      mv.cache_leaf = nullptr;
-      mv.cache_margin = nullptr;
-      mv.cache_K = 0;
-      HIP_TRY(hipMalloc(&mv.cache_leaf, sizeof(uint32_t) * (size_t)a.K * mv.L));
-      HIP_TRY(hipMalloc(&mv.cache_margin, sizeof(float) * (size_t)a.K * mv.L));
-      mv.cache_K = a.K;
-    }
+    RC_TRY(wait_moving(ctx, mv));
+    if (use_cache) RC_TRY(reserve_cache(ctx, mv, std::max(1, a.K)));
     Job& j = h_jobs[s];
-    std::memset(&j, 0, offsetof(Job, trees));
-    j.moving = mv.xyzn;
-    j.matched = mv.matched;
-    j.cache_leaf = (a.n_iters > 1 && !a.time_launches) ? mv.cache_leaf : nullptr;
-    j.cache_margin = j.cache_leaf ? mv.cache_margin : nullptr;
+    RC_TRY(fill_job(ctx, j, mv, a.tree_ids, a.K, a.X0 + 12 * s, a.params, a.n_iters, a.flags, use_cache));
     j.corr = (s == 0) ? a.d_corr : nullptr;
     j.x_iters = (s == 0) ? a.d_x_iters : nullptr;
-    j.L = mv.L;
-    j.K = a.K;
-    j.n_iters = a.n_iters;
-    j.iter = 0;
-    j.flags = a.flags | (ctx->cache_corr ? 0 : kFlagNoReuse);
-    std::memcpy(j.X, a.X0 + 12 * s, 12 * sizeof(double));
-    std::memcpy(j.Xring[0], a.X0 + 12 * s, 12 * sizeof(double));
-    std::memcpy(j.Xring[1], a.X0 + 12 * s, 12 * sizeof(double));
-    j.min_ball = a.params->min_ball;
-    j.rho = std::sqrt(a.params->rho_ker);  // MADicp ctor, mad_icp.cpp:32
-    j.b_ratio = a.params->b_ratio;
-    for (int k = 0; k < a.K; ++k) {
-      auto tit = ctx->trees.find(a.tree_ids[k]);
-      if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
-      j.trees[k] = tit->second.desc;
-    }
     max_L = std::max(max_L, mv.L);
     // flags are cleared on the device before the last round; with a single round that is "now"
     if (a.n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
@@ -297,18 +586,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
     h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
   }
-  // two round parities of partials — join_rows(grid) rows per scan, the rows beyond `grid` are zero and stay zero —
-  // then two parities of per-workgroup walk hints, + one padding row (the join's 16-byte loads read one double past)
-  const size_t prows = (size_t)madicp::join_rows(grid);
-  const size_t partial_doubles = (size_t)2 * a.n_scans * prows * kAcc + (size_t)2 * a.n_scans * grid + kAcc;
-  const int rc0 = ensure_partials(ctx, partial_doubles);
-  if (rc0 != MADICP_OK) return rc0;
-  if (ctx->partials_grid != grid || ctx->partials_batch != a.n_scans) {
-    // a row that is padding in this geometry may have been a real row in the previous one
-    HIP_TRY(hipMemsetAsync(ctx->d_partials, 0, partial_doubles * sizeof(double), ctx->stream));
-    ctx->partials_grid = grid;
-    ctx->partials_batch = a.n_scans;
-  }
+  RC_TRY(prepare_partials(ctx, grid, a.n_scans));
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -324,7 +602,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, launch, 0, nullptr);
+    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, launch, ctx->d_jobs, 0, nullptr);
     HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, ctx->stream));  // warm-up replay
@@ -342,7 +620,12 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     if (a.out_avg_us) *a.out_avg_us = 1e3 * ms / a.time_launches;
     return MADICP_OK;
   }
-  return run_rounds(ctx, launch);
+  // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
+  const int saved = ctx->use_graph;
+  if (ctx->comm) ctx->use_graph = 0;
+  const int rc = run_rounds(ctx, launch, ctx->d_jobs, -1, ctx->last_moving);
+  ctx->use_graph = saved;
+  return rc;
 }
 
 }  // namespace
@@ -350,7 +633,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
 extern "C" {
 
 const char* madicp_last_error(void) { return g_err.c_str(); }
-int madicp_abi_version(void) { return 1; }
+int madicp_abi_version(void) { return 2; }
 
 int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   if (!out) return fail(MADICP_ERR_INVALID, "out is null");
@@ -363,24 +646,34 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   ctx->device = device_id;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+  hipError_t e = hipSuccess;
   if (stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
       delete ctx;
       return fail(MADICP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     ctx->own_stream = true;
   }
-  hipError_t e = hipMalloc(&ctx->d_jobs, sizeof(Job) * MADICP_MAX_BATCH);
+  e = hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&ctx->d_jobs, sizeof(Job) * MADICP_MAX_BATCH);
   for (int i = 0; i < madicp_ctx::kStageSlots && e == hipSuccess; ++i) {
     e = hipHostMalloc(&ctx->h_stage[i], sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming);
   }
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->h_tree_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc(&ctx->h_fetch, sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(&ctx->d_totals, sizeof(double) * kAcc * MADICP_MAX_BATCH);
-  if (e == hipSuccess) e = hipMalloc(&ctx->d_scratch, sizeof(double) * 12);
+  for (int i = 0; i < madicp_ctx::kStreamSlots && e == hipSuccess; ++i) {
+    StreamSlot& sl = ctx->slots[i];
+    e = hipMalloc(&sl.d_job, sizeof(Job));
+    if (e == hipSuccess) e = hipHostMalloc(&sl.h_job, sizeof(Job), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(&sl.h_out, sizeof(HostResult), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming);
+  }
   if (e != hipSuccess) {
     madicp_ctx_destroy(ctx);
     return fail(MADICP_ERR_DEVICE, std::string("context allocation: ") + hipGetErrorString(e));
@@ -393,24 +686,18 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (!ctx) return MADICP_OK;
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  if (ctx->copy) hipStreamSynchronize(ctx->copy);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
-  for (auto& t : ctx->trees) {
-    hipFree(t.second.nodes);
-    hipFree(t.second.cnodes);
-    hipFree(t.second.leaves);
-    hipFree(t.second.top);
-    hipFree(t.second.top_exit);
-    hipFree(t.second.top_dfs);
-    hipFree(t.second.top_link);
-    hipFree(t.second.meta);
-  }
+  for (auto& t : ctx->trees)
+    if (t.second.ready) hipEventDestroy(t.second.ready);
   for (auto& m : ctx->movings) {
-    hipFree(m.second.xyzn);
-    hipFree(m.second.matched);
-    hipFree(m.second.cache_leaf);
-    hipFree(m.second.cache_margin);
+    if (m.second.h_in) hipHostFree(m.second.h_in);
+    if (m.second.h_in_read) hipEventDestroy(m.second.h_in_read);
+    if (m.second.ready) hipEventDestroy(m.second.ready);
   }
+  ctx->pool.clear();  // (drops the event holders)
+  for (auto& a : ctx->alloc_bytes) hipFree(a.first);  // every pooled or live device buffer
   if (ctx->ev_t0) hipEventDestroy(ctx->ev_t0);
   if (ctx->ev_t1) hipEventDestroy(ctx->ev_t1);
   if (ctx->d_jobs) hipFree(ctx->d_jobs);
@@ -418,10 +705,23 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
     if (ctx->stage_ev[i]) hipEventDestroy(ctx->stage_ev[i]);
   }
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->h_tree[i]) hipHostFree(ctx->h_tree[i]);
+    if (ctx->h_tree_ev[i]) hipEventDestroy(ctx->h_tree_ev[i]);
+  }
+  for (int i = 0; i < madicp_ctx::kStreamSlots; ++i) {
+    StreamSlot& sl = ctx->slots[i];
+    if (sl.d_job) hipFree(sl.d_job);
+    if (sl.h_job) hipHostFree(sl.h_job);
+    if (sl.h_out) hipHostFree(sl.h_out);
+    if (sl.h_matched) hipHostFree(sl.h_matched);
+    if (sl.ev_up) hipEventDestroy(sl.ev_up);
+    if (sl.ev_done) hipEventDestroy(sl.ev_done);
+  }
   if (ctx->h_fetch) hipHostFree(ctx->h_fetch);
   if (ctx->d_partials) hipFree(ctx->d_partials);
   if (ctx->d_totals) hipFree(ctx->d_totals);
-  if (ctx->d_scratch) hipFree(ctx->d_scratch);
+  if (ctx->copy) hipStreamDestroy(ctx->copy);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return MADICP_OK;
@@ -429,6 +729,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
 
 int madicp_ctx_synchronize(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  HIP_TRY(hipStreamSynchronize(ctx->copy));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return MADICP_OK;
 }
@@ -441,6 +742,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->blocks_per_cu = (int)value;
   } else if (k == "use_graph") {
     ctx->use_graph = value ? 1 : 0;
+  } else if (k == "comm_graph") {
+    ctx->comm_graph = value ? 1 : 0;
   } else if (k == "cache_correspondences") {
     ctx->cache_corr = value ? 1 : 0;
   } else if (k == "lds_stage_min_leaves") {
@@ -457,28 +760,39 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
 
 // ---- trees ------------------------------------------------------------------------------------------
 namespace {
-// (re)build the 16-byte screening records and the tree's origin / radius on the device
-int compact_tree(madicp_ctx* ctx, DevTree& t) {
-  HIP_TRY(hipMemsetAsync(&t.meta->rho2_bits, 0, sizeof(unsigned long long), ctx->stream));
-  hipLaunchKernelGGL(tree_compact, dim3((t.n_nodes + 255) / 256), dim3(256), 0, ctx->stream, t.meta, t.cnodes, t.leaves, t.n_nodes);
-  if (t.n_top > 0)
-    hipLaunchKernelGGL(tree_compact_top, dim3((t.n_top + 255) / 256), dim3(256), 0, ctx->stream, t.nodes, t.top, t.top_dfs,
-                       t.top_link, t.n_top);
-  HIP_TRY(hipGetLastError());
-  TreeMeta hm;
-  HIP_TRY(hipMemcpyAsync(&hm, t.meta, sizeof(hm), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  t.desc.nodes = t.nodes;
-  t.desc.cnodes = t.cnodes;
-  t.desc.leaves = t.leaves;
-  t.desc.top = t.top;
-  t.desc.top_exit = t.top_exit;
-  t.desc.top_dfs = t.top_dfs;
-  t.desc.n_top = t.n_top;
-  std::memcpy(t.desc.origin, hm.origin, sizeof(hm.origin));
-  double rho2;
-  std::memcpy(&rho2, &hm.rho2_bits, sizeof(double));
-  t.desc.rho = 1.7320508075688774 * rho2 * (1.0 + 1e-12);  // |v|_1 <= sqrt(3) |v|_2, rounded up
+
+// Structure check of a caller-supplied node array (it arrives through a public C ABI and is then walked by kernels
+// that trust its links): DFS preorder with every internal node's children inside the node's own extent, n leaves with
+// unique ordinals 0..n_leaves-1.  O(n), one pass with an explicit stack.  Also returns rho2 = max |m - o|_2 over the
+// internal nodes with finite means (o = mean of node 0) — what the screening bound needs.
+int validate_nodes(const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, double* out_rho2) {
+  std::vector<uint8_t> seen((size_t)n_leaves, 0);
+  std::vector<std::pair<int32_t, int32_t>> stack;  // [begin, end) extents still to parse
+  stack.emplace_back(0, n_nodes);
+  const double o0 = nodes[0].mean[0], o1 = nodes[0].mean[1], o2 = nodes[0].mean[2];
+  double rho2 = 0.0;
+  int32_t leaves = 0;
+  while (!stack.empty()) {
+    const auto [b, e] = stack.back();
+    stack.pop_back();
+    const madicp_node& nd = nodes[b];
+    if (nd.right == 0) {
+      if (e - b != 1) return fail(MADICP_ERR_INVALID, "node array: a leaf with a sub-tree behind it");
+      if (nd.leaf_id < 0 || nd.leaf_id >= n_leaves || seen[nd.leaf_id])
+        return fail(MADICP_ERR_INVALID, "node array: leaf_id out of range or repeated");
+      seen[nd.leaf_id] = 1;
+      ++leaves;
+    } else {
+      if (nd.right < 2 || (int64_t)b + nd.right >= e) return fail(MADICP_ERR_INVALID, "node array: child link out of range");
+      const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
+      const double r = std::sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+      if (std::isfinite(r)) rho2 = std::max(rho2, r);
+      stack.emplace_back(b + nd.right, e);
+      stack.emplace_back(b + 1, b + nd.right);
+    }
+  }
+  if (leaves != n_leaves) return fail(MADICP_ERR_INVALID, "node array: leaf count mismatch");
+  *out_rho2 = rho2;
   return MADICP_OK;
 }
 
@@ -508,17 +822,36 @@ void layout_top(const madicp_node* nodes, std::vector<int>& dfs, std::vector<uns
   }
 }
 
-void free_tree(DevTree& t) {
-  hipFree(t.nodes);
-  hipFree(t.cnodes);
-  hipFree(t.leaves);
-  hipFree(t.top);
-  hipFree(t.top_exit);
-  hipFree(t.top_dfs);
-  hipFree(t.top_link);
-  hipFree(t.meta);
+void set_desc(DevTree& t, const double origin[3]) {
+  t.desc.nodes = t.nodes;
+  t.desc.cnodes = t.cnodes;
+  t.desc.leaves = t.leaves;
+  t.desc.top = t.top;
+  t.desc.top_exit = t.top_exit;
+  t.desc.top_dfs = t.top_dfs;
+  t.desc.n_top = t.n_top;
+  std::memcpy(t.desc.origin, origin, 3 * sizeof(double));
+  t.desc.rho = 1.7320508075688774 * t.rho2 * (1.0 + 1e-12);  // |v|_1 <= sqrt(3) |v|_2, rounded up
+}
+
+// (re)build the 16-byte screening records, the dense leaf records and the LDS top records on stream `s`
+int compact_tree(DevTree& t, hipStream_t s) {
+  const double* o = t.desc.origin;
+  hipLaunchKernelGGL(tree_compact, dim3((t.n_nodes + 255) / 256), dim3(256), 0, s, (const madicp_node*)t.nodes, t.cnodes,
+                     t.leaves, t.n_nodes, o[0], o[1], o[2]);
+  if (t.n_top > 0)
+    hipLaunchKernelGGL(tree_compact_top, dim3((t.n_top + 255) / 256), dim3(256), 0, s, (const madicp_node*)t.nodes, t.top,
+                       (const int*)t.top_dfs, (const unsigned int*)t.top_link, t.n_top, o[0], o[1], o[2]);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
+}
+
+void release_tree(madicp_ctx* ctx, DevTree& t, const EventRef& after) {
+  pool_free(ctx, t.block, after);
+  if (t.ready) hipEventDestroy(t.ready);
   t = DevTree{};
 }
+
 }  // namespace
 
 int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id) {
@@ -529,37 +862,62 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   DevTree t;
   t.n_nodes = n_nodes;
   t.n_leaves = n_leaves;
-  hipError_t e = hipMalloc(&t.nodes, sizeof(madicp_node) * (size_t)n_nodes);
-  if (e == hipSuccess) e = hipMalloc(&t.cnodes, sizeof(CNode) * (size_t)n_nodes);
-  if (e == hipSuccess) e = hipMalloc(&t.leaves, sizeof(LeafRec) * (size_t)n_leaves);
-  if (e == hipSuccess) e = hipMalloc(&t.meta, sizeof(TreeMeta));
-  TreeMeta hm{};
-  hm.nodes = t.nodes;
-  hm.cnodes = t.cnodes;
-  hm.n_nodes = n_nodes;
-  hm.n_leaves = n_leaves;
-  if (e == hipSuccess) e = hipMemcpyAsync(t.meta, &hm, sizeof(hm), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(t.nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyHostToDevice, ctx->stream);
+  RC_TRY(validate_nodes(nodes, n_nodes, n_leaves, &t.rho2));
   std::vector<int> top_dfs;
   std::vector<unsigned int> top_link;
   std::vector<int2> top_exit;
   layout_top(nodes, top_dfs, top_link, top_exit);
   t.n_top = static_cast<int32_t>(top_dfs.size());
-  if (t.n_top > 0) {
-    if (e == hipSuccess) e = hipMalloc(&t.top, sizeof(CNode) * top_dfs.size());
-    if (e == hipSuccess) e = hipMalloc(&t.top_exit, sizeof(int2) * top_dfs.size());
-    if (e == hipSuccess) e = hipMalloc(&t.top_dfs, sizeof(int) * top_dfs.size());
-    if (e == hipSuccess) e = hipMalloc(&t.top_link, sizeof(unsigned int) * top_dfs.size());
-    if (e == hipSuccess) e = hipMemcpyAsync(t.top_exit, top_exit.data(), sizeof(int2) * top_dfs.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(t.top_dfs, top_dfs.data(), sizeof(int) * top_dfs.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(t.top_link, top_link.data(), sizeof(unsigned int) * top_dfs.size(), hipMemcpyHostToDevice, ctx->stream);
+  // one device block: what is uploaded first (contiguous, one copy), what the device derives from it behind
+  const size_t nt = (size_t)t.n_top;
+  const size_t off_nodes = 0;
+  const size_t off_exit = align_up(off_nodes + sizeof(madicp_node) * (size_t)n_nodes);
+  const size_t off_dfs = align_up(off_exit + sizeof(int2) * nt);
+  const size_t off_link = align_up(off_dfs + sizeof(int) * nt);
+  const size_t up_bytes = align_up(off_link + sizeof(unsigned int) * nt);
+  const size_t off_cnodes = up_bytes;
+  const size_t off_leaves = align_up(off_cnodes + sizeof(CNode) * (size_t)n_nodes);
+  const size_t off_top = align_up(off_leaves + sizeof(LeafRec) * (size_t)n_leaves);
+  const size_t total = align_up(off_top + sizeof(CNode) * std::max<size_t>(nt, 1));
+  // pinned staging (grow-only, two buffers so that the next upload can be staged while this one is in flight)
+  const int hb = ctx->h_tree_next;
+  ctx->h_tree_next ^= 1;
+  HIP_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
+  if (ctx->h_tree_cap[hb] < up_bytes) {
+    if (ctx->h_tree[hb]) HIP_TRY(hipHostFree(ctx->h_tree[hb]));
+    ctx->h_tree[hb] = nullptr;
+    ctx->h_tree_cap[hb] = 0;
+    const size_t cap = up_bytes + up_bytes / 4;
+    HIP_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
+    ctx->h_tree_cap[hb] = cap;
   }
+  char* hs = ctx->h_tree[hb];
+  std::memcpy(hs + off_nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes);
+  if (nt) {
+    std::memcpy(hs + off_exit, top_exit.data(), sizeof(int2) * nt);
+    std::memcpy(hs + off_dfs, top_dfs.data(), sizeof(int) * nt);
+    std::memcpy(hs + off_link, top_link.data(), sizeof(unsigned int) * nt);
+  }
+  void* blk = nullptr;
+  RC_TRY(pool_alloc(ctx, total, ctx->copy, &blk));
+  t.block = static_cast<char*>(blk);
+  t.nodes = reinterpret_cast<madicp_node*>(t.block + off_nodes);
+  t.top_exit = nt ? reinterpret_cast<int2*>(t.block + off_exit) : nullptr;
+  t.top_dfs = nt ? reinterpret_cast<int*>(t.block + off_dfs) : nullptr;
+  t.top_link = nt ? reinterpret_cast<unsigned int*>(t.block + off_link) : nullptr;
+  t.cnodes = reinterpret_cast<CNode*>(t.block + off_cnodes);
+  t.leaves = reinterpret_cast<LeafRec*>(t.block + off_leaves);
+  t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
+  set_desc(t, nodes[0].mean);
+  hipError_t e = hipMemcpyAsync(t.block, hs, up_bytes, hipMemcpyHostToDevice, ctx->copy);
+  if (e == hipSuccess) e = hipEventRecord(ctx->h_tree_ev[hb], ctx->copy);
   int rc = MADICP_OK;
-  if (e == hipSuccess) rc = compact_tree(ctx, t);
-  if (e == hipSuccess && rc == MADICP_OK) e = hipStreamSynchronize(ctx->stream);  // hm / nodes are caller memory
+  if (e == hipSuccess) rc = compact_tree(t, ctx->copy);
+  if (e == hipSuccess && rc == MADICP_OK) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
+  if (e == hipSuccess && rc == MADICP_OK) e = hipEventRecord(t.ready, ctx->copy);
   if (e != hipSuccess || rc != MADICP_OK) {
-    free_tree(t);
+    hipStreamSynchronize(ctx->copy);
+    release_tree(ctx, t, nullptr);
     return rc != MADICP_OK ? rc : fail(MADICP_ERR_DEVICE, std::string("tree upload: ") + hipGetErrorString(e));
   }
   const int id = ctx->next_id++;
@@ -573,8 +931,10 @@ int madicp_tree_release(madicp_ctx* ctx, int tree_id) {
   auto it = ctx->trees.find(tree_id);
   if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  free_tree(it->second);
+  // no synchronisation: the block goes back to the pool behind an event that covers everything enqueued so far
+  EventRef after;
+  RC_TRY(fence_event(ctx, &after));
+  release_tree(ctx, it->second, after);
   ctx->trees.erase(it);
   return MADICP_OK;
 }
@@ -585,6 +945,7 @@ int madicp_tree_download(madicp_ctx* ctx, int tree_id, madicp_node* out_nodes, i
   if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
   if (n_nodes != it->second.n_nodes) return fail(MADICP_ERR_INVALID, "n_nodes mismatch");
   HIP_TRY(hipSetDevice(ctx->device));
+  RC_TRY(wait_tree(ctx, it->second));
   HIP_TRY(hipMemcpyAsync(out_nodes, it->second.nodes, sizeof(madicp_node) * (size_t)n_nodes, hipMemcpyDeviceToHost,
                          ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -596,18 +957,21 @@ int madicp_tree_transform(madicp_ctx* ctx, int tree_id, const double R[9], const
   auto it = ctx->trees.find(tree_id);
   if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
   HIP_TRY(hipSetDevice(ctx->device));
-  double Rt[12];
-  std::memcpy(Rt, R, 9 * sizeof(double));
-  std::memcpy(Rt + 9, t, 3 * sizeof(double));
-  HIP_TRY(hipMemcpyAsync(ctx->d_scratch, Rt, sizeof(Rt), hipMemcpyHostToDevice, ctx->stream));
-  const int n = it->second.n_nodes;
-  hipLaunchKernelGGL(tree_transform, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, it->second.nodes, n,
-                     ctx->d_scratch);
+  DevTree& tr = it->second;
+  RC_TRY(wait_tree(ctx, tr));
+  // stream-ordered on the compute stream (behind every registration that used the tree so far), no host sync: the
+  // pose travels as a kernel argument, the new origin is computed here with the kernel's own operation order
+  Pose12 P;
+  std::memcpy(P.v, R, 9 * sizeof(double));
+  std::memcpy(P.v + 9, t, 3 * sizeof(double));
+  hipLaunchKernelGGL(tree_transform, dim3((tr.n_nodes + 255) / 256), dim3(256), 0, ctx->stream, tr.nodes, tr.n_nodes, P);
   HIP_TRY(hipGetLastError());
-  const int rc = compact_tree(ctx, it->second);  // screening records follow the nodes
-  if (rc != MADICP_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return MADICP_OK;
+  double o[3];
+  const double* m = tr.desc.origin;
+  for (int r = 0; r < 3; ++r) o[r] = (R[3 * r] * m[0] + (R[3 * r + 1] * m[1] + R[3 * r + 2] * m[2])) + t[r];
+  tr.rho2 *= (1.0 + 1e-12);  // rotation invariant up to rounding
+  set_desc(tr, o);
+  return compact_tree(tr, ctx->stream);  // screening records follow the nodes
 }
 
 int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* d_queries, int64_t n,
@@ -619,6 +983,7 @@ int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* 
   if (n <= 0) return MADICP_OK;
   if (!d_queries) return fail(MADICP_ERR_INVALID, "queries is null");
   HIP_TRY(hipSetDevice(ctx->device));
+  RC_TRY(wait_tree(ctx, it->second));
   const long long blocks = std::min<long long>((n + 255) / 256, (long long)ctx->n_cus * 8);
   hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.desc, d_queries,
                      (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
@@ -633,37 +998,35 @@ int madicp_nn_search(madicp_ctx* ctx, int tree_id, const double* queries, int64_
   if (n <= 0) return MADICP_OK;
   if (!queries) return fail(MADICP_ERR_INVALID, "queries is null");
   HIP_TRY(hipSetDevice(ctx->device));
-  double* d_q = nullptr;
-  uint32_t *d_leaf = nullptr, *d_node = nullptr;
-  double* d_dist = nullptr;
-  int32_t* d_depth = nullptr;
+  // one pooled device block: queries | leaf | node | dist | depth
+  const size_t nq = (size_t)n;
+  const size_t off_leaf = align_up(sizeof(double) * 3 * nq);
+  const size_t off_node = align_up(off_leaf + sizeof(uint32_t) * nq);
+  const size_t off_dist = align_up(off_node + sizeof(uint32_t) * nq);
+  const size_t off_depth = align_up(off_dist + sizeof(double) * nq);
+  const size_t total = align_up(off_depth + sizeof(int32_t) * nq);
+  void* blk = nullptr;
+  RC_TRY(pool_alloc(ctx, total, ctx->stream, &blk));
+  char* d = static_cast<char*>(blk);
   int rc = MADICP_OK;
-  auto cleanup = [&]() {
-    hipFree(d_q); hipFree(d_leaf); hipFree(d_node); hipFree(d_dist); hipFree(d_depth);
-  };
-#define NN_TRY(expr)                                                                                      \
-  do {                                                                                                    \
-    hipError_t e_ = (expr);                                                                               \
-    if (e_ != hipSuccess) {                                                                               \
-      cleanup();                                                                                          \
-      return fail(MADICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
-    }                                                                                                     \
-  } while (0)
-  NN_TRY(hipMalloc(&d_q, sizeof(double) * 3 * (size_t)n));
-  if (out_leaf_id) NN_TRY(hipMalloc(&d_leaf, sizeof(uint32_t) * (size_t)n));
-  if (out_node) NN_TRY(hipMalloc(&d_node, sizeof(uint32_t) * (size_t)n));
-  if (out_dist) NN_TRY(hipMalloc(&d_dist, sizeof(double) * (size_t)n));
-  if (out_depth) NN_TRY(hipMalloc(&d_depth, sizeof(int32_t) * (size_t)n));
-  NN_TRY(hipMemcpyAsync(d_q, queries, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  rc = madicp_nn_search_device_enqueue(ctx, tree_id, d_q, n, d_leaf, d_node, d_dist, d_depth);
-  if (rc != MADICP_OK) { cleanup(); return rc; }
-  if (out_leaf_id) NN_TRY(hipMemcpyAsync(out_leaf_id, d_leaf, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_node) NN_TRY(hipMemcpyAsync(out_node, d_node, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_dist) NN_TRY(hipMemcpyAsync(out_dist, d_dist, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  if (out_depth) NN_TRY(hipMemcpyAsync(out_depth, d_depth, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  NN_TRY(hipStreamSynchronize(ctx->stream));
-#undef NN_TRY
-  cleanup();
+  hipError_t e = hipMemcpyAsync(d, queries, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess)
+    rc = madicp_nn_search_device_enqueue(ctx, tree_id, reinterpret_cast<const double*>(d), n,
+                                         out_leaf_id ? reinterpret_cast<uint32_t*>(d + off_leaf) : nullptr,
+                                         out_node ? reinterpret_cast<uint32_t*>(d + off_node) : nullptr,
+                                         out_dist ? reinterpret_cast<double*>(d + off_dist) : nullptr,
+                                         out_depth ? reinterpret_cast<int32_t*>(d + off_depth) : nullptr);
+  if (rc == MADICP_OK) {
+    if (e == hipSuccess && out_leaf_id) e = hipMemcpyAsync(out_leaf_id, d + off_leaf, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && out_node) e = hipMemcpyAsync(out_node, d + off_node, sizeof(uint32_t) * nq, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && out_dist) e = hipMemcpyAsync(out_dist, d + off_dist, sizeof(double) * nq, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && out_depth) e = hipMemcpyAsync(out_depth, d + off_depth, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  pool_free(ctx, blk, nullptr);  // (stream drained: nothing can still touch it)
+  if (rc != MADICP_OK) return rc;
+  if (e != hipSuccess || e2 != hipSuccess)
+    return fail(MADICP_ERR_DEVICE, std::string("nn_search: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return MADICP_OK;
 }
 
@@ -673,23 +1036,10 @@ int madicp_moving_upload(madicp_ctx* ctx, const double* leaf_means, int32_t L, i
   if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
   HIP_TRY(hipSetDevice(ctx->device));
   DevMoving m;
-  m.L = L;
-  double* d_xyz = nullptr;
-  HIP_TRY(hipMalloc(&d_xyz, sizeof(double) * 3 * (size_t)L));
-  hipError_t e = hipMalloc(&m.xyzn, sizeof(double) * 4 * (size_t)L);
-  if (e == hipSuccess) e = hipMalloc(&m.matched, (size_t)L);
-  if (e == hipSuccess) e = hipMemsetAsync(m.matched, 0, (size_t)L, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_xyz, leaf_means, sizeof(double) * 3 * (size_t)L, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(moving_prep, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, d_xyz, m.xyzn, L);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(d_xyz);
-  if (e != hipSuccess) {
-    hipFree(m.xyzn);
-    hipFree(m.matched);
-    return fail(MADICP_ERR_DEVICE, std::string("moving upload: ") + hipGetErrorString(e));
+  const int rc = load_moving(ctx, m, leaf_means, L, ctx->stream);
+  if (rc != MADICP_OK) {
+    free_moving(ctx, m, nullptr);
+    return rc;
   }
   const int id = ctx->next_id++;
   ctx->movings[id] = m;
@@ -697,17 +1047,129 @@ int madicp_moving_upload(madicp_ctx* ctx, const double* leaf_means, int32_t L, i
   return MADICP_OK;
 }
 
+int madicp_moving_update(madicp_ctx* ctx, int moving_id, const double* leaf_means, int32_t L) {
+  if (!ctx || !leaf_means) return fail(MADICP_ERR_INVALID, "null argument");
+  if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
+  auto it = ctx->movings.find(moving_id);
+  if (it == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return load_moving(ctx, it->second, leaf_means, L, ctx->stream);
+}
+
 int madicp_moving_release(madicp_ctx* ctx, int moving_id) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   auto it = ctx->movings.find(moving_id);
   if (it == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+  for (const StreamSlot& sl : ctx->slots)
+    if (sl.moving_id == moving_id) return fail(MADICP_ERR_INVALID, "moving id belongs to a stream slot");
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  hipFree(it->second.xyzn);
-  hipFree(it->second.matched);
-  hipFree(it->second.cache_leaf);
-  hipFree(it->second.cache_margin);
+  EventRef after;
+  RC_TRY(fence_event(ctx, &after));
+  free_moving(ctx, it->second, after);
   ctx->movings.erase(it);
+  return MADICP_OK;
+}
+
+// ---- streamed registrations: new scan in -> X / H / b / matched flags out ----------------------------
+namespace {
+int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int moving_tree_id, const int* tree_ids, int K,
+                       const double* X0, const madicp_icp_params* params, int n_iters, int* out_ticket) {
+  RC_TRY(check_reg_args(ctx, X0, params, out_ticket, K, n_iters));
+  if (K > 0 && !tree_ids) return fail(MADICP_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int ticket = ctx->next_ticket;
+  StreamSlot& sl = ctx->slots[ticket % madicp_ctx::kStreamSlots];
+  if (sl.pending) return fail(MADICP_ERR_CAPACITY, "stream ring full: collect the oldest ticket first");
+  if (sl.moving_id < 0) {
+    sl.moving_id = ctx->next_id++;
+    ctx->movings[sl.moving_id] = DevMoving{};
+  }
+  DevMoving& mv = ctx->movings.at(sl.moving_id);
+  // ---- feed (copy stream): the scan's leaves, then its Job ------------------------------------------------
+  if (moving_tree_id >= 0) {
+    auto tit = ctx->trees.find(moving_tree_id);
+    if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown moving tree id");
+    DevTree& mt = tit->second;
+    L = mt.n_leaves;
+    RC_TRY(reserve_moving(ctx, mv, L, ctx->copy));
+    mv.L = L;
+    if (mt.compute_waited) {  // uploaded long ago: make the copy stream see whatever the compute stream did to it since
+      EventRef ev;
+      RC_TRY(fence_event(ctx, &ev));
+      HIP_TRY(hipStreamWaitEvent(ctx->copy, ev->ev, 0));
+    }
+    hipLaunchKernelGGL(moving_from_leaves, dim3((L + 255) / 256), dim3(256), 0, ctx->copy, (const LeafRec*)mt.leaves, mv.xyzn, L);
+    HIP_TRY(hipGetLastError());
+  } else {
+    if (!leaf_means) return fail(MADICP_ERR_INVALID, "null argument");
+    if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
+    RC_TRY(load_moving(ctx, mv, leaf_means, L, ctx->copy));
+    mv.on_copy = false;  // ordering is by ev_up below
+  }
+  const bool use_cache = n_iters > 1;
+  if (use_cache) RC_TRY(reserve_cache(ctx, mv, std::max(1, K)));
+  if (sl.h_matched_cap < (size_t)L + 16) {
+    if (sl.h_matched) HIP_TRY(hipHostFree(sl.h_matched));
+    sl.h_matched = nullptr;
+    sl.h_matched_cap = 0;
+    const size_t cap = (size_t)L + (size_t)L / 8 + 256;
+    HIP_TRY(hipHostMalloc(&sl.h_matched, cap, hipHostMallocDefault));
+    sl.h_matched_cap = cap;
+  }
+  Job& j = *sl.h_job;
+  RC_TRY(fill_job(ctx, j, mv, tree_ids, K, X0, params, n_iters, 0, use_cache));
+  const Geometry geo = pick_geometry(ctx, L, K, 1);
+  j.ranges_per_tree = geo.ranges_per_tree;
+  j.stage_min_leaves = ctx->stage_min_leaves;
+  j.lds_top = geo.lds_bytes ? 1 : 0;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_out), sl.h_out, 0));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_matched), sl.h_matched, 0));
+  const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, K);
+  HIP_TRY(hipMemcpyAsync(sl.d_job, sl.h_job, job_bytes, hipMemcpyHostToDevice, ctx->copy));
+  HIP_TRY(hipEventRecord(sl.ev_up, ctx->copy));
+  // ---- the registration (compute stream) --------------------------------------------------------------
+  HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.ev_up, 0));
+  if (n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)L, ctx->stream));
+  RC_TRY(prepare_partials(ctx, geo.grid, 1));
+  const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
+  const std::vector<int> ids{sl.moving_id};
+  RC_TRY(run_rounds(ctx, launch, sl.d_job, ticket % madicp_ctx::kStreamSlots, ids));
+  HIP_TRY(hipEventRecord(sl.ev_done, ctx->stream));
+  sl.pending = true;
+  sl.ticket = ticket;
+  sl.L = L;
+  ctx->next_ticket = ticket + 1;
+  *out_ticket = ticket;
+  return MADICP_OK;
+}
+}  // namespace
+
+int madicp_stream_submit(madicp_ctx* ctx, const double* leaf_means, int32_t L, const int* tree_ids, int K,
+                         const double X0[12], const madicp_icp_params* params, int n_iters, int* out_ticket) {
+  return stream_submit_impl(ctx, leaf_means, L, -1, tree_ids, K, X0, params, n_iters, out_ticket);
+}
+
+int madicp_stream_submit_tree(madicp_ctx* ctx, int moving_tree_id, const int* tree_ids, int K, const double X0[12],
+                              const madicp_icp_params* params, int n_iters, int* out_ticket) {
+  if (moving_tree_id < 0) return fail(MADICP_ERR_INVALID, "unknown moving tree id");
+  return stream_submit_impl(ctx, nullptr, 0, moving_tree_id, tree_ids, K, X0, params, n_iters, out_ticket);
+}
+
+int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double out_H[36], double out_b[6],
+                          uint8_t* out_matched, int32_t* out_n_matched, uint64_t* out_visits) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (ticket < 0) return fail(MADICP_ERR_INVALID, "unknown ticket");
+  StreamSlot& sl = ctx->slots[ticket % madicp_ctx::kStreamSlots];
+  if (!sl.pending || sl.ticket != ticket) return fail(MADICP_ERR_INVALID, "unknown or already collected ticket");
+  HIP_TRY(hipEventSynchronize(sl.ev_done));
+  const HostResult& r = *sl.h_out;
+  if (out_X) std::memcpy(out_X, r.X, sizeof(r.X));
+  if (out_H) std::memcpy(out_H, r.H, sizeof(r.H));
+  if (out_b) std::memcpy(out_b, r.b, sizeof(r.b));
+  if (out_matched) std::memcpy(out_matched, sl.h_matched, (size_t)sl.L);
+  if (out_n_matched) *out_n_matched = r.n_matched;
+  if (out_visits) *out_visits = r.visits;
+  sl.pending = false;
   return MADICP_OK;
 }
 
@@ -762,19 +1224,20 @@ int madicp_icp_register(madicp_ctx* ctx, int moving_id, const int* tree_ids, int
                         uint8_t* out_matched, double* out_X_iters, uint64_t* out_visits) {
   if (!ctx || !X) return fail(MADICP_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
-  double* d_xi = nullptr;
-  if (out_X_iters && n_iters > 0) HIP_TRY(hipMalloc(&d_xi, sizeof(double) * 12 * (size_t)n_iters));
-  RegArgs a{1, &moving_id, tree_ids, K, X, params, n_iters, 0, nullptr, d_xi};
+  void* d_xi = nullptr;
+  if (out_X_iters && n_iters > 0) RC_TRY(pool_alloc(ctx, sizeof(double) * 12 * (size_t)n_iters, ctx->stream, &d_xi));
+  RegArgs a{1, &moving_id, tree_ids, K, X, params, n_iters, 0, nullptr, static_cast<double*>(d_xi)};
   int rc = enqueue_registration(ctx, a);
   if (rc == MADICP_OK) rc = madicp_icp_fetch(ctx, 1, X, out_H, out_b, nullptr, out_visits);
   if (rc == MADICP_OK && out_matched) rc = madicp_icp_fetch_matched(ctx, 0, out_matched, ctx->movings.at(moving_id).L);
   if (rc == MADICP_OK && d_xi) {
-    hipError_t e = hipMemcpy(out_X_iters, d_xi, sizeof(double) * 12 * (size_t)n_iters, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(out_X_iters, d_xi, sizeof(double) * 12 * (size_t)n_iters, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("x_iters copy: ") + hipGetErrorString(e));
   }
   if (d_xi) {
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_xi);
+    pool_free(ctx, d_xi, nullptr);
   }
   return rc;
 }
@@ -787,9 +1250,9 @@ int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, in
   if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
   const int L = mit->second.L;
   HIP_TRY(hipSetDevice(ctx->device));
-  uint32_t* d_corr = nullptr;
-  if (out_corr && K > 0) HIP_TRY(hipMalloc(&d_corr, sizeof(uint32_t) * (size_t)K * L));
-  RegArgs a{1, &moving_id, tree_ids, K, X, params, 1, kFlagNoUpdate, d_corr, nullptr};
+  void* d_corr = nullptr;
+  if (out_corr && K > 0) RC_TRY(pool_alloc(ctx, sizeof(uint32_t) * (size_t)K * L, ctx->stream, &d_corr));
+  RegArgs a{1, &moving_id, tree_ids, K, X, params, 1, kFlagNoUpdate, static_cast<uint32_t*>(d_corr), nullptr};
   const int saved_graph = ctx->use_graph;
   ctx->use_graph = 0;  // pointers in the job differ per call; nothing to gain from a graph for one round
   int rc = enqueue_registration(ctx, a);
@@ -797,12 +1260,13 @@ int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, in
   if (rc == MADICP_OK) rc = madicp_icp_fetch(ctx, 1, nullptr, out_H, out_b, nullptr, out_visits);
   if (rc == MADICP_OK && out_matched) rc = madicp_icp_fetch_matched(ctx, 0, out_matched, L);
   if (rc == MADICP_OK && d_corr) {
-    hipError_t e = hipMemcpy(out_corr, d_corr, sizeof(uint32_t) * (size_t)K * L, hipMemcpyDeviceToHost);
+    hipError_t e = hipMemcpyAsync(out_corr, d_corr, sizeof(uint32_t) * (size_t)K * L, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = fail(MADICP_ERR_DEVICE, std::string("corr copy: ") + hipGetErrorString(e));
   }
   if (d_corr) {
     hipStreamSynchronize(ctx->stream);
-    hipFree(d_corr);
+    pool_free(ctx, d_corr, nullptr);
   }
   return rc;
 }
@@ -820,7 +1284,8 @@ int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_id
 
 int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
                                  const double* X0, const madicp_icp_params* params, int n_iters, int reps,
-                                 double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch) {
+                                 double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch,
+                                 uint64_t* out_walked_per_launch) {
   if (!ctx || reps < 1 || n_iters < 1) return fail(MADICP_ERR_INVALID, "bad argument");
   if (ctx->comm) return fail(MADICP_ERR_INVALID, "not available with a communicator");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -845,6 +1310,8 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
     if (rc != MADICP_OK) return rc;
     for (int s = 0; s < n_scans; ++s) out_visits_per_launch[s] /= (uint64_t)n_iters;
   }
+  if (out_walked_per_launch)  // (h_fetch still holds the Jobs madicp_icp_fetch just read)
+    for (int s = 0; s < n_scans; ++s) out_walked_per_launch[s] = ctx->h_fetch[s].walked / (uint64_t)n_iters;
   // icp_final alone, replayed `reps` times as a graph: what is left of a registration is its n_iters icp_round launches
   const Geometry geo = pick_geometry(ctx, [&] { int m = 0; for (int s = 0; s < n_scans; ++s) m = std::max(m, ctx->movings.at(moving_ids[s]).L); return m; }(), K, n_scans);
   hipGraph_t graph = nullptr;
@@ -874,6 +1341,95 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
   return rc;
 }
 
+int madicp_nn_time_descend(madicp_ctx* ctx, int tree_id, const double* queries, int64_t n, int reps, double* out_avg_us,
+                           uint64_t* out_depth_sum) {
+  if (!ctx || !queries || !out_avg_us) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n < 1 || reps < 1) return fail(MADICP_ERR_INVALID, "n and reps must be >= 1");
+  auto it = ctx->trees.find(tree_id);
+  if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->ev_t0) {
+    HIP_TRY(hipEventCreate(&ctx->ev_t0));
+    HIP_TRY(hipEventCreate(&ctx->ev_t1));
+  }
+  const size_t nq = (size_t)n;
+  const size_t off_leaf = align_up(sizeof(double) * 3 * nq);
+  const size_t off_dist = align_up(off_leaf + sizeof(uint32_t) * nq);
+  const size_t off_depth = align_up(off_dist + sizeof(double) * nq);
+  const size_t total = align_up(off_depth + sizeof(int32_t) * nq);
+  void* blk = nullptr;
+  RC_TRY(pool_alloc(ctx, total, ctx->stream, &blk));
+  char* d = static_cast<char*>(blk);
+  std::vector<int32_t> depth(nq);
+  int rc = MADICP_OK;
+  hipError_t e = hipMemcpyAsync(d, queries, sizeof(double) * 3 * nq, hipMemcpyHostToDevice, ctx->stream);
+  auto launch = [&]() {
+    return madicp_nn_search_device_enqueue(ctx, tree_id, reinterpret_cast<const double*>(d), n,
+                                           reinterpret_cast<uint32_t*>(d + off_leaf), nullptr,
+                                           reinterpret_cast<double*>(d + off_dist), reinterpret_cast<int32_t*>(d + off_depth));
+  };
+  if (e == hipSuccess) rc = launch();  // warm-up
+  if (e == hipSuccess && rc == MADICP_OK) e = hipEventRecord(ctx->ev_t0, ctx->stream);
+  for (int r = 0; r < reps && e == hipSuccess && rc == MADICP_OK; ++r) rc = launch();
+  if (e == hipSuccess && rc == MADICP_OK) e = hipEventRecord(ctx->ev_t1, ctx->stream);
+  if (e == hipSuccess && rc == MADICP_OK)
+    e = hipMemcpyAsync(depth.data(), d + off_depth, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  pool_free(ctx, blk, nullptr);
+  if (rc != MADICP_OK) return rc;
+  if (e != hipSuccess || e2 != hipSuccess)
+    return fail(MADICP_ERR_DEVICE, std::string("nn_time_descend: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+  *out_avg_us = 1e3 * ms / reps;
+  if (out_depth_sum) {
+    uint64_t sum = 0;
+    for (int32_t v : depth) sum += (uint64_t)v;
+    *out_depth_sum = sum;
+  }
+  return MADICP_OK;
+}
+
+// plain device-to-device stream copy (16 bytes per lane): the measured HBM rate of THIS box, and the known byte count
+// the PMC traffic counters are calibrated on (MI355X_MICROARCH.md, HBM section)
+namespace madicp_detail {
+__global__ void stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace madicp_detail
+
+int madicp_debug_stream_copy(madicp_ctx* ctx, int64_t bytes, int reps, double* out_gbs) {
+  if (!ctx || !out_gbs) return fail(MADICP_ERR_INVALID, "null argument");
+  if (bytes < 4096 || reps < 1) return fail(MADICP_ERR_INVALID, "bytes >= 4096 and reps >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->ev_t0) {
+    HIP_TRY(hipEventCreate(&ctx->ev_t0));
+    HIP_TRY(hipEventCreate(&ctx->ev_t1));
+  }
+  const size_t n16 = (size_t)bytes / 16;
+  void *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc(&a, n16 * 16));
+  hipError_t e = hipMalloc(&b, n16 * 16);
+  if (e == hipSuccess) e = hipMemsetAsync(a, 1, n16 * 16, ctx->stream);
+  const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)ctx->n_cus * 16);
+  auto run = [&]() {
+    hipLaunchKernelGGL(madicp_detail::stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16);
+  };
+  if (e == hipSuccess) {
+    run();
+    e = hipEventRecord(ctx->ev_t0, ctx->stream);
+    for (int r = 0; r < reps; ++r) run();
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_t1, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1);
+  hipFree(a);
+  hipFree(b);
+  if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("stream copy: ") + hipGetErrorString(e));
+  *out_gbs = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;  // read + write
+  return MADICP_OK;
+}
 
 // ---- multi-GPU --------------------------------------------------------------------------------------
 int madicp_comm_unique_id(uint8_t out_id[128]) {
@@ -895,6 +1451,9 @@ int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks,
   NCCL_TRY(ncclCommInitRank(&ctx->comm, n_ranks, id, rank));
   ctx->n_ranks = n_ranks;
   ctx->rank = rank;
+  // graphs captured without the collectives are no longer the right sequence
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+  ctx->graphs.clear();
   return MADICP_OK;
 }
 
@@ -902,6 +1461,8 @@ int madicp_comm_destroy(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   if (ctx->comm) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+    ctx->graphs.clear();
     NCCL_TRY(ncclCommDestroy(ctx->comm));
     ctx->comm = nullptr;
     ctx->n_ranks = 1;

@@ -2,7 +2,8 @@
 // Mirrors the reference class (mad_icp/src/odometry/mad_icp.h:41-79): same constructor arguments, the
 // public X_ / H_adder_ / b_adder_ that Pipeline reads (pipeline.cpp:195,223).  The per-round methods of the
 // reference (resetAdders / update / updateState, mad_icp.cpp:43-117) are one call here — compute() — because
-// the whole loop runs on the device without host round trips (madicp_icp_register).
+// the whole loop runs on the device without host round trips: one streamed submission (madicp_stream_submit /
+// madicp_stream_collect), no device allocation, free or synchronisation per scan.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -15,12 +16,13 @@ namespace madicp_host {
 class MADicp {
  public:
   MADicp(double min_ball, double rho_ker, double b_ratio, int num_threads);
-  ~MADicp();
+  ~MADicp() = default;  // owns nothing on the device: the stream slots belong to the context
   MADicp(const MADicp&) = delete;
   MADicp& operator=(const MADicp&) = delete;
 
-  // setMoving (mad_icp.cpp:53-55): the leaves of the current scan's tree, sensor frame
-  void setMoving(const MADtree& scan_tree);
+  // setMoving (mad_icp.cpp:53-55): the leaves of the current scan's tree, sensor frame.  With a tree that is (or is
+  // about to be) resident the moving set is taken from its leaf records on the device — nothing is uploaded twice.
+  void setMoving(MADtree& scan_tree);
   void setMoving(const ContainerType& leaf_means);
   void init(const Pose& moving_in_fixed) { X_ = moving_in_fixed; }  // mad_icp.cpp:57
 
@@ -29,7 +31,7 @@ class MADicp {
   void compute(const std::vector<MADtree*>& fixed, int n_iters);
 
   int numMoving() const { return L_; }
-  int numMatched() const;
+  int numMatched() const { return n_matched_; }
 
   Pose X_;
   double H_adder_[36];  // row-major
@@ -43,9 +45,10 @@ class MADicp {
   int num_threads_;
 
  private:
-  void releaseMoving();
-  int moving_id_ = -1;
+  ContainerType moving_;            // host leaf means (when set from a container)
+  MADtree* moving_tree_ = nullptr;  // or the resident tree whose leaves are the moving set
   int L_ = 0;
+  int n_matched_ = 0;
 };
 
 }  // namespace madicp_host

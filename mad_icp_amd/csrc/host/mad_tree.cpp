@@ -9,12 +9,15 @@
 namespace madicp_host {
 
 namespace {
-std::mutex g_mu;
+std::recursive_mutex g_mu;
 madicp_ctx* g_ctx = nullptr;
+unsigned g_gen = 1;
 }  // namespace
 
+std::recursive_mutex& Device::mutex() { return g_mu; }
+
 madicp_ctx* Device::ctx() {
-  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceLock lock(g_mu);
   if (!g_ctx) {
     int dev = 0;
     if (const char* e = std::getenv("MAD_ICP_DEVICE")) dev = std::atoi(e);
@@ -23,10 +26,21 @@ madicp_ctx* Device::ctx() {
   return g_ctx;
 }
 
+madicp_ctx* Device::current(unsigned generation) {
+  DeviceLock lock(g_mu);
+  return generation == g_gen ? g_ctx : nullptr;
+}
+
+unsigned Device::generation() {
+  DeviceLock lock(g_mu);
+  return g_gen;
+}
+
 void Device::shutdown() {
-  std::lock_guard<std::mutex> lock(g_mu);
+  DeviceLock lock(g_mu);
   if (g_ctx) madicp_ctx_destroy(g_ctx);
   g_ctx = nullptr;
+  ++g_gen;
 }
 
 MADtree::MADtree(ContainerType cloud, double b_max, double b_min, int max_parallel_level) {
@@ -34,41 +48,80 @@ MADtree::MADtree(ContainerType cloud, double b_max, double b_min, int max_parall
   tree_ = build_tree(cloud.front().data(), static_cast<int64_t>(cloud.size()), b_max, b_min, max_parallel_level);
 }
 
-MADtree::~MADtree() {
-  if (dev_id_ >= 0) madicp_tree_release(Device::ctx(), dev_id_);
+MADtree::MADtree(LinearTree&& built) : tree_(std::move(built)) {
+  if (tree_.nodes.empty()) throw std::invalid_argument("MADtree: empty tree");
 }
 
-ContainerType MADtree::leafMeans() const {
+MADtree::~MADtree() {
+  // never create a context from a destructor, never release an id into a context that did not issue it
+  if (dev_id_ < 0) return;
+  DeviceLock lock(Device::mutex());
+  if (madicp_ctx* c = Device::current(dev_gen_)) madicp_tree_release(c, dev_id_);
+}
+
+void MADtree::flushTransform() {
+  if (!pending_) return;
+  transform_tree(tree_, pending_R_, pending_t_);
+  pending_ = false;
+}
+
+const LinearTree& MADtree::linear() {
+  flushTransform();
+  return tree_;
+}
+
+ContainerType MADtree::leafMeans() {
+  flushTransform();
   ContainerType out(tree_.leaf_nodes.size());
   for (size_t i = 0; i < out.size(); ++i) std::memcpy(out[i].data(), tree_.nodes[tree_.leaf_nodes[i]].mean, 24);
   return out;
 }
 
 int MADtree::deviceId() {
-  if (dev_id_ < 0)
-    check(madicp_tree_upload(Device::ctx(), tree_.nodes.data(), tree_.num_nodes(), tree_.num_leaves(), &dev_id_),
-          "madicp_tree_upload");
+  DeviceLock lock(Device::mutex());
+  if (dev_id_ >= 0 && !Device::current(dev_gen_)) dev_id_ = -1;  // the context that held it is gone
+  if (dev_id_ < 0) {
+    flushTransform();
+    madicp_ctx* c = Device::ctx();
+    check(madicp_tree_upload(c, tree_.nodes.data(), tree_.num_nodes(), tree_.num_leaves(), &dev_id_), "madicp_tree_upload");
+    dev_gen_ = Device::generation();
+  }
   return dev_id_;
 }
 
 void MADtree::applyTransform(const double* R, const double* t) {
-  transform_tree(tree_, R, t);
-  if (dev_id_ >= 0) check(madicp_tree_transform(Device::ctx(), dev_id_, R, t), "madicp_tree_transform");
+  DeviceLock lock(Device::mutex());
+  const bool on_device = dev_id_ >= 0 && Device::current(dev_gen_);
+  if (on_device) check(madicp_tree_transform(Device::ctx(), dev_id_, R, t), "madicp_tree_transform");
+  if (pending_) flushTransform();  // (a second transform before the first was needed on the host: compose by applying)
+  if (on_device) {
+    std::memcpy(pending_R_, R, sizeof(pending_R_));
+    std::memcpy(pending_t_, t, sizeof(pending_t_));
+    pending_ = true;
+  } else {
+    transform_tree(tree_, R, t);
+  }
 }
 
 std::vector<LeafMatch> MADtree::search(const ContainerType& queries, bool with_dist) {
   std::vector<LeafMatch> out(queries.size());
   if (queries.empty()) return out;
-  std::vector<uint32_t> node(queries.size());
+  std::vector<uint32_t> node(queries.size()), leaf(queries.size());
   std::vector<double> dist(with_dist ? queries.size() : 0);
-  check(madicp_nn_search(Device::ctx(), deviceId(), queries.front().data(), static_cast<int64_t>(queries.size()), nullptr,
-                         node.data(), with_dist ? dist.data() : nullptr, nullptr),
-        "madicp_nn_search");
+  {
+    DeviceLock lock(Device::mutex());
+    const int id = deviceId();
+    check(madicp_nn_search(Device::ctx(), id, queries.front().data(), static_cast<int64_t>(queries.size()), leaf.data(),
+                           node.data(), with_dist ? dist.data() : nullptr, nullptr),
+          "madicp_nn_search");
+  }
+  flushTransform();
   for (size_t i = 0; i < out.size(); ++i) {
     const madicp_node& n = tree_.nodes[node[i]];
     std::memcpy(out[i].point.data(), n.mean, 24);
     std::memcpy(out[i].normal.data(), n.dir, 24);
     out[i].dist = with_dist ? dist[i] : 0.0;
+    out[i].leaf_idx = leaf[i];
   }
   return out;
 }

@@ -1,5 +1,7 @@
 #include "pipeline.h"
 
+#include "task_pool.h"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -50,9 +52,12 @@ Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, 
   std::memset(current_velocity_, 0, sizeof(current_velocity_));
   loop_time_ = (1. / sensor_hz_) * 1000;
   max_parallel_levels_ = static_cast<int>(std::log2(num_threads));  // pipeline.cpp:64
+  TaskPool::instance().set_limit(num_threads);  // omp_set_num_threads(num_threads), pipeline.cpp:65
 }
 
-Pipeline::~Pipeline() = default;  // Frames own their trees; trees release their HBM copies
+Pipeline::~Pipeline() {
+  if (prefetched_.valid()) prefetched_.wait();
+}  // Frames own their trees; trees release their HBM copies
 
 const std::vector<Matrix4d> Pipeline::trajectory() const {
   std::vector<Matrix4d> out;
@@ -111,20 +116,66 @@ void Pipeline::initialize(const double& curr_stamp, ContainerType& cloud) {
   seq_++;
 }
 
+void Pipeline::prefetch(ContainerType next_cloud) {
+  if (next_cloud.empty()) return;
+  // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it
+  if (deskew_ && is_initialized_) return;
+  if (prefetched_.valid()) prefetched_.wait();  // one look-ahead at a time
+  prefetched_n_ = next_cloud.size();
+  prefetched_first_ = next_cloud.front();
+  prefetched_last_ = next_cloud.back();
+  const double b_max = b_max_, b_min = b_min_;
+  const int levels = max_parallel_levels_;
+  prefetched_ = std::async(std::launch::async, [cloud = std::move(next_cloud), b_max, b_min, levels]() mutable {
+    return build_tree(cloud.front().data(), static_cast<int64_t>(cloud.size()), b_max, b_min, levels);
+  });
+}
+
 // pipeline.cpp:125-265
 void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   is_map_updated_ = false;
+  if (curr_cloud.empty()) throw std::invalid_argument("Pipeline::compute: empty cloud");
+  // a tree built ahead for exactly this scan?
+  std::unique_ptr<MADtree> current_tree;
+  const double t_pre = now_ms();
+  if (prefetched_.valid()) {
+    const bool same = prefetched_n_ == curr_cloud.size() &&
+                      std::memcmp(prefetched_first_.data(), curr_cloud.front().data(), 24) == 0 &&
+                      std::memcmp(prefetched_last_.data(), curr_cloud.back().data(), 24) == 0 &&
+                      !(deskew_ && is_initialized_ && trajectory_.size() > 1);
+    LinearTree built = prefetched_.get();  // (waits for the builder thread either way)
+    if (same) current_tree = std::make_unique<MADtree>(std::move(built));
+  }
   if (!is_initialized_) {
-    initialize(curr_stamp, curr_cloud);
+    if (current_tree) {
+      auto frame = std::make_unique<Frame>();
+      frame->frame_ = int(seq_);
+      frame->frame_to_map_ = frame_to_map_;
+      frame->stamp_ = curr_stamp;
+      frame->tree_ = std::move(current_tree);
+      frame->tree_->deviceId();
+      keyframes_.push_back(std::move(frame));
+      trajectory_.push_back(Pose::identity());
+      is_initialized_ = true;
+      is_map_updated_ = true;
+      seq_++;
+    } else {
+      initialize(curr_stamp, curr_cloud);
+    }
+    current_tree_view_ = keyframes_.back()->tree_.get();
+    current_num_leaves_ = size_t(current_tree_view_->numLeaves());
     return;
   }
-  const double t_pre = now_ms();
 
-  if (deskew_ && trajectory_.size() > 1)
-    deskew(curr_cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1]);
-
-  auto current_tree = std::make_unique<MADtree>(std::move(curr_cloud), b_max_, b_min_, max_parallel_levels_);
-  current_leaves_ = current_tree->leafMeans();
+  if (!current_tree) {
+    if (deskew_ && trajectory_.size() > 1)
+      deskew(curr_cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1]);
+    current_tree = std::make_unique<MADtree>(std::move(curr_cloud), b_max_, b_min_, max_parallel_levels_);
+  }
+  // resident from now on (frame window, maybe keyframe later); the copy runs on the library's copy stream while the
+  // host goes on, and the moving leaves are read from it on the device (pipeline.cpp:143-144,154)
+  current_tree->deviceId();
+  current_num_leaves_ = size_t(current_tree->numLeaves());
   last_build_ms_ = now_ms() - t_pre;
 
   // constant-velocity prediction (pipeline.cpp:146-152)
@@ -132,28 +183,35 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   for (int i = 0; i < 6; ++i) dx[i] = current_velocity_[i] * 1. / sensor_hz_;
   const Pose prediction = compose(frame_to_map_, motion_from_twist(dx));
 
-  icp_.setMoving(current_leaves_);
+  icp_.setMoving(*current_tree);
   icp_.init(prediction);
 
   const float preprocessing_time = float(now_ms() - t_pre);
   const double t_icp = now_ms();
-  // The reference re-checks its wall-clock budget before every round (pipeline.cpp:167-169).  The device
-  // loop is not interruptible — and at well under a millisecond it never needs to be — so the check is made
-  // once: either all MAX_ICP_ITS rounds run, or (budget already spent by preprocessing) none.
-  const float remaining_time = loop_time_ - 5.0f - preprocessing_time;
-  const bool run = !(realtime_ && remaining_time < 0);
+  // The reference re-checks its wall-clock budget before every round and stops when preprocessing + the rounds run so
+  // far exceed it (pipeline.cpp:167-169).  The device loop is one submission, so the same budget is turned into a round
+  // count BEFORE it starts: the rounds that fit, at the per-round time the previous frame measured (all MAX_ICP_ITS
+  // of them unless the budget is nearly spent: a round is ~0.02 ms here).  As in the reference, the matched flags are
+  // those of the last round that ran.
+  int rounds = MAX_ICP_ITS;
+  if (realtime_) {
+    const double remaining = double(loop_time_) - 5.0 - double(preprocessing_time);
+    // the reference runs round r iff the time spent before it is <= the budget: rounds = 1 + floor(remaining / round)
+    rounds = remaining < 0 ? 0 : int(std::min<double>(MAX_ICP_ITS, 1.0 + std::floor(remaining / std::max(round_ms_estimate_, 1e-3))));
+  }
   int matched_leaves = 0;
-  if (run) {
+  if (rounds > 0) {
     std::vector<MADtree*> fixed;
     fixed.reserve(keyframes_.size());
     for (auto& f : keyframes_) fixed.push_back(f->tree_.get());
-    icp_.compute(fixed, MAX_ICP_ITS);
+    icp_.compute(fixed, rounds);
     matched_leaves = icp_.numMatched();
   }
   last_icp_ms_ = now_ms() - t_icp;
+  if (rounds > 0) round_ms_estimate_ = last_icp_ms_ / rounds;
 
   frame_to_map_ = icp_.X_;
-  const double inliers_ratio = double(matched_leaves) / double(current_leaves_.size());
+  const double inliers_ratio = double(matched_leaves) / double(current_num_leaves_);
   last_inliers_ratio_ = inliers_ratio;
   trajectory_.push_back(frame_to_map_);
 
@@ -170,14 +228,13 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   current_frame->frame_to_map_ = frame_to_map_;
   current_frame->stamp_ = curr_stamp;
   current_frame->weight_ = det_of_inverse6(icp_.H_adder_);  // pipeline.cpp:223
+  // device copy: transformed now, stream-ordered behind the registration; host copy: when somebody reads it
   current_tree->applyTransform(frame_to_map_.R, frame_to_map_.t);
   current_frame->tree_ = std::move(current_tree);
-  // the reference's current_leaves_ are pointers into the tree, so after applyTransform they read map-frame
-  // means (pipeline.cpp:290-297 is only ever called after compute())
-  current_leaves_ = current_frame->tree_->leafMeans();
+  current_tree_view_ = current_frame->tree_.get();
 
   frames_.push_back(std::move(current_frame));
-  if (frames_.size() > size_t(FRAME_WINDOW)) frames_.pop_front();
+  if (frames_.size() > size_t(FRAME_WINDOW)) frames_.pop_front();  // its HBM buffers go back to the library's pool
 
   if (inliers_ratio < p_th_) {  // keyframe promotion (pipeline.cpp:234-262)
     double best_weight = std::numeric_limits<double>::max();
@@ -196,10 +253,10 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
         if (frames_.front()->frame_ == new_seq) best_frame = std::move(frames_.front());
         frames_.pop_front();
       }
-      best_frame->tree_->deviceId();  // promoted: the tree goes to HBM now
+      // promotion is a pointer move: the tree has been resident, in the map frame, since its own frame
       keyframe_to_map_ = best_frame->frame_to_map_;
       keyframes_.push_back(std::move(best_frame));
-      if (keyframes_.size() > size_t(num_keyframes_)) keyframes_.pop_front();  // eviction frees the HBM copy
+      if (keyframes_.size() > size_t(num_keyframes_)) keyframes_.pop_front();  // eviction: buffers back to the pool
       is_map_updated_ = true;
       seq_keyframe_ = new_seq;
     }
@@ -207,7 +264,9 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   seq_++;
 }
 
-const ContainerType Pipeline::currentLeaves() { return current_leaves_; }
+// the reference's current_leaves_ are pointers into the current tree, so after compute() they read map-frame means
+// (pipeline.cpp:290-297); here they are materialised when asked for (the visualiser), not every frame
+const ContainerType Pipeline::currentLeaves() { return current_tree_view_ ? current_tree_view_->leafMeans() : ContainerType{}; }
 
 const ContainerType Pipeline::modelLeaves() {  // pipeline.cpp:299-308
   ContainerType leaves;

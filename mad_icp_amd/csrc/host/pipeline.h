@@ -3,12 +3,20 @@
 // apps/cpp_runners/bin_runner.cpp:106-186 and the pybind module keep working unchanged.
 //
 // What moved: the data association + Gauss-Newton loop (pipeline.cpp:166-193) runs on the MI355X through
-// libmadicp_hip.so; keyframe trees live in HBM from the moment they are promoted (pipeline.cpp:253) until
-// they are evicted (pipeline.cpp:254-257).  What stayed on the CPU: tree construction of the incoming scan,
-// deskew, the constant-velocity predictor, the frame window and keyframe selection.
+// libmadicp_hip.so.  Every scan's MAD-tree is uploaded once, when it is built (asynchronously, on the library's copy
+// stream), and stays in HBM while the frame is in the 10-frame window or a keyframe: the scan's moving leaves are taken
+// from the resident tree, applyTransform runs on the device (pipeline.cpp:224), promotion to keyframe
+// (pipeline.cpp:234-253) is a pointer move, and leaving the window / eviction (pipeline.cpp:229-232,254-257) returns
+// the buffers to the library's pool without a synchronisation.  What stayed on the CPU: tree construction of the
+// incoming scan, deskew, the constant-velocity predictor, keyframe selection.
+//
+// Additive: prefetch(next_cloud) starts building the NEXT scan's tree on another thread — the build does not depend
+// on the current pose (pipeline.cpp:140-141 builds in the sensor frame) — so a caller that has scan i+1 in hand
+// (bin_runner / the launcher reading a dataset) overlaps that build with frame i.
 #pragma once
 #include <cstddef>
 #include <deque>
+#include <future>
 #include <memory>
 #include <vector>
 
@@ -51,6 +59,9 @@ class Pipeline {
   const ContainerType modelLeaves();
   void compute(const double& curr_stamp, ContainerType curr_cloud_mem);
 
+  // additive (not in the reference): start building the tree of the scan that the NEXT compute() will be given
+  void prefetch(ContainerType next_cloud);
+
   // instrumentation (not in the reference)
   double lastInliersRatio() const { return last_inliers_ratio_; }
   double lastIcpMs() const { return last_icp_ms_; }
@@ -71,7 +82,13 @@ class Pipeline {
   std::deque<std::unique_ptr<Frame>> keyframes_;
   std::deque<std::unique_ptr<Frame>> frames_;
   std::vector<Pose> trajectory_;
-  ContainerType current_leaves_;  // sensor-frame leaf means of the last scan, then map frame after compute()
+  MADtree* current_tree_view_ = nullptr;  // the last scan's tree (owned by a Frame in frames_ / keyframes_)
+  size_t current_num_leaves_ = 0;
+  // look-ahead build: the tree of the next scan and what identifies that scan
+  std::future<LinearTree> prefetched_;
+  size_t prefetched_n_ = 0;
+  Vector3d prefetched_first_{}, prefetched_last_{};
+  double round_ms_estimate_ = 0.05;  // device time of one GN round, from the previous frame (realtime budget)
   bool deskew_, realtime_;
   int num_keyframes_, num_threads_, max_parallel_levels_;
   double sensor_hz_, b_max_, p_th_, b_min_;

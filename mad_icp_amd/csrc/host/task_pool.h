@@ -8,6 +8,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -21,6 +22,7 @@ class TaskPool {
   struct Job {
     std::function<void()> fn;
     std::atomic<bool> done{false};
+    std::exception_ptr error;  // what fn threw, rethrown by wait()
   };
   using Handle = std::shared_ptr<Job>;
 
@@ -53,21 +55,37 @@ class TaskPool {
         cv_.wait(lk);
       }
     }
+    if (j->error) std::rethrow_exception(j->error);
   }
 
   int workers() const { return static_cast<int>(threads_.size()); }
+
+  // The caller's thread budget (the reference caps OpenMP and its async forks at num_threads: pipeline.cpp:64-65):
+  // at most `n` threads — the caller included — run tasks at any time; the other workers sleep.  Process-wide, like
+  // omp_set_num_threads; the last caller wins.
+  void set_limit(int n) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      limit_ = std::max(1, n);
+    }
+    cv_.notify_all();
+  }
 
  private:
   TaskPool() {
     const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
     const int n = std::max(0, std::min(hw, 32) - 1);
     threads_.reserve(static_cast<size_t>(n));
-    for (int i = 0; i < n; ++i) threads_.emplace_back([this] { worker(); });
+    for (int i = 0; i < n; ++i) threads_.emplace_back([this, i] { worker(i); });
     for (std::thread& t : threads_) t.detach();
   }
 
   void run(const Handle& j) {
-    j->fn();
+    try {
+      j->fn();
+    } catch (...) {
+      j->error = std::current_exception();  // a detached worker must not terminate the process; the waiter rethrows
+    }
     {
       std::lock_guard<std::mutex> lk(m_);  // pairs with the waiter's check under the same mutex
       j->done.store(true, std::memory_order_release);
@@ -75,10 +93,10 @@ class TaskPool {
     cv_.notify_all();
   }
 
-  void worker() {
+  void worker(int index) {
     std::unique_lock<std::mutex> lk(m_);
     for (;;) {
-      cv_.wait(lk, [this] { return !q_.empty(); });
+      cv_.wait(lk, [this, index] { return !q_.empty() && index < limit_ - 1; });
       Handle j = std::move(q_.front());
       q_.pop_front();
       lk.unlock();
@@ -91,6 +109,7 @@ class TaskPool {
   std::condition_variable cv_;
   std::deque<Handle> q_;
   std::vector<std::thread> threads_;
+  int limit_ = 1 << 30;
 };
 
 }  // namespace madicp_host

@@ -35,17 +35,20 @@ class MADtreeWrapper {
     const std::vector<LeafMatch> m = need().search(query_cloud, true);
     const py::ssize_t n = static_cast<py::ssize_t>(m.size());
     py::array_t<double> pts({n, py::ssize_t(3)}), nrm({n, py::ssize_t(3)}), dist(n);
+    py::array_t<uint32_t> leaf(n);
     auto p = pts.mutable_unchecked<2>();
     auto q = nrm.mutable_unchecked<2>();
     auto d = dist.mutable_unchecked<1>();
+    auto li = leaf.mutable_unchecked<1>();
     for (py::ssize_t i = 0; i < n; ++i) {
       for (int k = 0; k < 3; ++k) {
         p(i, k) = m[i].point[k];
         q(i, k) = m[i].normal[k];
       }
       d(i) = m[i].dist;
+      li(i) = m[i].leaf_idx;
     }
-    return py::make_tuple(pts, nrm, dist);
+    return py::make_tuple(pts, nrm, dist, leaf);  // (points, normals, dist, leaf_idx)
   }
   int numLeaves() { return need().numLeaves(); }
 

@@ -25,6 +25,12 @@ PYBIND11_MODULE(pypeline, m) {
          [](Pipeline& self, double stamp, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {
            self.compute(stamp, container_from_array(std::move(cloud)));
          })
+    // additive look-ahead: start building the next scan's MAD-tree while this frame is registered
+    .def("prefetch", &Pipeline::prefetch, py::arg("next_cloud"))
+    .def("prefetch",
+         [](Pipeline& self, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {
+           self.prefetch(container_from_array(std::move(cloud)));
+         })
     // instrumentation, not in the reference
     .def("lastInliersRatio", &Pipeline::lastInliersRatio)
     .def("lastIcpMs", &Pipeline::lastIcpMs)

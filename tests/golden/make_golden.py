@@ -46,6 +46,32 @@ def street(K):
              n_matched=int(r["matched"].sum()))
 
 
+def baseline(K, seed, n_queries, name):
+    """BASELINE.json's full-size configurations (119 725-point scans): what tests/test_gpu_baseline_configs.py checks
+    the HIP path against.  Per tree: sha-256 of scan 0's correspondence / gate arrays at the initial guess; per scan:
+    the pose before every round, the final pose and the matched-leaf count."""
+    from mad_icp_amd import synth
+
+    pb = synth.make_problem(K, seed=seed, n_queries=n_queries)
+    trees = []
+    for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        t = O.Tree(s, B_MAX, B_MIN, 3)
+        t.transform(T[:3, :3], T[:3, 3])
+        trees.append(t)
+    qs = [O.Tree(s, B_MAX, B_MIN, 3) for s in pb["query_scans"]]
+    corr_sha, rej_sha, depth = [], [], []
+    for t in trees:
+        _, _, corr, rej, _, d = O.icp_linearize(qs[0], t, pb["query_guess"][0], B_MAX, RHO_KER, B_RATIO)
+        corr_sha.append(digest(corr))
+        rej_sha.append(digest(rej))
+        depth.append(d)
+    rs = [O.icp_register(q, trees, T0, 15, B_MAX, RHO_KER, B_RATIO, num_threads=8) for q, T0 in zip(qs, pb["query_guess"])]
+    np.savez(os.path.join(HERE, name), scan_sha=digest(pb["query_scans"][0]), n_leaves=np.array([q.num_leaves for q in qs]),
+             tree_leaves=np.array([t.num_leaves for t in trees]), corr_sha=np.array(corr_sha), rej_sha=np.array(rej_sha),
+             depth=np.array(depth), X_iters=np.stack([r["X_iters"] for r in rs]), T=np.stack([r["T"] for r in rs]),
+             n_matched=np.array([int(r["matched"].sum()) for r in rs]), depth_sum=np.array([r["depth_sum"] for r in rs]))
+
+
 def walls():
     np.random.seed(42)
     cloud = four_walls(2000)
@@ -61,4 +87,7 @@ if __name__ == "__main__":
     street(1)
     street(3)
     walls()
+    baseline(1, 1, 1, "baseline_k1.npz")
+    baseline(16, 1, 1, "baseline_k16.npz")
+    baseline(64, 2, 8, "baseline_k64_b8.npz")
     print("golden vectors written to", HERE)

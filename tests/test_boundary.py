@@ -109,8 +109,11 @@ def test_nn_search_tool_flow(mods):
     assert tot == 0.0
     trip = tree.searchCloudDist(pyvector.VectorEigen3d(cloud[:100] + 0.01))
     assert len(trip) == 100 and all(len(t) == 3 for t in trip)
-    pts, nrm, dist = tree.searchCloudArrays(pyvector.VectorEigen3d(cloud[:100] + 0.01))
+    pts, nrm, dist, leaf_idx = tree.searchCloudArrays(pyvector.VectorEigen3d(cloud[:100] + 0.01))
     assert np.array_equal(pts, np.array([t[0] for t in trip])) and np.array_equal(dist, np.array([t[2] for t in trip]))
+    # leaf_idx is the getLeafs() ordinal; with one leaf per point the ordinals of distinct hits differ
+    assert leaf_idx.dtype == np.uint32 and leaf_idx.max() < tree.numLeaves()
+    assert len(np.unique(leaf_idx)) == len(np.unique(pts, axis=0))
 
 
 @pytest.mark.gpu
