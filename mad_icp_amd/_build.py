@@ -60,8 +60,8 @@ def _stamp(target, sources, flags=()):
 
 
 def _run(cmd):
-    print("[mad_icp_amd build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    print("[mad_icp_amd build]", " ".join(cmd), file=sys.stderr, flush=True)  # (stdout belongs to bench.py's JSON line)
+    subprocess.check_call(cmd, stdout=sys.stderr)
 
 
 def _glob(d, exts):

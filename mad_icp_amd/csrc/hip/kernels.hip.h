@@ -173,7 +173,7 @@ constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (optio
 // ---------------------------------------------------------------------------------------------------
 // fp64 helpers with the reference's evaluation order (see oracle/linalg.h for the derivation).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double dotc(double a0, double a1, double a2, double b0, double b1, double b2) {
+__host__ __device__ __forceinline__ double dotc(double a0, double a1, double a2, double b0, double b1, double b2) {
 #ifdef MADICP_REDUX_SCALAR_ONLY
   return a0 * b0 + (a1 * b1 + a2 * b2);
 #else
@@ -675,6 +675,183 @@ __device__ __forceinline__ void scale_column(double (&m)[6][6], int k /* unrolle
     default: break;
   }
 }
+// x = A^-1 rhs by LDLT with diagonal pivoting — Eigen::LDLT's algorithm (pivot order, transpositions, the zero-matrix and
+// tiny-pivot guards), evaluated for LATENCY: this solve sits on the serial path of every round, on one wave, with the
+// whole chip waiting for it.  The arithmetic is free to differ from Eigen's in the last bits — the contract on the pose
+// is 1e-5 m / 1e-5 rad, its inputs (the joined H, b) already differ from the reference's by their summation order, and no
+// branch of the descent or the gate depends on anything here except through the pose — so, unlike everywhere else in
+// this file: fused multiply-adds are allowed, a quotient is n * (1/d) with the reciprocal refined to full precision by
+// two Newton steps and the quotient by one residual step (8 dependent instructions instead of the ~12 of the correctly
+// rounded expansion, and ONE reciprocal serves a whole column), and independent terms are summed pairwise.  Every
+// workgroup (and icp_final) runs the same instructions on the same bits, so all of them still hold the same pose.
+// -DMADICP_EXACT_SOLVE restores Eigen's operation order with correctly rounded divisions.
+__device__ __forceinline__ double fast_rcp(double d) {
+#pragma clang fp contract(fast)
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+  return y;
+}
+__device__ __forceinline__ double fast_div(double n, double d, double y /* = fast_rcp(d) */) {
+#pragma clang fp contract(fast)
+  const double q = n * y;
+  return __builtin_fma(__builtin_fma(-d, q, n), y, q);
+}
+#ifndef MADICP_EXACT_SOLVE
+__device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, double* x) {
+#pragma clang fp contract(fast)
+  double m[6][6];
+  int tr[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) m[r][c] = A[r * 6 + c];
+  bool zero_matrix = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    // the pivot search reads the NOT YET updated diagonal (left-looking factorisation): off the dependent chain
+    int big = k;
+    double best = fabs(m[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double a = fabs(m[i][i]);
+      if (a > best) { best = a; big = i; }
+    }
+    if (zero_matrix) big = k;
+    // the pivot is the same in every lane: as a SCALAR it turns the symmetric row/column exchange into a uniform branch
+    // around plain register moves (as lane-wise selects the 15 possible exchanges were ~400 v_cndmask per solve —
+    // more issue time than the whole floating-point chain)
+    big = __builtin_amdgcn_readfirstlane(big);
+    tr[k] = big;
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p) {
+      if (big == p) {
+#pragma unroll
+        for (int j = 0; j < k; ++j) MADICP_SWAP(m[k][j], m[p][j]);
+#pragma unroll
+        for (int i = p + 1; i < 6; ++i) MADICP_SWAP(m[i][k], m[i][p]);
+        MADICP_SWAP(m[k][k], m[p][p]);
+#pragma unroll
+        for (int i = k + 1; i < p; ++i) MADICP_SWAP(m[i][k], m[p][i]);
+      }
+    }
+    if (k > 0 && !zero_matrix) {
+      double tmp[6];
+#pragma unroll
+      for (int j = 0; j < k; ++j) tmp[j] = m[j][j] * m[k][j];
+      // rows k..5 against tmp: k-term dot products, pairwise
+#pragma unroll
+      for (int i = k; i < 6; ++i) {
+        double s0 = m[i][0] * tmp[0], s1 = 0.0;
+        if (k > 1) s1 = m[i][1] * tmp[1];
+        if (k > 2) s0 = __builtin_fma(m[i][2], tmp[2], s0);
+        if (k > 3) s1 = __builtin_fma(m[i][3], tmp[3], s1);
+        if (k > 4) s0 = __builtin_fma(m[i][4], tmp[4], s0);
+        m[i][k] -= (s0 + s1);
+      }
+    }
+    const double akk = m[k][k];
+    const bool ok = fabs(akk) > 0.0;
+    if (k == 0 && !ok) zero_matrix = true;  // whole diagonal is zero: identity transpositions, no scaling
+    if (ok && !zero_matrix && k < 5) {
+      const double y = fast_rcp(akk);
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) m[i][k] = fast_div(m[i][k], akk, y);
+    }
+  }
+  double y[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] = rhs[i];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) MADICP_SWAP(y[k], y[p]);
+  }
+#pragma unroll
+  for (int i = 1; i < 6; ++i) {
+    double s0 = m[i][0] * y[0], s1 = 0.0;
+    if (i > 1) s1 = m[i][1] * y[1];
+    if (i > 2) s0 = __builtin_fma(m[i][2], y[2], s0);
+    if (i > 3) s1 = __builtin_fma(m[i][3], y[3], s1);
+    if (i > 4) s0 = __builtin_fma(m[i][4], y[4], s0);
+    y[i] -= (s0 + s1);
+  }
+  const double tol = 2.2250738585072014e-308;  // numeric_limits<double>::min()
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {  // six independent quotients: their chains overlap in the pipeline
+    const double d = m[i][i];
+    y[i] = (fabs(d) > tol) ? fast_div(y[i], d, fast_rcp(d)) : 0.0;
+  }
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    double s0 = m[i + 1][i] * y[i + 1], s1 = 0.0;
+    if (i + 2 < 6) s1 = m[i + 2][i] * y[i + 2];
+    if (i + 3 < 6) s0 = __builtin_fma(m[i + 3][i], y[i + 3], s0);
+    if (i + 4 < 6) s1 = __builtin_fma(m[i + 4][i], y[i + 4], s1);
+    if (i + 5 < 6) s0 = __builtin_fma(m[i + 5][i], y[i + 5], s0);
+    y[i] -= (s0 + s1);
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+#pragma unroll
+    for (int p = k + 1; p < 6; ++p)
+      if (tr[k] == p) MADICP_SWAP(y[k], y[p]);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
+}
+
+// sin(x) for |x| <= 0.5 by its Taylor series in Horner form (x^19/19! < 2e-23: below half an ulp of the result); the
+// library routine (argument reduction, branches) is a longer dependent chain than the solve's whole back-substitution
+__device__ __forceinline__ double sin_small(double x) {
+#pragma clang fp contract(fast)
+  const double z = x * x;
+  double p = -8.2206352466243297e-18;           // -1/19!
+  p = __builtin_fma(p, z, 2.8114572543455206e-15);   //  1/17!
+  p = __builtin_fma(p, z, -7.6471637318198164e-13);  // -1/15!
+  p = __builtin_fma(p, z, 1.6059043836821613e-10);   //  1/13!
+  p = __builtin_fma(p, z, -2.5052108385441720e-08);  // -1/11!
+  p = __builtin_fma(p, z, 2.7557319223985893e-06);   //  1/9!
+  p = __builtin_fma(p, z, -1.9841269841269841e-04);  // -1/7!
+  p = __builtin_fma(p, z, 8.3333333333333332e-03);   //  1/5!
+  p = __builtin_fma(p, z, -1.6666666666666666e-01);  // -1/3!
+  return __builtin_fma(x * z, p, x);
+}
+
+// lie_algebra.h:39-52, R row-major.  Wave-uniform.  Same formula as the reference (first-order branch below theta^2 = 1e-8,
+// Rodrigues with 2 sin^2(theta/2) above), evaluated like ldlt6_solve above: for latency.
+__device__ __forceinline__ void exp_so3(const double* w, double* R) {
+#pragma clang fp contract(fast)
+  const double th2 = dotc(w[0], w[1], w[2], w[0], w[1], w[2]);
+  if (th2 < 1e-8) {
+    const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + W[i];
+    return;
+  }
+  const double th = sqrt(th2);
+  const double ith = fast_rcp(th);
+  const double k[3] = {fast_div(w[0], th, ith), fast_div(w[1], th, ith), fast_div(w[2], th, ith)};
+  const double Kx[9] = {0.0, -k[2], k[1], k[2], 0.0, -k[0], -k[1], k[0], 0.0};
+  double sh, s;
+  if (th <= 0.5) {
+    sh = sin_small(0.5 * th);
+    s = sin_small(th);
+  } else {
+    sh = sin(0.5 * th);
+    s = sin(th);
+  }
+  const double omc = 2.0 * sh * sh;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double kk = Kx[3 * r] * Kx[c] + Kx[3 * r + 1] * Kx[3 + c] + Kx[3 * r + 2] * Kx[6 + c];
+      R[3 * r + c] = ((r == c) ? 1.0 : 0.0) + s * Kx[3 * r + c] + omc * kk;
+    }
+}
+#else
 __device__ __forceinline__ void ldlt6_solve(const double* A, const double* rhs, double* x) {
   double m[6][6];
   int tr[6];
@@ -800,6 +977,80 @@ __device__ __forceinline__ void exp_so3(const double* w, double* R) {
     }
 }
 
+#endif  // MADICP_EXACT_SOLVE
+
+// LDS written by some lanes of a wave, read by other lanes of the SAME wave: the hardware keeps a wave's LDS
+// operations in order; this only stops the compiler from reordering them
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef MADICP_EXACT_SOLVE
+// dx = H^-1 (-b) with the 64 LANES of the wave as the parallel resource.
+//
+// Run "wave-uniform" (every lane the same scalar program, ldlt6_solve above) the 6x6 solve is ~1500 instructions issued
+// by one wave at one fp64 instruction per four cycles: 2.2 us of every round, measured (profiles/r2_*_phase_stamps.md),
+// bound by ISSUE, not by the dependency chain — shortening the chain (FMA, reciprocal) moved it by 0.2 us, making the
+// pivot exchanges scalar by nothing.  Here lane 7i+j holds entry (i,j) of the augmented system [P H P^T | -P b] and a
+// Gauss-Jordan sweep updates all 42 entries with ONE instruction sequence per pivot: ~25 instructions per step, ~250
+// for the solve.
+//   * Pivot order.  Eigen::LDLT (mad_icp.cpp:111) picks, at step k, the largest |diagonal| among the rows not yet used
+//     — and its left-looking update has not touched those entries, so the order is simply the ORIGINAL diagonal sorted
+//     by decreasing magnitude.  The permutation is computed up front: lane 6i+j compares |H_jj| with |H_ii|, one ballot,
+//     six popcounts give every row's rank (scalar); the permuted entries are gathered from the packed totals in LDS.
+//   * The elimination is Gauss-Jordan (rows above the pivot are eliminated too: no back-substitution pass), the final
+//     x_i = a_i6 / a_ii guarded like Eigen's (|D_ii| <= DBL_MIN -> 0; a pivot that is exactly zero eliminates nothing).
+//     For the symmetric positive definite H of a registration with matches this is the same solution to rounding
+//     (the pose contract is 1e-5; measured agreement with the oracle's LDLT ~1e-15); a singular H (no matches: all
+//     zero) gives dx = 0 on both sides.
+// total: the joined adders in LDS (packed lower triangle, column by column: entry (r,c), r >= c, at 6c - c(c-1)/2 + r - c;
+// b at 21..26).  Whole wave, identical `total` -> identical dx in every lane.
+__device__ __forceinline__ void gn_solve_lanes(const double* total /*LDS*/, double (&dx)[6]) {
+#pragma clang fp contract(fast)
+  __shared__ double s_dx[8];
+  const int lane = threadIdx.x & 63;
+  unsigned int P;  // perm[r] = original row that goes to position r, 4 bits each
+  {
+    const int ci = min(lane / 6, 5), cj = lane % 6;
+    const double di = fabs(total[6 * ci - (ci * (ci - 1)) / 2]);
+    const double dj = fabs(total[6 * cj - (cj * (cj - 1)) / 2]);
+    const bool before = lane < 36 && (dj > di || (dj == di && cj < ci));  // row cj is taken before row ci
+    const unsigned long long mask = __ballot(before);
+    P = 0u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int rank = __builtin_popcountll((mask >> (6 * i)) & 63ull);  // (a NaN diagonal can tie ranks: indices stay in range)
+      P |= (unsigned int)i << (4 * rank);
+    }
+  }
+  const int i = min(lane / 7, 5), j = lane % 7;
+  const int pi = min((int)((P >> (4 * i)) & 7u), 5);
+  const int pj = min((int)((P >> (4 * min(j, 5))) & 7u), 5);
+  const int hi = max(pi, pj), lo = min(pi, pj);
+  const int src = (j < 6) ? (6 * lo - (lo * (lo - 1)) / 2 + (hi - lo)) : (21 + pi);
+  double a = total[src];
+  if (j == 6) a = -a;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double d = lane_get(a, 8 * k);          // pivot a_kk: the same in every lane
+    const double aik = __shfl(a, 7 * i + k, 64);  // own row, pivot column
+    const double akj = __shfl(a, 7 * k + j, 64);  // pivot row, own column
+    const double f = fast_div(aik, d, fast_rcp(d));
+    if (fabs(d) > 0.0 && i != k) a = __builtin_fma(-f, akj, a);
+  }
+  const double dii = __shfl(a, 8 * i, 64);
+  const double tol = 2.2250738585072014e-308;  // numeric_limits<double>::min(), Eigen's guard in LDLT::solve
+  const double sol = (fabs(dii) > tol) ? fast_div(a, dii, fast_rcp(dii)) : 0.0;
+  if (j == 6 && lane < 42) s_dx[pi] = sol;  // un-permute: position i holds the unknown of original row perm[i]
+  wave_lds_order();
+#pragma unroll
+  for (int r = 0; r < 6; ++r) dx[r] = s_dx[r];
+  wave_lds_order();  // (the next call's stores must not overtake these reads)
+}
+#endif
+
 // `moved[2]`: upper bounds of the update's rotation angle and translation length — what the correspondence reuse needs
 // to bound how far any leaf moves: |X_next p - X p| <= |R|_2 (|dR - I|_2 |p| + |dt|) <= (1+1e-6)(moved[0] |p| + moved[1])
 // (|expSO3(w) - I|_2 = 2 sin(|w|/2) <= |w|, and = |w| for the first-order branch; |R|_2 <= 1 + 1e-7 after 15 updates).
@@ -823,10 +1074,15 @@ __device__ __forceinline__ void solve_pose(const double* total, const double (&X
 #pragma unroll
   for (int i = 0; i < 12; ++i) Xn[i] = X[i];
   if (update) {
-    double nb[6], dx[6], dR[9];
+    double dx[6], dR[9];
+#ifndef MADICP_EXACT_SOLVE
+    gn_solve_lanes(total, dx);
+#else
+    double nb[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) nb[r] = -b[r];
     ldlt6_solve(H, nb, dx);
+#endif
     exp_so3(dx + 3, dR);
     moved[0] = sqrt(dotc(dx[3], dx[4], dx[5], dx[3], dx[4], dx[5])) * (1.0 + 1e-6);
     moved[1] = sqrt(dotc(dx[0], dx[1], dx[2], dx[0], dx[1], dx[2])) * (1.0 + 1e-6);
@@ -837,14 +1093,6 @@ __device__ __forceinline__ void solve_pose(const double* total, const double (&X
       Xn[9 + r] = dots(X[3 * r], X[3 * r + 1], X[3 * r + 2], dx[0], dx[1], dx[2]) + X[9 + r];
     }
   }
-}
-
-// LDS written by some lanes of a wave, read by other lanes of the SAME wave: the hardware keeps a wave's LDS
-// operations in order; this only stops the compiler from reordering them
-__device__ __forceinline__ void wave_lds_order() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Join of the per-workgroup partials in a fixed order.  Whole workgroup (kBlock threads): lane = (row group g = 0..3,
@@ -1012,6 +1260,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   uint8_t* __restrict__ matched = job->matched;
   uint32_t* __restrict__ corr = TRACE ? job->corr : nullptr;
   const double min_ball = job->min_ball, rho = job->rho, b_ratio = job->b_ratio;
+#ifndef MADICP_EXACT_SOLVE
+  const double inv_min_ball = fast_rcp(min_ball);
+#endif
   uint32_t* __restrict__ cache_leaf = job->cache_leaf;
   float* __restrict__ cache_margin = job->cache_margin;
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
@@ -1302,6 +1553,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 
         const double bbox0 = ld.x;
         const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
+#ifndef MADICP_EXACT_SOLVE
+        // From here on nothing decides a branch of the reference (the gate above was the last decision; the Huber
+        // switch below is continuous in e), and the kernel is bound by the INSTRUCTIONS its twelve waves issue: the
+        // residual, the Jacobian and the 27 accumulations use fused multiply-adds (one instruction where the
+        // reference's order needs two), the zero columns of skew(p) are not multiplied out, and the two quotients use
+        // the refined reciprocal (1/min_ball once per kernel).  (H, b) differ from the reference-order sums in the last
+        // bits — they already do by the order of the reduction; the pose contract is 1e-5.
+        {
+#pragma clang fp contract(fast)
+          // errorAndJacobian (mad_icp.cpp:59-72)
+          const double e = g0 * n0 + g1 * n1 + g2 * n2;
+          double J[6];
+          J[0] = n0 * R[0] + n1 * R[3] + n2 * R[6];
+          J[1] = n0 * R[1] + n1 * R[4] + n2 * R[7];
+          J[2] = n0 * R[2] + n1 * R[5] + n2 * R[8];
+          // -J[0:3] * skew(p)
+          J[3] = J[2] * py[j] - J[1] * pz[j];
+          J[4] = J[0] * pz[j] - J[2] * px[j];
+          J[5] = J[1] * px[j] - J[0] * py[j];
+          // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
+          double scale = 1.0;
+          const double chi = fabs(e);
+          if (chi > rho) scale = fast_div(rho, chi, fast_rcp(chi));
+          const double w = 1.0 - fast_div(bbox0, min_ball, inv_min_ball);
+          scale *= w * w;
+          double sJ[6];
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
+          int v = 0;
+#pragma unroll
+          for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+            for (int rr = cc; rr < 6; ++rr) {
+              acc[v] = __builtin_fma(sJ[rr], J[cc], acc[v]);
+              ++v;
+            }
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) acc[21 + rr] = __builtin_fma(sJ[rr], e, acc[21 + rr]);
+        }
+#else
 
         // errorAndJacobian (mad_icp.cpp:59-72)
         const double e = dotc(g0, g1, g2, n0, n1, n2);
@@ -1332,6 +1623,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
           for (int rr = cc; rr < 6; ++rr) acc[v++] += sJ[rr] * J[cc];
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
+#endif
         acc[27] += 1.0;
       }
       if (u == u_first && base == r * S) { MADICP_STAMP(9); }

@@ -96,10 +96,11 @@ struct DevMoving {
   uint32_t* cache_leaf = nullptr;
   float* cache_margin = nullptr;
   size_t cache_cap = 0;  // elements
-  // pinned staging of the leaf means (moving_prep reads it over PCIe: no separate H2D operation, no device scratch)
+  // pinned staging of the moving set, already in the device layout (x, y, z, |p|): ONE copy-engine transfer feeds the
+  // registration, no kernel shares the compute units with the registration in flight
   double* h_in = nullptr;
   size_t h_in_cap = 0;        // doubles
-  hipEvent_t h_in_read = nullptr;  // the kernel that reads h_in has run
+  hipEvent_t h_in_read = nullptr;  // the transfer that reads h_in has run
   hipEvent_t ready = nullptr;      // xyzn valid (recorded on whichever stream prepared it)
   bool on_copy = false;            // `ready` was recorded on the copy stream and the compute stream has not waited yet
 };
@@ -348,16 +349,31 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
   const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_rounds(ctx, l, d_jobs, moving_ids);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-    if (rc != MADICP_OK) return rc;
-    if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-    hipGraphExec_t exec = nullptr;
-    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    hipGraphDestroy(graph);
-    it = ctx->graphs.emplace(key, exec).first;
+    auto instantiate = [&](Job* jobs, const GraphKey& k) -> int {
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      const int rc = enqueue_rounds(ctx, l, jobs, moving_ids);
+      hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+      if (rc != MADICP_OK) return rc;
+      if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      hipGraphExec_t exec = nullptr;
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      ctx->graphs.emplace(k, exec);
+      return MADICP_OK;
+    };
+    if (slot >= 0 && !ctx->comm) {
+      // a streamed registration: instantiate this shape for EVERY slot now (a few ms each, once), so that the first
+      // lap around the ring costs the same as every later one
+      for (int s = 0; s < madicp_ctx::kStreamSlots; ++s) {
+        GraphKey k = key;
+        k.slot = s;
+        if (!ctx->graphs.count(k)) RC_TRY(instantiate(ctx->slots[s].d_job, k));
+      }
+    } else {
+      RC_TRY(instantiate(d_jobs, key));
+    }
+    it = ctx->graphs.find(key);
   }
   HIP_TRY(hipGraphLaunch(it->second, ctx->stream));
   return MADICP_OK;
@@ -422,7 +438,7 @@ int reserve_cache(madicp_ctx* ctx, DevMoving& m, int K) {
   return MADICP_OK;
 }
 int reserve_pinned_in(DevMoving& m, int L) {
-  const size_t need = 3 * (size_t)L;
+  const size_t need = 4 * (size_t)L;
   if (need <= m.h_in_cap) return MADICP_OK;
   if (m.h_in) {
     if (m.h_in_read) HIP_TRY(hipEventSynchronize(m.h_in_read));
@@ -437,17 +453,26 @@ int reserve_pinned_in(DevMoving& m, int L) {
   return MADICP_OK;
 }
 
-// leaf means (host, pageable) -> pinned staging -> moving_prep on `s` reads them over PCIe and writes (x,y,z,|p|)
+// leaf means (host, pageable) -> pinned staging in the device layout (x, y, z, |p|) -> one asynchronous copy on `s`.
+// |p| = sqrt(x.x) is the reference's `moving->mean_.norm()` (mad_icp.cpp:81), evaluated here on the host
+// with the same IEEE operations the device kernel uses (no contraction: -ffp-contract=off covers this file's host
+// code too; sqrt is correctly rounded on both sides) — the copy the host makes anyway, 8 bytes wider per leaf, instead
+// of a kernel that reads host memory over PCIe next to the registration in flight (measured: that kernel's waves
+// kept a registration workgroup off its CU and stretched a round by ~9 us).
 int load_moving(madicp_ctx* ctx, DevMoving& m, const double* leaf_means, int L, hipStream_t s) {
   RC_TRY(reserve_moving(ctx, m, L, s));
   RC_TRY(reserve_pinned_in(m, L));
   HIP_TRY(hipEventSynchronize(m.h_in_read));  // (never recorded: returns at once)
-  std::memcpy(m.h_in, leaf_means, sizeof(double) * 3 * (size_t)L);
+  for (int i = 0; i < L; ++i) {
+    const double x = leaf_means[3 * i], y = leaf_means[3 * i + 1], z = leaf_means[3 * i + 2];
+    double* o = m.h_in + 4 * (size_t)i;
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+    o[3] = std::sqrt(dotc(x, y, z, x, y, z));  // the kernel-side expression (moving_from_leaves), evaluation order included
+  }
   m.L = L;
-  double* d_in = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_in), m.h_in, 0));
-  hipLaunchKernelGGL(moving_prep, dim3((L + 255) / 256), dim3(256), 0, s, (const double*)d_in, m.xyzn, L);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(m.xyzn, m.h_in, sizeof(double) * 4 * (size_t)L, hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(m.h_in_read, s));
   if (!m.ready) HIP_TRY(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(m.ready, s));
@@ -1072,6 +1097,27 @@ int madicp_moving_release(madicp_ctx* ctx, int moving_id) {
 
 // ---- streamed registrations: new scan in -> X / H / b / matched flags out ----------------------------
 namespace {
+// everything a slot needs for a scan of L leaves against K trees (grow-only; a no-op in steady state)
+int prepare_slot(madicp_ctx* ctx, StreamSlot& sl, int L, int K, bool pinned_in, bool use_cache) {
+  if (sl.moving_id < 0) {
+    sl.moving_id = ctx->next_id++;
+    ctx->movings[sl.moving_id] = DevMoving{};
+  }
+  DevMoving& mv = ctx->movings.at(sl.moving_id);
+  RC_TRY(reserve_moving(ctx, mv, L, ctx->copy));
+  if (pinned_in) RC_TRY(reserve_pinned_in(mv, L));
+  if (use_cache) RC_TRY(reserve_cache(ctx, mv, std::max(1, K)));
+  if (sl.h_matched_cap < (size_t)L + 16) {
+    if (sl.h_matched) HIP_TRY(hipHostFree(sl.h_matched));
+    sl.h_matched = nullptr;
+    sl.h_matched_cap = 0;
+    const size_t cap = (size_t)L + (size_t)L / 8 + 256;
+    HIP_TRY(hipHostMalloc(&sl.h_matched, cap, hipHostMallocDefault));
+    sl.h_matched_cap = cap;
+  }
+  return MADICP_OK;
+}
+
 int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int moving_tree_id, const int* tree_ids, int K,
                        const double* X0, const madicp_icp_params* params, int n_iters, int* out_ticket) {
   RC_TRY(check_reg_args(ctx, X0, params, out_ticket, K, n_iters));
@@ -1080,18 +1126,24 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   const int ticket = ctx->next_ticket;
   StreamSlot& sl = ctx->slots[ticket % madicp_ctx::kStreamSlots];
   if (sl.pending) return fail(MADICP_ERR_CAPACITY, "stream ring full: collect the oldest ticket first");
-  if (sl.moving_id < 0) {
-    sl.moving_id = ctx->next_id++;
-    ctx->movings[sl.moving_id] = DevMoving{};
-  }
-  DevMoving& mv = ctx->movings.at(sl.moving_id);
-  // ---- feed (copy stream): the scan's leaves, then its Job ------------------------------------------------
   if (moving_tree_id >= 0) {
     auto tit = ctx->trees.find(moving_tree_id);
     if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown moving tree id");
-    DevTree& mt = tit->second;
-    L = mt.n_leaves;
-    RC_TRY(reserve_moving(ctx, mv, L, ctx->copy));
+    L = tit->second.n_leaves;
+  } else {
+    if (!leaf_means) return fail(MADICP_ERR_INVALID, "null argument");
+    if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
+  }
+  const bool use_cache = n_iters > 1;
+  // this slot — and, while they are idle, the other slots of the ring (consecutive scans are alike: the first
+  // submission sizes the whole ring, later ones find nothing to do)
+  RC_TRY(prepare_slot(ctx, sl, L, K, moving_tree_id < 0, use_cache));
+  for (StreamSlot& other : ctx->slots)
+    if (&other != &sl && !other.pending) RC_TRY(prepare_slot(ctx, other, L, K, moving_tree_id < 0, use_cache));
+  DevMoving& mv = ctx->movings.at(sl.moving_id);
+  // ---- feed (copy stream): the scan's leaves, then its Job ------------------------------------------------
+  if (moving_tree_id >= 0) {
+    DevTree& mt = ctx->trees.find(moving_tree_id)->second;
     mv.L = L;
     if (mt.compute_waited) {  // uploaded long ago: make the copy stream see whatever the compute stream did to it since
       EventRef ev;
@@ -1101,20 +1153,8 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
     hipLaunchKernelGGL(moving_from_leaves, dim3((L + 255) / 256), dim3(256), 0, ctx->copy, (const LeafRec*)mt.leaves, mv.xyzn, L);
     HIP_TRY(hipGetLastError());
   } else {
-    if (!leaf_means) return fail(MADICP_ERR_INVALID, "null argument");
-    if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
     RC_TRY(load_moving(ctx, mv, leaf_means, L, ctx->copy));
     mv.on_copy = false;  // ordering is by ev_up below
-  }
-  const bool use_cache = n_iters > 1;
-  if (use_cache) RC_TRY(reserve_cache(ctx, mv, std::max(1, K)));
-  if (sl.h_matched_cap < (size_t)L + 16) {
-    if (sl.h_matched) HIP_TRY(hipHostFree(sl.h_matched));
-    sl.h_matched = nullptr;
-    sl.h_matched_cap = 0;
-    const size_t cap = (size_t)L + (size_t)L / 8 + 256;
-    HIP_TRY(hipHostMalloc(&sl.h_matched, cap, hipHostMallocDefault));
-    sl.h_matched_cap = cap;
   }
   Job& j = *sl.h_job;
   RC_TRY(fill_job(ctx, j, mv, tree_ids, K, X0, params, n_iters, 0, use_cache));

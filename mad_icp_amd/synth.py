@@ -140,3 +140,18 @@ def make_problem(n_keyframes, seed=0, spacing=3.0, query_offset=1.2, n_beams=N_B
         q_guess.append(T @ perturbation(seed * 1000 + 900 + q + 7919 * query_stream))
     return dict(keyframe_scans=kf_scans, keyframe_poses=kf_poses, query_scans=q_scans, query_gt=q_gt,
                 query_guess=q_guess)
+
+
+def make_query_streams(n_keyframes, seed=0, n_streams=8, spacing=3.0, query_offset=1.2, n_beams=N_BEAMS, n_azimuth=N_AZIMUTH):
+    """`n_streams` independent query scans of the SAME difficulty for the keyframes of make_problem(n_keyframes, seed):
+    stream s is exactly make_problem(..., query_stream=s)'s query 0 — rendered `query_offset` (+ 5 cm per stream) past
+    the last keyframe, its own range noise and its own 0.3 m / 1 deg perturbation of the guess — without re-rendering the
+    keyframes.  Stream 0 is the BASELINE configs[2] query.  Returns (scans, gt poses, guesses)."""
+    scene = Scene(seed)
+    scans, gts, guesses = [], [], []
+    for st in range(n_streams):
+        T = path_pose((n_keyframes - 1) * spacing + query_offset + 0.05 * st)
+        gts.append(T)
+        scans.append(render_scan(scene, T, seed * 1000 + 500 + 7919 * st, n_beams=n_beams, n_azimuth=n_azimuth))
+        guesses.append(T @ perturbation(seed * 1000 + 900 + 7919 * st))
+    return scans, gts, guesses

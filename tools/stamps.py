@@ -29,6 +29,8 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 prob = synth.make_problem(K, seed=0)
 ctx = capi.Context(0)
 for kv in sys.argv[2:]:
+    if kv.startswith("--"):
+        continue
     k, v = kv.split("=")
     ctx.set_option(k, int(v))
 tids = []
