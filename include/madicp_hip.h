@@ -193,6 +193,40 @@ int madicp_nn_time_descend(madicp_ctx* ctx, int tree_id, const double* queries, 
  * calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE. */
 int madicp_debug_stream_copy(madicp_ctx* ctx, int64_t bytes, int reps, double* out_gbs);
 
+/* ---- device front-end: scans resident in HBM, ingest + deskew, MAD-tree build (row f-1) -- */
+/* Additive (the reference has no such interface: its Pipeline takes a host vector and builds on the CPU).  A "cloud" is
+ * an (n,3) float64 scan in device memory, referred to by id.  Everything here runs on the context's copy stream, i.e.
+ * concurrently with a registration in flight; results are handed to the compute stream by events. */
+int madicp_cloud_upload(madicp_ctx* ctx, const double* xyz, int64_t n, int* out_cloud_id);
+int madicp_cloud_release(madicp_ctx* ctx, int cloud_id);
+int madicp_cloud_size(madicp_ctx* ctx, int cloud_id, int64_t* out_n);
+int madicp_cloud_download(madicp_ctx* ctx, int cloud_id, double* out_xyz, int64_t n);
+/* apps/cpp_runners/bin_runner.cpp:126-166: float32 records (x, y, z, intensity ...; `stride_floats` floats apart) ->
+ * fp64 points in input order, dropping |p| < min_range, |p| > max_range (|p| in float, as there) and NaN coordinates;
+ * kitti_correction != 0 applies the VERTICAL_ANGLE_OFFSET rotation of :153-158.  Synchronises once (the number of
+ * surviving points sizes the cloud). */
+int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_records, int stride_floats, double min_range,
+                            double max_range, int kitti_correction, int* out_cloud_id, int64_t* out_n);
+/* Pipeline::deskew (mad_icp/src/odometry/pipeline.cpp:79-123) in place: azimuth sort, then every point moved by the pose
+ * of its time chunk.  velocity = naive_vel of :82-86 ([translation; logMapSO3(rotation)] of T_prev^-1 T_now, divided by
+ * the scan period), which the caller computes (six numbers, host libm like the reference); the thresholds, times and
+ * chunk poses are tabulated on the host with the reference's own running arithmetic.  The cloud ends up in azimuth
+ * order, like the reference's.  Points whose azimuths tie exactly may come out in a different order than std::sort
+ * leaves them (it is not stable), and the device atan2 may differ from libm's in the last bit: the result is the
+ * reference's up to the order of such ties.  out_chunks (n, optional): the time chunk of every point in walk order
+ * (largest azimuth first) — synchronises when given. */
+int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6], double sensor_hz, int32_t* out_chunks);
+/* MADtree::build + getLeafs + the upload, all on the device (mad_tree.cpp:47-142,154-163): the tree of the cloud becomes
+ * a resident tree exactly like one given to madicp_tree_upload (same node format, madicp_tree_download returns it).
+ * Same decisions as the reference node by node, but not the same bits: sums have a parallel shape and the
+ * eigen-solver's trigonometry comes from the device library (mad_icp_amd/csrc/hip/tree_build.hip.h); bit-reproducible
+ * run to run.  The cloud is left untouched.  Synchronises the copy stream once (the leaf count sizes the tree). */
+int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves);
+int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t* out_n_leaves);
+/* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] sub-trees finished by single
+ * lanes, out[2..65] nodes handled one-per-wavefront per level, out[66..129] nodes handled chip-wide per level */
+int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
+
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
 /* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte
  * ncclUniqueId produced by madicp_comm_unique_id on rank 0 and distributed by the caller (e.g. a

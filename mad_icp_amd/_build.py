@@ -73,10 +73,15 @@ def _glob(d, exts):
     return sorted(out)
 
 
+def _hip_deps(srcs):
+    return (srcs + _glob(os.path.join(CSRC, "hip"), (".h",)) + _glob(os.path.join(CSRC, "common"), (".h",)) +
+            _glob(INC, (".h",)))
+
+
 def build_hip(force=False):
     out = os.path.join(PKG, "libmadicp_hip.so")
     srcs = [os.path.join(CSRC, "hip", "madicp_capi.hip")]
-    deps = srcs + _glob(os.path.join(CSRC, "hip"), (".h",)) + _glob(INC, (".h",))
+    deps = _hip_deps(srcs)
     flags = HIP_FLAGS + EXTRA_HIP_FLAGS
     if force or _stale(out, deps, flags):
         _run([HIPCC] + flags + ["-I" + INC, "-I" + os.path.join(CSRC, "hip")] + srcs + ["-o", out, "-lrccl"])
@@ -86,8 +91,7 @@ def build_hip(force=False):
 
 def hip_source_hash():
     srcs = [os.path.join(CSRC, "hip", "madicp_capi.hip")]
-    deps = srcs + _glob(os.path.join(CSRC, "hip"), (".h",)) + _glob(INC, (".h",))
-    return source_hash(deps, HIP_FLAGS + EXTRA_HIP_FLAGS)
+    return source_hash(_hip_deps(srcs), HIP_FLAGS + EXTRA_HIP_FLAGS)
 
 
 HOST_SRCS = ("tree_builder.cpp", "host_capi.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp", "pipeline.cpp")
@@ -99,7 +103,7 @@ def build_host(force=False):
     out = os.path.join(PKG, "libmadicp_host.so")
     hdir = os.path.join(CSRC, "host")
     srcs = [os.path.join(hdir, f) for f in HOST_SRCS]
-    deps = srcs + _glob(hdir, (".h",)) + _glob(INC, (".h",))
+    deps = srcs + _glob(hdir, (".h",)) + _glob(os.path.join(CSRC, "common"), (".h",)) + _glob(INC, (".h",))
     flags = HOST_FLAGS + EXTRA_HOST_FLAGS
     if force or _stale(out, deps, flags):
         _run([CXX] + flags + ["-shared", "-I" + INC, "-I" + hdir] + srcs +
@@ -116,7 +120,8 @@ def build_pybind(force=False):
     outdir = os.path.join(PKG, "pybind")
     os.makedirs(outdir, exist_ok=True)
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
-    deps_h = _glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(INC, (".h",))
+    deps_h = (_glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(os.path.join(CSRC, "common"), (".h",)) +
+              _glob(INC, (".h",)))
     flags = HOST_FLAGS + EXTRA_HOST_FLAGS
     built = []
     for mod in ("pyvector", "pymadtree", "pymadicp", "pypeline"):

@@ -87,6 +87,16 @@ def hip_lib():
                                                    C.c_int, _dp, _dp, _u64p, _u64p]
         L.madicp_icp_fetch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_fetch_matched.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int32]
+        L.madicp_cloud_upload.argtypes = [C.c_void_p, _dp, C.c_int64, _ip]
+        L.madicp_cloud_release.argtypes = [C.c_void_p, C.c_int]
+        L.madicp_cloud_size.argtypes = [C.c_void_p, C.c_int, _i64p]
+        L.madicp_cloud_download.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64]
+        L.madicp_cloud_ingest_f32.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_double, C.c_double,
+                                              C.c_int, _ip, _i64p]
+        L.madicp_cloud_deskew.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, _i32p]
+        L.madicp_tree_build.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _ip, _i32p]
+        L.madicp_tree_info.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
+        L.madicp_tree_build_stats.argtypes = [C.c_void_p, _i32p]
         L.madicp_comm_unique_id.argtypes = [_u8p]
         L.madicp_comm_init.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
         L.madicp_comm_destroy.argtypes = [C.c_void_p]
@@ -263,6 +273,61 @@ class Context:
     def nn_search_device(self, tid, d_queries_ptr, n, d_leaf=None, d_node=None, d_dist=None, d_depth=None):
         _check(hip_lib().madicp_nn_search_device_enqueue(self._h, tid, d_queries_ptr, n, d_leaf, d_node, d_dist,
                                                          d_depth))
+
+    # ---- device front-end: clouds, ingest, deskew, tree build ----
+    def cloud_upload(self, xyz):
+        a = _f64(xyz)
+        cid = C.c_int(0)
+        _check(hip_lib().madicp_cloud_upload(self._h, a.ctypes.data_as(_dp), a.shape[0], C.byref(cid)))
+        return cid.value
+
+    def cloud_release(self, cid):
+        _check(hip_lib().madicp_cloud_release(self._h, cid))
+
+    def cloud_size(self, cid):
+        n = C.c_int64(0)
+        _check(hip_lib().madicp_cloud_size(self._h, cid, C.byref(n)))
+        return n.value
+
+    def cloud_download(self, cid):
+        n = self.cloud_size(cid)
+        out = np.empty((n, 3))
+        _check(hip_lib().madicp_cloud_download(self._h, cid, out.ctypes.data_as(_dp), n))
+        return out
+
+    def cloud_ingest_f32(self, records, min_range, max_range, kitti_correction):
+        """records: (n, stride >= 3) float32, x y z first (a KITTI .bin is (n,4)).  Returns (cloud id, points kept)."""
+        r = np.ascontiguousarray(records, dtype=np.float32)
+        if r.ndim != 2 or r.shape[1] < 3:
+            raise ValueError("records must be (n, >=3) float32")
+        cid, kept = C.c_int(0), C.c_int64(0)
+        _check(hip_lib().madicp_cloud_ingest_f32(self._h, r.ctypes.data_as(C.POINTER(C.c_float)), r.shape[0], r.shape[1],
+                                                 float(min_range), float(max_range), int(bool(kitti_correction)),
+                                                 C.byref(cid), C.byref(kept)))
+        return cid.value, kept.value
+
+    def cloud_deskew(self, cid, velocity, sensor_hz, want_chunks=False):
+        v = _f64(velocity, (6,))
+        chunks = np.empty(self.cloud_size(cid), np.int32) if want_chunks else None
+        _check(hip_lib().madicp_cloud_deskew(self._h, cid, v.ctypes.data_as(_dp), float(sensor_hz),
+                                             chunks.ctypes.data_as(_i32p) if want_chunks else None))
+        return chunks
+
+    def tree_build(self, cid, b_max, b_min):
+        """MAD-tree of a resident cloud, built on the device.  Returns (tree id, leaves)."""
+        tid, nl = C.c_int(0), C.c_int32(0)
+        _check(hip_lib().madicp_tree_build(self._h, cid, float(b_max), float(b_min), C.byref(tid), C.byref(nl)))
+        return tid.value, nl.value
+
+    def tree_info(self, tid):
+        nn, nl = C.c_int32(0), C.c_int32(0)
+        _check(hip_lib().madicp_tree_info(self._h, tid, C.byref(nn), C.byref(nl)))
+        return nn.value, nl.value
+
+    def tree_build_stats(self):
+        out = np.zeros(130, np.int32)
+        _check(hip_lib().madicp_tree_build_stats(self._h, out.ctypes.data_as(_i32p)))
+        return dict(max_level=int(out[0]), lane_subtrees=int(out[1]), wave_nodes=out[2:66].copy(), chip_nodes=out[66:130].copy())
 
     # ---- moving ----
     def moving_upload(self, leaf_means):

@@ -1,0 +1,528 @@
+// Part of madicp_capi.hip (included at its end): the device front-end — scans resident in HBM (madicp_cloud_*), ingest
+// and deskew, MAD-tree construction on the device (row f-1).  Everything runs on the context's copy
+// stream: like a tree upload it feeds the registrations, so the front-end of scan i+1 overlaps the registration of scan i,
+// and the compute stream is only made to wait (by event) where it reads the result.
+//
+// One host synchronisation per build: after the last level the host reads 1 KB of counters (leaf count, top size,
+// rho, error flags) because the launch geometry and the buffer sizes of everything downstream need the leaf count.
+
+namespace {
+
+struct DevCloud {
+  double* xyz = nullptr;  // (n,3)
+  int64_t n = 0;
+  hipEvent_t ready = nullptr;  // recorded on the copy stream behind whatever produced xyz
+};
+
+// grow-only scratch of the tree builder / deskew / ingest
+struct FrontScratch {
+  char* block = nullptr;
+  size_t cap = 0;
+  int64_t n_cap = 0;  // points the block was laid out for
+  tb::Params P{};
+  uint32_t* S = nullptr;         // (n + 1) scan result
+  uint32_t* tile_sums = nullptr; // (n / 1024 + 2)
+  // deskew
+  double* key[2] = {nullptr, nullptr};
+  uint32_t* idx[2] = {nullptr, nullptr};
+  int32_t* g = nullptr;
+  int32_t* tile_min = nullptr;
+  double* table = nullptr;       // thresholds | poses
+  void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  tb::State* h_state = nullptr;  // pinned
+  double* h_table = nullptr;     // pinned, same layout as `table`
+  hipEvent_t h_table_read = nullptr;
+};
+
+constexpr int kDeskewTableMax = 1040;  // > CHUNKS + a few: thresholds fall below -pi after ~1024 steps
+
+std::unordered_map<madicp_ctx*, std::unordered_map<int, DevCloud>>& cloud_registry() {
+  static std::unordered_map<madicp_ctx*, std::unordered_map<int, DevCloud>> r;
+  return r;
+}
+std::unordered_map<madicp_ctx*, FrontScratch>& scratch_registry() {
+  static std::unordered_map<madicp_ctx*, FrontScratch> r;
+  return r;
+}
+
+size_t sort_temp_bytes(int64_t n);  // (defined below, needs rocPRIM)
+
+int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
+  FrontScratch& fs = scratch_registry()[ctx];
+  *out = &fs;
+  if (!fs.h_state) {
+    HIP_TRY(hipHostMalloc(&fs.h_state, sizeof(tb::State), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&fs.h_table, sizeof(double) * kDeskewTableMax * 13, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&fs.h_table_read, hipEventDisableTiming));
+  }
+  if (n <= fs.n_cap) return MADICP_OK;
+  if (fs.block) {
+    HIP_TRY(hipStreamSynchronize(ctx->copy));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(fs.block));
+    fs.block = nullptr;
+    fs.cap = 0;
+    fs.n_cap = 0;
+  }
+  const int64_t nc = n + n / 8 + 1024;  // head-room: consecutive scans differ by a few per cent
+  const size_t slots = (size_t)nc / tb::kChunk + tb::kMaxBig + 8;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes);
+    return o;
+  };
+  const size_t o_state = take(sizeof(tb::State));
+  const size_t o_buf0 = take(sizeof(double) * 3 * (size_t)nc);
+  const size_t o_buf1 = take(sizeof(double) * 3 * (size_t)nc);
+  const size_t o_nodes = take(sizeof(tb::BNode) * 2 * (size_t)nc);
+  const size_t o_q0 = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_q1 = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_big0 = take(sizeof(int32_t) * tb::kMaxBig);
+  const size_t o_big1 = take(sizeof(int32_t) * tb::kMaxBig);
+  const size_t o_small = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_leaf = take(sizeof(uint32_t) * ((size_t)nc + 8));
+  const size_t o_S = take(sizeof(uint32_t) * ((size_t)nc + 8));
+  const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
+  const size_t o_p1 = take(sizeof(double) * 12 * slots);
+  const size_t o_p2 = take(sizeof(double) * 8 * slots);
+  const size_t o_key0 = take(sizeof(double) * (size_t)nc);
+  const size_t o_key1 = take(sizeof(double) * (size_t)nc);
+  const size_t o_idx0 = take(sizeof(uint32_t) * (size_t)nc);
+  const size_t o_idx1 = take(sizeof(uint32_t) * (size_t)nc);
+  const size_t o_g = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_tmin = take(sizeof(int32_t) * ((size_t)nc / tb::kScanTile + 8));
+  const size_t o_table = take(sizeof(double) * kDeskewTableMax * 13);
+  const size_t sort_bytes = sort_temp_bytes(nc);
+  const size_t o_sort = take(sort_bytes);
+  HIP_TRY(hipMalloc(&fs.block, off));
+  fs.cap = off;
+  fs.n_cap = nc;
+  char* b = fs.block;
+  fs.P = tb::Params{};
+  fs.P.st = reinterpret_cast<tb::State*>(b + o_state);
+  fs.P.buf[0] = reinterpret_cast<double*>(b + o_buf0);
+  fs.P.buf[1] = reinterpret_cast<double*>(b + o_buf1);
+  fs.P.nodes = reinterpret_cast<tb::BNode*>(b + o_nodes);
+  fs.P.node_cap = static_cast<int32_t>(std::min<int64_t>(2 * nc, 0x7ffffff0));
+  fs.P.q[0] = reinterpret_cast<int32_t*>(b + o_q0);
+  fs.P.q[1] = reinterpret_cast<int32_t*>(b + o_q1);
+  fs.P.big[0] = reinterpret_cast<int32_t*>(b + o_big0);
+  fs.P.big[1] = reinterpret_cast<int32_t*>(b + o_big1);
+  fs.P.small = reinterpret_cast<int32_t*>(b + o_small);
+  fs.P.leaf_start = reinterpret_cast<uint32_t*>(b + o_leaf);
+  fs.P.part1 = reinterpret_cast<double*>(b + o_p1);
+  fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
+  fs.S = reinterpret_cast<uint32_t*>(b + o_S);
+  fs.tile_sums = reinterpret_cast<uint32_t*>(b + o_tiles);
+  fs.key[0] = reinterpret_cast<double*>(b + o_key0);
+  fs.key[1] = reinterpret_cast<double*>(b + o_key1);
+  fs.idx[0] = reinterpret_cast<uint32_t*>(b + o_idx0);
+  fs.idx[1] = reinterpret_cast<uint32_t*>(b + o_idx1);
+  fs.g = reinterpret_cast<int32_t*>(b + o_g);
+  fs.tile_min = reinterpret_cast<int32_t*>(b + o_tmin);
+  fs.table = reinterpret_cast<double*>(b + o_table);
+  fs.sort_tmp = b + o_sort;
+  fs.sort_tmp_bytes = sort_bytes;
+  return MADICP_OK;
+}
+
+void front_destroy(madicp_ctx* ctx) {  // called by madicp_ctx_destroy (streams already drained)
+  auto cit = cloud_registry().find(ctx);
+  if (cit != cloud_registry().end()) {
+    for (auto& c : cit->second)
+      if (c.second.ready) hipEventDestroy(c.second.ready);  // (the device buffers belong to the pool)
+    cloud_registry().erase(cit);
+  }
+  auto sit = scratch_registry().find(ctx);
+  if (sit != scratch_registry().end()) {
+    FrontScratch& fs = sit->second;
+    if (fs.block) hipFree(fs.block);
+    if (fs.h_state) hipHostFree(fs.h_state);
+    if (fs.h_table) hipHostFree(fs.h_table);
+    if (fs.h_table_read) hipEventDestroy(fs.h_table_read);
+    scratch_registry().erase(sit);
+  }
+}
+
+DevCloud* find_cloud(madicp_ctx* ctx, int id) {
+  auto cit = cloud_registry().find(ctx);
+  if (cit == cloud_registry().end()) return nullptr;
+  auto it = cit->second.find(id);
+  return it == cit->second.end() ? nullptr : &it->second;
+}
+
+int new_cloud(madicp_ctx* ctx, int64_t n, DevCloud* out) {
+  void* p = nullptr;
+  RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)std::max<int64_t>(n, 1), ctx->copy, &p));
+  out->xyz = static_cast<double*>(p);
+  out->n = n;
+  HIP_TRY(hipEventCreateWithFlags(&out->ready, hipEventDisableTiming));
+  return MADICP_OK;
+}
+
+int scan_marks(madicp_ctx* ctx, FrontScratch& fs, const uint32_t* marks, int64_t n, int32_t* d_total) {
+  const int tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
+  hipLaunchKernelGGL(tb::tb_scan_tiles, dim3(tiles), dim3(256), 0, ctx->copy, marks, (int)n, fs.tile_sums);
+  hipLaunchKernelGGL(tb::tb_scan_top, dim3(1), dim3(256), 0, ctx->copy, fs.tile_sums, tiles, d_total);
+  hipLaunchKernelGGL(tb::tb_scan_apply, dim3(tiles), dim3(256), 0, ctx->copy, marks, (int)n, (const uint32_t*)fs.tile_sums, fs.S);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int madicp_cloud_upload(madicp_ctx* ctx, const double* xyz, int64_t n, int* out_cloud_id) {
+  if (!ctx || !xyz || !out_cloud_id) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n < 1 || n > 0x3fffffff) return fail(MADICP_ERR_INVALID, "a cloud holds 1 .. 2^30 points");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevCloud c;
+  RC_TRY(new_cloud(ctx, n, &c));
+  // pinned staging shared with the tree uploads (two buffers, alternating)
+  const size_t bytes = sizeof(double) * 3 * (size_t)n;
+  const int hb = ctx->h_tree_next;
+  ctx->h_tree_next ^= 1;
+  HIP_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
+  if (ctx->h_tree_cap[hb] < bytes) {
+    if (ctx->h_tree[hb]) HIP_TRY(hipHostFree(ctx->h_tree[hb]));
+    ctx->h_tree[hb] = nullptr;
+    ctx->h_tree_cap[hb] = 0;
+    const size_t cap = bytes + bytes / 4;
+    HIP_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
+    ctx->h_tree_cap[hb] = cap;
+  }
+  std::memcpy(ctx->h_tree[hb], xyz, bytes);
+  HIP_TRY(hipMemcpyAsync(c.xyz, ctx->h_tree[hb], bytes, hipMemcpyHostToDevice, ctx->copy));
+  HIP_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
+  HIP_TRY(hipEventRecord(c.ready, ctx->copy));
+  const int id = ctx->next_id++;
+  cloud_registry()[ctx][id] = c;
+  *out_cloud_id = id;
+  return MADICP_OK;
+}
+
+int madicp_cloud_release(madicp_ctx* ctx, int cloud_id) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  DevCloud* c = find_cloud(ctx, cloud_id);
+  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  EventRef after;
+  RC_TRY(fence_event(ctx, &after));
+  pool_free(ctx, c->xyz, after);
+  if (c->ready) hipEventDestroy(c->ready);
+  cloud_registry()[ctx].erase(cloud_id);
+  return MADICP_OK;
+}
+
+int madicp_cloud_size(madicp_ctx* ctx, int cloud_id, int64_t* out_n) {
+  if (!ctx || !out_n) return fail(MADICP_ERR_INVALID, "null argument");
+  DevCloud* c = find_cloud(ctx, cloud_id);
+  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
+  *out_n = c->n;
+  return MADICP_OK;
+}
+
+int madicp_cloud_download(madicp_ctx* ctx, int cloud_id, double* out_xyz, int64_t n) {
+  if (!ctx || !out_xyz) return fail(MADICP_ERR_INVALID, "null argument");
+  DevCloud* c = find_cloud(ctx, cloud_id);
+  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
+  if (n != c->n) return fail(MADICP_ERR_INVALID, "n mismatch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMemcpyAsync(out_xyz, c->xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->copy));
+  HIP_TRY(hipStreamSynchronize(ctx->copy));
+  return MADICP_OK;
+}
+
+int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_records, int stride_floats, double min_range,
+                            double max_range, int kitti_correction, int* out_cloud_id, int64_t* out_n) {
+  if (!ctx || !records || !out_cloud_id || !out_n) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n_records < 1 || n_records > 0x3fffffff) return fail(MADICP_ERR_INVALID, "1 .. 2^30 records");
+  if (stride_floats < 3) return fail(MADICP_ERR_INVALID, "a record holds at least x, y, z");
+  HIP_TRY(hipSetDevice(ctx->device));
+  FrontScratch* fs = nullptr;
+  RC_TRY(ensure_scratch(ctx, n_records, &fs));
+  // the raw records go through the pinned staging into buf[0] of the scratch (they are 16 bytes per point)
+  const size_t bytes = sizeof(float) * (size_t)stride_floats * (size_t)n_records;
+  if (bytes > sizeof(double) * 3 * (size_t)fs->n_cap) return fail(MADICP_ERR_INVALID, "record stride too large");
+  const int hb = ctx->h_tree_next;
+  ctx->h_tree_next ^= 1;
+  HIP_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
+  if (ctx->h_tree_cap[hb] < bytes) {
+    if (ctx->h_tree[hb]) HIP_TRY(hipHostFree(ctx->h_tree[hb]));
+    ctx->h_tree[hb] = nullptr;
+    ctx->h_tree_cap[hb] = 0;
+    const size_t cap = bytes + bytes / 4;
+    HIP_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
+    ctx->h_tree_cap[hb] = cap;
+  }
+  std::memcpy(ctx->h_tree[hb], records, bytes);
+  float* d_rec = reinterpret_cast<float*>(fs->P.buf[0]);
+  HIP_TRY(hipMemcpyAsync(d_rec, ctx->h_tree[hb], bytes, hipMemcpyHostToDevice, ctx->copy));
+  HIP_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
+  uint32_t* keep = fs->P.leaf_start;
+  const int blocks = static_cast<int>(std::min<int64_t>((n_records + 255) / 256, (int64_t)ctx->n_cus * 8));
+  hipLaunchKernelGGL(fe::ingest_mark, dim3(blocks), dim3(256), 0, ctx->copy, (const float*)d_rec, (long)n_records, stride_floats,
+                     min_range, max_range, keep);
+  RC_TRY(scan_marks(ctx, *fs, keep, n_records, &fs->P.st->n_leaves));
+  HIP_TRY(hipMemcpyAsync(&fs->h_state->n_leaves, &fs->P.st->n_leaves, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->copy));
+  HIP_TRY(hipStreamSynchronize(ctx->copy));  // the size of the result decides the allocation
+  const int64_t kept = fs->h_state->n_leaves;
+  if (kept < 1) return fail(MADICP_ERR_INVALID, "no point survives the range filter");
+  DevCloud c;
+  RC_TRY(new_cloud(ctx, kept, &c));
+  // VERTICAL_ANGLE_OFFSET = (0.205 * M_PI) / 180.0 (bin_runner.cpp:55); libm sin / cos like Eigen::AngleAxisd
+  const double angle = (0.205 * M_PI) / 180.0;
+  hipLaunchKernelGGL(fe::ingest_scatter, dim3(blocks), dim3(256), 0, ctx->copy, (const float*)d_rec, (long)n_records, stride_floats,
+                     (const uint32_t*)keep, (const uint32_t*)fs->S, kitti_correction ? 1 : 0, std::sin(angle), std::cos(angle), c.xyz);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c.ready, ctx->copy));
+  const int id = ctx->next_id++;
+  cloud_registry()[ctx][id] = c;
+  *out_cloud_id = id;
+  *out_n = kept;
+  return MADICP_OK;
+}
+
+}  // extern "C"
+
+// ---- deskew --------------------------------------------------------------------------------------------------------
+#include <rocprim/rocprim.hpp>
+
+namespace {
+size_t sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  double* k = nullptr;
+  uint32_t* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, 64, (hipStream_t) nullptr);
+  return bytes + 256;
+}
+}  // namespace
+
+extern "C" {
+
+int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6], double sensor_hz, int32_t* out_chunks) {
+  if (!ctx || !velocity) return fail(MADICP_ERR_INVALID, "null argument");
+  DevCloud* c = find_cloud(ctx, cloud_id);
+  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
+  if (!(sensor_hz > 0.0)) return fail(MADICP_ERR_INVALID, "sensor_hz must be positive");
+  HIP_TRY(hipSetDevice(ctx->device));
+  FrontScratch* fs = nullptr;
+  RC_TRY(ensure_scratch(ctx, c->n, &fs));
+  const int64_t n = c->n;
+  // The reference's running threshold and time (pipeline.cpp:99-106,109-117), tabulated with its own arithmetic
+  // (repeated subtraction / addition), and the pose of every chunk by the host's expSO3 (libm, like the reference).
+  constexpr int CHUNKS = 1024;  // tools/constants.h:31
+  const double ts = 1. / sensor_hz;
+  const double resolution = 2 * M_PI / double(CHUNKS);
+  const double delta = ts / double(CHUNKS - 1);
+  HIP_TRY(hipEventSynchronize(fs->h_table_read));
+  double* thr = fs->h_table;
+  double* poses = fs->h_table + kDeskewTableMax;
+  double angle = M_PI - resolution;
+  double t = -ts;
+  int n_thr = 0;
+  for (int k = 0; k < kDeskewTableMax; ++k) {
+    double dx[6];
+    for (int i = 0; i < 6; ++i) dx[i] = velocity[i] * t;
+    double* Pk = poses + 12 * k;
+    {  // lie_algebra.h:39-52, with the reference's first-order branch
+      const double* w = dx + 3;
+      const double th2 = dotc(w[0], w[1], w[2], w[0], w[1], w[2]);
+      const double th = std::sqrt(th2);
+      const double W[9] = {0.0, -w[2], w[1], w[2], 0.0, -w[0], -w[1], w[0], 0.0};
+      if (th2 < 1e-8) {
+        for (int i = 0; i < 9; ++i) Pk[i] = ((i % 4 == 0) ? 1.0 : 0.0) + W[i];
+      } else {
+        double K[9], cK[9];
+        const double omc = 2.0 * std::sin(th / 2.0) * std::sin(th / 2.0);
+        const double s = std::sin(th);
+        for (int i = 0; i < 9; ++i) {
+          K[i] = W[i] / th;
+          cK[i] = omc * K[i];
+        }
+        for (int r = 0; r < 3; ++r)
+          for (int q = 0; q < 3; ++q) {
+            const double kk = cK[3 * r] * K[q] + (cK[3 * r + 1] * K[3 + q] + cK[3 * r + 2] * K[6 + q]);
+            Pk[3 * r + q] = (((r == q) ? 1.0 : 0.0) + s * K[3 * r + q]) + kk;
+          }
+      }
+      Pk[9] = dx[0]; Pk[10] = dx[1]; Pk[11] = dx[2];
+    }
+    thr[k] = angle;
+    if (angle >= -M_PI - resolution) n_thr = k + 1;  // thresholds at or below -pi can never be undercut again
+    angle -= resolution;
+    t += delta;
+  }
+  const int n_poses = std::min(n_thr + 1, kDeskewTableMax);
+  HIP_TRY(hipMemcpyAsync(fs->table, fs->h_table, sizeof(double) * kDeskewTableMax * 13, hipMemcpyHostToDevice, ctx->copy));
+  HIP_TRY(hipEventRecord(fs->h_table_read, ctx->copy));
+  const int blocks = static_cast<int>(std::min<int64_t>((n + 255) / 256, (int64_t)ctx->n_cus * 8));
+  hipLaunchKernelGGL(fe::deskew_keys, dim3(blocks), dim3(256), 0, ctx->copy, (const double*)c->xyz, (long)n, fs->key[0], fs->idx[0]);
+  HIP_TRY(hipGetLastError());
+  size_t tmp_bytes = fs->sort_tmp_bytes;
+  HIP_TRY(rocprim::radix_sort_pairs(fs->sort_tmp, tmp_bytes, fs->key[0], fs->key[1], fs->idx[0], fs->idx[1], (size_t)n, 0, 64,
+                                    ctx->copy));
+  hipLaunchKernelGGL(fe::deskew_targets, dim3(blocks), dim3(256), 0, ctx->copy, (const double*)fs->key[1], (long)n,
+                     (const double*)fs->table, n_thr, fs->g);
+  const int tiles = static_cast<int>((n + tb::kScanTile - 1) / tb::kScanTile);
+  hipLaunchKernelGGL(fe::pmin_tiles, dim3(tiles), dim3(256), 0, ctx->copy, (const int32_t*)fs->g, (long)n, fs->tile_min);
+  hipLaunchKernelGGL(fe::pmin_top, dim3(1), dim3(256), 0, ctx->copy, fs->tile_min, tiles);
+  // the compensated cloud replaces the input: written to a fresh buffer, the old one goes back to the pool
+  void* fresh = nullptr;
+  RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)n, ctx->copy, &fresh));
+  int32_t* d_chunks = out_chunks ? reinterpret_cast<int32_t*>(fs->P.q[0]) : nullptr;
+  hipLaunchKernelGGL(fe::deskew_apply, dim3(tiles), dim3(256), 0, ctx->copy, (const double*)c->xyz, (const uint32_t*)fs->idx[1], (long)n,
+                     (const int32_t*)fs->g, (const int32_t*)fs->tile_min, (const double*)(fs->table + kDeskewTableMax), n_poses,
+                     static_cast<double*>(fresh), d_chunks);
+  HIP_TRY(hipGetLastError());
+  EventRef after;
+  RC_TRY(fence_event(ctx, &after));
+  pool_free(ctx, c->xyz, after);
+  c->xyz = static_cast<double*>(fresh);
+  HIP_TRY(hipEventRecord(c->ready, ctx->copy));
+  if (out_chunks) {  // debugging / parity aid: the time chunk of every point, in walk order (largest azimuth first)
+    HIP_TRY(hipMemcpyAsync(out_chunks, d_chunks, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->copy));
+    HIP_TRY(hipStreamSynchronize(ctx->copy));
+  }
+  return MADICP_OK;
+}
+
+// ---- MAD-tree construction on the device ------------------------------------------------------------------------------
+int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves) {
+  if (!ctx || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
+  DevCloud* c = find_cloud(ctx, cloud_id);
+  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  FrontScratch* fs = nullptr;
+  RC_TRY(ensure_scratch(ctx, c->n, &fs));
+  const int64_t n = c->n;
+  tb::Params P = fs->P;
+  P.cloud = c->xyz;
+  P.n_points = static_cast<int32_t>(n);
+  P.b_max = b_max;
+  P.b_min = b_min;
+  hipStream_t s = ctx->copy;
+  HIP_TRY(hipMemsetAsync(P.st, 0, sizeof(tb::State), s));
+  HIP_TRY(hipMemsetAsync(P.leaf_start, 0, sizeof(uint32_t) * ((size_t)n + 1), s));
+  hipLaunchKernelGGL(tb::tb_init, dim3(1), dim3(64), 0, s, P);
+  const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + 64, (int64_t)ctx->n_cus * 4));
+  const int wave_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + 1)));
+  auto run_levels = [&](int from, int to) {
+    for (int level = from; level < to; ++level) {
+      if (level < tb::kChipLevels && n > tb::kChipMin) {
+        hipLaunchKernelGGL(tb::tb_chip_sums, dim3(chip_grid), dim3(256), 0, s, P, level);
+        hipLaunchKernelGGL(tb::tb_chip_stats, dim3(chip_grid), dim3(256), 0, s, P, level);
+        hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(chip_grid), dim3(256), 0, s, P, level);
+      }
+      hipLaunchKernelGGL(tb::tb_level_wave, dim3(wave_grid), dim3(256), 0, s, P, level);
+    }
+  };
+  const int small_grid = static_cast<int>((n + 63) / 64);
+  auto finish = [&](int start) -> int {
+    hipLaunchKernelGGL(tb::tb_finish_small, dim3(small_grid), dim3(64), 64 * tb::kSlabStride, s, P, start);
+    // what the host needs: leaf count (scan of the leaf starts), root mean, rho, size of the LDS-staged top
+    HIP_TRY(hipMemsetAsync(&P.st->n_top, 0, sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(&P.st->max_level, 0, sizeof(int32_t) + sizeof(unsigned long long), s));
+    RC_TRY(scan_marks(ctx, *fs, P.leaf_start, n, &P.st->n_leaves));
+    hipLaunchKernelGGL(tb::tb_summary, dim3(std::min(ctx->n_cus * 2, 512)), dim3(256), 0, s, P, kTopLevels);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(fs->h_state, P.st, sizeof(tb::State), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return MADICP_OK;
+  };
+  int levels_done = 26;  // a 120 k-point scan at b_max = 0.2 needs ~17 levels before every node is in the lane regime
+  run_levels(0, levels_done);
+  RC_TRY(finish(0));
+  while (fs->h_state->error == 0 && levels_done < tb::kMaxLevels && fs->h_state->q_count[levels_done] > 0) {
+    const int prev_small = fs->h_state->small_count;  // rare: an unusually deep tree — more levels, then the new small ones
+    const int to = std::min(levels_done + 8, tb::kMaxLevels);
+    run_levels(levels_done, to);
+    levels_done = to;
+    RC_TRY(finish(prev_small));
+  }
+  const tb::State& st = *fs->h_state;
+  if (st.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
+  if (st.error == 2 || st.q_count[levels_done] > 0) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
+  const int32_t n_leaves = st.n_leaves, n_nodes = 2 * st.n_leaves - 1;
+  if (n_leaves < 1 || st.n_nodes != n_nodes)
+    return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(st.n_nodes) + " nodes, " +
+                                       std::to_string(n_leaves) + " leaves)");
+  DevTree t;
+  t.n_nodes = n_nodes;
+  t.n_leaves = n_leaves;
+  t.n_top = std::min<int32_t>(st.n_top, kTopMax - 1);
+  double rho;
+  std::memcpy(&rho, &st.rho_bits, sizeof(rho));
+  t.rho2 = rho;
+  const size_t nt = (size_t)t.n_top;
+  const size_t off_nodes = 0;
+  const size_t off_exit = align_up(off_nodes + sizeof(madicp_node) * (size_t)n_nodes);
+  const size_t off_dfs = align_up(off_exit + sizeof(int2) * nt);
+  const size_t off_link = align_up(off_dfs + sizeof(int) * nt);
+  const size_t up_bytes = align_up(off_link + sizeof(unsigned int) * nt);
+  const size_t off_cnodes = up_bytes;
+  const size_t off_leaves = align_up(off_cnodes + sizeof(CNode) * (size_t)n_nodes);
+  const size_t off_top = align_up(off_leaves + sizeof(LeafRec) * (size_t)n_leaves);
+  const size_t total = align_up(off_top + sizeof(CNode) * std::max<size_t>(nt, 1));
+  void* blk = nullptr;
+  RC_TRY(pool_alloc(ctx, total, s, &blk));
+  t.block = static_cast<char*>(blk);
+  t.nodes = reinterpret_cast<madicp_node*>(t.block + off_nodes);
+  t.top_exit = nt ? reinterpret_cast<int2*>(t.block + off_exit) : nullptr;
+  t.top_dfs = nt ? reinterpret_cast<int*>(t.block + off_dfs) : nullptr;
+  t.top_link = nt ? reinterpret_cast<unsigned int*>(t.block + off_link) : nullptr;
+  t.cnodes = reinterpret_cast<CNode*>(t.block + off_cnodes);
+  t.leaves = reinterpret_cast<LeafRec*>(t.block + off_leaves);
+  t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
+  set_desc(t, st.origin);
+  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256), dim3(256), 0, s, (const tb::BNode*)P.nodes, n_nodes, (const uint32_t*)fs->S,
+                     t.nodes, n_nodes);
+  if (nt)
+    hipLaunchKernelGGL(tb::tb_layout_top, dim3(1), dim3(1024), 0, s, (const madicp_node*)t.nodes, kTopLevels, kTopMax, t.top_dfs,
+                       t.top_link, t.top_exit, &P.st->n_top);
+  hipError_t e = hipGetLastError();
+  int rc = MADICP_OK;
+  if (e == hipSuccess) rc = compact_tree(t, s);
+  if (e == hipSuccess && rc == MADICP_OK) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
+  if (e == hipSuccess && rc == MADICP_OK) e = hipEventRecord(t.ready, s);
+  if (e != hipSuccess || rc != MADICP_OK) {
+    hipStreamSynchronize(s);
+    release_tree(ctx, t, nullptr);
+    return rc != MADICP_OK ? rc : fail(MADICP_ERR_DEVICE, std::string("tree build: ") + hipGetErrorString(e));
+  }
+  const int id = ctx->next_id++;
+  ctx->trees[id] = t;
+  *out_tree_id = id;
+  if (out_n_leaves) *out_n_leaves = n_leaves;
+  return MADICP_OK;
+}
+
+int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t* out_n_leaves) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  auto it = ctx->trees.find(tree_id);
+  if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+  if (out_n_nodes) *out_n_nodes = it->second.n_nodes;
+  if (out_n_leaves) *out_n_leaves = it->second.n_leaves;
+  return MADICP_OK;
+}
+
+// per-level node counts of the last build on this context (diagnostics for tests / tools): out[0] = levels reached,
+// out[1] = lane-regime sub-trees, then 2 x 64 ints: wave-regime and chip-regime nodes per level
+int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
+  if (!ctx || !out) return fail(MADICP_ERR_INVALID, "null argument");
+  auto sit = scratch_registry().find(ctx);
+  if (sit == scratch_registry().end() || !sit->second.h_state) return fail(MADICP_ERR_INVALID, "no build yet");
+  const tb::State& st = *sit->second.h_state;
+  out[0] = st.max_level;
+  out[1] = st.small_count;
+  for (int i = 0; i < 64; ++i) {
+    out[2 + i] = st.q_count[i];
+    out[66 + i] = st.big_count[i];
+  }
+  return MADICP_OK;
+}
+
+}  // extern "C"

@@ -8,6 +8,7 @@
 // release has passed), pinned staging is grow-only, results are written by the last kernel of a registration straight
 // into a pinned host block (Job::host_out) that the caller reads after one event wait.
 #include "kernels.hip.h"
+#include "frontend.hip.h"  // + tree_build.hip.h: device front-end
 
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
@@ -196,6 +197,8 @@ struct madicp_ctx {
 };
 
 namespace {
+
+void front_destroy(madicp_ctx* ctx);  // frontend_capi.inc.h
 
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
@@ -714,6 +717,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->copy) hipStreamSynchronize(ctx->copy);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+  front_destroy(ctx);
   for (auto& t : ctx->trees)
     if (t.second.ready) hipEventDestroy(t.second.ready);
   for (auto& m : ctx->movings) {
@@ -1522,3 +1526,5 @@ extern "C" int madicp_debug_stamps(madicp_ctx* ctx, unsigned long long* out) {
              ? 0 : MADICP_ERR_DEVICE;
 }
 #endif
+
+#include "frontend_capi.inc.h"

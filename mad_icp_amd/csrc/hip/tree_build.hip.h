@@ -1,0 +1,954 @@
+// MAD-tree construction on the device.  Replaces MADtree::build / makeSubtree / getLeafs
+// (reference mad_tree.cpp:47-142,154-163 with utils.h:37-97) for callers that opt in: the scan goes to HBM once, the
+// linear 64-byte node array is produced there, and nothing of the tree ever crosses PCIe.
+//
+// Same decisions as the reference, node by node — mean / sample covariance of the node's points (utils.h:54-73), the
+// closed-form eigen-decomposition (common/eig3.h, the one source the host builder uses), extents in the eigen frame with 0
+// included (utils.h:75-97), leaf rule bbox(2) < b_max, normal inheritance from the top-most flat ancestor or the nearest
+// ancestor with >= 3 points (mad_tree.cpp:64-74), leaf mean snapped to the member nearest the centroid (:76-86), split
+// at the centroid along the largest eigenvector (:95-97) — but NOT the same bits: the reference adds a node's points
+// one after the other in the order its in-place partition left them, a serial chain that no parallel machine can
+// follow, and the eigen-solver's atan2 / cos / sin come from a different math library.  Every sum here has a FIXED
+// shape (lane-strided partial sums, xor butterfly, chunk partials in chunk order), the partition is stable, so a build
+// is bit-reproducible run to run and independent of scheduling; against the host builder it agrees node for node
+// except where a decision sits within rounding of its threshold (tests/test_gpu_tree_build.py states the measured
+// rates and the pose bound).
+//
+// Shape of the computation (N = 120 k points, ~20 k leaves, ~17 levels until nodes are small):
+//   * level-synchronous from the root down, one launch sequence per level, points ping-pong between two buffers so
+//     that a node's stable partition is an out-of-place scatter inside its own range;
+//   * three regimes by node size, because a node needs sums -> eigen -> extents -> partition in sequence and the only
+//     question is how many lanes can share that chain:
+//       chip  (n > 4096, first levels only): the node's points are cut into 2048-point chunks, one workgroup per chunk;
+//              three kernels per level (sums | stats + extents + left counts | scatter), every workgroup recombines
+//              the per-chunk partials of its node in chunk order, so no kernel waits for a single combiner;
+//       wave  (32 < n <= 4096, and anything larger past the chip levels): one wavefront per node does all of it with
+//              no barrier — strided partial sums, butterfly reduction, wave-uniform eigen, ballot-based stable scatter;
+//       lane  (n <= 32): the node and its WHOLE sub-tree are built by one lane, depth first, in a private slab of LDS
+//              (the bulk of a MAD-tree's nodes hold a handful of points: one eigen-solve per lane instead of per wave);
+//   * nodes are created in scheduling order into a temporary array; the final DFS-preorder position needs no
+//     bottom-up pass: the leaves partition the (permuted) point array, so with S[i] = number of leaves that start
+//     before point i (one exclusive scan of the leaf-start marks), a node owning points [b, e) that was reached by
+//     `t` left turns sits at preorder index 2 S[b] + t, its right child 2 (S[mid] - S[b]) further, and a leaf's
+//     getLeafs() ordinal is S[b].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../common/eig3.h"
+#include "madicp_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace madicp {
+namespace tb {
+
+constexpr int kSmallMax = 32;    // lane regime: a node with at most this many points is finished by one lane
+constexpr int kChipMin = 4096;   // chip regime above this many points ...
+constexpr int kChipLevels = 7;   // ... during the first levels only (afterwards the wave regime takes any size)
+constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
+constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
+constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
+constexpr int kSlabStride = kSmallMax * 24 + 8;  // bytes of LDS per lane in the lane regime (+8: bank spreading)
+
+enum : int { kLeaf = 1, kHasPlane = 2, kHasSmall = 4, kDone = 8, kLeafPending = 16 };
+
+struct BNode {          // a node while the tree is being built
+  double mean[3];       // internal: centroid; leaf: the member nearest to it
+  double dir[3];        // internal: split normal (eigenvector 2); leaf: surface normal
+  double col0[3];       // internal: own normal (eigenvector 0) — children may inherit it
+  double plane_n[3];    // inherited: normal of the top-most flat ancestor (kHasPlane)
+  double small_n[3];    // inherited: normal of the nearest ancestor with >= 3 points (kHasSmall)
+  double bbox0;
+  int32_t begin, end, mid, left_turns;
+  int32_t flags, level, parent, child;  // child: temporary id of the left child, the right one is child + 1
+};
+static_assert(sizeof(BNode) == 160, "BNode layout");
+
+struct State {  // counters and results of one build, device resident
+  int32_t n_nodes;      // temporary nodes allocated
+  int32_t small_count;  // lane-regime sub-tree roots queued
+  int32_t n_leaves;     // after the scan
+  int32_t n_top;        // internal nodes above level kTopLevels (the LDS-staged top of icp_round)
+  int32_t error;        // 1: node capacity, 2: depth
+  int32_t max_level;
+  unsigned long long rho_bits;  // max |mean - origin|_2 over the internal nodes, as the bits of a non-negative double
+  double origin[3];             // the root's mean
+  int32_t q_count[kMaxLevels + 1];    // wave-regime nodes queued per level
+  int32_t big_count[kMaxLevels + 1];  // chip-regime nodes queued per level
+};
+
+struct Params {
+  const double* cloud;  // level 0 reads the caller's cloud
+  double* buf[2];       // level l > 0 reads buf[l & 1]; level l writes buf[(l + 1) & 1]
+  BNode* nodes;
+  int32_t node_cap;
+  State* st;
+  int32_t* q[2];        // wave-regime queues, by level parity
+  int32_t* big[2];      // chip-regime lists, by level parity
+  int32_t* small;       // lane-regime list
+  uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
+  double* part1;        // chip regime: per chunk slot 12 doubles (9 sums)
+  double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
+  int32_t n_points;
+  double b_max, b_min;
+};
+
+// (selects, not P.buf[level & 1]: a dynamically indexed member sends the whole by-value Params to scratch memory)
+__device__ __forceinline__ const double* level_in(const Params& P, int level) {
+  return level == 0 ? P.cloud : ((level & 1) ? P.buf[1] : P.buf[0]);
+}
+__device__ __forceinline__ double* level_out(const Params& P, int level) { return (level & 1) ? P.buf[0] : P.buf[1]; }
+__device__ __forceinline__ int32_t* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
+__device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
+
+// ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
+// utils.h:54-73 after the sums: s = {sum x, sum y, sum z, sum xx, xy, xz, yy, yz, zz}
+__device__ __forceinline__ void mean_cov_from_sums(const double* s, int k, double* mean, double* cov) {
+  const double inv_k = 1. / k;
+  #pragma unroll
+  for (int i = 0; i < 3; ++i) mean[i] = s[i] * inv_k;
+  const double S9[9] = {s[3], s[4], s[5], s[4], s[6], s[7], s[5], s[7], s[8]};
+  const double bessel = double(k) / double(k - 1);
+  #pragma unroll
+  for (int r = 0; r < 3; ++r)
+    #pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      double x = S9[3 * r + q] * inv_k;
+      x -= mean[r] * mean[q];
+      cov[3 * r + q] = x * bessel;
+    }
+}
+__device__ __forceinline__ void add_point(double* s, double x, double y, double z) {
+  s[0] += x; s[1] += y; s[2] += z;
+  s[3] += x * x; s[4] += x * y; s[5] += x * z;
+  s[6] += y * y; s[7] += y * z;
+  s[8] += z * z;
+}
+// coordinates of p - mean in the eigen frame (utils.h:85): v_a = col_a . d, contiguous-reduction order
+__device__ __forceinline__ void eigen_coords(const double* V, const double* mean, double x, double y, double z, double* v) {
+  const double d0 = x - mean[0], d1 = y - mean[1], d2 = z - mean[2];
+  v[0] = madicp_host::sum3c(V[0] * d0, V[3] * d1, V[6] * d2);
+  v[1] = madicp_host::sum3c(V[1] * d0, V[4] * d1, V[7] * d2);
+  v[2] = madicp_host::sum3c(V[2] * d0, V[5] * d1, V[8] * d2);
+}
+// the split test (mad_tree.cpp:96): (p - mean) . col2 < 0  — the same products as v[2] above, commuted
+__device__ __forceinline__ bool goes_left(const double* mean, const double* col2, double x, double y, double z) {
+  const double d0 = x - mean[0], d1 = y - mean[1], d2 = z - mean[2];
+  return madicp_host::sum3c(d0 * col2[0], d1 * col2[1], d2 * col2[2]) < 0.0;
+}
+__device__ __forceinline__ void minmax_update(double* lo, double* hi, const double* v) {
+  #pragma unroll
+  for (int a = 0; a < 3; ++a) {  // `if`, not fmin/fmax: a NaN coordinate leaves the running value alone (utils.h:87-88)
+    if (v[a] < lo[a]) lo[a] = v[a];
+    if (hi[a] < v[a]) hi[a] = v[a];
+  }
+}
+
+// what the children of an internal node inherit (mad_tree.cpp:64-74,90-93)
+__device__ __forceinline__ void make_child(BNode& c, const BNode& p, int parent_id, const double* col0, double ext0, int n_parent,
+                                           double b_min, int begin, int end, bool is_left) {
+  int fl = 0;
+  if (p.flags & kHasPlane) {
+    fl |= kHasPlane;
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) c.plane_n[i] = p.plane_n[i];
+  } else if (ext0 < b_min) {
+    fl |= kHasPlane;
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) c.plane_n[i] = col0[i];
+  } else {
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) c.plane_n[i] = 0.0;
+  }
+  if (n_parent >= 3 || !(p.flags & kHasSmall)) {
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) c.small_n[i] = col0[i];
+  } else {
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) c.small_n[i] = p.small_n[i];
+  }
+  fl |= kHasSmall;
+  c.flags = fl;
+  c.begin = begin;
+  c.end = end;
+  c.mid = 0;
+  c.left_turns = p.left_turns + (is_left ? 1 : 0);
+  c.level = p.level + 1;
+  c.parent = parent_id;
+  c.child = -1;
+  c.bbox0 = 0.0;
+}
+
+// queue a freshly created child for the regime its size calls for
+__device__ __forceinline__ void enqueue_child(const Params& P, int id, int n, int level /* of the child */) {
+  State* st = P.st;
+  if (level > kMaxLevels) {
+    st->error = 2;
+    return;
+  }
+  if (n <= kSmallMax) {
+    P.small[atomicAdd(&st->small_count, 1)] = id;
+    return;
+  }
+  if (n > kChipMin && level < kChipLevels) {
+    const int pos = atomicAdd(&st->big_count[level], 1);
+    if (pos < kMaxBig) {
+      level_big(P, level)[pos] = id;
+      return;
+    }
+  }
+  level_q(P, level)[atomicAdd(&st->q_count[level], 1)] = id;
+}
+
+// two temporary nodes for the children; -1 when the array is full (cannot happen: a tree over n points has < 2n nodes)
+__device__ __forceinline__ int alloc_children(const Params& P) {
+  const int c = atomicAdd(&P.st->n_nodes, 2);
+  if (c + 2 > P.node_cap) {
+    P.st->error = 1;
+    return -1;
+  }
+  return c;
+}
+
+// the surface normal of a leaf (mad_tree.cpp:64-74)
+__device__ __forceinline__ void leaf_normal(const BNode& nd, int n, const double* V, double* out) {
+  if (nd.flags & kHasPlane) {
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = nd.plane_n[i];
+  } else if (n < 3 && (nd.flags & kHasSmall)) {
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = nd.small_n[i];
+  } else {
+    out[0] = V[0]; out[1] = V[3]; out[2] = V[6];
+  }
+}
+
+// ---- wave helpers ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {  // xor butterfly: every lane ends with the same bits
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min_keep(double v) {  // min with "keep mine unless the other is smaller"
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double o = __shfl_xor(v, m, 64);
+    if (o < v) v = o;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_max_keep(double v) {
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double o = __shfl_xor(v, m, 64);
+    if (v < o) v = o;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_int(int v) {
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ---- init ---------------------------------------------------------------------------------------------------
+__global__ void tb_init(const Params P) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  State* st = P.st;
+  BNode& r = P.nodes[0];
+  #pragma unroll
+  for (int i = 0; i < 3; ++i) { r.mean[i] = 0; r.dir[i] = 0; r.col0[i] = 0; r.plane_n[i] = 0; r.small_n[i] = 0; }
+  r.bbox0 = 0.0;
+  r.begin = 0;
+  r.end = P.n_points;
+  r.mid = 0;
+  r.left_turns = 0;
+  r.flags = 0;
+  r.level = 0;
+  r.parent = -1;
+  r.child = -1;
+  st->n_nodes = 1;
+  enqueue_child(P, 0, P.n_points, 0);
+}
+
+// ---- wave regime: one wavefront per node ------------------------------------------------------------------------
+__device__ __forceinline__ void wave_node(const Params& P, int id) {
+  const int lane = threadIdx.x & 63;
+  BNode& nd = P.nodes[id];
+  const int b = nd.begin, e = nd.end, n = e - b, level = nd.level;
+  const double* __restrict__ in = level_in(P, level);
+  double mean[3], V[9], w[3], ext[3];
+  if (nd.flags & kLeafPending) {  // a chip-regime node that turned out to be a leaf: statistics are already there
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) mean[i] = nd.mean[i];
+    V[0] = nd.col0[0]; V[3] = nd.col0[1]; V[6] = nd.col0[2];
+  } else {
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int i = b + lane; i < e; i += 64) add_point(s, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2]);
+    #pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    double cov[9];
+    mean_cov_from_sums(s, n, mean, cov);
+    madicp_host::eig3_sym(cov, w, V);
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int nl = 0;
+#pragma unroll 4
+    for (int i = b + lane; i < e; i += 64) {
+      double v[3];
+      eigen_coords(V, mean, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2], v);
+      minmax_update(lo, hi, v);
+      nl += (v[2] < 0.0) ? 1 : 0;
+    }
+    #pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = wave_min_keep(lo[a]);
+      hi[a] = wave_max_keep(hi[a]);
+      ext[a] = hi[a] - lo[a];
+    }
+    nl = wave_sum_int(nl);
+    nd.bbox0 = ext[0];
+    const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
+    if (!leaf) {
+      const double col0[3] = {V[0], V[3], V[6]}, col2[3] = {V[2], V[5], V[8]};
+      const int mid = b + nl;
+      double* __restrict__ out = level_out(P, level);
+      int lpos = b, rpos = mid;
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      for (int base = b; base < e; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < e;
+        double x = 0, y = 0, z = 0;
+        if (valid) { x = in[3 * (long)i]; y = in[3 * (long)i + 1]; z = in[3 * (long)i + 2]; }
+        const bool left = valid && goes_left(mean, col2, x, y, z);
+        const unsigned long long lm = __ballot(left), vm = __ballot(valid);
+        const unsigned long long rm = vm & ~lm;
+        if (valid) {
+          const long d = left ? lpos + __popcll(lm & lt) : rpos + __popcll(rm & lt);
+          out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+        }
+        lpos += __popcll(lm);
+        rpos += __popcll(rm);
+      }
+      int c = 0;
+      if (lane == 0) c = alloc_children(P);
+      c = __shfl(c, 0, 64);
+      if (lane == 0) {
+        if (c >= 0) {
+          make_child(P.nodes[c], nd, id, col0, ext[0], n, P.b_min, b, mid, true);
+          make_child(P.nodes[c + 1], nd, id, col0, ext[0], n, P.b_min, mid, e, false);
+          enqueue_child(P, c, mid - b, level + 1);
+          enqueue_child(P, c + 1, e - mid, level + 1);
+        }
+        #pragma unroll
+        for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = col2[i]; nd.col0[i] = col0[i]; }
+        nd.mid = mid;
+        nd.child = c;
+        nd.flags |= kDone;
+      }
+      return;
+    }
+  }
+  // leaf: normal, and the member nearest to the centroid (first one on ties, mad_tree.cpp:76-86)
+  double best = 1.7976931348623157e308;
+  int besti = 0x7fffffff;
+  for (int i = b + lane; i < e; i += 64) {
+    const double d[3] = {in[3 * (long)i] - mean[0], in[3 * (long)i + 1] - mean[1], in[3 * (long)i + 2] - mean[2]};
+    const double dist = madicp_host::norm3(d);
+    if (dist < best) { best = dist; besti = i; }
+  }
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double ob = __shfl_xor(best, m, 64);
+    const int oi = __shfl_xor(besti, m, 64);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (besti == 0x7fffffff) besti = b;  // every distance NaN: the reference keeps *begin
+  if (lane == 0) {
+    double nrm[3];
+    leaf_normal(nd, n, V, nrm);
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) { nd.mean[i] = in[3 * (long)besti + i]; nd.dir[i] = nrm[i]; }
+    nd.flags = (nd.flags & ~kLeafPending) | kLeaf | kDone;
+    P.leaf_start[b] = 1u;
+  }
+}
+
+__global__ __launch_bounds__(256) void tb_level_wave(const Params P, int level) {
+  const int cnt = P.st->q_count[level];
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  const int32_t* q = level_q(P, level);
+  for (int t = wave; t < cnt; t += n_waves) wave_node(P, q[t]);
+}
+
+// ---- chip regime: one workgroup per 2048-point chunk of a big node; three kernels per level --------------------
+// chunk slots of this level: exclusive prefix of the per-node chunk counts (list order); every workgroup computes it
+struct ChunkMap {
+  int node_slot;  // index into the level's big list
+  int chunk;      // chunk of that node
+  int first_slot; // slot of the node's chunk 0
+  int n_chunks;   // chunks of the node
+};
+__device__ __forceinline__ int chip_prefix(const Params& P, int level, int* s_off /* LDS [kMaxBig + 1] */) {
+  const int cnt = min(P.st->big_count[level], kMaxBig);
+  const int32_t* big = level_big(P, level);
+  // 256 threads, <= 256 entries: Hillis-Steele inclusive scan in LDS
+  int v = 0;
+  if ((int)threadIdx.x < cnt) {
+    const BNode& nd = P.nodes[big[threadIdx.x]];
+    v = (nd.end - nd.begin + kChunk - 1) / kChunk;
+  }
+  __shared__ int s_tmp[2][kMaxBig];
+  int cur = 0;
+  s_tmp[0][threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 1; d < kMaxBig; d <<= 1) {
+    int x = s_tmp[cur][threadIdx.x];
+    if ((int)threadIdx.x >= d) x += s_tmp[cur][threadIdx.x - d];
+    s_tmp[cur ^ 1][threadIdx.x] = x;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s_off[0] = 0;
+  s_off[threadIdx.x + 1] = s_tmp[cur][threadIdx.x];
+  __syncthreads();
+  return cnt;
+}
+__device__ __forceinline__ ChunkMap chip_find(const int* s_off, int cnt, int slot) {
+  int lo = 0, hi = cnt;  // largest j with s_off[j] <= slot
+  while (hi - lo > 1) {
+    const int m = (lo + hi) >> 1;
+    if (s_off[m] <= slot) lo = m; else hi = m;
+  }
+  ChunkMap cm;
+  cm.node_slot = lo;
+  cm.first_slot = s_off[lo];
+  cm.chunk = slot - s_off[lo];
+  cm.n_chunks = s_off[lo + 1] - s_off[lo];
+  return cm;
+}
+
+// C1: per-chunk sums
+__global__ __launch_bounds__(256) void tb_chip_sums(const Params P, int level) {
+  __shared__ int s_off[kMaxBig + 1];
+  __shared__ double s_red[4][9];
+  const int cnt = chip_prefix(P, level, s_off);
+  const int total = s_off[cnt];
+  const double* __restrict__ in = level_in(P, level);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
+    const ChunkMap cm = chip_find(s_off, cnt, slot);
+    const BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
+    const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int i = cb + (int)threadIdx.x; i < ce; i += 256) add_point(s, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2]);
+    #pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    if (lane == 0)
+      #pragma unroll
+      for (int k = 0; k < 9; ++k) s_red[wv][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 9) P.part1[(long)slot * 12 + threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// C2: node statistics (recombined by every chunk of the node, chunk order), extents and left count of the chunk
+__global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) {
+  __shared__ int s_off[kMaxBig + 1];
+  __shared__ double s_tot[9], s_mean[3], s_V[9];
+  __shared__ double s_lo[4][3], s_hi[4][3];
+  __shared__ int s_nl[4];
+  const int cnt = chip_prefix(P, level, s_off);
+  const int total = s_off[cnt];
+  const double* __restrict__ in = level_in(P, level);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
+    const ChunkMap cm = chip_find(s_off, cnt, slot);
+    BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
+    const int n = nd.end - nd.begin;
+    if (threadIdx.x < 9) {
+      double a = 0.0;
+      for (int c = 0; c < cm.n_chunks; ++c) a += P.part1[(long)(cm.first_slot + c) * 12 + threadIdx.x];
+      s_tot[threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0, every lane the same values
+      double tot[9], mean[3], cov[9], w[3], V[9];
+      #pragma unroll
+      for (int k = 0; k < 9; ++k) tot[k] = s_tot[k];
+      mean_cov_from_sums(tot, n, mean, cov);
+      madicp_host::eig3_sym(cov, w, V);
+      if (threadIdx.x == 0) {
+        #pragma unroll
+        for (int k = 0; k < 3; ++k) s_mean[k] = mean[k];
+        #pragma unroll
+        for (int k = 0; k < 9; ++k) s_V[k] = V[k];
+        if (cm.chunk == 0) {
+          #pragma unroll
+          for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = V[3 * k + 2]; nd.col0[k] = V[3 * k]; }
+        }
+      }
+    }
+    __syncthreads();
+    double mean[3], V[9];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) mean[k] = s_mean[k];
+    #pragma unroll
+    for (int k = 0; k < 9; ++k) V[k] = s_V[k];
+    const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int nl = 0;
+#pragma unroll 4
+    for (int i = cb + (int)threadIdx.x; i < ce; i += 256) {
+      double v[3];
+      eigen_coords(V, mean, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2], v);
+      minmax_update(lo, hi, v);
+      nl += (v[2] < 0.0) ? 1 : 0;
+    }
+    #pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = wave_min_keep(lo[a]);
+      hi[a] = wave_max_keep(hi[a]);
+    }
+    nl = wave_sum_int(nl);
+    if (lane == 0) {
+      #pragma unroll
+      for (int a = 0; a < 3; ++a) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
+      s_nl[wv] = nl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double L[3], H[3];
+      #pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        L[a] = s_lo[0][a]; H[a] = s_hi[0][a];
+        #pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          if (s_lo[k][a] < L[a]) L[a] = s_lo[k][a];
+          if (H[a] < s_hi[k][a]) H[a] = s_hi[k][a];
+        }
+        P.part2[(long)slot * 8 + a] = L[a];
+        P.part2[(long)slot * 8 + 3 + a] = H[a];
+      }
+      P.part2[(long)slot * 8 + 6] = (double)(s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3]);
+    }
+    __syncthreads();
+  }
+}
+
+// C3: leaf test, children, stable scatter of the chunk
+__global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level) {
+  __shared__ int s_off[kMaxBig + 1];
+  __shared__ double s_ext[3];
+  __shared__ int s_before, s_left_total;
+  __shared__ int s_wsum[4];
+  const int cnt = chip_prefix(P, level, s_off);
+  const int total = s_off[cnt];
+  const double* __restrict__ in = level_in(P, level);
+  double* __restrict__ out = level_out(P, level);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
+    const ChunkMap cm = chip_find(s_off, cnt, slot);
+    const int id = level_big(P, level)[cm.node_slot];
+    BNode& nd = P.nodes[id];
+    const int b = nd.begin, e = nd.end, n = e - b;
+    if (threadIdx.x < 3) {
+      const int a = threadIdx.x;
+      double L = 0.0, H = 0.0;
+      for (int c = 0; c < cm.n_chunks; ++c) {
+        const double l = P.part2[(long)(cm.first_slot + c) * 8 + a], h = P.part2[(long)(cm.first_slot + c) * 8 + 3 + a];
+        if (l < L) L = l;
+        if (H < h) H = h;
+      }
+      s_ext[a] = H - L;
+    } else if (threadIdx.x == 3) {
+      int before = 0, tot = 0;
+      for (int c = 0; c < cm.n_chunks; ++c) {
+        const int v = (int)P.part2[(long)(cm.first_slot + c) * 8 + 6];
+        if (c < cm.chunk) before += v;
+        tot += v;
+      }
+      s_before = before;
+      s_left_total = tot;
+    }
+    __syncthreads();
+    const double ext0 = s_ext[0], ext2 = s_ext[2];
+    const int nl = s_left_total, before = s_before;
+    const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
+    const int mid = b + nl;
+    double mean[3], col2[3];
+    #pragma unroll
+    for (int k = 0; k < 3; ++k) { mean[k] = nd.mean[k]; col2[k] = nd.dir[k]; }
+    __syncthreads();  // (everybody has read the node before chunk 0 rewrites parts of it)
+    if (leaf) {
+      if (cm.chunk == 0 && threadIdx.x == 0) {  // rare: finished by the wave regime of the next level (nearest member)
+        nd.bbox0 = ext0;
+        nd.flags |= kLeafPending;
+        level_q(P, level + 1)[atomicAdd(&P.st->q_count[level + 1], 1)] = id;
+      }
+      continue;
+    }
+    if (cm.chunk == 0 && threadIdx.x == 0) {
+      const double col0[3] = {nd.col0[0], nd.col0[1], nd.col0[2]};
+      const int c = alloc_children(P);
+      if (c >= 0) {
+        make_child(P.nodes[c], nd, id, col0, ext0, n, P.b_min, b, mid, true);
+        make_child(P.nodes[c + 1], nd, id, col0, ext0, n, P.b_min, mid, e, false);
+        enqueue_child(P, c, mid - b, level + 1);
+        enqueue_child(P, c + 1, e - mid, level + 1);
+      }
+      nd.bbox0 = ext0;
+      nd.mid = mid;
+      nd.child = c;
+      nd.flags |= kDone;
+    }
+    // thread t owns points cb + 8 t .. cb + 8 t + 7 (consecutive: one scan keeps the partition stable)
+    const int cb = b + cm.chunk * kChunk, ce = min(cb + kChunk, e);
+    const int i0 = cb + 8 * (int)threadIdx.x;
+    double px[8], py[8], pz[8];
+    unsigned int lmask = 0;
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k;
+      px[k] = py[k] = pz[k] = 0.0;
+      if (i < ce) {
+        px[k] = in[3 * (long)i]; py[k] = in[3 * (long)i + 1]; pz[k] = in[3 * (long)i + 2];
+        if (goes_left(mean, col2, px[k], py[k], pz[k])) lmask |= 1u << k;
+        ++nvalid;
+      }
+    }
+    const int mine = __popc(lmask);
+    // exclusive scan of `mine` over the 256 threads: wave scan + wave totals
+    int incl = mine;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int k = 0; k < wv; ++k) wave_off += s_wsum[k];
+    const int lefts_before = wave_off + incl - mine;                   // in this chunk, before this thread
+    const int valid_before = min(8 * (int)threadIdx.x, ce - cb);       // points of this chunk before this thread
+    const int chunk_points_before = cm.chunk * kChunk;                 // points of the node before this chunk
+    long lpos = (long)b + before + lefts_before;
+    long rpos = (long)mid + (chunk_points_before - before) + (valid_before - lefts_before);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < nvalid) {
+        const bool left = (lmask >> k) & 1u;
+        const long d = left ? lpos++ : rpos++;
+        out[3 * d] = px[k]; out[3 * d + 1] = py[k]; out[3 * d + 2] = pz[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- lane regime: one lane builds a whole sub-tree of <= 32 points in its LDS slab, depth first --------------------
+__device__ __forceinline__ double* slab_pt(char* slab, int i) { return reinterpret_cast<double*>(slab + 24 * i); }
+
+__global__ __launch_bounds__(64) void tb_finish_small(const Params P, int start) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x;
+  const int cnt = P.st->small_count;
+  const int t = start + blockIdx.x * 64 + lane;
+  char* slab = lds + (size_t)lane * kSlabStride;
+  const bool have = t < cnt;
+  const int root = have ? P.small[t] : -1;
+  int rb = 0, rn = 0;
+  if (have) {
+    const BNode& r = P.nodes[root];
+    rb = r.begin;
+    rn = r.end - r.begin;
+    const double* __restrict__ in = level_in(P, r.level);
+    for (int i = 0; i < rn; ++i) {
+      double* d = slab_pt(slab, i);
+      d[0] = in[3 * (long)(rb + i)]; d[1] = in[3 * (long)(rb + i) + 1]; d[2] = in[3 * (long)(rb + i) + 2];
+    }
+  }
+  int cur = root;
+  // every node of the sub-tree once; a sub-tree over rn points has at most 2 rn - 1 nodes
+  for (int step = 0; step < 2 * kSmallMax && cur >= 0; ++step) {
+    BNode& nd = P.nodes[cur];
+    const int b = nd.begin - rb, e = nd.end - rb, n = e - b;  // slab coordinates
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = b; i < e; ++i) {
+      const double* p = slab_pt(slab, i);
+      add_point(s, p[0], p[1], p[2]);
+    }
+    double mean[3], cov[9], w[3], V[9];
+    mean_cov_from_sums(s, n, mean, cov);
+    madicp_host::eig3_sym(cov, w, V);
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int nl = 0;
+    for (int i = b; i < e; ++i) {
+      const double* p = slab_pt(slab, i);
+      double v[3];
+      eigen_coords(V, mean, p[0], p[1], p[2], v);
+      minmax_update(lo, hi, v);
+      nl += (v[2] < 0.0) ? 1 : 0;
+    }
+    const double ext0 = hi[0] - lo[0], ext2 = hi[2] - lo[2];
+    nd.bbox0 = ext0;
+    const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
+    bool descended = false;
+    if (!leaf) {
+      const double col0[3] = {V[0], V[3], V[6]}, col2[3] = {V[2], V[5], V[8]};
+      // in-place partition: lefts keep their order, rights end up reversed (any order is a valid MAD-tree input)
+      int i = b, j = e - 1;
+      while (i <= j) {
+        double* p = slab_pt(slab, i);
+        if (goes_left(mean, col2, p[0], p[1], p[2])) {
+          ++i;
+        } else {
+          double* q = slab_pt(slab, j);
+          const double t0 = p[0], t1 = p[1], t2 = p[2];
+          p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+          q[0] = t0; q[1] = t1; q[2] = t2;
+          --j;
+        }
+      }
+      const int mid = i;  // == b + nl
+      const int c = alloc_children(P);
+      #pragma unroll
+      for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = col2[k]; nd.col0[k] = col0[k]; }
+      nd.mid = mid + rb;
+      nd.child = c;
+      nd.flags |= kDone;
+      if (c >= 0 && nd.level + 1 <= kMaxLevels) {
+        make_child(P.nodes[c], nd, cur, col0, ext0, n, P.b_min, b + rb, mid + rb, true);
+        make_child(P.nodes[c + 1], nd, cur, col0, ext0, n, P.b_min, mid + rb, e + rb, false);
+        cur = c;
+        descended = true;
+      } else if (c >= 0) {
+        P.st->error = 2;
+      }
+    } else {
+      double best = 1.7976931348623157e308;
+      int besti = b;
+      for (int i = b; i < e; ++i) {
+        const double* p = slab_pt(slab, i);
+        const double d[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
+        const double dist = madicp_host::norm3(d);
+        if (dist < best) { best = dist; besti = i; }
+      }
+      double nrm[3];
+      leaf_normal(nd, n, V, nrm);
+      const double* p = slab_pt(slab, besti);
+      #pragma unroll
+      for (int k = 0; k < 3; ++k) { nd.mean[k] = p[k]; nd.dir[k] = nrm[k]; }
+      nd.flags |= kLeaf | kDone;
+      P.leaf_start[nd.begin] = 1u;
+    }
+    if (!descended) {  // climb to the next unvisited right sibling
+      int x = cur;
+      cur = -1;
+      while (x != root) {
+        const int par = P.nodes[x].parent;
+        const int left_child = P.nodes[par].child;
+        if (x == left_child) {
+          cur = left_child + 1;
+          break;
+        }
+        x = par;
+      }
+    }
+  }
+}
+
+// ---- exclusive scan of the leaf-start marks (3 kernels, 1024 elements per workgroup) ----------------------------
+constexpr int kScanTile = 1024;
+__global__ __launch_bounds__(256) void tb_scan_tiles(const uint32_t* __restrict__ marks, int n, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t s_w[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t v = 0;
+  #pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (base + k < n) v += marks[base + k];
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// one workgroup: exclusive scan of the tile sums in place (any count), the grand total into *out_total
+__global__ __launch_bounds__(256) void tb_scan_top(uint32_t* __restrict__ tile_sums, int n_tiles, int32_t* __restrict__ out_total) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int base = 0; base < n_tiles; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = i < n_tiles ? tile_sums[i] : 0u;
+    uint32_t incl = v;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    uint32_t off = s_carry;
+    for (int k = 0; k < wv; ++k) off += s_w[k];
+    if (i < n_tiles) tile_sums[i] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = off + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out_total = (int32_t)s_carry;
+}
+// S[i] = marks before i, for i in [0, n]
+__global__ __launch_bounds__(256) void tb_scan_apply(const uint32_t* __restrict__ marks, int n, const uint32_t* __restrict__ tile_sums,
+                                                     uint32_t* __restrict__ S) {
+  __shared__ uint32_t s_w[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  uint32_t m[4], v = 0;
+  #pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    m[k] = (base + k < n) ? marks[base + k] : 0u;
+    v += m[k];
+  }
+  uint32_t incl = v;
+  #pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  uint32_t off = tile_sums[blockIdx.x];
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+  uint32_t run = off + incl - v;
+  #pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k <= n) S[base + k] = run;
+    run += m[k];
+  }
+}
+
+// ---- what the host needs before it can size the tree: root mean, rho, size of the LDS-staged top -----------------
+__global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels) {
+  State* st = P.st;
+  const int n = min(st->n_nodes, P.node_cap);
+  const double o0 = P.nodes[0].mean[0], o1 = P.nodes[0].mean[1], o2 = P.nodes[0].mean[2];
+  double r = 0.0;
+  int tops = 0, lvl = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const BNode& nd = P.nodes[i];
+    lvl = max(lvl, nd.level);
+    if (nd.flags & kLeaf) continue;
+    const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
+    const double d = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+    if (d > r && d < 1.7976931348623157e308) r = d;  // finite only (validate_nodes' rule)
+    if (nd.level < top_levels) ++tops;
+  }
+  r = wave_max_keep(r);
+  tops = wave_sum_int(tops);
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) lvl = max(lvl, __shfl_xor(lvl, m, 64));
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&st->rho_bits, (unsigned long long)__double_as_longlong(r));
+    if (tops) atomicAdd(&st->n_top, tops);
+    atomicMax(&st->max_level, lvl);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->origin[0] = o0; st->origin[1] = o1; st->origin[2] = o2;
+  }
+}
+
+// ---- emission: temporary nodes -> the DFS-preorder madicp_node array ------------------------------------------
+__global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, int n_nodes, const uint32_t* __restrict__ S,
+                                               madicp_node* __restrict__ out, int out_cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  const BNode& nd = nodes[i];
+  const int sb = (int)S[nd.begin];
+  const int idx = 2 * sb + nd.left_turns;
+  if (idx < 0 || idx >= out_cap) return;
+  madicp_node o;
+  #pragma unroll
+  for (int k = 0; k < 3; ++k) { o.mean[k] = nd.mean[k]; o.dir[k] = nd.dir[k]; }
+  o.bbox0 = nd.bbox0;
+  if (nd.flags & kLeaf) {
+    o.right = 0;
+    o.leaf_id = sb;
+  } else {
+    o.right = 2 * ((int)S[nd.mid] - sb);
+    o.leaf_id = -1;
+  }
+  out[idx] = o;
+}
+
+// ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---
+// one workgroup of 1024 threads; a level has at most 1024 internal nodes
+__global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restrict__ nodes, int top_levels, int top_max,
+                                                      int* __restrict__ dfs, unsigned int* __restrict__ link, int2* __restrict__ exits,
+                                                      int* __restrict__ out_n_top) {
+  __shared__ int s_cur[1024], s_next[1024];
+  __shared__ int s_w[16];
+  __shared__ int s_total;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ncur = 0, base = 0;
+  if (nodes[0].right != 0) {
+    ncur = 1;
+    if (threadIdx.x == 0) s_cur[0] = 0;
+  }
+  __syncthreads();
+  for (int lev = 0; lev < top_levels && ncur > 0; ++lev) {
+    const bool on = (int)threadIdx.x < ncur && base + (int)threadIdx.x < top_max - 1;
+    int i = 0, l = 0, r = 0;
+    bool l_leaf = false, r_leaf = false, l_in = false, r_in = false;
+    if (on) {
+      i = s_cur[threadIdx.x];
+      l = i + 1;
+      r = i + nodes[i].right;
+      l_leaf = nodes[l].right == 0;
+      r_leaf = nodes[r].right == 0;
+      const bool deeper = lev + 1 < top_levels;
+      l_in = !l_leaf && deeper;
+      r_in = !r_leaf && deeper;
+    }
+    const int c = (l_in ? 1 : 0) + (r_in ? 1 : 0);
+    int incl = c;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += s_w[k];
+    if (threadIdx.x == 1023) s_total = off + incl;
+    const int excl = off + incl - c;
+    const int next_base = base + ncur;
+    if (on) {
+      const int first = next_base + excl;
+      unsigned int w = (unsigned int)first & kTopFirst;
+      if (l_in) { s_next[excl] = l; w |= kTopLeftIn; }
+      if (r_in) { s_next[excl + (l_in ? 1 : 0)] = r; w |= kTopRightIn; }
+      if (l_leaf) w |= kTopLeftLeaf;
+      if (r_leaf) w |= kTopRightLeaf;
+      dfs[base + threadIdx.x] = i;
+      link[base + threadIdx.x] = w;
+      exits[base + threadIdx.x] = make_int2(l, r);
+    }
+    __syncthreads();
+    base = next_base;
+    ncur = s_total;
+    if ((int)threadIdx.x < ncur) s_cur[threadIdx.x] = s_next[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out_n_top = base;
+}
+
+}  // namespace tb
+}  // namespace madicp

@@ -261,6 +261,29 @@ int64_t orc_pipeline_model_leaves(void* p, double* out, int64_t cap) {
   return int64_t(l.size());
 }
 
+// Pipeline::deskew on its own (pipeline.cpp:79-123) — the checker of the device front-end's madicp_cloud_deskew.
+// pts: (n,3) in / out; out_vel6 (optional): naive_vel of :82-86, what the device entry point is given.
+void orc_deskew(double* pts, int64_t n, const double* Tprev12, const double* Tnow12, double sensor_hz, double* out_vel6) {
+  struct Open : Pipeline {
+    using Pipeline::Pipeline;
+    using Pipeline::deskew;
+  };
+  Open p(sensor_hz, true, 0.2, 0.1, 0.8, 0.1, 0.02, 4, 1, false);
+  ContainerType c = cloud_from(pts, n);
+  const Iso3 Tp = pose_from(Tprev12), Tn = pose_from(Tnow12);
+  p.deskew(&c, Tp, Tn);
+  if (n) std::memcpy(pts, c.data(), size_t(n) * sizeof(Vec3));
+  if (out_vel6) {
+    const double ts = 1. / sensor_hz;
+    const Iso3 rel = compose(inverse(Tp), Tn);
+    const Vec3 w = logMapSO3(rel.R);
+    for (int i = 0; i < 3; ++i) {
+      out_vel6[i] = rel.t[i] / ts;
+      out_vel6[3 + i] = w[i] / ts;
+    }
+  }
+}
+
 int orc_num_procs() { return omp_get_num_procs(); }
 
 }  // extern "C"

@@ -72,6 +72,7 @@ def lib():
         L.orc_pipeline_current_leaves.argtypes = [C.c_void_p, c_dp, C.c_int64]
         L.orc_pipeline_model_leaves.restype = C.c_int64
         L.orc_pipeline_model_leaves.argtypes = [C.c_void_p, c_dp, C.c_int64]
+        L.orc_deskew.argtypes = [c_dp, C.c_int64, c_dp, c_dp, C.c_double, c_dp]
         _LIB = L
     return _LIB
 
@@ -204,6 +205,47 @@ def logmap_so3(R):
     w = np.empty(3)
     lib().orc_logmap_so3(_dp(R), _dp(w))
     return w
+
+
+def deskew(points, T_prev, T_now, sensor_hz):
+    """Pipeline::deskew (pipeline.cpp:79-123): returns (compensated cloud in azimuth order, naive_vel (6,))."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).copy()
+    vel = np.empty(6)
+    lib().orc_deskew(_dp(pts), pts.shape[0], _dp(pose12(T_prev)), _dp(pose12(T_now)), float(sensor_hz), _dp(vel))
+    return pts, vel
+
+
+def ingest_f32(records, min_range, max_range, kitti):
+    """apps/cpp_runners/bin_runner.cpp:126-166 restated in numpy (float32 norm, Eigen's AngleAxisd rotation), the checker
+    of madicp_cloud_ingest_f32.  records: (n, >=3) float32."""
+    r = np.asarray(records, dtype=np.float32)
+    x, y, z = r[:, 0], r[:, 1], r[:, 2]
+    nrm = np.sqrt(x * x + (y * y + z * z))          # Vector3f::norm(): float, unrolled scalar reduction x0 + (x1 + x2)
+    with np.errstate(invalid="ignore"):
+        drop = (nrm.astype(np.float64) < min_range) | (nrm.astype(np.float64) > max_range) | np.isnan(x) | np.isnan(y) | np.isnan(z)
+    p = r[~drop, :3].astype(np.float64)
+    if not kitti:
+        return p
+    X, Y, Z = p[:, 0], p[:, 1], p[:, 2]
+    r0, r1, r2 = Y * 1.0 - Z * 0.0, Z * 0.0 - X * 1.0, X * 0.0 - Y * 0.0   # p.cross((0,0,1))
+    sq = (r0 * r0 + r1 * r1) + r2 * r2                                        # squaredNorm of a contiguous Vector3d
+    nn = np.sqrt(sq)
+    pos = sq > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        a0, a1, a2 = np.where(pos, r0 / nn, r0), np.where(pos, r1 / nn, r1), np.where(pos, r2 / nn, r2)
+    ang = (0.205 * np.pi) / 180.0                                             # VERTICAL_ANGLE_OFFSET, bin_runner.cpp:55
+    s, c = np.sin(ang), np.cos(ang)
+    s0, s1, s2 = s * a0, s * a1, s * a2
+    c0, c1, c2 = (1.0 - c) * a0, (1.0 - c) * a1, (1.0 - c) * a2
+    R = np.empty((p.shape[0], 3, 3))
+    t = c0 * a1; R[:, 0, 1] = t - s2; R[:, 1, 0] = t + s2
+    t = c0 * a2; R[:, 0, 2] = t + s1; R[:, 2, 0] = t - s1
+    t = c1 * a2; R[:, 1, 2] = t - s0; R[:, 2, 1] = t + s0
+    R[:, 0, 0] = c0 * a0 + c; R[:, 1, 1] = c1 * a1 + c; R[:, 2, 2] = c2 * a2 + c
+    out = np.empty_like(p)
+    for i in range(3):
+        out[:, i] = R[:, i, 0] * X + (R[:, i, 1] * Y + R[:, i, 2] * Z)       # row . vector, strided: x0 + (x1 + x2)
+    return out
 
 
 class Pipeline:
