@@ -46,10 +46,25 @@ void Device::shutdown() {
 MADtree::MADtree(ContainerType cloud, double b_max, double b_min, int max_parallel_level) {
   if (cloud.empty()) throw std::invalid_argument("MADtree: empty cloud");
   tree_ = build_tree(cloud.front().data(), static_cast<int64_t>(cloud.size()), b_max, b_min, max_parallel_level);
+  n_leaves_ = tree_.num_leaves();
+  n_nodes_ = tree_.num_nodes();
+}
+
+MADtree::MADtree(DeviceCloud cloud, double b_max, double b_min) {
+  DeviceLock lock(Device::mutex());
+  madicp_ctx* c = Device::ctx();
+  int32_t leaves = 0;
+  check(madicp_tree_build(c, cloud.cloud_id, b_max, b_min, &dev_id_, &leaves), "madicp_tree_build");
+  dev_gen_ = Device::generation();
+  n_leaves_ = leaves;
+  n_nodes_ = 2 * leaves - 1;
+  host_copy_ = false;
 }
 
 MADtree::MADtree(LinearTree&& built) : tree_(std::move(built)) {
   if (tree_.nodes.empty()) throw std::invalid_argument("MADtree: empty tree");
+  n_leaves_ = tree_.num_leaves();
+  n_nodes_ = tree_.num_nodes();
 }
 
 MADtree::~MADtree() {
@@ -59,7 +74,22 @@ MADtree::~MADtree() {
   if (madicp_ctx* c = Device::current(dev_gen_)) madicp_tree_release(c, dev_id_);
 }
 
+void MADtree::fetchHostCopy() {
+  if (host_copy_) return;
+  DeviceLock lock(Device::mutex());
+  madicp_ctx* c = Device::current(dev_gen_);
+  if (!c || dev_id_ < 0) throw std::runtime_error("MADtree: the device context that built this tree is gone");
+  tree_.nodes.resize(static_cast<size_t>(n_nodes_));
+  check(madicp_tree_download(c, dev_id_, tree_.nodes.data(), n_nodes_), "madicp_tree_download");
+  tree_.leaf_nodes.resize(static_cast<size_t>(n_leaves_));
+  for (int32_t i = 0; i < n_nodes_; ++i)
+    if (tree_.nodes[i].right == 0) tree_.leaf_nodes[tree_.nodes[i].leaf_id] = i;
+  host_copy_ = true;
+  pending_ = false;  // the download is the tree as it stands on the device, transforms included
+}
+
 void MADtree::flushTransform() {
+  fetchHostCopy();
   if (!pending_) return;
   transform_tree(tree_, pending_R_, pending_t_);
   pending_ = false;
@@ -81,6 +111,7 @@ int MADtree::deviceId() {
   DeviceLock lock(Device::mutex());
   if (dev_id_ >= 0 && !Device::current(dev_gen_)) dev_id_ = -1;  // the context that held it is gone
   if (dev_id_ < 0) {
+    if (!host_copy_) throw std::runtime_error("MADtree: device-built tree lost with its context");
     flushTransform();
     madicp_ctx* c = Device::ctx();
     check(madicp_tree_upload(c, tree_.nodes.data(), tree_.num_nodes(), tree_.num_leaves(), &dev_id_), "madicp_tree_upload");
@@ -93,6 +124,7 @@ void MADtree::applyTransform(const double* R, const double* t) {
   DeviceLock lock(Device::mutex());
   const bool on_device = dev_id_ >= 0 && Device::current(dev_gen_);
   if (on_device) check(madicp_tree_transform(Device::ctx(), dev_id_, R, t), "madicp_tree_transform");
+  if (!host_copy_) return;         // device-built, never downloaded: the device copy is the only one
   if (pending_) flushTransform();  // (a second transform before the first was needed on the host: compose by applying)
   if (on_device) {
     std::memcpy(pending_R_, R, sizeof(pending_R_));

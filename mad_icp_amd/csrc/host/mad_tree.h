@@ -25,12 +25,18 @@ class MADtree {
   MADtree(ContainerType cloud, double b_max, double b_min, int max_parallel_level);
   // adopt a tree that was built elsewhere (Pipeline::prefetch builds the next scan's tree on another thread)
   explicit MADtree(LinearTree&& built);
+  // build ON THE DEVICE from a cloud that is already resident there (madicp_cloud_*); the host keeps
+  // no copy of the tree unless somebody asks for one (linear(), leafMeans(), search result decoding download it)
+  struct DeviceCloud {
+    int cloud_id;
+  };
+  MADtree(DeviceCloud cloud, double b_max, double b_min);
   ~MADtree();
   MADtree(const MADtree&) = delete;
   MADtree& operator=(const MADtree&) = delete;
 
-  int numLeaves() const { return tree_.num_leaves(); }
-  int numNodes() const { return tree_.num_nodes(); }
+  int numLeaves() const { return n_leaves_; }
+  int numNodes() const { return n_nodes_; }
   const madicp_node& leaf(int leaf_id) { return linear().nodes[tree_.leaf_nodes[leaf_id]]; }
   const LinearTree& linear();       // host copy, with any pending transform applied
   ContainerType leafMeans();        // getLeafs() order (mad_tree.cpp:154-163)
@@ -47,7 +53,10 @@ class MADtree {
 
  private:
   void flushTransform();
+  void fetchHostCopy();   // device-built trees: download the node array on first host-side use
   LinearTree tree_;
+  bool host_copy_ = true; // tree_ holds the nodes (false: device-built and not downloaded yet)
+  int n_leaves_ = 0, n_nodes_ = 0;
   int dev_id_ = -1;
   unsigned dev_gen_ = 0;  // context generation dev_id_ belongs to
   bool pending_ = false;  // host copy still to be transformed by pending_R_, pending_t_

@@ -1,9 +1,11 @@
 #include "pipeline.h"
 
+#include "device.h"
 #include "task_pool.h"
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -53,6 +55,7 @@ Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, 
   loop_time_ = (1. / sensor_hz_) * 1000;
   max_parallel_levels_ = static_cast<int>(std::log2(num_threads));  // pipeline.cpp:64
   TaskPool::instance().set_limit(num_threads);  // omp_set_num_threads(num_threads), pipeline.cpp:65
+  if (const char* e = std::getenv("MAD_ICP_GPU_BUILD")) device_frontend_ = (e[0] == '1');
 }
 
 Pipeline::~Pipeline() {
@@ -66,16 +69,24 @@ const std::vector<Matrix4d> Pipeline::trajectory() const {
   return out;
 }
 
-// pipeline.cpp:79-123 — motion compensation in 1024 azimuth chunks (CPU; out of the GPU scope)
-void Pipeline::deskew(ContainerType& cloud, const Pose& T_prev, const Pose& T_now) {
+// pipeline.cpp:82-86: [translation; logMapSO3(rotation)] of T_prev^-1 T_now over one scan period
+void Pipeline::naiveVelocity(const Pose& T_prev, const Pose& T_now, double* vel) const {
   const double ts = 1. / sensor_hz_;
   const Pose rel = compose(inverse(T_prev), T_now);
-  double w[3], vel[6];
+  double w[3];
   log_so3(rel.R, w);
   for (int i = 0; i < 3; ++i) {
     vel[i] = rel.t[i] / ts;
     vel[3 + i] = w[i] / ts;
   }
+}
+
+// pipeline.cpp:79-123 — motion compensation in 1024 azimuth chunks, host version (the device front-end runs
+// madicp_cloud_deskew instead)
+void Pipeline::deskew(ContainerType& cloud, const Pose& T_prev, const Pose& T_now) {
+  const double ts = 1. / sensor_hz_;
+  double vel[6];
+  naiveVelocity(T_prev, T_now, vel);
   using AzimuthPair = std::pair<double, Vector3d>;
   std::vector<AzimuthPair> sorted(cloud.size());
   for (size_t i = 0; i < sorted.size(); ++i) sorted[i] = std::make_pair(std::atan2(cloud[i][1], cloud[i][0]), cloud[i]);
@@ -131,6 +142,44 @@ void Pipeline::prefetch(ContainerType next_cloud) {
   });
 }
 
+// the device front-end for one frame: the cloud is resident; deskew when the reference would (pipeline.cpp:138-139),
+// build, hand the cloud's buffer back
+std::unique_ptr<MADtree> Pipeline::buildOnDevice(int cloud_id) {
+  DeviceLock lock(Device::mutex());
+  madicp_ctx* ctx = Device::ctx();
+  std::unique_ptr<MADtree> tree;
+  try {
+    if (is_initialized_ && deskew_ && trajectory_.size() > 1) {
+      double vel[6];
+      naiveVelocity(trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1], vel);
+      check(madicp_cloud_deskew(ctx, cloud_id, vel, sensor_hz_, nullptr), "madicp_cloud_deskew");
+    }
+    tree = std::make_unique<MADtree>(MADtree::DeviceCloud{cloud_id}, b_max_, b_min_);
+  } catch (...) {
+    madicp_cloud_release(ctx, cloud_id);
+    throw;
+  }
+  check(madicp_cloud_release(ctx, cloud_id), "madicp_cloud_release");
+  return tree;
+}
+
+void Pipeline::computeRecords(const double& curr_stamp, const float* records, size_t n_records, int stride_floats,
+                              double min_range, double max_range, bool kitti_correction) {
+  is_map_updated_ = false;
+  if (!records || n_records == 0) throw std::invalid_argument("Pipeline::computeRecords: no records");
+  const double t_pre = now_ms();
+  if (prefetched_.valid()) prefetched_.wait();
+  int cloud_id = -1;
+  {
+    DeviceLock lock(Device::mutex());
+    int64_t kept = 0;
+    check(madicp_cloud_ingest_f32(Device::ctx(), records, static_cast<int64_t>(n_records), stride_floats, min_range, max_range,
+                                  kitti_correction ? 1 : 0, &cloud_id, &kept),
+          "madicp_cloud_ingest_f32");
+  }
+  computeWithTree(curr_stamp, buildOnDevice(cloud_id), nullptr, t_pre);
+}
+
 // pipeline.cpp:125-265
 void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   is_map_updated_ = false;
@@ -138,7 +187,16 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   // a tree built ahead for exactly this scan?
   std::unique_ptr<MADtree> current_tree;
   const double t_pre = now_ms();
-  if (prefetched_.valid()) {
+  if (device_frontend_) {
+    if (prefetched_.valid()) prefetched_.wait();
+    int cloud_id = -1;
+    {
+      DeviceLock lock(Device::mutex());
+      check(madicp_cloud_upload(Device::ctx(), curr_cloud.front().data(), static_cast<int64_t>(curr_cloud.size()), &cloud_id),
+            "madicp_cloud_upload");
+    }
+    current_tree = buildOnDevice(cloud_id);
+  } else if (prefetched_.valid()) {
     const bool same = prefetched_n_ == curr_cloud.size() &&
                       std::memcmp(prefetched_first_.data(), curr_cloud.front().data(), 24) == 0 &&
                       std::memcmp(prefetched_last_.data(), curr_cloud.back().data(), 24) == 0 &&
@@ -146,6 +204,12 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
     LinearTree built = prefetched_.get();  // (waits for the builder thread either way)
     if (same) current_tree = std::make_unique<MADtree>(std::move(built));
   }
+  computeWithTree(curr_stamp, std::move(current_tree), &curr_cloud, t_pre);
+}
+
+// the frame step once the scan's tree exists (or, host path, is still to be built from *cloud)
+void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree> current_tree, ContainerType* cloud,
+                               double t_pre) {
   if (!is_initialized_) {
     if (current_tree) {
       auto frame = std::make_unique<Frame>();
@@ -160,7 +224,7 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
       is_map_updated_ = true;
       seq_++;
     } else {
-      initialize(curr_stamp, curr_cloud);
+      initialize(curr_stamp, *cloud);
     }
     current_tree_view_ = keyframes_.back()->tree_.get();
     current_num_leaves_ = size_t(current_tree_view_->numLeaves());
@@ -169,8 +233,8 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
 
   if (!current_tree) {
     if (deskew_ && trajectory_.size() > 1)
-      deskew(curr_cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1]);
-    current_tree = std::make_unique<MADtree>(std::move(curr_cloud), b_max_, b_min_, max_parallel_levels_);
+      deskew(*cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1]);
+    current_tree = std::make_unique<MADtree>(std::move(*cloud), b_max_, b_min_, max_parallel_levels_);
   }
   // resident from now on (frame window, maybe keyframe later); the copy runs on the library's copy stream while the
   // host goes on, and the moving leaves are read from it on the device (pipeline.cpp:143-144,154)

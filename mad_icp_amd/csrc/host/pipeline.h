@@ -62,6 +62,19 @@ class Pipeline {
   // additive (not in the reference): start building the tree of the scan that the NEXT compute() will be given
   void prefetch(ContainerType next_cloud);
 
+  // additive, opt-in: the device front-end.  When on, compute() uploads the scan once and
+  // deskew (pipeline.cpp:79-123) and MADtree::build (mad_tree.cpp:47-130) run on the MI355X; the tree never exists on
+  // the host unless currentLeaves() / modelLeaves() ask for it.  Default: the MAD_ICP_GPU_BUILD environment variable
+  // ("1" = on), else off.  Device-built trees agree with host-built ones statistically, not bitwise
+  // (mad_icp_amd/csrc/hip/tree_build.hip.h), so poses differ from the host path's at the 1e-4 m level.
+  void setDeviceFrontEnd(bool on) { device_frontend_ = on; }
+  bool deviceFrontEnd() const { return device_frontend_; }
+  // additive: one frame straight from sensor records — float32 (x, y, z, intensity ...) `stride_floats` apart, range
+  // filter and optional KITTI correction as in apps/cpp_runners/bin_runner.cpp:126-166 — ingest, deskew, build and
+  // registration all on the device (implies the device front-end for this frame)
+  void computeRecords(const double& curr_stamp, const float* records, size_t n_records, int stride_floats, double min_range,
+                      double max_range, bool kitti_correction);
+
   // instrumentation (not in the reference)
   double lastInliersRatio() const { return last_inliers_ratio_; }
   double lastIcpMs() const { return last_icp_ms_; }
@@ -73,6 +86,9 @@ class Pipeline {
  protected:
   void initialize(const double& curr_stamp, ContainerType& curr_cloud);
   void deskew(ContainerType& curr_cloud, const Pose& T_prev, const Pose& T_now);
+  void naiveVelocity(const Pose& T_prev, const Pose& T_now, double* vel6) const;  // pipeline.cpp:82-86
+  std::unique_ptr<MADtree> buildOnDevice(int cloud_id);  // deskew (if due) + build + release of the cloud
+  void computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree> current_tree, ContainerType* curr_cloud, double t_pre);
 
   MADicp icp_;
   VelEstimator vel_estimator_;
@@ -89,6 +105,7 @@ class Pipeline {
   size_t prefetched_n_ = 0;
   Vector3d prefetched_first_{}, prefetched_last_{};
   double round_ms_estimate_ = 0.05;  // device time of one GN round, from the previous frame (realtime budget)
+  bool device_frontend_ = false;
   bool deskew_, realtime_;
   int num_keyframes_, num_threads_, max_parallel_levels_;
   double sensor_hz_, b_max_, p_th_, b_min_;

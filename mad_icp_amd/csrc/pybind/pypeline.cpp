@@ -31,6 +31,19 @@ PYBIND11_MODULE(pypeline, m) {
          [](Pipeline& self, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {
            self.prefetch(container_from_array(std::move(cloud)));
          })
+    // additive, opt-in: deskew + MAD-tree construction on the device; env MAD_ICP_GPU_BUILD=1
+    .def("setDeviceFrontEnd", &Pipeline::setDeviceFrontEnd, py::arg("on"))
+    .def("deviceFrontEnd", &Pipeline::deviceFrontEnd)
+    // additive: a frame straight from sensor records, (n, >=3) float32 (a KITTI .bin is (n,4)): range filter, optional
+    // KITTI correction (apps/cpp_runners/bin_runner.cpp:126-166), deskew, build and registration on the device
+    .def("computeRecords",
+         [](Pipeline& self, double stamp, py::array_t<float, py::array::c_style | py::array::forcecast> rec, double min_range,
+            double max_range, bool kitti) {
+           if (rec.ndim() != 2 || rec.shape(1) < 3) throw py::cast_error("records must be an (n, >=3) float32 array");
+           self.computeRecords(stamp, rec.data(), static_cast<size_t>(rec.shape(0)), static_cast<int>(rec.shape(1)), min_range,
+                               max_range, kitti);
+         },
+         py::arg("stamp"), py::arg("records"), py::arg("min_range"), py::arg("max_range"), py::arg("kitti_correction") = false)
     // instrumentation, not in the reference
     .def("lastInliersRatio", &Pipeline::lastInliersRatio)
     .def("lastIcpMs", &Pipeline::lastIcpMs)
