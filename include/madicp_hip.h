@@ -223,8 +223,7 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
  * run to run.  The cloud is left untouched.  Synchronises the copy stream once (the leaf count sizes the tree). */
 int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves);
 int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t* out_n_leaves);
-/* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] sub-trees finished by single
- * lanes, out[2..65] nodes handled one-per-wavefront per level, out[66..129] nodes handled chip-wide per level */
+/* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] nodes handled one-per-lane, out[2..65] nodes handled one-per-wavefront per level, out[66..129] nodes handled chip-wide per level */
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
 
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */

