@@ -408,6 +408,43 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
           "note": "queries and outputs resident; one launch = all queries against one tree (pymadtree searchCloud)"}
     ctx.tree_release(dense_id)
 
+    # ---- the device front-end: the query scan's MAD-tree built on the device ----------------
+    front = None
+    try:
+        scan0 = pb["query_scans"][0]
+        cid = ctx.cloud_upload(scan0)
+        for _ in range(3):
+            t_, _nl = ctx.tree_build(cid, B_MAX, B_MIN)
+            ctx.tree_release(t_)
+        ctx.synchronize()
+        tb, tub = [], []
+        for _ in range(15):
+            t1 = time.perf_counter()
+            t_, dev_leaves = ctx.tree_build(cid, B_MAX, B_MIN)
+            ctx.synchronize()
+            tb.append(time.perf_counter() - t1)
+            ctx.tree_release(t_)
+        ctx.cloud_release(cid)
+        for _ in range(8):
+            t1 = time.perf_counter()
+            c2 = ctx.cloud_upload(scan0)
+            t_, _nl = ctx.tree_build(c2, B_MAX, B_MIN)
+            ctx.synchronize()
+            tub.append(time.perf_counter() - t1)
+            ctx.tree_release(t_)
+            ctx.cloud_release(c2)
+        st = ctx.tree_build_stats()
+        front = {"device_tree_build_ms_per_scan": round(float(np.median(tb)) * 1e3, 3),
+                 "device_upload_plus_build_ms_per_scan": round(float(np.median(tub)) * 1e3, 3),
+                 "host_tree_build_ms_per_scan": round(t_build * 1e3, 2),
+                 "points": int(scan0.shape[0]), "device_leaves": int(dev_leaves), "host_leaves": int(Ls[0]),
+                 "levels": int(st["max_level"]),
+                 "note": "madicp_tree_build on a resident cloud (wall time incl. its one host synchronisation); upload = "
+                         "pageable host memory -> pinned staging -> HBM; the host figure is the product's CPU builder on this "
+                         "box's cores (bit-identical to the oracle's), which the streamed headline does NOT include either"}
+    except Exception as e:  # noqa: BLE001 — a secondary figure never takes the bench line down
+        front = {"error": str(e)[:200]}
+
     # ---- the headline: streamed registrations, a different scan every step (measured after the secondary figures:
     # the W warm-up steps below are then the only thing between a busy device and the timed region) --------------
     streamed_loop(ctx, capi, leaves, guesses, tids, args.warmup)
@@ -466,6 +503,7 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                           "note": "round-1 definition: same pre-uploaded scans re-registered, nothing read back"},
         "single_registration_latency_ms": round(lat_ms, 3),
         "host_tree_build_ms_per_scan": round(t_build * 1e3, 2),
+        "front_end": front,
         "nn_descend": nn,
         "roofline": roofline,
         "cpu_baseline": cpu,

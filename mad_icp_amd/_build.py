@@ -17,6 +17,10 @@ ROOT = os.path.dirname(PKG)
 INC = os.path.join(ROOT, "include")
 CSRC = os.path.join(PKG, "csrc")
 
+# MADICP_NATIVE_DIR: build into (and load from, see capi._load) another directory — used by tests/test_redux_variant.py to
+# build the whole stack a second time with other defines without touching the in-tree libraries
+OUT = os.environ.get("MADICP_NATIVE_DIR") or PKG
+
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
 
@@ -79,7 +83,7 @@ def _hip_deps(srcs):
 
 
 def build_hip(force=False):
-    out = os.path.join(PKG, "libmadicp_hip.so")
+    out = os.path.join(OUT, "libmadicp_hip.so")
     srcs = [os.path.join(CSRC, "hip", "madicp_capi.hip")]
     deps = _hip_deps(srcs)
     flags = HIP_FLAGS + EXTRA_HIP_FLAGS
@@ -100,14 +104,14 @@ HOST_SRCS = ("tree_builder.cpp", "host_capi.cpp", "mad_tree.cpp", "mad_icp.cpp",
 def build_host(force=False):
     """libmadicp_host.so: tree builder + the host classes (MADtree, MADicp, VelEstimator, Pipeline).  Links
     against libmadicp_hip.so — the host classes have no other implementation to call."""
-    out = os.path.join(PKG, "libmadicp_host.so")
+    out = os.path.join(OUT, "libmadicp_host.so")
     hdir = os.path.join(CSRC, "host")
     srcs = [os.path.join(hdir, f) for f in HOST_SRCS]
     deps = srcs + _glob(hdir, (".h",)) + _glob(os.path.join(CSRC, "common"), (".h",)) + _glob(INC, (".h",))
     flags = HOST_FLAGS + EXTRA_HOST_FLAGS
     if force or _stale(out, deps, flags):
         _run([CXX] + flags + ["-shared", "-I" + INC, "-I" + hdir] + srcs +
-             ["-o", out, "-L" + PKG, "-lmadicp_hip", "-Wl,-rpath,$ORIGIN", "-pthread"])
+             ["-o", out, "-L" + OUT, "-lmadicp_hip", "-Wl,-rpath,$ORIGIN", "-pthread"])
         _stamp(out, deps, flags)
     return out
 
@@ -117,7 +121,7 @@ def build_pybind(force=False):
 
     hdir = os.path.join(CSRC, "host")
     pdir = os.path.join(CSRC, "pybind")
-    outdir = os.path.join(PKG, "pybind")
+    outdir = os.path.join(OUT, "pybind")
     os.makedirs(outdir, exist_ok=True)
     suffix = sysconfig.get_config_var("EXT_SUFFIX")
     deps_h = (_glob(hdir, (".h",)) + _glob(pdir, (".h",)) + _glob(os.path.join(CSRC, "common"), (".h",)) +
@@ -130,7 +134,7 @@ def build_pybind(force=False):
         if force or _stale(out, [src] + deps_h, flags):
             _run([CXX] + flags + ["-shared", "-fvisibility=hidden", "-I" + INC, "-I" + hdir, "-I" + pdir,
                                   "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src,
-                                  "-o", out, "-L" + PKG, "-lmadicp_host", "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..",
+                                  "-o", out, "-L" + OUT, "-lmadicp_host", "-lmadicp_hip", "-Wl,-rpath,$ORIGIN/..",
                                   "-pthread"])
             _stamp(out, [src] + deps_h, flags)
         built.append(out)

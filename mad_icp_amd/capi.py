@@ -41,7 +41,7 @@ _host = None
 
 
 def _load(name):
-    path = os.path.join(_PKG, name)
+    path = os.path.join(os.environ.get("MADICP_NATIVE_DIR") or _PKG, name)  # (same variable as _build.OUT)
     if name == "libmadicp_hip.so" and os.environ.get("MADICP_HIP_LIB"):
         path = os.environ["MADICP_HIP_LIB"]  # an instrumented build of the same library (tools/stamps.py)
     if not os.path.exists(path):

@@ -19,9 +19,10 @@ c_u8p = C.POINTER(C.c_uint8)
 
 
 def build(force=False):
-    so = os.path.join(_DIR, "libmad_oracle.so")
+    out = os.environ.get("MADICP_ORACLE_DIR")  # a second build with other defines (tests/test_redux_variant.py)
+    so = os.path.join(out or _DIR, "libmad_oracle.so")
     if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _DIR, "-s"])
+        subprocess.check_call(["make", "-C", _DIR, "-s"] + (["OUT=" + out] if out else []))
     return so
 
 

@@ -136,3 +136,98 @@ def test_native_rccl_path_single_rank(ctx):
     for t in tids:
         ctx.tree_release(t)
     ctx.moving_release(mid)
+
+
+# ---- the native RCCL path with more than one rank (runs whenever >= 2 GPUs are visible; skips on a 1-GPU box) ---------
+_NATIVE_WORKER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ["MADICP_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MADICP_ROOT"], "tests"))
+from mad_icp_amd import capi
+from fixtures import street_problem, B_MAX, B_MIN, PARAMS
+rank, world, K, tmp, graph = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+pb = street_problem(max(K, 1))
+ctx = capi.Context(rank)
+idf = os.path.join(tmp, "uid.bin")
+if rank == 0:
+    uid = capi.Context.comm_unique_id()
+    with open(idf + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(idf + ".tmp", idf)
+else:
+    t0 = time.time()
+    while not os.path.exists(idf):
+        if time.time() - t0 > 120:
+            sys.exit(7)
+        time.sleep(0.05)
+    uid = open(idf, "rb").read()
+ctx.comm_init(uid, world, rank)
+if graph:
+    ctx.set_option("comm_graph", 1)
+tids = []
+for k in range(K):
+    if k % world != rank:
+        continue
+    ht = capi.HostTree(pb["keyframe_scans"][k], B_MAX, B_MIN, 2)
+    T = pb["keyframe_poses"][k]
+    ht.transform(T[:3, :3], T[:3, 3])
+    tids.append(ctx.upload(ht))
+qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+mid = ctx.moving_upload(qh.leaf_means())
+r = ctx.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+np.savez(os.path.join(tmp, "rank%d.npz" % rank), X=r["X"], H=r["H"], matched=r["matched"], n_local=len(tids))
+ctx.comm_destroy()
+ctx.close()
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,graph", [(4, 0), (1, 0), (4, 1)])
+def test_native_rccl_path_two_ranks(ctx, tmp_path, K, graph):
+    """Two processes, one GPU each, through libmadicp_hip.so's own communicator: keyframe trees sharded k % 2, one
+    ncclAllReduce of [H b n] per round, matched flags OR-ed once (replaces mad_icp.cpp:106-109 across GPUs).  Both ranks
+    must hold the same pose bit for bit and agree with the single-GPU registration to rounding (the sum order differs).
+    K = 1: rank 1 owns no tree and still has to join every collective.  graph = 1: the RCCL calls captured in the
+    registration's hipGraph."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the native multi-rank path is covered on one GPU by the 1-rank test above)")
+    from fixtures import PARAMS
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_NATIVE_WORKER)
+    env = dict(os.environ, MADICP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(K), str(tmp_path), str(graph)], env=env)
+             for r in range(2)]
+    try:
+        rcs = [p.wait(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0, 0], rcs
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["H"], b["H"]) and np.array_equal(a["matched"], b["matched"])
+    assert int(a["n_local"]) + int(b["n_local"]) == K
+    # against the single-GPU path on this process's context
+    pb = street_problem(max(K, 1))
+    tids = []
+    for k in range(K):
+        ht = capi.HostTree(pb["keyframe_scans"][k], B_MAX, B_MIN, 2)
+        T = pb["keyframe_poses"][k]
+        ht.transform(T[:3, :3], T[:3, 3])
+        tids.append(ctx.upload(ht))
+    qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+    mid = ctx.moving_upload(qh.leaf_means())
+    ref = ctx.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+    d = np.linalg.inv(ref["T"]) @ capi.pose44(a["X"])
+    assert np.linalg.norm(d[:3, 3]) <= 1e-9 and np.abs(d[:3, :3] - np.eye(3)).max() <= 1e-9
+    assert (a["matched"] != ref["matched"]).sum() <= 1
+    for t in tids:
+        ctx.tree_release(t)
+    ctx.moving_release(mid)
