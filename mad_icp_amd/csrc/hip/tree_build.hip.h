@@ -54,7 +54,7 @@ constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
 
-enum : int { kLeaf = 1, kHasPlane = 2, kHasSmall = 4, kDone = 8, kLeafPending = 16 };
+enum : int { kLeaf = 1, kHasPlane = 2, kHasSmall = 4, kDone = 8, kLeafPending = 16, kHasSums = 32 };
 
 struct BNode {          // a node while the tree is being built
   double mean[3];       // internal: centroid; leaf: the member nearest to it
@@ -63,10 +63,11 @@ struct BNode {          // a node while the tree is being built
   double plane_n[3];    // inherited: normal of the top-most flat ancestor (kHasPlane)
   double small_n[3];    // inherited: normal of the nearest ancestor with >= 3 points (kHasSmall)
   double bbox0;
+  double sums[9];       // kHasSums: the nine sums of this node's points, accumulated by the parent's scatter sweep
   int32_t begin, end, mid, left_turns;
   int32_t flags, level, parent, child;  // child: temporary id of the left child, the right one is child + 1
 };
-static_assert(sizeof(BNode) == 160, "BNode layout");
+static_assert(sizeof(BNode) == 232, "BNode layout");
 
 struct Counter {  // one 128-byte line per counter: atomics on different counters do not queue behind each other
   int32_t v;
@@ -293,6 +294,7 @@ struct Split {
   int b, mid, e;
   double col0[3];
   double ext0;
+  double sL[9], sR[9];  // sums of the points that went left / right (the children start from them)
 };
 
 // clamped 8-deep strided access: lane's points i0, i0 + 64, ..., i0 + 448 of [b, e); all twenty-four loads are issued
@@ -325,33 +327,54 @@ __device__ __forceinline__ Split wave_node(const Params& P, int id) {
     V[0] = nd.col0[0]; V[3] = nd.col0[1]; V[6] = nd.col0[2];
   } else {
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
-      double x[kWU], y[kWU], z[kWU];
-      bool ok[kWU];
-      TB_LOAD4(in, i0, e, b, x, y, z, ok)
+    if (nd.flags & kHasSums) {  // the parent's scatter sweep already added this node's points up
 #pragma unroll
-      for (int u = 0; u < kWU; ++u)
-        if (ok[u]) add_point(s, x[u], y[u], z[u]);
+      for (int k = 0; k < 9; ++k) s[k] = nd.sums[k];
+    } else {
+      for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
+        double x[kWU], y[kWU], z[kWU];
+        bool ok[kWU];
+        TB_LOAD4(in, i0, e, b, x, y, z, ok)
+#pragma unroll
+        for (int u = 0; u < kWU; ++u)
+          if (ok[u]) add_point(s, x[u], y[u], z[u]);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
     double cov[9];
     mean_cov_from_sums(s, n, mean, cov);
     madicp_host::eig3_sym(cov, w, V);
+    // ONE sweep for the rest: extents in the eigen frame, the side of every point, and — speculatively, before the leaf
+    // test can be made — the scatter (lefts ascending from b, rights DESCENDING from e - 1: no count needed in advance;
+    // a node that turns out to be a leaf simply leaves its half of the other buffer unused) and the children's sums
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    int nl = 0;
+    double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double* __restrict__ out = level_out(P, level);
+    int lpos = b, rpos = e - 1;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
       double x[kWU], y[kWU], z[kWU];
       bool ok[kWU];
       TB_LOAD4(in, i0, e, b, x, y, z, ok)
 #pragma unroll
-      for (int u = 0; u < kWU; ++u)
+      for (int u = 0; u < kWU; ++u) {  // (wave-uniform: the ballots below need every lane)
+        double v[3] = {0, 0, 0};
         if (ok[u]) {
-          double v[3];
           eigen_coords(V, mean, x[u], y[u], z[u], v);
           minmax_update(lo, hi, v);
-          nl += (v[2] < 0.0) ? 1 : 0;
         }
+        const bool left = ok[u] && v[2] < 0.0;  // the split test of mad_tree.cpp:96 (v[2] holds its very products)
+        const unsigned long long lm = __ballot(left), vm = __ballot(ok[u]);
+        const unsigned long long rm = vm & ~lm;
+        if (ok[u]) {
+          const long d = left ? lpos + __popcll(lm & lt) : rpos - __popcll(rm & lt);
+          out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+          if (left) add_point(sL, x[u], y[u], z[u]); else add_point(sR, x[u], y[u], z[u]);
+        }
+        lpos += __popcll(lm);
+        rpos -= __popcll(rm);
+      }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -359,35 +382,19 @@ __device__ __forceinline__ Split wave_node(const Params& P, int id) {
       hi[a] = wave_max_keep(hi[a]);
       ext[a] = hi[a] - lo[a];
     }
-    nl = wave_sum_int(nl);
+    const int nl = lpos - b;
     if (lane == 0) nd.bbox0 = ext[0];
     const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
     if (!leaf) {
-      const double col2[3] = {V[2], V[5], V[8]};
       const int mid = b + nl;
-      double* __restrict__ out = level_out(P, level);
-      int lpos = b, rpos = mid;
-      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
-        double x[kWU], y[kWU], z[kWU];
-        bool ok[kWU];
-        TB_LOAD4(in, i0, e, b, x, y, z, ok)
 #pragma unroll
-        for (int u = 0; u < kWU; ++u) {  // (wave-uniform: the ballots below need every lane)
-          const bool left = ok[u] && goes_left(mean, col2, x[u], y[u], z[u]);
-          const unsigned long long lm = __ballot(left), vm = __ballot(ok[u]);
-          const unsigned long long rm = vm & ~lm;
-          if (ok[u]) {
-            const long d = left ? lpos + __popcll(lm & lt) : rpos + __popcll(rm & lt);
-            out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
-          }
-          lpos += __popcll(lm);
-          rpos += __popcll(rm);
-        }
+      for (int k = 0; k < 9; ++k) {
+        sp.sL[k] = wave_sum(sL[k]);
+        sp.sR[k] = wave_sum(sR[k]);
       }
       if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = col2[i]; nd.col0[i] = V[3 * i]; }
+        for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = V[3 * i + 2]; nd.col0[i] = V[3 * i]; }
         nd.mid = mid;
       }
       sp.split = true;
@@ -464,17 +471,26 @@ __device__ __forceinline__ Split lane_node(const Params& P, int id) {
     }                                                                                            \
   }
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = b; i < e; i += 4) {
-    TB_LANE4(i)
+  if (nd.flags & kHasSums) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (i + u < e) add_point(s, x[u], y[u], z[u]);
+    for (int k = 0; k < 9; ++k) s[k] = nd.sums[k];
+  } else {
+    for (int i = b; i < e; i += 4) {
+      TB_LANE4(i)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + u < e) add_point(s, x[u], y[u], z[u]);
+    }
   }
   double mean[3], cov[9], w[3], V[9];
   mean_cov_from_sums(s, n, mean, cov);
   madicp_host::eig3_sym(cov, w, V);
+  // one sweep: extents, side, speculative scatter (lefts ascending, rights descending) and the children's sums
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  int nl = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { sp.sL[k] = 0.0; sp.sR[k] = 0.0; }
+  double* __restrict__ out = level_out(P, level);
+  long lp = b, rp = (long)e - 1;
   for (int i = b; i < e; i += 4) {
     TB_LANE4(i)
 #pragma unroll
@@ -483,28 +499,20 @@ __device__ __forceinline__ Split lane_node(const Params& P, int id) {
         double v[3];
         eigen_coords(V, mean, x[u], y[u], z[u], v);
         minmax_update(lo, hi, v);
-        nl += (v[2] < 0.0) ? 1 : 0;
+        const bool left = v[2] < 0.0;
+        const long d = left ? lp++ : rp--;
+        out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+        if (left) add_point(sp.sL, x[u], y[u], z[u]); else add_point(sp.sR, x[u], y[u], z[u]);
       }
   }
+  const int nl = (int)(lp - b);
   const double ext0 = hi[0] - lo[0], ext2 = hi[2] - lo[2];
   nd.bbox0 = ext0;
   const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
   if (!leaf) {
-    const double col2[3] = {V[2], V[5], V[8]};
     const int mid = b + nl;
-    double* __restrict__ out = level_out(P, level);
-    long lp = b, rp = mid;
-    for (int i = b; i < e; i += 4) {  // stable, out of place: lefts from b, rights from mid
-      TB_LANE4(i)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i + u < e) {
-          const long d = goes_left(mean, col2, x[u], y[u], z[u]) ? lp++ : rp++;
-          out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = col2[k]; nd.col0[k] = V[3 * k]; }
+    for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = V[3 * k + 2]; nd.col0[k] = V[3 * k]; }
     nd.mid = mid;
     sp.split = true;
     sp.mid = mid;
@@ -542,6 +550,10 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   const int n = sp.e - sp.b;
   make_child(P.nodes[c], nd, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
   make_child(P.nodes[c + 1], nd, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { P.nodes[c].sums[k] = sp.sL[k]; P.nodes[c + 1].sums[k] = sp.sR[k]; }
+  P.nodes[c].flags |= kHasSums;
+  P.nodes[c + 1].flags |= kHasSums;
   nd.child = c;
   nd.flags |= kDone;
   const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;

