@@ -445,6 +445,37 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
     except Exception as e:  # noqa: BLE001 — a secondary figure never takes the bench line down
         front = {"error": str(e)[:200]}
 
+    # ---- end to end: Pipeline.compute on a short synthetic drive ("an end-to-end Pipeline::compute figure")
+    pipe = None
+    try:
+        from mad_icp_amd import _build as _b
+
+        _b.build_pybind()
+        from mad_icp.src.pybind import pypeline as pm
+
+        scene = synth.Scene(0)
+        drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in range(10)]
+        threads = min(os.cpu_count() or 1, 16)
+        pipe = {"frames": len(drive), "points_per_scan": int(drive[0].shape[0]), "host_threads": threads}
+        for key, dev in (("host_path", False), ("device_front_end", True)):
+            pl = pm.Pipeline(10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)
+            pl.setDeviceFrontEnd(dev)
+            ts = []
+            for i, sc in enumerate(drive):
+                t1 = time.perf_counter()
+                pl.compute(0.1 * i, sc)
+                ts.append(time.perf_counter() - t1)
+            gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(1.0 * (len(drive) - 1))
+            pipe[key] = {"ms_per_frame": round(float(np.median(ts[2:])) * 1e3, 3),
+                         "frames_per_s": round(1.0 / float(np.median(ts[2:])), 1),
+                         "tree_ms": round(pl.lastBuildMs(), 3), "registration_ms": round(pl.lastIcpMs(), 3),
+                         "end_translation_error_m": round(float(np.linalg.norm(np.asarray(pl.currentPose())[:3, 3] - gt[:3, 3])), 4)}
+        pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: host_path = the default (host tree builder, "
+                        "bit-identical to the oracle's, + upload); device_front_end = setDeviceFrontEnd(True): upload, MAD-tree "
+                        "build and registration on the GPU")
+    except Exception as e:  # noqa: BLE001
+        pipe = {"error": str(e)[:200]}
+
     # ---- the headline: streamed registrations, a different scan every step (measured after the secondary figures:
     # the W warm-up steps below are then the only thing between a busy device and the timed region) --------------
     streamed_loop(ctx, capi, leaves, guesses, tids, args.warmup)
@@ -504,6 +535,7 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         "single_registration_latency_ms": round(lat_ms, 3),
         "host_tree_build_ms_per_scan": round(t_build * 1e3, 2),
         "front_end": front,
+        "pipeline_end_to_end": pipe,
         "nn_descend": nn,
         "roofline": roofline,
         "cpu_baseline": cpu,
