@@ -77,12 +77,12 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_buf0 = take(sizeof(double) * 3 * (size_t)nc);
   const size_t o_buf1 = take(sizeof(double) * 3 * (size_t)nc);
   const size_t o_nodes = take(sizeof(tb::BNode) * 2 * (size_t)nc);
-  const size_t o_q0 = take(sizeof(int32_t) * (size_t)nc);
-  const size_t o_q1 = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_q0 = take(sizeof(int4) * ((size_t)nc / tb::kSmallMax + 64));  // wave-regime nodes hold > kSmallMax points
+  const size_t o_q1 = take(sizeof(int4) * ((size_t)nc / tb::kSmallMax + 64));
   const size_t o_big0 = take(sizeof(int32_t) * tb::kMaxBig);
   const size_t o_big1 = take(sizeof(int32_t) * tb::kMaxBig);
-  const size_t o_small0 = take(sizeof(int32_t) * (size_t)nc);
-  const size_t o_small1 = take(sizeof(int32_t) * (size_t)nc);
+  const size_t o_small0 = take(sizeof(int4) * (size_t)nc);
+  const size_t o_small1 = take(sizeof(int4) * (size_t)nc);
   const size_t o_leaf = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_S = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
@@ -107,12 +107,12 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.buf[1] = reinterpret_cast<double*>(b + o_buf1);
   fs.P.nodes = reinterpret_cast<tb::BNode*>(b + o_nodes);
   fs.P.node_cap = static_cast<int32_t>(std::min<int64_t>(2 * nc, 0x7ffffff0));
-  fs.P.q[0] = reinterpret_cast<int32_t*>(b + o_q0);
-  fs.P.q[1] = reinterpret_cast<int32_t*>(b + o_q1);
+  fs.P.q[0] = reinterpret_cast<int4*>(b + o_q0);
+  fs.P.q[1] = reinterpret_cast<int4*>(b + o_q1);
   fs.P.big[0] = reinterpret_cast<int32_t*>(b + o_big0);
   fs.P.big[1] = reinterpret_cast<int32_t*>(b + o_big1);
-  fs.P.small[0] = reinterpret_cast<int32_t*>(b + o_small0);
-  fs.P.small[1] = reinterpret_cast<int32_t*>(b + o_small1);
+  fs.P.small[0] = reinterpret_cast<int4*>(b + o_small0);
+  fs.P.small[1] = reinterpret_cast<int4*>(b + o_small1);
   fs.P.leaf_start = reinterpret_cast<uint32_t*>(b + o_leaf);
   fs.P.part1 = reinterpret_cast<double*>(b + o_p1);
   fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
@@ -375,7 +375,7 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
   // the compensated cloud replaces the input: written to a fresh buffer, the old one goes back to the pool
   void* fresh = nullptr;
   RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)n, ctx->copy, &fresh));
-  int32_t* d_chunks = out_chunks ? reinterpret_cast<int32_t*>(fs->P.q[0]) : nullptr;
+  int32_t* d_chunks = out_chunks ? reinterpret_cast<int32_t*>(fs->P.small[0]) : nullptr;
   hipLaunchKernelGGL(fe::deskew_apply, dim3(tiles), dim3(256), 0, ctx->copy, (const double*)c->xyz, (const uint32_t*)fs->idx[1], (long)n,
                      (const int32_t*)fs->g, (const int32_t*)fs->tile_min, (const double*)(fs->table + kDeskewTableMax), n_poses,
                      static_cast<double*>(fresh), d_chunks);
@@ -532,3 +532,17 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
 }
 
 }  // extern "C"
+
+#ifdef MADICP_TB_STAMPS
+// development only (tools/tb_stamps.py): reset / fetch the per-wave wall-clock stamps of tb_level
+extern "C" int madicp_debug_tb_stamps(madicp_ctx* ctx, unsigned long long* out, int reset) {
+  if (!ctx) return MADICP_ERR_INVALID;
+  hipStreamSynchronize(ctx->copy);
+  const size_t bytes = sizeof(unsigned long long) * 24 * 512 * 4 * 16;
+  if (reset) {
+    std::vector<unsigned long long> init(24 * 512 * 4 * 16, 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(madicp::tb::g_tb_stamps), init.data(), bytes) == hipSuccess ? 0 : MADICP_ERR_DEVICE;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(madicp::tb::g_tb_stamps), bytes) == hipSuccess ? 0 : MADICP_ERR_DEVICE;
+}
+#endif

@@ -47,7 +47,10 @@
 namespace madicp {
 namespace tb {
 
-constexpr int kSmallMax = 32;    // lane regime: a node with at most this many points is handled by one lane
+#ifndef MADICP_TB_SMALL
+#define MADICP_TB_SMALL 32
+#endif
+constexpr int kSmallMax = MADICP_TB_SMALL;  // lane regime: a node with at most this many points is handled by one lane
 constexpr int kChipMin = 4096;   // chip regime above this many points ...
 constexpr int kChipLevels = 6;   // ... during the first levels only (afterwards the wave regime takes any size)
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
@@ -99,9 +102,10 @@ struct Params {
   BNode* nodes;
   int32_t node_cap;
   State* st;
-  int32_t* q[2];        // wave-regime queues, by level parity
+  int4* q[2];           // wave-regime queues, by level parity; an entry is {node id, begin, end, level}: one hop
+                        // from the queue to everything the sweep needs
   int32_t* big[2];      // chip-regime lists, by level parity
-  int32_t* small[2];    // lane-regime queues, by level parity
+  int4* small[2];       // lane-regime queues, by level parity (same entries)
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
   double* part1;        // chip regime: per chunk slot 12 doubles (9 sums)
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
@@ -114,9 +118,9 @@ __device__ __forceinline__ const double* level_in(const Params& P, int level) {
   return level == 0 ? P.cloud : ((level & 1) ? P.buf[1] : P.buf[0]);
 }
 __device__ __forceinline__ double* level_out(const Params& P, int level) { return (level & 1) ? P.buf[0] : P.buf[1]; }
-__device__ __forceinline__ int32_t* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
+__device__ __forceinline__ int4* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
 __device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
-__device__ __forceinline__ int32_t* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
+__device__ __forceinline__ int4* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
 
 // ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
 // utils.h:54-73 after the sums: s = {sum x, sum y, sum z, sum xx, xy, xz, yy, yz, zz}
@@ -162,26 +166,40 @@ __device__ __forceinline__ void minmax_update(double* lo, double* hi, const doub
 }
 
 // what the children of an internal node inherit (mad_tree.cpp:64-74,90-93)
-__device__ __forceinline__ void make_child(BNode& c, const BNode& p, int parent_id, const double* col0, double ext0, int n_parent,
+// what a node read of itself when it started (one batch of independent loads) and hands to its children
+struct Inherit {
+  int flags, left_turns, level;
+  double plane_n[3], small_n[3];
+};
+__device__ __forceinline__ Inherit load_inherit(const BNode& nd, int level) {
+  Inherit h;
+  h.flags = nd.flags;
+  h.left_turns = nd.left_turns;
+  h.level = level;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { h.plane_n[i] = nd.plane_n[i]; h.small_n[i] = nd.small_n[i]; }
+  return h;
+}
+__device__ __forceinline__ void make_child(BNode& c, const Inherit& p, int parent_id, const double* col0, double ext0, int n_parent,
                                            double b_min, int begin, int end, bool is_left) {
   int fl = 0;
   if (p.flags & kHasPlane) {
     fl |= kHasPlane;
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) c.plane_n[i] = p.plane_n[i];
   } else if (ext0 < b_min) {
     fl |= kHasPlane;
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) c.plane_n[i] = col0[i];
   } else {
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) c.plane_n[i] = 0.0;
   }
   if (n_parent >= 3 || !(p.flags & kHasSmall)) {
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) c.small_n[i] = col0[i];
   } else {
-    #pragma unroll
+#pragma unroll
     for (int i = 0; i < 3; ++i) c.small_n[i] = p.small_n[i];
   }
   fl |= kHasSmall;
@@ -203,7 +221,8 @@ __device__ __forceinline__ int regime_of(int n, int level) {
   return 1;
 }
 // queue a node with one atomic of its own (root, children of chip-regime nodes: a handful per level)
-__device__ __forceinline__ void enqueue_single(const Params& P, int id, int n, int level) {
+__device__ __forceinline__ void enqueue_single(const Params& P, int id, int begin, int end, int level) {
+  const int n = end - begin;
   State* st = P.st;
   if (level > kMaxLevels) {
     st->n_nodes.error = 2;
@@ -219,13 +238,13 @@ __device__ __forceinline__ void enqueue_single(const Params& P, int id, int n, i
     kind = 1;
   }
   if (kind == 0)
-    level_small(P, level)[atomicAdd(&st->small_count[level].v, 1)] = id;
+    level_small(P, level)[atomicAdd(&st->small_count[level].v, 1)] = make_int4(id, begin, end, level);
   else
-    level_q(P, level)[atomicAdd(&st->q_count[level].v, 1)] = id;
+    level_q(P, level)[atomicAdd(&st->q_count[level].v, 1)] = make_int4(id, begin, end, level);
 }
 
 // the surface normal of a leaf (mad_tree.cpp:64-74)
-__device__ __forceinline__ void leaf_normal(const BNode& nd, int n, const double* V, double* out) {
+__device__ __forceinline__ void leaf_normal(const Inherit& nd, int n, const double* V, double* out) {
   if (nd.flags & kHasPlane) {
     #pragma unroll
     for (int i = 0; i < 3; ++i) out[i] = nd.plane_n[i];
@@ -282,8 +301,22 @@ __global__ void tb_init(const Params P) {
   r.parent = -1;
   r.child = -1;
   st->n_nodes.v = 1;
-  enqueue_single(P, 0, P.n_points, 0);
+  enqueue_single(P, 0, 0, P.n_points, 0);
 }
+
+// development instrumentation (-DMADICP_TB_STAMPS, tools/tb_stamps.py): per level, the 100 MHz wall clock at a few points
+#ifdef MADICP_TB_STAMPS
+// [level][workgroup < 512][wave 4][slot 16]: plain stores by lane 0 of each wave (no atomics: they perturb what they measure)
+__device__ unsigned long long g_tb_stamps[24][512][4][16];
+__device__ __forceinline__ void tb_stamp(int level, int k) {
+  if (level < 24 && blockIdx.x < 512 && k < 16) g_tb_stamps[level][blockIdx.x][(threadIdx.x >> 6) & 3][k] = wall_clock64();
+}
+#define TB_STAMP_MIN(level, k) tb_stamp(level, k)
+#define TB_STAMP_MAX(level, k) tb_stamp(level, k)
+#else
+#define TB_STAMP_MIN(level, k)
+#define TB_STAMP_MAX(level, k)
+#endif
 
 typedef double vd2a __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load of two doubles at 8-byte alignment
 
@@ -295,6 +328,7 @@ struct Split {
   double col0[3];
   double ext0;
   double sL[9], sR[9];  // sums of the points that went left / right (the children start from them)
+  Inherit inh;          // what the node read of itself when it started
 };
 
 // clamped 8-deep strided access: lane's points i0, i0 + 64, ..., i0 + 448 of [b, e); all twenty-four loads are issued
@@ -310,26 +344,41 @@ constexpr int kWU = 8;
 
 // Everything of a node except handing out the children's ids: statistics, leaf test, a leaf's representative, or the
 // stable scatter of an internal node.  Whole wave, every lane the same control flow.
-__device__ __forceinline__ Split wave_node(const Params& P, int id) {
+__device__ __forceinline__ Split wave_node(const Params& P, const int4 ent) {
   const int lane = threadIdx.x & 63;
+  const int id = ent.x, b = ent.y, e = ent.z, n = e - b, level = ent.w;
   BNode& nd = P.nodes[id];
-  const int b = nd.begin, e = nd.end, n = e - b, level = nd.level;
   const double* __restrict__ in = level_in(P, level);
   Split sp;
   sp.split = false;
   sp.b = b; sp.e = e; sp.mid = b;
   sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
   sp.ext0 = 0.0;
+  // Everything the node needs of itself in ONE batch of independent loads, and its points touched (one load per
+  // 64-byte line, first 1365 points) so that they are on their way while the eigen-solve runs: a level is a chain of
+  // dependent first touches of memory another kernel has just written — count -> queue entry -> node -> points ->
+  // atomics — at ~2 us each, and that chain, not arithmetic or bandwidth, was most of a level's time.
+  sp.inh = load_inherit(nd, level);
+  double s9[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s9[k] = nd.sums[k];
+  double touch[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long j = min(8 * ((long)lane + 64 * u), 3 * (long)n - 1);  // doubles: one per 64-byte line
+    touch[u] = in[3 * (long)b + j];
+  }
   double mean[3], V[9], w[3], ext[3];
-  if (nd.flags & kLeafPending) {  // a chip-regime node that turned out to be a leaf: statistics are already there
+  if (lane == 0) TB_STAMP_MAX(level, 3);
+  if (sp.inh.flags & kLeafPending) {  // a chip-regime node that turned out to be a leaf: statistics are already there
 #pragma unroll
     for (int i = 0; i < 3; ++i) mean[i] = nd.mean[i];
     V[0] = nd.col0[0]; V[3] = nd.col0[1]; V[6] = nd.col0[2];
   } else {
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (nd.flags & kHasSums) {  // the parent's scatter sweep already added this node's points up
+    if (sp.inh.flags & kHasSums) {  // the parent's scatter sweep already added this node's points up
 #pragma unroll
-      for (int k = 0; k < 9; ++k) s[k] = nd.sums[k];
+      for (int k = 0; k < 9; ++k) s[k] = s9[k];
     } else {
       for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
         double x[kWU], y[kWU], z[kWU];
@@ -343,8 +392,12 @@ __device__ __forceinline__ Split wave_node(const Params& P, int id) {
       for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
     }
     double cov[9];
+    if (lane == 0) TB_STAMP_MAX(level, 4);
     mean_cov_from_sums(s, n, mean, cov);
     madicp_host::eig3_sym(cov, w, V);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(touch[u]));  // (the touches are consumed here, not before)
+    if (lane == 0) TB_STAMP_MAX(level, 5);
     // ONE sweep for the rest: extents in the eigen frame, the side of every point, and — speculatively, before the leaf
     // test can be made — the scatter (lefts ascending from b, rights DESCENDING from e - 1: no count needed in advance;
     // a node that turns out to be a leaf simply leaves its half of the other buffer unused) and the children's sums
@@ -376,6 +429,7 @@ __device__ __forceinline__ Split wave_node(const Params& P, int id) {
         rpos -= __popcll(rm);
       }
     }
+    if (lane == 0) TB_STAMP_MAX(level, 6);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       lo[a] = wave_min_keep(lo[a]);
@@ -401,6 +455,7 @@ __device__ __forceinline__ Split wave_node(const Params& P, int id) {
       sp.mid = mid;
       sp.col0[0] = V[0]; sp.col0[1] = V[3]; sp.col0[2] = V[6];
       sp.ext0 = ext[0];
+      if (lane == 0) TB_STAMP_MAX(level, 7);
       return sp;
     }
   }
@@ -421,29 +476,33 @@ __device__ __forceinline__ Split wave_node(const Params& P, int id) {
   if (besti == 0x7fffffff) besti = b;  // every distance NaN: the reference keeps *begin
   if (lane == 0) {
     double nrm[3];
-    leaf_normal(nd, n, V, nrm);
+    leaf_normal(sp.inh, n, V, nrm);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { nd.mean[i] = in[3 * (long)besti + i]; nd.dir[i] = nrm[i]; }
-    nd.flags = (nd.flags & ~kLeafPending) | kLeaf | kDone;
+    nd.flags = (sp.inh.flags & ~kLeafPending) | kLeaf | kDone;
     P.leaf_start[b] = 1u;
   }
   return sp;
 }
 
 // ---- lane regime: one lane per node of at most kSmallMax points ---------------------------------------------------
-__device__ __forceinline__ Split lane_node(const Params& P, int id) {
+__device__ __forceinline__ Split lane_node(const Params& P, const int4 ent) {
+  const int id = ent.x, b = ent.y, e = ent.z, n = e - b, level = ent.w;
   BNode& nd = P.nodes[id];
-  const int b = nd.begin, e = nd.end, n = e - b, level = nd.level;
   const double* __restrict__ in = level_in(P, level);
   Split sp;
   sp.split = false;
   sp.b = b; sp.e = e; sp.mid = b;
   sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
   sp.ext0 = 0.0;
+  sp.inh = load_inherit(nd, level);  // (one batch with the sums below and the first points)
+  double s9[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s9[k] = nd.sums[k];
+  const double touch0 = in[3 * (long)b], touch1 = in[3 * (long)(b + (n - 1) / 2)], touch2 = in[3 * (long)(e - 1) + 2];
   // four points per step, their twelve loads issued together (clamped index, used in order): a lane's loop of one
   // dependent load per iteration is a memory round trip per point
-#define TB_LANE4(i)                                                                              \
-  double x[4], y[4], z[4];                                                                       \
+#define TB_LANE4_INTO(i, PX, PY, PZ)                                                                \
   {                                                                                              \
     /* 12 contiguous doubles = six 16-byte loads (8-byte aligned), clamped to the node's range */ \
     const long j0_ = min((long)(i), (long)e - 4 >= (long)b ? (long)e - 4 : (long)b);            \
@@ -465,15 +524,18 @@ __device__ __forceinline__ Split lane_node(const Params& P, int id) {
       /* point i + u_ sits at window slot u_ + sh_ (sh_ in 0..3); slots past the end are unused */ \
       int k_ = u_ + (int)sh_;                                                                    \
       k_ = (e - b >= 4) ? min(k_, 3) : u_;                                                       \
-      x[u_] = k_ == 0 ? t_[0] : (k_ == 1 ? t_[3] : (k_ == 2 ? t_[6] : t_[9]));                   \
-      y[u_] = k_ == 0 ? t_[1] : (k_ == 1 ? t_[4] : (k_ == 2 ? t_[7] : t_[10]));                  \
-      z[u_] = k_ == 0 ? t_[2] : (k_ == 1 ? t_[5] : (k_ == 2 ? t_[8] : t_[11]));                  \
+      PX[u_] = k_ == 0 ? t_[0] : (k_ == 1 ? t_[3] : (k_ == 2 ? t_[6] : t_[9]));                   \
+      PY[u_] = k_ == 0 ? t_[1] : (k_ == 1 ? t_[4] : (k_ == 2 ? t_[7] : t_[10]));                  \
+      PZ[u_] = k_ == 0 ? t_[2] : (k_ == 1 ? t_[5] : (k_ == 2 ? t_[8] : t_[11]));                  \
     }                                                                                            \
   }
+#define TB_LANE4(i)          \
+  double x[4], y[4], z[4];   \
+  TB_LANE4_INTO(i, x, y, z)
   double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (nd.flags & kHasSums) {
+  if (sp.inh.flags & kHasSums) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = nd.sums[k];
+    for (int k = 0; k < 9; ++k) s[k] = s9[k];
   } else {
     for (int i = b; i < e; i += 4) {
       TB_LANE4(i)
@@ -483,29 +545,43 @@ __device__ __forceinline__ Split lane_node(const Params& P, int id) {
     }
   }
   double mean[3], cov[9], w[3], V[9];
+  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 10);
   mean_cov_from_sums(s, n, mean, cov);
   madicp_host::eig3_sym(cov, w, V);
+  asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));
+  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 11);
   // one sweep: extents, side, speculative scatter (lefts ascending, rights descending) and the children's sums
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 9; ++k) { sp.sL[k] = 0.0; sp.sR[k] = 0.0; }
   double* __restrict__ out = level_out(P, level);
   long lp = b, rp = (long)e - 1;
-  for (int i = b; i < e; i += 4) {
-    TB_LANE4(i)
+  {  // software-pipelined: the next four points are requested before the current four are processed (a lane's loop of
+     // request -> wait -> process is a memory round trip per step, and this sweep was the longest thing on a level)
+    double nx[4], ny[4], nz[4];
+    TB_LANE4_INTO(b, nx, ny, nz)
+    for (int i = b; i < e; i += 4) {
+      double x[4], y[4], z[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (i + u < e) {
-        double v[3];
-        eigen_coords(V, mean, x[u], y[u], z[u], v);
-        minmax_update(lo, hi, v);
-        const bool left = v[2] < 0.0;
-        const long d = left ? lp++ : rp--;
-        out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
-        if (left) add_point(sp.sL, x[u], y[u], z[u]); else add_point(sp.sR, x[u], y[u], z[u]);
+      for (int u = 0; u < 4; ++u) { x[u] = nx[u]; y[u] = ny[u]; z[u] = nz[u]; }
+      if (i + 4 < e) {
+        TB_LANE4_INTO(i + 4, nx, ny, nz)
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + u < e) {
+          double v[3];
+          eigen_coords(V, mean, x[u], y[u], z[u], v);
+          minmax_update(lo, hi, v);
+          const bool left = v[2] < 0.0;
+          const long d = left ? lp++ : rp--;
+          out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+          if (left) add_point(sp.sL, x[u], y[u], z[u]); else add_point(sp.sR, x[u], y[u], z[u]);
+        }
+    }
   }
   const int nl = (int)(lp - b);
+  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 12);
   const double ext0 = hi[0] - lo[0], ext2 = hi[2] - lo[2];
   nd.bbox0 = ext0;
   const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
@@ -533,33 +609,36 @@ __device__ __forceinline__ Split lane_node(const Params& P, int id) {
       }
   }
   double nrm[3];
-  leaf_normal(nd, n, V, nrm);
+  leaf_normal(sp.inh, n, V, nrm);
   nd.mean[0] = bx; nd.mean[1] = by; nd.mean[2] = bz;
 #pragma unroll
   for (int k = 0; k < 3; ++k) nd.dir[k] = nrm[k];
-  nd.flags |= kLeaf | kDone;
+  nd.flags = sp.inh.flags | kLeaf | kDone;
   P.leaf_start[b] = 1u;
+  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 13);
   return sp;
 #undef TB_LANE4
+#undef TB_LANE4_INTO
 }
 
 // the two children of a split node: records, and their places in the next level's queues
 __device__ __forceinline__ void emit_children(const Params& P, int id, const Split& sp, int c, int slot_small, int slot_wave) {
   BNode& nd = P.nodes[id];
-  const int level = nd.level;
+  const int level = sp.inh.level;
   const int n = sp.e - sp.b;
-  make_child(P.nodes[c], nd, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
-  make_child(P.nodes[c + 1], nd, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
+  make_child(P.nodes[c], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
+  make_child(P.nodes[c + 1], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
 #pragma unroll
   for (int k = 0; k < 9; ++k) { P.nodes[c].sums[k] = sp.sL[k]; P.nodes[c + 1].sums[k] = sp.sR[k]; }
   P.nodes[c].flags |= kHasSums;
   P.nodes[c + 1].flags |= kHasSums;
   nd.child = c;
-  nd.flags |= kDone;
+  nd.flags = sp.inh.flags | kDone;
   const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
   // (children of a wave/lane node are never chip-regime: n <= 4096, or past the chip levels)
-  if (nL <= kSmallMax) level_small(P, level + 1)[slot_small++] = c; else level_q(P, level + 1)[slot_wave++] = c;
-  if (nR <= kSmallMax) level_small(P, level + 1)[slot_small] = c + 1; else level_q(P, level + 1)[slot_wave] = c + 1;
+  const int4 eL = make_int4(c, sp.b, sp.mid, level + 1), eR = make_int4(c + 1, sp.mid, sp.e, level + 1);
+  if (nL <= kSmallMax) level_small(P, level + 1)[slot_small++] = eL; else level_q(P, level + 1)[slot_wave++] = eL;
+  if (nR <= kSmallMax) level_small(P, level + 1)[slot_small] = eR; else level_q(P, level + 1)[slot_wave] = eR;
 }
 
 // One level of the wave and lane regimes.  256 threads = 4 wavefronts.
@@ -567,6 +646,7 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cntW = st->q_count[level].v, cntS = st->small_count[level].v;
+  if (lane == 0) TB_STAMP_MIN(level, 0);
   if (level + 1 > kMaxLevels) {
     if ((cntW > 0 || cntS > 0) && blockIdx.x == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
     return;
@@ -575,23 +655,27 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
   // children come from ONE atomic each per workgroup
   __shared__ int s_split[4], s_ns[4], s_nw[4];
   __shared__ int s_base_id, s_base_small, s_base_wave;
-  // The two regimes run side by side: the first ceil(cntW / 4) workgroups (as many as the grid allows, at least one
-  // left for the lanes) take the wave-regime queue, the others the lane-regime queue.
-  const int want_w = (cntW + 3) / 4;
+  // The two regimes run side by side: the FIRST ceil(cntS / 256) workgroups take the lane-regime queue (first, because
+  // workgroups are dispatched in order and only two fit a CU: behind the wave-regime workgroups the lanes would start
+  // when those finish — measured: a level then costs the sum of the two sides instead of the longer one), the others
+  // the wave-regime queue.
   const bool single = gridDim.x == 1;  // (tiny clouds: the one workgroup does both, one after the other)
-  int wgW = min(want_w, (int)gridDim.x);
-  if (!single && cntS > 0 && wgW >= (int)gridDim.x) wgW = (int)gridDim.x - 1;
-  const int32_t* qw = level_q(P, level);
-  if ((int)blockIdx.x < wgW)
-  for (int t0 = blockIdx.x * 4; t0 < cntW; t0 += wgW * 4) {  // (workgroup-uniform trip count)
+  int wgS = min((cntS + 255) / 256, (int)gridDim.x);
+  if (!single && cntW > 0 && wgS >= (int)gridDim.x) wgS = (int)gridDim.x - 1;
+  const int wgW = single ? 1 : (int)gridDim.x - wgS;
+  const int wblock = single ? 0 : (int)blockIdx.x - wgS;  // index among the wave-side workgroups
+  const int4* qw = level_q(P, level);
+  if (wblock >= 0 && wgW > 0)
+  for (int t0 = wblock * 4; t0 < cntW; t0 += wgW * 4) {  // (workgroup-uniform trip count)
     const int t = t0 + wv;
     const bool active = t < cntW;
     int id = -1;
     Split sp;
     sp.split = false;
     if (active) {
-      id = qw[t];
-      sp = wave_node(P, id);
+      const int4 ent = qw[t];
+      id = ent.x;
+      sp = wave_node(P, ent);
     }
     const int nL = sp.split ? sp.mid - sp.b : 0, nR = sp.split ? sp.e - sp.mid : 0;
     const int my_small = sp.split ? ((nL <= kSmallMax) + (nR <= kSmallMax)) : 0;
@@ -604,11 +688,16 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
     if (threadIdx.x == 0) {
       const int tot = s_split[0] + s_split[1] + s_split[2] + s_split[3];
       const int ts = s_ns[0] + s_ns[1] + s_ns[2] + s_ns[3], tw = s_nw[0] + s_nw[1] + s_nw[2] + s_nw[3];
-      s_base_id = tot ? atomicAdd(&st->n_nodes.v, 2 * tot) : 0;
-      s_base_small = ts ? atomicAdd(&st->small_count[level + 1].v, ts) : 0;
-      s_base_wave = tw ? atomicAdd(&st->q_count[level + 1].v, tw) : 0;
+      // unconditional (adding 0 is harmless): three independent returning atomics in flight together, one round trip
+      const int a0 = atomicAdd(&st->n_nodes.v, 2 * tot);
+      const int a1 = atomicAdd(&st->small_count[level + 1].v, ts);
+      const int a2 = atomicAdd(&st->q_count[level + 1].v, tw);
+      s_base_id = a0;
+      s_base_small = a1;
+      s_base_wave = a2;
     }
     __syncthreads();
+    if (lane == 0) TB_STAMP_MAX(level, 8);
     if (sp.split && lane == 0) {
       int before = 0, bs = 0, bw = 0;
       for (int k = 0; k < wv; ++k) { before += s_split[k]; bs += s_ns[k]; bw += s_nw[k]; }
@@ -620,31 +709,35 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
       }
     }
     __syncthreads();
+    if (lane == 0) TB_STAMP_MAX(level, 9);
   }
   // ---- lane regime: a wave takes 64 consecutive queue entries, one per lane; one atomic each per WAVE
-  const int32_t* qs = level_small(P, level);
-  const int wgS = single ? 1 : (int)gridDim.x - wgW;
-  if (!single && ((int)blockIdx.x < wgW || wgS <= 0)) return;
-  const int n_waves = wgS * 4, wave = (single ? 0 : (int)blockIdx.x - wgW) * 4 + wv;
+  const int4* qs = level_small(P, level);
+  if (!single && ((int)blockIdx.x >= wgS || wgS <= 0)) return;
+  const int n_waves = max(wgS, 1) * 4, wave = (int)blockIdx.x * 4 + wv;
   for (int t0 = wave * 64; t0 < cntS; t0 += n_waves * 64) {  // (wave-uniform trip count)
     const int t = t0 + lane;
     int id = -1;
     Split sp;
     sp.split = false;
     if (t < cntS) {
-      id = qs[t];
-      sp = lane_node(P, id);
+      const int4 ent = qs[t];
+      id = ent.x;
+      sp = lane_node(P, ent);
     }
     const unsigned long long sm = __ballot(sp.split);
     const int tot = __popcll(sm);
     if (tot == 0) continue;
     int base_id = 0, base_q = 0;
-    if (lane == 0) {
-      base_id = atomicAdd(&st->n_nodes.v, 2 * tot);
-      base_q = atomicAdd(&st->small_count[level + 1].v, 2 * tot);
+    if (lane == 0) {  // (two independent atomics, one round trip)
+      const int a0 = atomicAdd(&st->n_nodes.v, 2 * tot);
+      const int a1 = atomicAdd(&st->small_count[level + 1].v, 2 * tot);
+      base_id = a0;
+      base_q = a1;
     }
     base_id = __shfl(base_id, 0, 64);
     base_q = __shfl(base_q, 0, 64);
+    if (lane == 0) TB_STAMP_MAX(level, 14);
     if (sp.split) {
       const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       const int rank = __popcll(sm & lt);
@@ -655,7 +748,9 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
         emit_children(P, id, sp, c, base_q + 2 * rank, 0);  // children of a lane node are lane nodes
       }
     }
+    if (lane == 0) TB_STAMP_MAX(level, 15);
   }
+  if (lane == 0) TB_STAMP_MAX(level, 1);
 }
 
 // ---- chip regime: one workgroup per 2048-point chunk of a big node; three kernels per level --------------------
@@ -913,7 +1008,7 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       if (cm.chunk == 0 && threadIdx.x == 0) {  // rare: finished by the wave regime of the next level (nearest member)
         nd.bbox0 = ext0;
         nd.flags |= kLeafPending;
-        level_q(P, level + 1)[atomicAdd(&P.st->q_count[level + 1].v, 1)] = id;
+        level_q(P, level + 1)[atomicAdd(&P.st->q_count[level + 1].v, 1)] = make_int4(id, b, e, level);  // (its points stay at `level`)
       }
       continue;
     }
@@ -923,10 +1018,11 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       if (c + 2 > P.node_cap) {
         P.st->n_nodes.error = 1;
       } else {
-        make_child(P.nodes[c], nd, id, col0, ext0, n, P.b_min, b, mid, true);
-        make_child(P.nodes[c + 1], nd, id, col0, ext0, n, P.b_min, mid, e, false);
-        enqueue_single(P, c, mid - b, level + 1);
-        enqueue_single(P, c + 1, e - mid, level + 1);
+        const Inherit inh = load_inherit(nd, level);
+        make_child(P.nodes[c], inh, id, col0, ext0, n, P.b_min, b, mid, true);
+        make_child(P.nodes[c + 1], inh, id, col0, ext0, n, P.b_min, mid, e, false);
+        enqueue_single(P, c, b, mid, level + 1);
+        enqueue_single(P, c + 1, mid, e, level + 1);
         nd.child = c;
       }
       nd.bbox0 = ext0;
