@@ -77,7 +77,8 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
  * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves),
- * "comm_graph" (0/1: with a communicator, capture the per-round RCCL all-reduces into the registration's hipGraph
+ * "nn_lds_top" (0/1: madicp_nn_search batches of >= 16 k queries stage the tree's top levels in LDS; default 0, measured
+ * slower for single launches), "comm_graph" (0/1: with a communicator, capture the per-round RCCL all-reduces into the registration's hipGraph
  * instead of launching the rounds eagerly)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
 

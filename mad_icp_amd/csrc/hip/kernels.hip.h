@@ -514,6 +514,43 @@ __global__ void nn_descend(const TreeDesc td, const double* __restrict__ q, long
   }
 }
 
+// The same with the tree's top levels staged in LDS (as icp_round does): each workgroup copies the first kTopLevels
+// levels (<= 48 KiB) once and walks them there — ~15 cycles per level instead of an L1/L2 gather — then continues in
+// global memory.  Same descent, same results (descend_multi is the routine the registration uses); pays when a
+// workgroup walks many queries, i.e. for searchCloud-sized batches.  Dynamic LDS: kTopLdsBytes.
+__global__ __launch_bounds__(1024) void nn_descend_top(const TreeDesc td, const double* __restrict__ q, long long n,
+                                                       uint32_t* __restrict__ out_leaf, uint32_t* __restrict__ out_node,
+                                                       double* __restrict__ out_dist, int32_t* __restrict__ out_depth) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
+  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
+  const int n_top = min(td.n_top, kTopMax);
+  {
+    gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
+    const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+    for (int e = threadIdx.x; e < n_top; e += blockDim.x) {
+      s_top[e] = gt[e];
+      reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+    }
+  }
+  __syncthreads();
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double a0[1] = {q[3 * i]}, a1[1] = {q[3 * i + 1]}, a2[1] = {q[3 * i + 2]};
+    const bool wv[1] = {true};
+    int xi[1], xl[1], xd[1];
+    double xm[1] = {3.0e38};
+    descend_multi<1>(td, s_top, s_exit, n_top, a0, a1, a2, wv, xi, xl, xd, xm);
+    if (out_leaf) out_leaf[i] = static_cast<uint32_t>(xl[0]);
+    if (out_node) out_node[i] = static_cast<uint32_t>(xi[0]);
+    if (out_depth) out_depth[i] = xd[0];
+    if (out_dist) {
+      const LeafRec* lr = td.leaves + xl[0];
+      const double e0 = a0[0] - lr->mean[0], e1 = a1[0] - lr->mean[1], e2 = a2[0] - lr->mean[2];
+      out_dist[i] = sqrt(dotc(e0, e1, e2, e0, e1, e2));
+    }
+  }
+}
+
 // mean <- R mean + t ; dir <- R dir   (R row-major)
 struct Pose12 {
   double v[12];  // R row-major, t

@@ -185,6 +185,10 @@ struct madicp_ctx {
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
+  int nn_lds_top = 0;  // option "nn_lds_top": nn_search batches of >= 16 k queries walk the tree's top levels from LDS
+                       // (nn_descend_top).  Off: measured SLOWER for one 120 k-query launch (8.7 vs 6.6 us against a
+                       // 20 k-leaf tree, 10.7 vs 9.2 us against a 120 k-leaf tree) — staging 48 KiB per workgroup costs
+                       // more than the ~11 LDS levels save in a kernel this short
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -778,6 +782,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "lds_stage_min_leaves") {
     if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
     ctx->stage_min_leaves = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (k == "nn_lds_top") {
+    ctx->nn_lds_top = value ? 1 : 0;
   } else if (k == "queries_per_lane") {
     if (value != 0 && value != 1 && value != 2) return fail(MADICP_ERR_INVALID, "queries_per_lane must be 0 (default), 1 or 2");
     ctx->qpt_override = (int)value;
@@ -1013,9 +1019,16 @@ int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* 
   if (!d_queries) return fail(MADICP_ERR_INVALID, "queries is null");
   HIP_TRY(hipSetDevice(ctx->device));
   RC_TRY(wait_tree(ctx, it->second));
-  const long long blocks = std::min<long long>((n + 255) / 256, (long long)ctx->n_cus * 8);
-  hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.desc, d_queries,
-                     (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
+  if (n >= 16384 && it->second.desc.n_top > 0 && ctx->nn_lds_top) {
+    // searchCloud-sized batch: one 1024-thread workgroup per CU stages the tree's top levels in LDS and walks them there
+    const long long blocks = std::min<long long>((n + 1023) / 1024, (long long)ctx->n_cus);
+    hipLaunchKernelGGL(nn_descend_top, dim3((unsigned)blocks), dim3(1024), kTopLdsBytes, ctx->stream, it->second.desc, d_queries,
+                       (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
+  } else {
+    const long long blocks = std::min<long long>((n + 255) / 256, (long long)ctx->n_cus * 8);
+    hipLaunchKernelGGL(nn_descend, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, it->second.desc, d_queries,
+                       (long long)n, d_out_leaf_id, d_out_node, d_out_dist, d_out_depth);
+  }
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }

@@ -72,6 +72,29 @@ def test_nn_search_matches_oracle(ctx, b_max):
     ctx.tree_release(tid)
 
 
+def test_nn_search_lds_top_equals_plain_kernel(ctx):
+    """Option nn_lds_top = 1: batches of >= 16 k queries walk the tree's top levels from LDS (nn_descend_top) instead of
+    the plain kernel (the default: the staged variant measured slower for a single launch).  Same descent: leaf, node,
+    depth and distance identical, and equal to the oracle's."""
+    pb = street_problem(2)
+    s, T = pb["keyframe_scans"][0], pb["keyframe_poses"][0]
+    ht = capi.HostTree(s, B_MAX, B_MIN, 2)
+    ot = O.Tree(s, B_MAX, B_MIN, 2)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    rng = np.random.default_rng(11)
+    q = np.concatenate([pb["query_scans"][0], s[::3] + rng.normal(scale=0.05, size=s[::3].shape)])
+    assert q.shape[0] >= 16384
+    ctx.set_option("nn_lds_top", 1)
+    a = ctx.nn_search(tid, q)
+    ctx.set_option("nn_lds_top", 0)
+    b = ctx.nn_search(tid, q)
+    for k in ("leaf", "node", "depth", "dist"):
+        assert np.array_equal(a[k], b[k]), k
+    leaf, depth, dist = ot.search(q, want_dist=True)
+    assert np.array_equal(a["leaf"], leaf) and np.array_equal(a["depth"], depth) and np.array_equal(a["dist"], dist)
+    ctx.tree_release(tid)
+
+
 def test_screening_fallback_is_exact(ctx):
     """Queries placed ON split planes (and a hair off them) defeat the 16-byte screening test, so the lanes
     must take the exact fp64 path — and still agree with the oracle bit for bit."""
