@@ -60,7 +60,7 @@ def check_exact_properties(ctx, pts, tid, nodes):
     assert np.array_equal(r["leaf"][finite], np.arange(nl)[finite])
 
 
-@pytest.mark.parametrize("name", ["1pt", "2pt", "dup40", "line100", "gauss3000", "street19k", "scan120k"])
+@pytest.mark.parametrize("name", ["1pt", "2pt", "dup40", "line100", "expline36", "gauss3000", "street19k", "scan120k"])
 def test_device_tree_build_vs_host_builder(ctx, name):
     rng = np.random.default_rng(5)
     pts = {
@@ -68,6 +68,9 @@ def test_device_tree_build_vs_host_builder(ctx, name):
         "2pt": lambda: np.array([[1.0, 2.0, 3.0], [1.5, 2.0, 3.0]]),
         "dup40": lambda: np.repeat(np.array([[1.0, 2.0, 3.0]]), 40, axis=0),
         "line100": lambda: np.stack([np.linspace(0, 10, 100), np.zeros(100), np.zeros(100)], 1),
+        # collinear points a factor 100 apart: the mean split peels one point per level — a tree 35 levels deep, past
+        # the launch sequence's first 20 levels (the builder's continue-and-check loop)
+        "expline36": lambda: np.stack([100.0 ** np.arange(36), np.zeros(36), np.zeros(36)], 1),
         "gauss3000": lambda: rng.normal(size=(3000, 3)) * [5, 3, 0.05],
         "street19k": lambda: street_problem(2)["query_scans"][0],
         "scan120k": lambda: synth.make_problem(1, seed=1, n_queries=1)["query_scans"][0],
@@ -82,6 +85,8 @@ def test_device_tree_build_vs_host_builder(ctx, name):
         same_topology = np.mean(nodes["right"] == hn["right"])
         assert same_topology >= 0.99, same_topology
     shared = len(keyset(nodes["mean"][nodes["right"] == 0]) & keyset(hn["mean"][hn["right"] == 0])) / ht.num_leaves
+    if name == "expline36":
+        assert ctx.tree_build_stats()["max_level"] > 20
     if name not in ("line100",):  # (equally spaced collinear points: nearly every leaf is a two-point tie)
         assert shared >= 0.90, shared
     # bit-reproducible: a second build of the same cloud gives the same bytes
