@@ -528,6 +528,9 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
     out[2 + i] = st.q_count[i].v;
     out[66 + i] = st.big_count[i].v;
   }
+#ifdef MADICP_TB_CHECK
+  out[129] = st.n_nodes.pad_[0];  // development: mismatches counted by the in-kernel self-check
+#endif
   return MADICP_OK;
 }
 

@@ -344,7 +344,9 @@ constexpr int kWU = 8;
 
 // Everything of a node except handing out the children's ids: statistics, leaf test, a leaf's representative, or the
 // stable scatter of an internal node.  Whole wave, every lane the same control flow.
-__device__ __forceinline__ Split wave_node(const Params& P, const int4 ent) {
+constexpr int kRedStride = 65;  // doubles per row of a wave's reduction scratch (64 lanes + 1: lanes reading different rows
+                                // hit different banks)
+__device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, double* red /* LDS, 18 x kRedStride of this wave */) {
   const int lane = threadIdx.x & 63;
   const int id = ent.x, b = ent.y, e = ent.z, n = e - b, level = ent.w;
   BNode& nd = P.nodes[id];
@@ -380,7 +382,8 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) s[k] = s9[k];
     } else {
-      for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
+      for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
+        const int i0 = base + lane;
         double x[kWU], y[kWU], z[kWU];
         bool ok[kWU];
         TB_LOAD4(in, i0, e, b, x, y, z, ok)
@@ -406,7 +409,8 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent) {
     double* __restrict__ out = level_out(P, level);
     int lpos = b, rpos = e - 1;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int i0 = b + lane; i0 < e; i0 += 64 * kWU) {
+    for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
+        const int i0 = base + lane;
       double x[kWU], y[kWU], z[kWU];
       bool ok[kWU];
       TB_LOAD4(in, i0, e, b, x, y, z, ok)
@@ -441,10 +445,27 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent) {
     const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
     if (!leaf) {
       const int mid = b + nl;
+      {  // the children's 18 sums are only needed by lane 0 (it writes the child records): through LDS — every lane
+         // stores its 18 partials (column-major, conflict-free), lanes 0..17 add one column each in lane order, lane 0
+         // collects — instead of 18 xor butterflies through the LDS crossbar (216 ds_bpermute: ~3 us of every node)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        sp.sL[k] = wave_sum(sL[k]);
-        sp.sR[k] = wave_sum(sR[k]);
+        for (int k = 0; k < 9; ++k) {
+          red[k * kRedStride + lane] = sL[k];
+          red[(9 + k) * kRedStride + lane] = sR[k];
+        }
+        wave_lds_order();
+        double col = 0.0;
+        if (lane < 18) {
+          for (int j = 0; j < 64; ++j) col += red[lane * kRedStride + j];
+        }
+        wave_lds_order();
+        if (lane < 18) red[lane] = col;  // (row 0, lanes 0..17: every row has been read by now)
+        wave_lds_order();
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { sp.sL[k] = red[k]; sp.sR[k] = red[9 + k]; }
+        }
+        wave_lds_order();  // (the next node's stores must not overtake these reads)
       }
       if (lane == 0) {
 #pragma unroll
@@ -655,6 +676,7 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
   // children come from ONE atomic each per workgroup
   __shared__ int s_split[4], s_ns[4], s_nw[4];
   __shared__ int s_base_id, s_base_small, s_base_wave;
+  __shared__ double s_red[4][18 * kRedStride];
   // The two regimes run side by side: the FIRST ceil(cntS / 256) workgroups take the lane-regime queue (first, because
   // workgroups are dispatched in order and only two fit a CU: behind the wave-regime workgroups the lanes would start
   // when those finish — measured: a level then costs the sum of the two sides instead of the longer one), the others
@@ -675,7 +697,7 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
     if (active) {
       const int4 ent = qw[t];
       id = ent.x;
-      sp = wave_node(P, ent);
+      sp = wave_node(P, ent, s_red[wv]);
     }
     const int nL = sp.split ? sp.mid - sp.b : 0, nR = sp.split ? sp.e - sp.mid : 0;
     const int my_small = sp.split ? ((nL <= kSmallMax) + (nR <= kSmallMax)) : 0;
