@@ -164,6 +164,21 @@ int new_cloud(madicp_ctx* ctx, int64_t n, DevCloud* out) {
   return MADICP_OK;
 }
 
+// a cloud that was allocated but never registered (an error on the way): buffer back to the pool, event destroyed
+int drop_cloud(madicp_ctx* ctx, DevCloud& c, int rc) {
+  EventRef after;
+  if (fence_event(ctx, &after) != MADICP_OK) after = nullptr;
+  pool_free(ctx, c.xyz, after);
+  if (c.ready) hipEventDestroy(c.ready);
+  c = DevCloud{};
+  return rc;
+}
+#define CLOUD_TRY(expr)                                                                                          \
+  do {                                                                                                           \
+    hipError_t e_ = (expr);                                                                                      \
+    if (e_ != hipSuccess) return drop_cloud(ctx, c, fail(MADICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+  } while (0)
+
 int scan_marks(madicp_ctx* ctx, FrontScratch& fs, const uint32_t* marks, int64_t n, int32_t* d_total) {
   const int tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
   hipLaunchKernelGGL(tb::tb_scan_tiles, dim3(tiles), dim3(256), 0, ctx->copy, marks, (int)n, fs.tile_sums);
@@ -187,19 +202,19 @@ int madicp_cloud_upload(madicp_ctx* ctx, const double* xyz, int64_t n, int* out_
   const size_t bytes = sizeof(double) * 3 * (size_t)n;
   const int hb = ctx->h_tree_next;
   ctx->h_tree_next ^= 1;
-  HIP_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
+  CLOUD_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
   if (ctx->h_tree_cap[hb] < bytes) {
-    if (ctx->h_tree[hb]) HIP_TRY(hipHostFree(ctx->h_tree[hb]));
+    if (ctx->h_tree[hb]) CLOUD_TRY(hipHostFree(ctx->h_tree[hb]));
     ctx->h_tree[hb] = nullptr;
     ctx->h_tree_cap[hb] = 0;
     const size_t cap = bytes + bytes / 4;
-    HIP_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
+    CLOUD_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
     ctx->h_tree_cap[hb] = cap;
   }
   std::memcpy(ctx->h_tree[hb], xyz, bytes);
-  HIP_TRY(hipMemcpyAsync(c.xyz, ctx->h_tree[hb], bytes, hipMemcpyHostToDevice, ctx->copy));
-  HIP_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
-  HIP_TRY(hipEventRecord(c.ready, ctx->copy));
+  CLOUD_TRY(hipMemcpyAsync(c.xyz, ctx->h_tree[hb], bytes, hipMemcpyHostToDevice, ctx->copy));
+  CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
+  CLOUD_TRY(hipEventRecord(c.ready, ctx->copy));
   const int id = ctx->next_id++;
   cloud_registry()[ctx][id] = c;
   *out_cloud_id = id;
@@ -279,8 +294,8 @@ int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_rec
   const double angle = (0.205 * M_PI) / 180.0;
   hipLaunchKernelGGL(fe::ingest_scatter, dim3(blocks), dim3(256), 0, ctx->copy, (const float*)d_rec, (long)n_records, stride_floats,
                      (const uint32_t*)keep, (const uint32_t*)fs->S, kitti_correction ? 1 : 0, std::sin(angle), std::cos(angle), c.xyz);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c.ready, ctx->copy));
+  CLOUD_TRY(hipGetLastError());
+  CLOUD_TRY(hipEventRecord(c.ready, ctx->copy));
   const int id = ctx->next_id++;
   cloud_registry()[ctx][id] = c;
   *out_cloud_id = id;
