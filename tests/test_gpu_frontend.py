@@ -266,3 +266,32 @@ def test_pipeline_compute_records(natives, drive):
         a.computeRecords(0.1 * i, rec, 0.7, 120.0, False)
         b.compute(0.1 * i, O.ingest_f32(rec, 0.7, 120.0, False))
         assert np.array_equal(np.asarray(a.currentPose()), np.asarray(b.currentPose()))
+
+
+def test_front_end_abi_errors_are_loud(ctx):
+    """Bad arguments to the additive entry points raise with the library's message; nothing is left half-made."""
+    with pytest.raises(capi.MadIcpError, match="unknown cloud id"):
+        ctx.tree_build(987654, B_MAX, B_MIN)
+    with pytest.raises(capi.MadIcpError, match="unknown cloud id"):
+        ctx.cloud_release(987654)
+    with pytest.raises(capi.MadIcpError, match="unknown cloud id"):
+        ctx.cloud_deskew(987654, np.zeros(6), 10.0)
+    cid = ctx.cloud_upload(np.array([[1.0, 2.0, 3.0], [2.0, 3.0, 4.0]]))
+    with pytest.raises(capi.MadIcpError, match="sensor_hz"):
+        ctx.cloud_deskew(cid, np.zeros(6), 0.0)
+    out = np.empty((5, 3))
+    rc = capi.hip_lib().madicp_cloud_download(ctx._h, cid, out.ctypes.data_as(capi._dp), 5)
+    assert rc != 0 and b"mismatch" in capi.hip_lib().madicp_last_error()
+    ctx.cloud_release(cid)
+    with pytest.raises(capi.MadIcpError, match="no point survives"):
+        ctx.cloud_ingest_f32(np.full((10, 4), 500.0, np.float32), 0.7, 120.0, 0)
+    with pytest.raises(ValueError):
+        ctx.cloud_ingest_f32(np.zeros((10, 2), np.float32), 0.7, 120.0, 0)
+    with pytest.raises(capi.MadIcpError, match="unknown tree id"):
+        ctx.tree_info(987654)
+    # and the context still works afterwards
+    c2 = ctx.cloud_upload(street_problem(2)["query_scans"][0])
+    t2, nl = ctx.tree_build(c2, B_MAX, B_MIN)
+    assert nl > 100
+    ctx.tree_release(t2)
+    ctx.cloud_release(c2)
