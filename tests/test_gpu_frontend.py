@@ -6,7 +6,8 @@ What "parity" means here, stated per piece:
   * ingest        — bit-identical (conversion, float-norm range filter, Eigen's AngleAxisd rotation in its own order).
   * deskew        — every output point is bit-identical to one of the oracle's output points and vice versa (the cloud as
                     a multiset), same time chunks; the ORDER of points whose azimuths tie may differ (std::sort is not
-                    stable and the synthetic scans hold 64 points per azimuth column).
+                    stable and the synthetic scans hold 64 points per azimuth column); with distinct azimuths the output
+                    is the oracle's row for row.
   * tree build    — not bitwise, by construction (mad_icp_amd/csrc/hip/tree_build.hip.h: parallel sums, device
                     trigonometry).  Measured on these inputs and asserted with margin: identical leaf count, identical
                     topology wherever the leaf count is identical, every leaf mean is an input point, >= 90 % of the leaf
@@ -295,3 +296,19 @@ def test_front_end_abi_errors_are_loud(ctx):
     assert nl > 100
     ctx.tree_release(t2)
     ctx.cloud_release(c2)
+
+
+def test_deskew_is_bit_identical_without_azimuth_ties(ctx):
+    """With distinct azimuths (a random cloud: no two points share atan2(y, x)) there is nothing std::sort's instability
+    could reorder, and the device deskew is the oracle's row for row, bit for bit — the device atan2 only has to ORDER
+    the points and place them against the chunk thresholds like libm's does."""
+    rng = np.random.default_rng(21)
+    pts = rng.normal(size=(60000, 3)) * [30.0, 30.0, 2.0]
+    az = np.arctan2(pts[:, 1], pts[:, 0])
+    assert np.unique(az).size == az.size
+    ref, vel = O.deskew(pts, np.eye(4), _pose(0.8, -0.1, 0.03, 0.01), 10.0)
+    cid = ctx.cloud_upload(pts)
+    ctx.cloud_deskew(cid, vel, 10.0)
+    out = ctx.cloud_download(cid)
+    assert np.array_equal(out, ref)
+    ctx.cloud_release(cid)
