@@ -792,19 +792,21 @@ __device__ __forceinline__ int chip_prefix(const Params& P, int level, int* s_of
     const BNode& nd = P.nodes[big[threadIdx.x]];
     v = (nd.end - nd.begin + kChunk - 1) / kChunk;
   }
-  __shared__ int s_tmp[2][kMaxBig];
-  int cur = 0;
-  s_tmp[0][threadIdx.x] = v;
-  __syncthreads();
-  for (int d = 1; d < kMaxBig; d <<= 1) {
-    int x = s_tmp[cur][threadIdx.x];
-    if ((int)threadIdx.x >= d) x += s_tmp[cur][threadIdx.x - d];
-    s_tmp[cur ^ 1][threadIdx.x] = x;
-    cur ^= 1;
-    __syncthreads();
+  // inclusive scan over the 256 threads: wave scans (shuffles) + the four wave totals through LDS (two barriers)
+  __shared__ int s_wtot[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
   }
+  if (lane == 63) s_wtot[wv] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int k = 0; k < wv; ++k) off += s_wtot[k];
   if (threadIdx.x == 0) s_off[0] = 0;
-  s_off[threadIdx.x + 1] = s_tmp[cur][threadIdx.x];
+  s_off[threadIdx.x + 1] = off + incl;
   __syncthreads();
   return cnt;
 }
