@@ -435,7 +435,11 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
         hipLaunchKernelGGL(tb::tb_chip_stats, dim3(chip_grid), dim3(256), 0, s, P, level);
         hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(chip_grid), dim3(256), 0, s, P, level);
       }
-      hipLaunchKernelGGL(tb::tb_level, dim3(level_grid), dim3(256), 0, s, P, level);
+      // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
+      // workgroups that only look at an empty queue still cost their dispatch)
+      const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, n) : n;
+      const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(level_grid, (nodes_max + 3) / 4 + (nodes_max + 255) / 256 + 1)));
+      hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
     }
   };
   auto finish = [&]() -> int {
