@@ -426,8 +426,9 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   HIP_TRY(hipMemsetAsync(P.leaf_start, 0, sizeof(uint32_t) * ((size_t)n + 1), s));
   hipLaunchKernelGGL(tb::tb_init, dim3(1), dim3(64), 0, s, P);
   const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + 64, (int64_t)ctx->n_cus * 4));
-  // one wave per wave-regime node (at most n / 33 of them on a level) and one lane per lane-regime node
-  const int level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + 1)));
+  // one wave per wave-regime node (at most n / 33 of them on a level) and four lanes per small node (most levels hold far
+  // fewer than the n of them this bound allows for: the queues are walked with a stride)
+  const int level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + n / 256 + 1)));
   auto run_levels = [&](int from, int to) {
     for (int level = from; level < to; ++level) {
       if (level < tb::kChipLevels && n > tb::kChipMin) {
@@ -438,7 +439,7 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
       // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
       // workgroups that only look at an empty queue still cost their dispatch)
       const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, n) : n;
-      const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(level_grid, (nodes_max + 3) / 4 + (nodes_max + 255) / 256 + 1)));
+      const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1)));
       hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
     }
   };

@@ -26,10 +26,11 @@
 //          single combiner and the result does not depend on scheduling;
 //   wave  (32 < n <= 4096, or larger past the chip levels): one wavefront per node, no barrier — 4-deep unrolled
 //          strided sums, xor butterfly, wave-uniform eigen-solve, ballot-based stable scatter;
-//   lane  (n <= 32): one LANE per node (most nodes of a MAD-tree hold a handful of points; a wave-uniform eigen-solve
-//          per such node would spend 64 lanes on one), serial loops over its few points, serial stable partition.
+//   quad  (n <= 32): FOUR lanes per node, 16 nodes per wavefront (most nodes of a MAD-tree hold a handful of points; a
+//          wave-uniform eigen-solve per such node would spend 64 lanes on one, a single lane per node makes the sweep a
+//          long serial loop): the wave regime in miniature — quad ballots, two-step xor reductions.
 // Nodes are created in scheduling order into a temporary array; ids and queue slots are handed out by ONE atomic per
-// workgroup (wave regime) or per wavefront (lane regime) on counters that each own a 128-byte line — with one atomic
+// workgroup (wave regime) or per wavefront (quad regime) on counters that each own a 128-byte line — with one atomic
 // per node on shared lines the allocation alone cost 60 us per level (1 600 nodes x 3 atomics x ~12 ns).  The final
 // DFS-preorder position needs no bottom-up pass: the leaves partition the (permuted) point array, so with S[i] = number
 // of leaves that start before point i (one exclusive scan of the leaf-start marks), a node owning points [b, e) that
@@ -50,7 +51,7 @@ namespace tb {
 #ifndef MADICP_TB_SMALL
 #define MADICP_TB_SMALL 32
 #endif
-constexpr int kSmallMax = MADICP_TB_SMALL;  // lane regime: a node with at most this many points is handled by one lane
+constexpr int kSmallMax = MADICP_TB_SMALL;  // quad regime: a node with at most this many points is handled by four lanes
 constexpr int kChipMin = 4096;   // chip regime above this many points ...
 constexpr int kChipLevels = 6;   // ... during the first levels only (afterwards the wave regime takes any size)
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
@@ -92,7 +93,7 @@ struct State {  // counters and results of one build, device resident
   double origin[3];             // the root's mean
   int32_t pad_[20];
   Counter q_count[kMaxLevels + 2];      // wave-regime nodes queued per level
-  Counter small_count[kMaxLevels + 2];  // lane-regime nodes queued per level
+  Counter small_count[kMaxLevels + 2];  // quad-regime nodes queued per level
   Counter big_count[kMaxLevels + 2];    // chip-regime nodes queued per level
 };
 
@@ -105,7 +106,7 @@ struct Params {
   int4* q[2];           // wave-regime queues, by level parity; an entry is {node id, begin, end, level}: one hop
                         // from the queue to everything the sweep needs
   int32_t* big[2];      // chip-regime lists, by level parity
-  int4* small[2];       // lane-regime queues, by level parity (same entries)
+  int4* small[2];       // quad-regime queues, by level parity (same entries)
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
   double* part1;        // chip regime: per chunk slot 12 doubles (9 sums)
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
@@ -506,9 +507,22 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
   return sp;
 }
 
-// ---- lane regime: one lane per node of at most kSmallMax points ---------------------------------------------------
-__device__ __forceinline__ Split lane_node(const Params& P, const int4 ent) {
-  const int id = ent.x, b = ent.y, e = ent.z, n = e - b, level = ent.w;
+// ---- quad regime: FOUR lanes per node of at most kSmallMax points (16 nodes per wavefront) -------------------------
+// A single lane per node makes the per-node chain long because one lane does everything serially (a 32-point sweep is ~12 us on a
+// wave that has its SIMD to itself).  Four lanes share a node here: point i of the node belongs to lane i % 4, the
+// scatter positions come from the quad's four bits of a wave ballot (like the wave regime, with a quad as the "wave"),
+// sums and extents are reduced over the quad with two xor shuffles.  The eigen-solve runs on all four lanes (identical
+// inputs, identical results): 16 solves per wave instead of 64, still 16 times fewer than the wave regime's one.
+// Control flow is wave-uniform (`steps` = the wave's longest node, lanes past their node's end are masked out), so the
+// ballots and shuffles always see whole quads.
+__device__ __forceinline__ double quad_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+__device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool have, int steps) {
+  const int lane = threadIdx.x & 63, ql = lane & 3, qshift = lane & ~3;
+  const int id = have ? ent.x : 0, b = ent.y, e = have ? ent.z : ent.y, n = e - b, level = ent.w;
   BNode& nd = P.nodes[id];
   const double* __restrict__ in = level_in(P, level);
   Split sp;
@@ -516,130 +530,117 @@ __device__ __forceinline__ Split lane_node(const Params& P, const int4 ent) {
   sp.b = b; sp.e = e; sp.mid = b;
   sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
   sp.ext0 = 0.0;
-  sp.inh = load_inherit(nd, level);  // (one batch with the sums below and the first points)
-  double s9[9];
+  sp.inh = load_inherit(nd, level);
+  double s[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) s9[k] = nd.sums[k];
-  const double touch0 = in[3 * (long)b], touch1 = in[3 * (long)(b + (n - 1) / 2)], touch2 = in[3 * (long)(e - 1) + 2];
-  // four points per step, their twelve loads issued together (clamped index, used in order): a lane's loop of one
-  // dependent load per iteration is a memory round trip per point
-#define TB_LANE4_INTO(i, PX, PY, PZ)                                                                \
-  {                                                                                              \
-    /* 12 contiguous doubles = six 16-byte loads (8-byte aligned), clamped to the node's range */ \
-    const long j0_ = min((long)(i), (long)e - 4 >= (long)b ? (long)e - 4 : (long)b);            \
-    const long sh_ = (long)(i) - j0_; /* > 0 only in the last step: the window was pulled back */ \
-    double t_[12];                                                                               \
-    if (e - b >= 4) {                                                                            \
-      const vd2a* q_ = reinterpret_cast<const vd2a*>(in + 3 * j0_);                              \
-      _Pragma("unroll") for (int u_ = 0; u_ < 6; ++u_) {                                         \
-        const vd2a v_ = q_[u_];                                                                  \
-        t_[2 * u_] = v_.x; t_[2 * u_ + 1] = v_.y;                                                \
-      }                                                                                          \
-    } else {                                                                                     \
-      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                         \
-        const long j_ = min((long)(i) + u_, (long)e - 1);                                        \
-        t_[3 * u_] = in[3 * j_]; t_[3 * u_ + 1] = in[3 * j_ + 1]; t_[3 * u_ + 2] = in[3 * j_ + 2]; \
-      }                                                                                          \
-    }                                                                                            \
-    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                           \
-      /* point i + u_ sits at window slot u_ + sh_ (sh_ in 0..3); slots past the end are unused */ \
-      int k_ = u_ + (int)sh_;                                                                    \
-      k_ = (e - b >= 4) ? min(k_, 3) : u_;                                                       \
-      PX[u_] = k_ == 0 ? t_[0] : (k_ == 1 ? t_[3] : (k_ == 2 ? t_[6] : t_[9]));                   \
-      PY[u_] = k_ == 0 ? t_[1] : (k_ == 1 ? t_[4] : (k_ == 2 ? t_[7] : t_[10]));                  \
-      PZ[u_] = k_ == 0 ? t_[2] : (k_ == 1 ? t_[5] : (k_ == 2 ? t_[8] : t_[11]));                  \
-    }                                                                                            \
-  }
-#define TB_LANE4(i)          \
-  double x[4], y[4], z[4];   \
-  TB_LANE4_INTO(i, x, y, z)
-  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (sp.inh.flags & kHasSums) {
+  for (int k = 0; k < 9; ++k) s[k] = nd.sums[k];
+  const long last = (long)max(e - 1, b);
+  auto load_pt = [&](int step, double& x, double& y, double& z) {
+    const long j = min((long)b + 4 * step + ql, last);
+    x = in[3 * j]; y = in[3 * j + 1]; z = in[3 * j + 2];
+  };
+  if (!(sp.inh.flags & kHasSums)) {  // (a tiny child of a chip-regime node: nobody summed it yet) — wave-uniform loop
 #pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = s9[k];
-  } else {
-    for (int i = b; i < e; i += 4) {
-      TB_LANE4(i)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i + u < e) add_point(s, x[u], y[u], z[u]);
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int st = 0; st < steps; ++st) {
+      double x, y, z;
+      load_pt(st, x, y, z);
+      if (have && b + 4 * st + ql < e) add_point(s, x, y, z);
     }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = quad_sum(s[k]);
   }
   double mean[3], cov[9], w[3], V[9];
-  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 10);
-  mean_cov_from_sums(s, n, mean, cov);
+  mean_cov_from_sums(s, max(n, 1), mean, cov);
   madicp_host::eig3_sym(cov, w, V);
-  asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));
-  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 11);
-  // one sweep: extents, side, speculative scatter (lefts ascending, rights descending) and the children's sums
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { sp.sL[k] = 0.0; sp.sR[k] = 0.0; }
+  double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double* __restrict__ out = level_out(P, level);
-  long lp = b, rp = (long)e - 1;
-  {  // software-pipelined: the next four points are requested before the current four are processed (a lane's loop of
-     // request -> wait -> process is a memory round trip per step, and this sweep was the longest thing on a level)
-    double nx[4], ny[4], nz[4];
-    TB_LANE4_INTO(b, nx, ny, nz)
-    for (int i = b; i < e; i += 4) {
-      double x[4], y[4], z[4];
+  int lpos = b, rpos = e - 1;
+  const unsigned int below = (1u << ql) - 1u;
+  double nx, ny, nz;
+  load_pt(0, nx, ny, nz);
+  for (int st = 0; st < steps; ++st) {  // (wave-uniform trip count; the next point is requested before this one is used)
+    const double x = nx, y = ny, z = nz;
+    if (st + 1 < steps) load_pt(st + 1, nx, ny, nz);
+    const bool valid = have && b + 4 * st + ql < e;
+    double v[3] = {0, 0, 0};
+    if (valid) {
+      eigen_coords(V, mean, x, y, z, v);
+      minmax_update(lo, hi, v);
+    }
+    const bool left = valid && v[2] < 0.0;
+    const unsigned int lm = (unsigned int)(__ballot(left) >> qshift) & 0xfu, vm = (unsigned int)(__ballot(valid) >> qshift) & 0xfu;
+    const unsigned int rm = vm & ~lm;
+    if (valid) {
+      const long d = left ? lpos + __popc(lm & below) : rpos - __popc(rm & below);
+      out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+      if (left) add_point(sL, x, y, z); else add_point(sR, x, y, z);
+    }
+    lpos += __popc(lm);
+    rpos -= __popc(rm);
+  }
+  double ext[3];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { x[u] = nx[u]; y[u] = ny[u]; z[u] = nz[u]; }
-      if (i + 4 < e) {
-        TB_LANE4_INTO(i + 4, nx, ny, nz)
-      }
+  for (int a = 0; a < 3; ++a) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i + u < e) {
-          double v[3];
-          eigen_coords(V, mean, x[u], y[u], z[u], v);
-          minmax_update(lo, hi, v);
-          const bool left = v[2] < 0.0;
-          const long d = left ? lp++ : rp--;
-          out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
-          if (left) add_point(sp.sL, x[u], y[u], z[u]); else add_point(sp.sR, x[u], y[u], z[u]);
-        }
+    for (int m = 1; m <= 2; m <<= 1) {
+      const double ol = __shfl_xor(lo[a], m, 64), oh = __shfl_xor(hi[a], m, 64);
+      if (ol < lo[a]) lo[a] = ol;
+      if (hi[a] < oh) hi[a] = oh;
+    }
+    ext[a] = hi[a] - lo[a];
+  }
+  const int nl = lpos - b;
+  const bool leaf = !have || (ext[2] < P.b_max) || nl == 0 || nl == n;
+  // (both branches below keep whole quads together: `leaf` is the same in the four lanes of a node)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {  // outside the branch: the shuffles need every lane
+    sp.sL[k] = quad_sum(sL[k]);
+    sp.sR[k] = quad_sum(sR[k]);
+  }
+  // nearest member (leaves): every lane over its own points, then the quad's best, smallest index on ties
+  double best = 1.7976931348623157e308;
+  int besti = 0x7fffffff;
+  for (int st = 0; st < steps; ++st) {
+    const int i = b + 4 * st + ql;
+    if (have && leaf && i < e) {
+      const double d[3] = {in[3 * (long)i] - mean[0], in[3 * (long)i + 1] - mean[1], in[3 * (long)i + 2] - mean[2]};
+      const double dist = madicp_host::norm3(d);
+      if (dist < best) { best = dist; besti = i; }
     }
   }
-  const int nl = (int)(lp - b);
-  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 12);
-  const double ext0 = hi[0] - lo[0], ext2 = hi[2] - lo[2];
-  nd.bbox0 = ext0;
-  const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+    const double ob = __shfl_xor(best, m, 64);
+    const int oi = __shfl_xor(besti, m, 64);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (!have) return sp;
+  if (ql == 0) nd.bbox0 = ext[0];
   if (!leaf) {
     const int mid = b + nl;
+    if (ql == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = V[3 * k + 2]; nd.col0[k] = V[3 * k]; }
-    nd.mid = mid;
+      for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = V[3 * k + 2]; nd.col0[k] = V[3 * k]; }
+      nd.mid = mid;
+    }
     sp.split = true;
     sp.mid = mid;
     sp.col0[0] = V[0]; sp.col0[1] = V[3]; sp.col0[2] = V[6];
-    sp.ext0 = ext0;
+    sp.ext0 = ext[0];
     return sp;
   }
-  double best = 1.7976931348623157e308;
-  double bx = in[3 * (long)b], by = in[3 * (long)b + 1], bz = in[3 * (long)b + 2];  // (every distance NaN: the reference keeps *begin)
-  for (int i = b; i < e; i += 4) {
-    TB_LANE4(i)
+  if (besti == 0x7fffffff) besti = b;  // every distance NaN: the reference keeps *begin
+  if (ql == 0) {
+    double nrm[3];
+    leaf_normal(sp.inh, n, V, nrm);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (i + u < e) {
-        const double d[3] = {x[u] - mean[0], y[u] - mean[1], z[u] - mean[2]};
-        const double dist = madicp_host::norm3(d);
-        if (dist < best) { best = dist; bx = x[u]; by = y[u]; bz = z[u]; }
-      }
+    for (int k = 0; k < 3; ++k) { nd.mean[k] = in[3 * (long)besti + k]; nd.dir[k] = nrm[k]; }
+    nd.flags = sp.inh.flags | kLeaf | kDone;
+    P.leaf_start[b] = 1u;
   }
-  double nrm[3];
-  leaf_normal(sp.inh, n, V, nrm);
-  nd.mean[0] = bx; nd.mean[1] = by; nd.mean[2] = bz;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) nd.dir[k] = nrm[k];
-  nd.flags = sp.inh.flags | kLeaf | kDone;
-  P.leaf_start[b] = 1u;
-  if ((threadIdx.x & 63) == 0) TB_STAMP_MAX(level, 13);
   return sp;
-#undef TB_LANE4
-#undef TB_LANE4_INTO
 }
 
 // the two children of a split node: records, and their places in the next level's queues
@@ -662,7 +663,7 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   if (nR <= kSmallMax) level_small(P, level + 1)[slot_small] = eR; else level_q(P, level + 1)[slot_wave] = eR;
 }
 
-// One level of the wave and lane regimes.  256 threads = 4 wavefronts.
+// One level of the wave and quad regimes.  256 threads = 4 wavefronts.
 __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -677,12 +678,12 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
   __shared__ int s_split[4], s_ns[4], s_nw[4];
   __shared__ int s_base_id, s_base_small, s_base_wave;
   __shared__ double s_red[4][18 * kRedStride];
-  // The two regimes run side by side: the FIRST ceil(cntS / 256) workgroups take the lane-regime queue (first, because
+  // The two regimes run side by side: the FIRST ceil(cntS / 64) workgroups take the quad-regime queue (first, because
   // workgroups are dispatched in order and only two fit a CU: behind the wave-regime workgroups the lanes would start
   // when those finish — measured: a level then costs the sum of the two sides instead of the longer one), the others
   // the wave-regime queue.
   const bool single = gridDim.x == 1;  // (tiny clouds: the one workgroup does both, one after the other)
-  int wgS = min((cntS + 255) / 256, (int)gridDim.x);
+  int wgS = min((cntS + 63) / 64, (int)gridDim.x);
   if (!single && cntW > 0 && wgS >= (int)gridDim.x) wgS = (int)gridDim.x - 1;
   const int wgW = single ? 1 : (int)gridDim.x - wgS;
   const int wblock = single ? 0 : (int)blockIdx.x - wgS;  // index among the wave-side workgroups
@@ -733,21 +734,21 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
     __syncthreads();
     if (lane == 0) TB_STAMP_MAX(level, 9);
   }
-  // ---- lane regime: a wave takes 64 consecutive queue entries, one per lane; one atomic each per WAVE
+  // ---- quad regime: a wave takes 16 consecutive queue entries, four lanes each; one atomic each per WAVE
   const int4* qs = level_small(P, level);
   if (!single && ((int)blockIdx.x >= wgS || wgS <= 0)) return;
   const int n_waves = max(wgS, 1) * 4, wave = (int)blockIdx.x * 4 + wv;
-  for (int t0 = wave * 64; t0 < cntS; t0 += n_waves * 64) {  // (wave-uniform trip count)
-    const int t = t0 + lane;
-    int id = -1;
-    Split sp;
-    sp.split = false;
-    if (t < cntS) {
-      const int4 ent = qs[t];
-      id = ent.x;
-      sp = lane_node(P, ent);
-    }
-    const unsigned long long sm = __ballot(sp.split);
+  for (int t0 = wave * 16; t0 < cntS; t0 += n_waves * 16) {  // (wave-uniform trip count)
+    const int t = t0 + (lane >> 2);
+    const bool have = t < cntS;
+    int4 ent = make_int4(0, 0, 0, level);
+    if (have) ent = qs[t];
+    int steps = have ? (ent.z - ent.y + 3) / 4 : 0;
+#pragma unroll
+    for (int m = 32; m >= 4; m >>= 1) steps = max(steps, __shfl_xor(steps, m, 64));  // the wave's longest node
+    Split sp = quad_node(P, ent, have, steps);
+    const bool mine = sp.split && (lane & 3) == 0;
+    const unsigned long long sm = __ballot(mine);
     const int tot = __popcll(sm);
     if (tot == 0) continue;
     int base_id = 0, base_q = 0;
@@ -759,18 +760,16 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
     }
     base_id = __shfl(base_id, 0, 64);
     base_q = __shfl(base_q, 0, 64);
-    if (lane == 0) TB_STAMP_MAX(level, 14);
-    if (sp.split) {
+    if (mine) {
       const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       const int rank = __popcll(sm & lt);
       const int c = base_id + 2 * rank;
       if (c + 2 > P.node_cap) {
         st->n_nodes.error = 1;
       } else {
-        emit_children(P, id, sp, c, base_q + 2 * rank, 0);  // children of a lane node are lane nodes
+        emit_children(P, ent.x, sp, c, base_q + 2 * rank, 0);  // children of a quad node are quad nodes
       }
     }
-    if (lane == 0) TB_STAMP_MAX(level, 15);
   }
   if (lane == 0) TB_STAMP_MAX(level, 1);
 }
