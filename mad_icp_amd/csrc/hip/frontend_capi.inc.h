@@ -86,7 +86,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_leaf = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_S = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
-  const size_t o_p1 = take(sizeof(double) * 12 * slots);
+  const size_t o_p1a = take(sizeof(double) * 18 * slots);
+  const size_t o_p1b = take(sizeof(double) * 18 * slots);
   const size_t o_p2 = take(sizeof(double) * 8 * slots);
   const size_t o_key0 = take(sizeof(double) * (size_t)nc);
   const size_t o_key1 = take(sizeof(double) * (size_t)nc);
@@ -114,7 +115,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.small[0] = reinterpret_cast<int4*>(b + o_small0);
   fs.P.small[1] = reinterpret_cast<int4*>(b + o_small1);
   fs.P.leaf_start = reinterpret_cast<uint32_t*>(b + o_leaf);
-  fs.P.part1 = reinterpret_cast<double*>(b + o_p1);
+  fs.P.partLR[0] = reinterpret_cast<double*>(b + o_p1a);
+  fs.P.partLR[1] = reinterpret_cast<double*>(b + o_p1b);
   fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
   fs.S = reinterpret_cast<uint32_t*>(b + o_S);
   fs.tile_sums = reinterpret_cast<uint32_t*>(b + o_tiles);
@@ -432,7 +434,7 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   auto run_levels = [&](int from, int to) {
     for (int level = from; level < to; ++level) {
       if (level < tb::kChipLevels && n > tb::kChipMin) {
-        hipLaunchKernelGGL(tb::tb_chip_sums, dim3(chip_grid), dim3(256), 0, s, P, level);
+        if (level == 0) hipLaunchKernelGGL(tb::tb_chip_sums, dim3(chip_grid), dim3(256), 0, s, P, level);
         hipLaunchKernelGGL(tb::tb_chip_stats, dim3(chip_grid), dim3(256), 0, s, P, level);
         hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(chip_grid), dim3(256), 0, s, P, level);
       }

@@ -58,7 +58,7 @@ constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
 
-enum : int { kLeaf = 1, kHasPlane = 2, kHasSmall = 4, kDone = 8, kLeafPending = 16, kHasSums = 32 };
+enum : int { kLeaf = 1, kHasPlane = 2, kHasSmall = 4, kDone = 8, kLeafPending = 16, kHasSums = 32, kChunkSums = 64, kSumRight = 128 };
 
 struct BNode {          // a node while the tree is being built
   double mean[3];       // internal: centroid; leaf: the member nearest to it
@@ -69,7 +69,9 @@ struct BNode {          // a node while the tree is being built
   double bbox0;
   double sums[9];       // kHasSums: the nine sums of this node's points, accumulated by the parent's scatter sweep
   int32_t begin, end, mid, left_turns;
-  int32_t flags, level, parent, child;  // child: temporary id of the left child, the right one is child + 1
+  int32_t flags, level;
+  int32_t sum_first, sum_n;  // kChunkSums: the node's sums are the per-chunk partials [sum_first, sum_first + sum_n) that its
+                             // chip-regime parent's scatter left behind (left or right half: kSumRight), added in order
 };
 static_assert(sizeof(BNode) == 232, "BNode layout");
 
@@ -108,7 +110,9 @@ struct Params {
   int32_t* big[2];      // chip-regime lists, by level parity
   int4* small[2];       // quad-regime queues, by level parity (same entries)
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
-  double* part1;        // chip regime: per chunk slot 12 doubles (9 sums)
+  double* partLR[2];    // chip regime, by level parity: per chunk slot 18 doubles — the nine sums of the chunk's points that
+                        // go left, then of those that go right (written by the PARENT level's scatter; level 0: by
+                        // tb_chip_sums into the first nine)
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
   int32_t n_points;
   double b_max, b_min;
@@ -122,6 +126,7 @@ __device__ __forceinline__ double* level_out(const Params& P, int level) { retur
 __device__ __forceinline__ int4* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
 __device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
 __device__ __forceinline__ int4* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
+__device__ __forceinline__ double* level_part(const Params& P, int level) { return (level & 1) ? P.partLR[1] : P.partLR[0]; }
 
 // ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
 // utils.h:54-73 after the sums: s = {sum x, sum y, sum z, sum xx, xy, xz, yy, yz, zz}
@@ -169,7 +174,7 @@ __device__ __forceinline__ void minmax_update(double* lo, double* hi, const doub
 // what the children of an internal node inherit (mad_tree.cpp:64-74,90-93)
 // what a node read of itself when it started (one batch of independent loads) and hands to its children
 struct Inherit {
-  int flags, left_turns, level;
+  int flags, left_turns, level, sum_first, sum_n;
   double plane_n[3], small_n[3];
 };
 __device__ __forceinline__ Inherit load_inherit(const BNode& nd, int level) {
@@ -177,6 +182,8 @@ __device__ __forceinline__ Inherit load_inherit(const BNode& nd, int level) {
   h.flags = nd.flags;
   h.left_turns = nd.left_turns;
   h.level = level;
+  h.sum_first = nd.sum_first;
+  h.sum_n = nd.sum_n;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { h.plane_n[i] = nd.plane_n[i]; h.small_n[i] = nd.small_n[i]; }
   return h;
@@ -210,9 +217,23 @@ __device__ __forceinline__ void make_child(BNode& c, const Inherit& p, int paren
   c.mid = 0;
   c.left_turns = p.left_turns + (is_left ? 1 : 0);
   c.level = p.level + 1;
-  c.parent = parent_id;
-  c.child = -1;
+  c.sum_first = 0;
+  c.sum_n = 0;
+  (void)parent_id;
   c.bbox0 = 0.0;
+}
+
+// the sums of a node whose chip-regime parent left them as per-chunk partials: added in chunk order (every lane the same
+// loads, the same order: identical totals everywhere)
+__device__ __forceinline__ void chunk_sums(const Params& P, const Inherit& h, double* s) {
+  const double* part = level_part(P, h.level) + ((h.flags & kSumRight) ? 9 : 0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = 0.0;
+  for (int c = 0; c < h.sum_n; ++c) {
+    const double* q = part + (long)(h.sum_first + c) * 18;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] += q[k];
+  }
 }
 
 // which queue a node of n points at `level` belongs to: 0 lane, 1 wave, 2 chip
@@ -299,8 +320,8 @@ __global__ void tb_init(const Params P) {
   r.left_turns = 0;
   r.flags = 0;
   r.level = 0;
-  r.parent = -1;
-  r.child = -1;
+  r.sum_first = 0;
+  r.sum_n = 0;
   st->n_nodes.v = 1;
   enqueue_single(P, 0, 0, P.n_points, 0);
 }
@@ -382,6 +403,8 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
     if (sp.inh.flags & kHasSums) {  // the parent's scatter sweep already added this node's points up
 #pragma unroll
       for (int k = 0; k < 9; ++k) s[k] = s9[k];
+    } else if (sp.inh.flags & kChunkSums) {
+      chunk_sums(P, sp.inh, s);
     } else {
       for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
         const int i0 = base + lane;
@@ -539,7 +562,9 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
     const long j = min((long)b + 4 * step + ql, last);
     x = in[3 * j]; y = in[3 * j + 1]; z = in[3 * j + 2];
   };
-  if (!(sp.inh.flags & kHasSums)) {  // (a tiny child of a chip-regime node: nobody summed it yet) — wave-uniform loop
+  if (have && (sp.inh.flags & kChunkSums)) {  // a tiny child of a chip-regime node: its sums are chunk partials
+    chunk_sums(P, sp.inh, s);
+  } else if (!(sp.inh.flags & kHasSums)) {  // (nobody summed it: only the root of a tiny cloud) — wave-uniform loop
 #pragma unroll
     for (int k = 0; k < 9; ++k) s[k] = 0.0;
     for (int st = 0; st < steps; ++st) {
@@ -654,7 +679,6 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   for (int k = 0; k < 9; ++k) { P.nodes[c].sums[k] = sp.sL[k]; P.nodes[c + 1].sums[k] = sp.sR[k]; }
   P.nodes[c].flags |= kHasSums;
   P.nodes[c + 1].flags |= kHasSums;
-  nd.child = c;
   nd.flags = sp.inh.flags | kDone;
   const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
   // (children of a wave/lane node are never chip-regime: n <= 4096, or past the chip levels)
@@ -823,7 +847,8 @@ __device__ __forceinline__ ChunkMap chip_find(const int* s_off, int cnt, int slo
   return cm;
 }
 
-// C1: per-chunk sums
+// C1: per-chunk sums — level 0 only (the root has no parent to hand them down); deeper chip nodes get theirs from the
+// scatter of the level above
 __global__ __launch_bounds__(256) void tb_chip_sums(const Params P, int level) {
   __shared__ int s_off[kMaxBig + 1];
   __shared__ double s_red[4][9];
@@ -857,7 +882,7 @@ __global__ __launch_bounds__(256) void tb_chip_sums(const Params P, int level) {
       for (int k = 0; k < 9; ++k) s_red[wv][k] = s[k];
     }
     __syncthreads();
-    if (threadIdx.x < 9) P.part1[(long)slot * 12 + threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+    if (threadIdx.x < 9) level_part(P, level)[(long)slot * 18 + threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
     __syncthreads();
   }
 }
@@ -878,17 +903,22 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
     const ChunkMap cm = chip_find(s_off, cnt, slot);
     BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
     const int n = nd.end - nd.begin;
-    if (threadIdx.x < 9) s_tot[threadIdx.x] = 0.0;
-    for (int base = 0; base < cm.n_chunks; base += 256) {
+    // the node's nine sums: per-chunk partials of its PARENT's scatter (left or right half), or of tb_chip_sums (root)
+    const int nflags = nd.flags;
+    const int pfirst = (nflags & kChunkSums) ? nd.sum_first : cm.first_slot;
+    const int pcount = (nflags & kChunkSums) ? nd.sum_n : cm.n_chunks;
+    const double* part = level_part(P, level) + ((nflags & kSumRight) ? 9 : 0);
+    if (threadIdx.x < 9) s_tot[threadIdx.x] = (nflags & kHasSums) ? nd.sums[threadIdx.x] : 0.0;
+    for (int base = 0; base < pcount && !(nflags & kHasSums); base += 256) {
       const int c = base + threadIdx.x;
-      if (c < cm.n_chunks) {
+      if (c < pcount) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s_part[threadIdx.x][k] = P.part1[(long)(cm.first_slot + c) * 12 + k];
+        for (int k = 0; k < 9; ++k) s_part[threadIdx.x][k] = part[(long)(pfirst + c) * 18 + k];
       }
       __syncthreads();
       if (threadIdx.x < 9) {
         double a = s_tot[threadIdx.x];
-        const int m = min(256, cm.n_chunks - base);
+        const int m = min(256, pcount - base);
         for (int c2 = 0; c2 < m; ++c2) a += s_part[c2][threadIdx.x];
         s_tot[threadIdx.x] = a;
       }
@@ -977,6 +1007,7 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
   __shared__ double s_lo[3], s_hi[3];
   __shared__ int s_before, s_left_total;
   __shared__ int s_wsum[4];
+  __shared__ double s_cs[4][18];
   const int cnt = chip_prefix(P, level, s_off);
   const int total = s_off[cnt];
   const double* __restrict__ in = level_in(P, level);
@@ -1044,9 +1075,13 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
         const Inherit inh = load_inherit(nd, level);
         make_child(P.nodes[c], inh, id, col0, ext0, n, P.b_min, b, mid, true);
         make_child(P.nodes[c + 1], inh, id, col0, ext0, n, P.b_min, mid, e, false);
+        // their sums: this node's per-chunk partials, written below by every chunk of it
+        P.nodes[c].flags |= kChunkSums;
+        P.nodes[c + 1].flags |= kChunkSums | kSumRight;
+        P.nodes[c].sum_first = P.nodes[c + 1].sum_first = cm.first_slot;
+        P.nodes[c].sum_n = P.nodes[c + 1].sum_n = cm.n_chunks;
         enqueue_single(P, c, b, mid, level + 1);
         enqueue_single(P, c + 1, mid, e, level + 1);
-        nd.child = c;
       }
       nd.bbox0 = ext0;
       nd.mid = mid;
@@ -1069,6 +1104,27 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       if (k < nvalid && goes_left(mean, col2, px[k], py[k], pz[k])) lmask |= 1u << k;
+    {  // the children's sums over this chunk (they will not have to sweep their points for them)
+      double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < nvalid) {
+          if ((lmask >> k) & 1u) add_point(sL, px[k], py[k], pz[k]); else add_point(sR, px[k], py[k], pz[k]);
+        }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        sL[k] = wave_sum(sL[k]);
+        sR[k] = wave_sum(sR[k]);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { s_cs[wv][k] = sL[k]; s_cs[wv][9 + k] = sR[k]; }
+      }
+      __syncthreads();
+      if (threadIdx.x < 18)
+        level_part(P, level + 1)[(long)slot * 18 + threadIdx.x] =
+            ((s_cs[0][threadIdx.x] + s_cs[1][threadIdx.x]) + s_cs[2][threadIdx.x]) + s_cs[3][threadIdx.x];
+    }
     const int mine = __popc(lmask);
     // exclusive scan of `mine` over the 256 threads: wave scan + wave totals
     int incl = mine;
