@@ -1300,33 +1300,38 @@ __global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, 
 __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restrict__ nodes, int top_levels, int top_max,
                                                       int* __restrict__ dfs, unsigned int* __restrict__ link, int2* __restrict__ exits,
                                                       int* __restrict__ out_n_top) {
-  __shared__ int s_cur[1024], s_next[1024];
+  // (node index, its `right` offset) of the current level's entries, in breadth-first order: the offset of an entry was
+  // read by its PARENT's step (to tell whether the child is a leaf), so a level costs one dependent memory hop, not two
+  __shared__ int s_cur[1024], s_next[1024], s_cur_right[1024], s_next_right[1024];
   __shared__ int s_w[16];
   __shared__ int s_total;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int ncur = 0, base = 0;
-  if (nodes[0].right != 0) {
+  const int root_right = nodes[0].right;
+  if (root_right != 0) {
     ncur = 1;
-    if (threadIdx.x == 0) s_cur[0] = 0;
+    if (threadIdx.x == 0) { s_cur[0] = 0; s_cur_right[0] = root_right; }
   }
   __syncthreads();
   for (int lev = 0; lev < top_levels && ncur > 0; ++lev) {
     const bool on = (int)threadIdx.x < ncur && base + (int)threadIdx.x < top_max - 1;
-    int i = 0, l = 0, r = 0;
+    int i = 0, l = 0, r = 0, l_right = 0, r_right = 0;
     bool l_leaf = false, r_leaf = false, l_in = false, r_in = false;
     if (on) {
       i = s_cur[threadIdx.x];
       l = i + 1;
-      r = i + nodes[i].right;
-      l_leaf = nodes[l].right == 0;
-      r_leaf = nodes[r].right == 0;
+      r = i + s_cur_right[threadIdx.x];
+      l_right = nodes[l].right;
+      r_right = nodes[r].right;
+      l_leaf = l_right == 0;
+      r_leaf = r_right == 0;
       const bool deeper = lev + 1 < top_levels;
       l_in = !l_leaf && deeper;
       r_in = !r_leaf && deeper;
     }
     const int c = (l_in ? 1 : 0) + (r_in ? 1 : 0);
     int incl = c;
-    #pragma unroll
+#pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int o = __shfl_up(incl, d, 64);
       if (lane >= d) incl += o;
@@ -1341,8 +1346,8 @@ __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restr
     if (on) {
       const int first = next_base + excl;
       unsigned int w = (unsigned int)first & kTopFirst;
-      if (l_in) { s_next[excl] = l; w |= kTopLeftIn; }
-      if (r_in) { s_next[excl + (l_in ? 1 : 0)] = r; w |= kTopRightIn; }
+      if (l_in) { s_next[excl] = l; s_next_right[excl] = l_right; w |= kTopLeftIn; }
+      if (r_in) { s_next[excl + (l_in ? 1 : 0)] = r; s_next_right[excl + (l_in ? 1 : 0)] = r_right; w |= kTopRightIn; }
       if (l_leaf) w |= kTopLeftLeaf;
       if (r_leaf) w |= kTopRightLeaf;
       dfs[base + threadIdx.x] = i;
@@ -1352,7 +1357,7 @@ __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restr
     __syncthreads();
     base = next_base;
     ncur = s_total;
-    if ((int)threadIdx.x < ncur) s_cur[threadIdx.x] = s_next[threadIdx.x];
+    if ((int)threadIdx.x < ncur) { s_cur[threadIdx.x] = s_next[threadIdx.x]; s_cur_right[threadIdx.x] = s_next_right[threadIdx.x]; }
     __syncthreads();
   }
   if (threadIdx.x == 0) *out_n_top = base;
