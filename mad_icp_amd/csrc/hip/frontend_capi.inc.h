@@ -37,19 +37,25 @@ struct FrontScratch {
 
 constexpr int kDeskewTableMax = 1040;  // > CHUNKS + a few: thresholds fall below -pi after ~1024 steps
 
-std::unordered_map<madicp_ctx*, std::unordered_map<int, DevCloud>>& cloud_registry() {
-  static std::unordered_map<madicp_ctx*, std::unordered_map<int, DevCloud>> r;
-  return r;
-}
-std::unordered_map<madicp_ctx*, FrontScratch>& scratch_registry() {
-  static std::unordered_map<madicp_ctx*, FrontScratch> r;
-  return r;
+}  // namespace
+
+// per context, so that contexts driven from different host threads share nothing
+struct madicp_ctx::Front {
+  std::unordered_map<int, DevCloud> clouds;
+  FrontScratch scratch;
+};
+
+namespace {
+
+madicp_ctx::Front& front_of(madicp_ctx* ctx) {
+  if (!ctx->front) ctx->front = new madicp_ctx::Front();
+  return *ctx->front;
 }
 
 size_t sort_temp_bytes(int64_t n);  // (defined below, needs rocPRIM)
 
 int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
-  FrontScratch& fs = scratch_registry()[ctx];
+  FrontScratch& fs = front_of(ctx).scratch;
   *out = &fs;
   if (!fs.h_state) {
     HIP_TRY(hipHostMalloc(&fs.h_state, sizeof(tb::State), hipHostMallocDefault));
@@ -133,28 +139,22 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
 }
 
 void front_destroy(madicp_ctx* ctx) {  // called by madicp_ctx_destroy (streams already drained)
-  auto cit = cloud_registry().find(ctx);
-  if (cit != cloud_registry().end()) {
-    for (auto& c : cit->second)
-      if (c.second.ready) hipEventDestroy(c.second.ready);  // (the device buffers belong to the pool)
-    cloud_registry().erase(cit);
-  }
-  auto sit = scratch_registry().find(ctx);
-  if (sit != scratch_registry().end()) {
-    FrontScratch& fs = sit->second;
-    if (fs.block) hipFree(fs.block);
-    if (fs.h_state) hipHostFree(fs.h_state);
-    if (fs.h_table) hipHostFree(fs.h_table);
-    if (fs.h_table_read) hipEventDestroy(fs.h_table_read);
-    scratch_registry().erase(sit);
-  }
+  if (!ctx->front) return;
+  for (auto& c : ctx->front->clouds)
+    if (c.second.ready) hipEventDestroy(c.second.ready);  // (the device buffers belong to the pool)
+  FrontScratch& fs = ctx->front->scratch;
+  if (fs.block) hipFree(fs.block);
+  if (fs.h_state) hipHostFree(fs.h_state);
+  if (fs.h_table) hipHostFree(fs.h_table);
+  if (fs.h_table_read) hipEventDestroy(fs.h_table_read);
+  delete ctx->front;
+  ctx->front = nullptr;
 }
 
 DevCloud* find_cloud(madicp_ctx* ctx, int id) {
-  auto cit = cloud_registry().find(ctx);
-  if (cit == cloud_registry().end()) return nullptr;
-  auto it = cit->second.find(id);
-  return it == cit->second.end() ? nullptr : &it->second;
+  if (!ctx->front) return nullptr;
+  auto it = ctx->front->clouds.find(id);
+  return it == ctx->front->clouds.end() ? nullptr : &it->second;
 }
 
 int new_cloud(madicp_ctx* ctx, int64_t n, DevCloud* out) {
@@ -218,7 +218,7 @@ int madicp_cloud_upload(madicp_ctx* ctx, const double* xyz, int64_t n, int* out_
   CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
   CLOUD_TRY(hipEventRecord(c.ready, ctx->copy));
   const int id = ctx->next_id++;
-  cloud_registry()[ctx][id] = c;
+  front_of(ctx).clouds[id] = c;
   *out_cloud_id = id;
   return MADICP_OK;
 }
@@ -232,7 +232,7 @@ int madicp_cloud_release(madicp_ctx* ctx, int cloud_id) {
   RC_TRY(fence_event(ctx, &after));
   pool_free(ctx, c->xyz, after);
   if (c->ready) hipEventDestroy(c->ready);
-  cloud_registry()[ctx].erase(cloud_id);
+  ctx->front->clouds.erase(cloud_id);
   return MADICP_OK;
 }
 
@@ -262,10 +262,12 @@ int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_rec
   if (stride_floats < 3) return fail(MADICP_ERR_INVALID, "a record holds at least x, y, z");
   HIP_TRY(hipSetDevice(ctx->device));
   FrontScratch* fs = nullptr;
-  RC_TRY(ensure_scratch(ctx, n_records, &fs));
-  // the raw records go through the pinned staging into buf[0] of the scratch (they are 16 bytes per point)
+  // the raw records go through the pinned staging into buf[0] of the scratch (a KITTI record is 16 bytes, a point of the
+  // scratch 24: wider records ask for a scratch laid out for proportionally more points)
   const size_t bytes = sizeof(float) * (size_t)stride_floats * (size_t)n_records;
-  if (bytes > sizeof(double) * 3 * (size_t)fs->n_cap) return fail(MADICP_ERR_INVALID, "record stride too large");
+  const int64_t n_layout = std::max<int64_t>(n_records, (int64_t)((bytes + 23) / 24));
+  if (n_layout > 0x3fffffff) return fail(MADICP_ERR_INVALID, "records too large");
+  RC_TRY(ensure_scratch(ctx, n_layout, &fs));
   const int hb = ctx->h_tree_next;
   ctx->h_tree_next ^= 1;
   HIP_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
@@ -299,7 +301,7 @@ int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_rec
   CLOUD_TRY(hipGetLastError());
   CLOUD_TRY(hipEventRecord(c.ready, ctx->copy));
   const int id = ctx->next_id++;
-  cloud_registry()[ctx][id] = c;
+  front_of(ctx).clouds[id] = c;
   *out_cloud_id = id;
   *out_n = kept;
   return MADICP_OK;
@@ -539,9 +541,8 @@ int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t
 // out[1] = lane-regime sub-trees, then 2 x 64 ints: wave-regime and chip-regime nodes per level
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
   if (!ctx || !out) return fail(MADICP_ERR_INVALID, "null argument");
-  auto sit = scratch_registry().find(ctx);
-  if (sit == scratch_registry().end() || !sit->second.h_state) return fail(MADICP_ERR_INVALID, "no build yet");
-  const tb::State& st = *sit->second.h_state;
+  if (!ctx->front || !ctx->front->scratch.h_state) return fail(MADICP_ERR_INVALID, "no build yet");
+  const tb::State& st = *ctx->front->scratch.h_state;
   out[0] = st.max_level;
   int lanes = 0;
   for (int i = 0; i <= tb::kMaxLevels; ++i) lanes += st.small_count[i].v;

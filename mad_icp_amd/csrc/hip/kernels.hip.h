@@ -130,6 +130,8 @@ struct HostResult {
   unsigned long long walked;
   int32_t n_matched;
   int32_t iter;
+  int32_t seq;    // written LAST (system-scope release): Job::seq of the registration these results belong to
+  int32_t pad_;
 };
 
 // One registration in flight; lives in device memory, written by the host before each launch sequence
@@ -159,7 +161,7 @@ struct Job {
   int32_t ranges_per_tree;  // launch geometry: every tree's moving leaves are cut into this many ranges
   int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
   int32_t lds_top;          // 1 when the launch carries kTopLdsBytes of dynamic LDS
-  int32_t pad2_;
+  int32_t seq;              // streamed registrations: what icp_final leaves in HostResult::seq when everything is written
 #ifdef MADICP_ABLATE
   unsigned long long* dbg;  // profiling builds: per-workgroup phase time stamps of the last launch
 #endif
@@ -1769,8 +1771,15 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
       }
     }
   }
+  // The caller's completion signal is HostResult::seq in its pinned block (no event behind the registration: a
+  // barrier packet on the queue costs more than this kernel).  Every thread orders its own host stores (flags, H, X, b)
+  // before the barrier; thread 0 then writes the count and releases the sequence number at system scope.
+  if (job->host_out) __threadfence_system();
   __syncthreads();  // count_matched's n_matched (thread 0) is final
-  if (threadIdx.x == 0 && job->host_out) job->host_out->n_matched = job->n_matched;
+  if (threadIdx.x == 0 && job->host_out) {
+    job->host_out->n_matched = job->n_matched;
+    __hip_atomic_store(&job->host_out->seq, job->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // multi-GPU: this rank's partials of the round just linearised -> totals[scan][kAcc], then ncclAllReduce(sum)

@@ -131,6 +131,7 @@ struct StreamSlot {
   hipEvent_t ev_up = nullptr;    // copy stream: Job + moving leaves are on the device
   hipEvent_t ev_done = nullptr;  // compute stream: the registration has finished
   bool pending = false;
+  bool by_seq = false;      // completion is published through h_out->seq (no event was recorded)
   int ticket = -1;
   int L = 0;
 };
@@ -189,6 +190,9 @@ struct madicp_ctx {
                        // (nn_descend_top).  Off: measured SLOWER for one 120 k-query launch (8.7 vs 6.6 us against a
                        // 20 k-leaf tree, 10.7 vs 9.2 us against a 120 k-leaf tree) — staging 48 KiB per workgroup costs
                        // more than the ~11 LDS levels save in a kernel this short
+  int eager_when_busy = 1; // a registration queued behind another is launched kernel by kernel, not as a graph (run_rounds)
+  int seq_completion = 1;  // streamed registrations publish completion through HostResult::seq instead of an event
+  int host_feed_wait = 1;  // ... and the host, not the stream, waits for their feed while another one is in flight
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -198,6 +202,10 @@ struct madicp_ctx {
   // multi-GPU
   ncclComm_t comm = nullptr;
   int n_ranks = 1, rank = 0;
+
+  // device front-end (frontend_capi.inc.h): resident clouds + builder scratch, created on first use
+  struct Front;
+  Front* front = nullptr;
 };
 
 namespace {
@@ -346,10 +354,14 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vec
 }
 
 // slot: which device Job array the sequence works on (-1: ctx->d_jobs; >= 0: that stream slot's) — part of the graph key
-int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const std::vector<int>& moving_ids) {
+// queued_behind: the stream is known to be busy with an earlier registration.  A graph launch costs the QUEUE ~8 us more
+// than the same kernels launched one by one (markers around the graph: 234 vs 229 us per streamed registration) but costs
+// the HOST less, so a registration that would start at once goes as a graph (its first kernel starts sooner: 300 vs 307 us
+// submit-to-result) and one that has to wait for its predecessor anyway goes kernel by kernel.
+int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const std::vector<int>& moving_ids, bool queued_behind) {
   // with a communicator the RCCL calls are captured only on request (option "comm_graph"): it could not be
   // exercised on more than one rank where this was developed
-  const bool graph_ok = ctx->use_graph && (!ctx->comm || ctx->comm_graph);
+  const bool graph_ok = ctx->use_graph && (!ctx->comm || ctx->comm_graph) && !(queued_behind && ctx->eager_when_busy && !ctx->comm);
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
   // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
@@ -655,7 +667,8 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
   const int saved = ctx->use_graph;
   if (ctx->comm) ctx->use_graph = 0;
-  const int rc = run_rounds(ctx, launch, ctx->d_jobs, -1, ctx->last_moving);
+  const bool queued_behind = ctx->use_graph && ctx->eager_when_busy && hipStreamQuery(ctx->stream) == hipErrorNotReady;
+  const int rc = run_rounds(ctx, launch, ctx->d_jobs, -1, ctx->last_moving, queued_behind);
   ctx->use_graph = saved;
   return rc;
 }
@@ -782,6 +795,12 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "lds_stage_min_leaves") {
     if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
     ctx->stage_min_leaves = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (k == "eager_when_busy") {
+    ctx->eager_when_busy = value ? 1 : 0;
+  } else if (k == "seq_completion") {
+    ctx->seq_completion = value ? 1 : 0;
+  } else if (k == "host_feed_wait") {
+    ctx->host_feed_wait = value ? 1 : 0;
   } else if (k == "nn_lds_top") {
     ctx->nn_lds_top = value ? 1 : 0;
   } else if (k == "queries_per_lane") {
@@ -1182,16 +1201,27 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_out), sl.h_out, 0));
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_matched), sl.h_matched, 0));
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, K);
+  j.seq = ticket + 1;
+  sl.h_out->seq = 0;
   HIP_TRY(hipMemcpyAsync(sl.d_job, sl.h_job, job_bytes, hipMemcpyHostToDevice, ctx->copy));
   HIP_TRY(hipEventRecord(sl.ev_up, ctx->copy));
   // ---- the registration (compute stream) --------------------------------------------------------------
-  HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.ev_up, 0));
+  // The compute stream must not start before the feed has landed.  While an earlier registration is still in flight
+  // the HOST waits for the feed (tens of microseconds, hidden behind that registration) and the kernels follow it with
+  // no barrier packet between two registrations; with nothing in flight the wait is the stream's (lowest latency).
+  bool busy = false;
+  for (const StreamSlot& other : ctx->slots) busy = busy || other.pending;
+  if (busy && ctx->host_feed_wait)
+    HIP_TRY(hipEventSynchronize(sl.ev_up));
+  else
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.ev_up, 0));
   if (n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)L, ctx->stream));
   RC_TRY(prepare_partials(ctx, geo.grid, 1));
   const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
   const std::vector<int> ids{sl.moving_id};
-  RC_TRY(run_rounds(ctx, launch, sl.d_job, ticket % madicp_ctx::kStreamSlots, ids));
-  HIP_TRY(hipEventRecord(sl.ev_done, ctx->stream));
+  RC_TRY(run_rounds(ctx, launch, sl.d_job, ticket % madicp_ctx::kStreamSlots, ids, busy));
+  if (!ctx->seq_completion) HIP_TRY(hipEventRecord(sl.ev_done, ctx->stream));
+  sl.by_seq = ctx->seq_completion != 0;
   sl.pending = true;
   sl.ticket = ticket;
   sl.L = L;
@@ -1218,7 +1248,24 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
   if (ticket < 0) return fail(MADICP_ERR_INVALID, "unknown ticket");
   StreamSlot& sl = ctx->slots[ticket % madicp_ctx::kStreamSlots];
   if (!sl.pending || sl.ticket != ticket) return fail(MADICP_ERR_INVALID, "unknown or already collected ticket");
-  HIP_TRY(hipEventSynchronize(sl.ev_done));
+  if (sl.by_seq) {
+    // icp_final releases HostResult::seq after everything else it writes to the pinned block (kernels.hip.h)
+    const int32_t want = ticket + 1;
+    const int32_t* seq = &sl.h_out->seq;
+    for (unsigned spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != want; ++spins) {
+      if ((spins & 0x3ff) == 0) {  // every few tens of microseconds: is the stream still alive?
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) {
+          if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) break;
+          return fail(MADICP_ERR_DEVICE, "registration finished without publishing its results");
+        }
+        if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("registration failed: ") + hipGetErrorString(q));
+      }
+      __builtin_ia32_pause();
+    }
+  } else {
+    HIP_TRY(hipEventSynchronize(sl.ev_done));
+  }
   const HostResult& r = *sl.h_out;
   if (out_X) std::memcpy(out_X, r.X, sizeof(r.X));
   if (out_H) std::memcpy(out_H, r.H, sizeof(r.H));

@@ -157,6 +157,45 @@ def test_config2_sixteen_keyframes_bench_problem(ctx):
         su.close()
 
 
+def test_streamed_ring_is_launch_policy_independent(ctx):
+    """Streamed registrations queued behind each other take another launch route than a lone one (kernel by kernel instead
+    of a hipGraph, the host instead of the stream waiting for the feed, completion by sequence number instead of an event:
+    options eager_when_busy / host_feed_wait / seq_completion).  The route must not show in the results."""
+    su = Setup(ctx, 16, 1, 3)
+    try:
+        leaves = [q.leaf_means() for q in su.qh]
+        guesses = [su.pb["query_guess"][i] for i in range(3)]
+
+        def ring(depth, n=9):
+            out, pend = [], []
+            for i in range(n):
+                pend.append((ctx.stream_submit(leaves[i % 3], su.tids, guesses[i % 3], PARAMS, N_ITERS), leaves[i % 3].shape[0]))
+                while len(pend) > depth:
+                    out.append(ctx.stream_collect(*pend.pop(0)))
+            while pend:
+                out.append(ctx.stream_collect(*pend.pop(0)))
+            return out
+
+        ref = ring(0)  # one at a time: graph launch, stream-side wait
+        for i in range(3, 9):  # the same scan gives the same bits every time
+            assert np.array_equal(ref[i]["X"], ref[i % 3]["X"]) and np.array_equal(ref[i]["matched"], ref[i % 3]["matched"])
+        for opts in ({}, {"eager_when_busy": 0}, {"host_feed_wait": 0}, {"seq_completion": 0},
+                     {"eager_when_busy": 0, "host_feed_wait": 0, "seq_completion": 0}, {"use_graph": 0}):
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            try:
+                for depth in (1, 3):
+                    got = ring(depth)
+                    for a, b in zip(got, ref):
+                        assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["H"], b["H"]) and np.array_equal(a["b"], b["b"]), opts
+                        assert np.array_equal(a["matched"], b["matched"]) and a["n_matched"] == b["n_matched"], opts
+            finally:
+                for k in opts:
+                    ctx.set_option(k, 1)
+    finally:
+        su.close()
+
+
 def test_config4_sixtyfour_keyframes_eight_scans_in_flight(ctx):
     """BASELINE configs[4]: 64 keyframes resident, 8 query scans batched in flight; every scan checked against the
     oracle, the batch against the same scans registered one by one."""

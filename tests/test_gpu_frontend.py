@@ -192,6 +192,57 @@ def test_ingest_is_bit_identical(ctx, kitti):
     ctx.cloud_release(cid)
 
 
+def test_ingest_accepts_wide_records(ctx):
+    """records wider than a scratch point (x, y, z + 6 more floats = 36 bytes): first call on a fresh scratch layout"""
+    rng = np.random.default_rng(9)
+    rec = rng.normal(0, 8, (5000, 9)).astype(np.float32)
+    ref = O.ingest_f32(rec, 0.7, 120.0, 0)
+    c2 = ctx.__class__()
+    try:
+        cid, kept = c2.cloud_ingest_f32(rec, 0.7, 120.0, 0)
+        out = c2.cloud_download(cid)
+        assert kept == ref.shape[0] and (out == ref).all()
+    finally:
+        c2.close()
+
+
+def test_two_contexts_on_two_threads(ctx):
+    """the front-end state (resident clouds, builder scratch) belongs to its context: two contexts driven from two host
+    threads build their own clouds' trees concurrently and get what a lone context gets"""
+    import threading
+    rng = np.random.default_rng(21)
+    clouds = [rng.normal(0, 5, (30000, 3)) * [1, 1, 0.2], rng.normal(0, 9, (45000, 3)) * [1, 0.3, 1]]
+    want = []
+    for c in clouds:
+        cid = ctx.cloud_upload(c)
+        t, nl = ctx.tree_build(cid, B_MAX, B_MIN)
+        want.append(nl)
+        ctx.tree_release(t)
+        ctx.cloud_release(cid)
+    got, errs = [[], []], []
+
+    def work(i):
+        try:
+            c2 = ctx.__class__()
+            for _ in range(6):
+                cid = c2.cloud_upload(clouds[i])
+                t, nl = c2.tree_build(cid, B_MAX, B_MIN)
+                got[i].append(nl)
+                c2.tree_release(t)
+                c2.cloud_release(cid)
+            c2.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert got[0] == [want[0]] * 6 and got[1] == [want[1]] * 6
+
+
 # ---- the device front-end behind Pipeline.compute (opt-in) -------------------------------------------------------------
 N_FRAMES = 12
 

@@ -16,6 +16,12 @@ if use_torch:
     ctx = capi.Context(0, st.cuda_stream)
 else:
     ctx = capi.Context(0)
+if "--eager" in sys.argv:
+    ctx.set_option("use_graph", 0)
+for a in sys.argv[1:]:
+    if "=" in a:
+        k, v = a.split("=")
+        ctx.set_option(k, int(v))
 tids = []
 for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
     ht = capi.HostTree(s, 0.2, 0.1, 3); ht.transform(T[:3, :3], T[:3, 3]); tids.append(ctx.upload(ht))
@@ -23,7 +29,7 @@ leaves = [capi.HostTree(s, 0.2, 0.1, 3).leaf_means() for s in scans]
 guess = [capi.pose12(T) for T in gs]
 P = (0.2, 0.1, 0.02)
 NQ = 8
-for depth in (1, 0, 1, 2):
+for depth in (1, 0, 1):
     ts, tc, tstep = [], [], []
     pend = []
     n = 400
