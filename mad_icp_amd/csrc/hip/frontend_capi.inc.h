@@ -30,7 +30,10 @@ struct FrontScratch {
   double* table = nullptr;       // thresholds | poses
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
-  tb::State* h_state = nullptr;  // pinned
+  tb::State* h_state = nullptr;  // pinned: copy of the device State (diagnostics, big clouds)
+  tb::HostLine* h_line = nullptr; // pinned: what a build publishes to the host (tb_finish_b)
+  int build_seq = 0;
+  bool state_stale = false;      // h_state is older than the device State
   double* h_table = nullptr;     // pinned, same layout as `table`
   hipEvent_t h_table_read = nullptr;
 };
@@ -59,6 +62,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   *out = &fs;
   if (!fs.h_state) {
     HIP_TRY(hipHostMalloc(&fs.h_state, sizeof(tb::State), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&fs.h_line, sizeof(tb::HostLine), hipHostMallocDefault));
+    std::memset(fs.h_line, 0, sizeof(tb::HostLine));
     HIP_TRY(hipHostMalloc(&fs.h_table, sizeof(double) * kDeskewTableMax * 13, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&fs.h_table_read, hipEventDisableTiming));
   }
@@ -92,8 +97,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_leaf = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_S = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
-  const size_t o_p1a = take(sizeof(double) * 18 * slots);
-  const size_t o_p1b = take(sizeof(double) * 18 * slots);
+  const size_t o_p1 = take(sizeof(double) * 18 * slots * (tb::kChipLevels + 1));
   const size_t o_p2 = take(sizeof(double) * 8 * slots);
   const size_t o_key0 = take(sizeof(double) * (size_t)nc);
   const size_t o_key1 = take(sizeof(double) * (size_t)nc);
@@ -121,11 +125,13 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.small[0] = reinterpret_cast<int4*>(b + o_small0);
   fs.P.small[1] = reinterpret_cast<int4*>(b + o_small1);
   fs.P.leaf_start = reinterpret_cast<uint32_t*>(b + o_leaf);
-  fs.P.partLR[0] = reinterpret_cast<double*>(b + o_p1a);
-  fs.P.partLR[1] = reinterpret_cast<double*>(b + o_p1b);
+  fs.P.partLR = reinterpret_cast<double*>(b + o_p1);
+  fs.P.part_stride = (long)(18 * slots);
   fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
   fs.S = reinterpret_cast<uint32_t*>(b + o_S);
   fs.tile_sums = reinterpret_cast<uint32_t*>(b + o_tiles);
+  fs.P.S = fs.S;
+  fs.P.tile_sums = fs.tile_sums;
   fs.key[0] = reinterpret_cast<double*>(b + o_key0);
   fs.key[1] = reinterpret_cast<double*>(b + o_key1);
   fs.idx[0] = reinterpret_cast<uint32_t*>(b + o_idx0);
@@ -145,6 +151,7 @@ void front_destroy(madicp_ctx* ctx) {  // called by madicp_ctx_destroy (streams 
   FrontScratch& fs = ctx->front->scratch;
   if (fs.block) hipFree(fs.block);
   if (fs.h_state) hipHostFree(fs.h_state);
+  if (fs.h_line) hipHostFree(fs.h_line);
   if (fs.h_table) hipHostFree(fs.h_table);
   if (fs.h_table_read) hipEventDestroy(fs.h_table_read);
   delete ctx->front;
@@ -426,20 +433,23 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   P.b_max = b_max;
   P.b_min = b_min;
   hipStream_t s = ctx->copy;
+  const bool chip = n > tb::kChipMin;
+  P.first_step = chip ? tb::kChipLevels : 0;
   HIP_TRY(hipMemsetAsync(P.st, 0, sizeof(tb::State), s));
   HIP_TRY(hipMemsetAsync(P.leaf_start, 0, sizeof(uint32_t) * ((size_t)n + 1), s));
   hipLaunchKernelGGL(tb::tb_init, dim3(1), dim3(64), 0, s, P);
-  const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + 64, (int64_t)ctx->n_cus * 4));
+  const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
   // one wave per wave-regime node (at most n / 33 of them on a level) and four lanes per small node (most levels hold far
   // fewer than the n of them this bound allows for: the queues are walked with a stride)
   const int level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + n / 256 + 1)));
   auto run_levels = [&](int from, int to) {
     for (int level = from; level < to; ++level) {
-      if (level < tb::kChipLevels && n > tb::kChipMin) {
+      if (chip && level < tb::kChipLevels) {
         if (level == 0) hipLaunchKernelGGL(tb::tb_chip_sums, dim3(chip_grid), dim3(256), 0, s, P, level);
         hipLaunchKernelGGL(tb::tb_chip_stats, dim3(chip_grid), dim3(256), 0, s, P, level);
         hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(chip_grid), dim3(256), 0, s, P, level);
       }
+      if (level < P.first_step) continue;  // (wave / quad nodes born up here wait for step first_step: tree_build.hip.h)
       // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
       // workgroups that only look at an empty queue still cost their dispatch)
       const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, n) : n;
@@ -447,37 +457,63 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
       hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
     }
   };
-  auto finish = [&]() -> int {
-    // what the host needs: leaf count (scan of the leaf starts), root mean, rho, size of the LDS-staged top
-    HIP_TRY(hipMemsetAsync(&P.st->n_leaves, 0, offsetof(tb::State, q_count) - offsetof(tb::State, n_leaves), s));  // the results line
+  // What the host needs before it can size the tree — leaf count (scan of the leaf starts), root mean, rho, size of the
+  // LDS-staged top, error flags, whether a queue is still waiting — arrives in fs->h_line.
+  tb::HostLine& hl = *fs->h_line;
+  const int n_tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
+  auto finish = [&](int next_step, bool again) -> int {
+    if (again)  // (a fresh State is all zero; a second summary must not add to the first)
+      HIP_TRY(hipMemsetAsync(&P.st->n_leaves, 0, offsetof(tb::State, q_count) - offsetof(tb::State, n_leaves), s));  // the results line
+    if (n_tiles <= tb::kScanDirectMax) {
+      const int seq = ++fs->build_seq;
+      hipLaunchKernelGGL(tb::tb_finish_a, dim3(n_tiles + 64), dim3(256), 0, s, P, kTopLevels, n_tiles);
+      hipLaunchKernelGGL(tb::tb_finish_b, dim3(n_tiles), dim3(256), 0, s, P, n_tiles, next_step, fs->h_line, seq);
+      HIP_TRY(hipGetLastError());
+      for (unsigned spins = 1; __atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
+        if ((spins & 0x3ff) == 0) {  // every few tens of microseconds: is the stream still alive?
+          const hipError_t q = hipStreamQuery(s);
+          if (q == hipSuccess) {
+            if (__atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) == seq) break;
+            return fail(MADICP_ERR_DEVICE, "tree build: finished without publishing its summary");
+          }
+          if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("tree build: ") + hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+      }
+      return MADICP_OK;
+    }
+    // huge clouds: three-kernel scan, summary, the State copied back
     RC_TRY(scan_marks(ctx, *fs, P.leaf_start, n, &P.st->n_leaves));
     hipLaunchKernelGGL(tb::tb_summary, dim3(64), dim3(256), 0, s, P, kTopLevels);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(fs->h_state, P.st, sizeof(tb::State), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    const tb::State& h = *fs->h_state;
+    hl.n_nodes = h.n_nodes.v; hl.error = h.n_nodes.error; hl.n_leaves = h.n_leaves; hl.n_top = h.n_top;
+    hl.max_level = h.max_level; hl.n_valid = h.n_valid; hl.rho_bits = h.rho_bits;
+    hl.pending_wave = h.q_count[next_step].v; hl.pending_quad = h.small_count[next_step].v;
+    for (int i = 0; i < 3; ++i) hl.origin[i] = h.origin[i];
     return MADICP_OK;
   };
   // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop below
   int levels_done = 20;
   run_levels(0, levels_done);
-  RC_TRY(finish());
-  auto pending = [&]() {
-    const tb::State& h = *fs->h_state;
-    return h.q_count[levels_done].v > 0 || h.small_count[levels_done].v > 0;
-  };
-  while (fs->h_state->n_nodes.error == 0 && levels_done < tb::kMaxLevels && pending()) {
+  RC_TRY(finish(levels_done, false));
+  auto pending = [&]() { return hl.pending_wave > 0 || hl.pending_quad > 0; };
+  while (hl.error == 0 && levels_done < tb::kMaxLevels && pending()) {
     const int to = std::min(levels_done + 8, tb::kMaxLevels);
     run_levels(levels_done, to);
     levels_done = to;
-    RC_TRY(finish());
+    RC_TRY(finish(levels_done, true));
   }
-  const tb::State& st = *fs->h_state;
-  if (st.n_nodes.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
-  if (st.n_nodes.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
-  const int32_t n_leaves = st.n_leaves, n_nodes = 2 * st.n_leaves - 1;
-  if (n_leaves < 1 || st.n_nodes.v != n_nodes || st.n_valid != n_nodes)
-    return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(st.n_nodes.v) + " nodes, " +
-                                       std::to_string(st.n_valid) + " finished, " + std::to_string(n_leaves) + " leaves)");
+  fs->state_stale = true;
+  if (hl.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
+  if (hl.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
+  const int32_t n_leaves = hl.n_leaves, n_nodes = 2 * hl.n_leaves - 1;
+  if (n_leaves < 1 || hl.n_nodes != n_nodes || hl.n_valid != n_nodes)
+    return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(hl.n_nodes) + " nodes, " +
+                                       std::to_string(hl.n_valid) + " finished, " + std::to_string(n_leaves) + " leaves)");
+  struct { int32_t n_top; unsigned long long rho_bits; double origin[3]; } st{hl.n_top, hl.rho_bits, {hl.origin[0], hl.origin[1], hl.origin[2]}};
   DevTree t;
   t.n_nodes = n_nodes;
   t.n_leaves = n_leaves;
@@ -541,8 +577,15 @@ int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t
 // out[1] = lane-regime sub-trees, then 2 x 64 ints: wave-regime and chip-regime nodes per level
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
   if (!ctx || !out) return fail(MADICP_ERR_INVALID, "null argument");
-  if (!ctx->front || !ctx->front->scratch.h_state) return fail(MADICP_ERR_INVALID, "no build yet");
-  const tb::State& st = *ctx->front->scratch.h_state;
+  if (!ctx->front || !ctx->front->scratch.h_state || !ctx->front->scratch.block) return fail(MADICP_ERR_INVALID, "no build yet");
+  FrontScratch& fs = ctx->front->scratch;
+  if (fs.state_stale) {  // (a build publishes one line to the host; the per-level counters are fetched when asked for)
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(fs.h_state, fs.P.st, sizeof(tb::State), hipMemcpyDeviceToHost, ctx->copy));
+    HIP_TRY(hipStreamSynchronize(ctx->copy));
+    fs.state_stale = false;
+  }
+  const tb::State& st = *fs.h_state;
   out[0] = st.max_level;
   int lanes = 0;
   for (int i = 0; i <= tb::kMaxLevels; ++i) lanes += st.small_count[i].v;

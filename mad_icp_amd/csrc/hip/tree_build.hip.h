@@ -52,8 +52,14 @@ namespace tb {
 #define MADICP_TB_SMALL 32
 #endif
 constexpr int kSmallMax = MADICP_TB_SMALL;  // quad regime: a node with at most this many points is handled by four lanes
-constexpr int kChipMin = 4096;   // chip regime above this many points ...
-constexpr int kChipLevels = 6;   // ... during the first levels only (afterwards the wave regime takes any size)
+#ifndef MADICP_TB_CHIP_MIN
+#define MADICP_TB_CHIP_MIN 512
+#endif
+#ifndef MADICP_TB_CHIP_LEVELS
+#define MADICP_TB_CHIP_LEVELS 6
+#endif
+constexpr int kChipMin = MADICP_TB_CHIP_MIN;        // chip regime above this many points ...
+constexpr int kChipLevels = MADICP_TB_CHIP_LEVELS;  // ... during the first levels only (afterwards the wave regime takes any size)
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
@@ -110,12 +116,20 @@ struct Params {
   int32_t* big[2];      // chip-regime lists, by level parity
   int4* small[2];       // quad-regime queues, by level parity (same entries)
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
-  double* partLR[2];    // chip regime, by level parity: per chunk slot 18 doubles — the nine sums of the chunk's points that
-                        // go left, then of those that go right (written by the PARENT level's scatter; level 0: by
-                        // tb_chip_sums into the first nine)
+  uint32_t* S;          // (n_points + 1): its exclusive scan — leaves in front of a point (made when the levels are done)
+  uint32_t* tile_sums;  // scan scratch: marks per 1024-point tile
+  double* partLR;       // chip regime, one block of part_stride doubles per level 0 .. kChipLevels: per chunk slot 18 doubles —
+                        // the nine sums of the chunk's points that go left, then of those that go right (written by the
+                        // PARENT level's scatter; level 0: by tb_chip_sums into the first nine).  Per level, not by parity:
+                        // a small child of a chip node reads its block when its step comes, levels later.
+  long part_stride;
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
   int32_t n_points;
   double b_max, b_min;
+  int32_t first_step;   // wave / quad nodes created above this level wait in its queues: while the chip regime runs (levels
+                        // 0 .. kChipLevels - 1 of a big cloud) such nodes are rare, and a launch per level that looks at
+                        // two empty queues cost 3 us each.  A queue index is therefore a STEP (>= the node's level); the
+                        // level proper travels in the entry (it selects the point buffer) and in the node.
 };
 
 // (selects, not P.buf[level & 1]: a dynamically indexed member sends the whole by-value Params to scratch memory)
@@ -126,7 +140,7 @@ __device__ __forceinline__ double* level_out(const Params& P, int level) { retur
 __device__ __forceinline__ int4* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
 __device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
 __device__ __forceinline__ int4* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
-__device__ __forceinline__ double* level_part(const Params& P, int level) { return (level & 1) ? P.partLR[1] : P.partLR[0]; }
+__device__ __forceinline__ double* level_part(const Params& P, int level) { return P.partLR + (long)min(level, kChipLevels) * P.part_stride; }
 
 // ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
 // utils.h:54-73 after the sums: s = {sum x, sum y, sum z, sum xx, xy, xz, yy, yz, zz}
@@ -259,10 +273,11 @@ __device__ __forceinline__ void enqueue_single(const Params& P, int id, int begi
     }
     kind = 1;
   }
+  const int step = max(level, P.first_step);
   if (kind == 0)
-    level_small(P, level)[atomicAdd(&st->small_count[level].v, 1)] = make_int4(id, begin, end, level);
+    level_small(P, step)[atomicAdd(&st->small_count[step].v, 1)] = make_int4(id, begin, end, level);
   else
-    level_q(P, level)[atomicAdd(&st->q_count[level].v, 1)] = make_int4(id, begin, end, level);
+    level_q(P, step)[atomicAdd(&st->q_count[step].v, 1)] = make_int4(id, begin, end, level);
 }
 
 // the surface normal of a leaf (mad_tree.cpp:64-74)
@@ -669,7 +684,7 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
 }
 
 // the two children of a split node: records, and their places in the next level's queues
-__device__ __forceinline__ void emit_children(const Params& P, int id, const Split& sp, int c, int slot_small, int slot_wave) {
+__device__ __forceinline__ void emit_children(const Params& P, int id, const Split& sp, int c, int slot_small, int slot_wave, int next_step) {
   BNode& nd = P.nodes[id];
   const int level = sp.inh.level;
   const int n = sp.e - sp.b;
@@ -683,11 +698,12 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
   // (children of a wave/lane node are never chip-regime: n <= 4096, or past the chip levels)
   const int4 eL = make_int4(c, sp.b, sp.mid, level + 1), eR = make_int4(c + 1, sp.mid, sp.e, level + 1);
-  if (nL <= kSmallMax) level_small(P, level + 1)[slot_small++] = eL; else level_q(P, level + 1)[slot_wave++] = eL;
-  if (nR <= kSmallMax) level_small(P, level + 1)[slot_small] = eR; else level_q(P, level + 1)[slot_wave] = eR;
+  if (nL <= kSmallMax) level_small(P, next_step)[slot_small++] = eL; else level_q(P, next_step)[slot_wave++] = eL;
+  if (nR <= kSmallMax) level_small(P, next_step)[slot_small] = eR; else level_q(P, next_step)[slot_wave] = eR;
 }
 
-// One level of the wave and quad regimes.  256 threads = 4 wavefronts.
+// One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
+// 256 threads = 4 wavefronts.
 __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -752,7 +768,7 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
       if (c + 2 > P.node_cap) {
         st->n_nodes.error = 1;
       } else {
-        emit_children(P, id, sp, c, s_base_small + bs, s_base_wave + bw);
+        emit_children(P, id, sp, c, s_base_small + bs, s_base_wave + bw, level + 1);
       }
     }
     __syncthreads();
@@ -791,7 +807,7 @@ __global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
       if (c + 2 > P.node_cap) {
         st->n_nodes.error = 1;
       } else {
-        emit_children(P, ent.x, sp, c, base_q + 2 * rank, 0);  // children of a quad node are quad nodes
+        emit_children(P, ent.x, sp, c, base_q + 2 * rank, 0, level + 1);  // children of a quad node are quad nodes
       }
     }
   }
@@ -1062,7 +1078,8 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       if (cm.chunk == 0 && threadIdx.x == 0) {  // rare: finished by the wave regime of the next level (nearest member)
         nd.bbox0 = ext0;
         nd.flags |= kLeafPending;
-        level_q(P, level + 1)[atomicAdd(&P.st->q_count[level + 1].v, 1)] = make_int4(id, b, e, level);  // (its points stay at `level`)
+        const int step = max(level + 1, P.first_step);
+        level_q(P, step)[atomicAdd(&P.st->q_count[step].v, 1)] = make_int4(id, b, e, level);  // (its points stay at `level`)
       }
       continue;
     }
@@ -1154,11 +1171,11 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
   }
 }
 
-// ---- exclusive scan of the leaf-start marks (3 kernels, 1024 elements per workgroup) ----------------------------
+// ---- exclusive scan of the leaf-start marks (1024 elements per workgroup) ----------------------------------------
 constexpr int kScanTile = 1024;
-__global__ __launch_bounds__(256) void tb_scan_tiles(const uint32_t* __restrict__ marks, int n, uint32_t* __restrict__ tile_sums) {
+__device__ __forceinline__ void scan_tiles_body(const uint32_t* __restrict__ marks, int n, uint32_t* __restrict__ tile_sums, int block) {
   __shared__ uint32_t s_w[4];
-  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  const int base = block * kScanTile + threadIdx.x * 4;
   uint32_t v = 0;
   #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -1167,7 +1184,10 @@ __global__ __launch_bounds__(256) void tb_scan_tiles(const uint32_t* __restrict_
   for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (threadIdx.x == 0) tile_sums[block] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void tb_scan_tiles(const uint32_t* __restrict__ marks, int n, uint32_t* __restrict__ tile_sums) {
+  scan_tiles_body(marks, n, tile_sums, blockIdx.x);
 }
 // one workgroup: exclusive scan of the tile sums in place (any count), the grand total into *out_total
 __global__ __launch_bounds__(256) void tb_scan_top(uint32_t* __restrict__ tile_sums, int n_tiles, int32_t* __restrict__ out_total) {
@@ -1196,12 +1216,12 @@ __global__ __launch_bounds__(256) void tb_scan_top(uint32_t* __restrict__ tile_s
   }
   if (threadIdx.x == 0) *out_total = (int32_t)s_carry;
 }
-// S[i] = marks before i, for i in [0, n]
-__global__ __launch_bounds__(256) void tb_scan_apply(const uint32_t* __restrict__ marks, int n, const uint32_t* __restrict__ tile_sums,
-                                                     uint32_t* __restrict__ S) {
+// S[i] = marks before i, for i in [0, n]; tile_offset = marks before this tile.  Returns (to every thread) the marks of the tile.
+__device__ __forceinline__ uint32_t scan_apply_body(const uint32_t* __restrict__ marks, int n, uint32_t tile_offset, uint32_t* __restrict__ S,
+                                                    int block) {
   __shared__ uint32_t s_w[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int base = blockIdx.x * kScanTile + threadIdx.x * 4;
+  const int base = block * kScanTile + threadIdx.x * 4;
   uint32_t m[4], v = 0;
   #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -1216,7 +1236,7 @@ __global__ __launch_bounds__(256) void tb_scan_apply(const uint32_t* __restrict_
   }
   if (lane == 63) s_w[wv] = incl;
   __syncthreads();
-  uint32_t off = tile_sums[blockIdx.x];
+  uint32_t off = tile_offset;
   for (int k = 0; k < wv; ++k) off += s_w[k];
   uint32_t run = off + incl - v;
   #pragma unroll
@@ -1224,10 +1244,15 @@ __global__ __launch_bounds__(256) void tb_scan_apply(const uint32_t* __restrict_
     if (base + k <= n) S[base + k] = run;
     run += m[k];
   }
+  return s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void tb_scan_apply(const uint32_t* __restrict__ marks, int n, const uint32_t* __restrict__ tile_sums,
+                                                     uint32_t* __restrict__ S) {
+  scan_apply_body(marks, n, tile_sums[blockIdx.x], S, blockIdx.x);
 }
 
 // ---- what the host needs before it can size the tree: root mean, rho, size of the LDS-staged top -----------------
-__global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels) {
+__device__ __forceinline__ void summary_body(const Params& P, int top_levels, int block, int n_blocks) {
   State* st = P.st;
   __shared__ double s_r[4];
   __shared__ int s_tops[4], s_lvl[4], s_valid[4];
@@ -1235,7 +1260,7 @@ __global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels
   const double o0 = P.nodes[0].mean[0], o1 = P.nodes[0].mean[1], o2 = P.nodes[0].mean[2];
   double r = 0.0;
   int tops = 0, lvl = 0, valid = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = block * blockDim.x + threadIdx.x; i < n; i += n_blocks * blockDim.x) {
     const BNode& nd = P.nodes[i];
     lvl = max(lvl, nd.level);
     valid += (nd.flags & kDone) ? 1 : 0;
@@ -1266,9 +1291,56 @@ __global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels
     if (T) atomicAdd(&st->n_top, T);
     if (Lv) atomicMax(&st->max_level, Lv);
     if (Vd) atomicAdd(&st->n_valid, Vd);
-    if (blockIdx.x == 0) {
+    if (block == 0) {
       st->origin[0] = o0; st->origin[1] = o1; st->origin[2] = o2;
     }
+  }
+}
+__global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels) { summary_body(P, top_levels, blockIdx.x, gridDim.x); }
+
+// The end of a build in two launches (clouds of up to kScanDirectMax tiles).  First: the tile sums of the leaf-start marks
+// by the first n_tiles workgroups, the summary by the others.  Second: the scan proper — every workgroup adds up the tile
+// sums in front of its own, no third kernel for that — and the last workgroup publishes what the host is waiting for in
+// its pinned block, sequence number last (system-scope release): the host polls it, no copy command, no event.
+constexpr int kScanDirectMax = 4096;
+struct HostLine {
+  int32_t n_nodes, error, n_leaves, n_top, max_level, n_valid;
+  int32_t pending_wave, pending_quad;  // queue counts of the first step that was not launched
+  unsigned long long rho_bits;
+  double origin[3];
+  int32_t seq, pad_;
+};
+__global__ __launch_bounds__(256) void tb_finish_a(const Params P, int top_levels, int n_tiles) {
+  if ((int)blockIdx.x < n_tiles)
+    scan_tiles_body(P.leaf_start, P.n_points, P.tile_sums, blockIdx.x);
+  else
+    summary_body(P, top_levels, (int)blockIdx.x - n_tiles, (int)gridDim.x - n_tiles);
+}
+__global__ __launch_bounds__(256) void tb_finish_b(const Params P, int n_tiles, int next_step, HostLine* __restrict__ host, int seq) {
+  __shared__ uint32_t s_part[4];
+  uint32_t before = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += blockDim.x) before += P.tile_sums[i];
+  #pragma unroll
+  for (int m = 32; m > 0; m >>= 1) before += __shfl_xor(before, m, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
+  __syncthreads();
+  before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+  __syncthreads();
+  const uint32_t own = scan_apply_body(P.leaf_start, P.n_points, before, P.S, blockIdx.x);
+  if ((int)blockIdx.x == n_tiles - 1 && threadIdx.x == 0) {
+    State* st = P.st;
+    st->n_leaves = (int32_t)(before + own);
+    host->n_nodes = st->n_nodes.v;
+    host->error = st->n_nodes.error;
+    host->n_leaves = (int32_t)(before + own);
+    host->n_top = st->n_top;
+    host->max_level = st->max_level;
+    host->n_valid = st->n_valid;
+    host->pending_wave = st->q_count[next_step].v;
+    host->pending_quad = st->small_count[next_step].v;
+    host->rho_bits = st->rho_bits;
+    host->origin[0] = st->origin[0]; host->origin[1] = st->origin[1]; host->origin[2] = st->origin[2];
+    __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
