@@ -435,9 +435,8 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   hipStream_t s = ctx->copy;
   const bool chip = n > tb::kChipMin;
   P.first_step = chip ? tb::kChipLevels : 0;
-  HIP_TRY(hipMemsetAsync(P.st, 0, sizeof(tb::State), s));
-  HIP_TRY(hipMemsetAsync(P.leaf_start, 0, sizeof(uint32_t) * ((size_t)n + 1), s));
-  hipLaunchKernelGGL(tb::tb_init, dim3(1), dim3(64), 0, s, P);
+  // (State and leaf-start marks are cleared by tb_init itself)
+  hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, P);
   const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
   // one wave per wave-regime node (at most n / 33 of them on a level) and four lanes per small node (most levels hold far
   // fewer than the n of them this bound allows for: the queues are walked with a stride)

@@ -322,9 +322,24 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 }
 
 // ---- init ---------------------------------------------------------------------------------------------------
-__global__ void tb_init(const Params P) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Workgroup 0 clears the State and sets the root up; the others clear the leaf-start marks (no fill commands in front of
+// a build: each was a dispatch of its own).  256 threads.
+__global__ __launch_bounds__(256) void tb_init(const Params P) {
+  if (blockIdx.x != 0) {
+    const long n = (long)P.n_points + 1;
+    uint32_t* __restrict__ m = P.leaf_start;  // (256-byte aligned, padded to a multiple of 4 and more: ensure_scratch)
+    const long n4 = (n + 3) / 4;
+    for (long i = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x; i < n4; i += (long)(gridDim.x - 1) * blockDim.x)
+      reinterpret_cast<uint4*>(m)[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   State* st = P.st;
+  {
+    uint4* z = reinterpret_cast<uint4*>(st);
+    for (int i = threadIdx.x; i < (int)(sizeof(State) / sizeof(uint4)); i += blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   BNode& r = P.nodes[0];
   #pragma unroll
   for (int i = 0; i < 3; ++i) { r.mean[i] = 0; r.dir[i] = 0; r.col0[i] = 0; r.plane_n[i] = 0; r.small_n[i] = 0; }
@@ -340,6 +355,7 @@ __global__ void tb_init(const Params P) {
   st->n_nodes.v = 1;
   enqueue_single(P, 0, 0, P.n_points, 0);
 }
+static_assert(sizeof(State) % sizeof(uint4) == 0, "State is cleared 16 bytes at a time");
 
 // development instrumentation (-DMADICP_TB_STAMPS, tools/tb_stamps.py): per level, the 100 MHz wall clock at a few points
 #ifdef MADICP_TB_STAMPS
@@ -370,7 +386,10 @@ struct Split {
 
 // clamped 8-deep strided access: lane's points i0, i0 + 64, ..., i0 + 448 of [b, e); all twenty-four loads are issued
 // before the first use (a dependent-latency loop of one load per iteration costs ~700 cycles per 64 points)
-constexpr int kWU = 8;
+#ifndef MADICP_TB_WU
+#define MADICP_TB_WU 8
+#endif
+constexpr int kWU = MADICP_TB_WU;
 #define TB_LOAD4(in, i0, e, b, x, y, z, ok)                         \
   _Pragma("unroll") for (int u_ = 0; u_ < kWU; ++u_) {             \
     const int i_ = (i0) + 64 * u_;                                  \
@@ -704,7 +723,10 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
 
 // One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
 // 256 threads = 4 wavefronts.
-__global__ __launch_bounds__(256) void tb_level(const Params P, int level) {
+#ifndef MADICP_TB_WPE
+#define MADICP_TB_WPE 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_WPE, MADICP_TB_WPE))) void tb_level(const Params P, int level) {
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cntW = st->q_count[level].v, cntS = st->small_count[level].v;
