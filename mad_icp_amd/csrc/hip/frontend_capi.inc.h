@@ -220,8 +220,15 @@ int madicp_cloud_upload(madicp_ctx* ctx, const double* xyz, int64_t n, int* out_
     CLOUD_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
     ctx->h_tree_cap[hb] = cap;
   }
-  std::memcpy(ctx->h_tree[hb], xyz, bytes);
-  CLOUD_TRY(hipMemcpyAsync(c.xyz, ctx->h_tree[hb], bytes, hipMemcpyHostToDevice, ctx->copy));
+  // staged and sent in pieces: the copy engine moves piece k while the host stages piece k + 1
+  {
+    const size_t piece = std::max<size_t>(align_up(bytes / 4), 256 << 10);
+    for (size_t off = 0; off < bytes; off += piece) {
+      const size_t len = std::min(piece, bytes - off);
+      std::memcpy(ctx->h_tree[hb] + off, reinterpret_cast<const char*>(xyz) + off, len);
+      CLOUD_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c.xyz) + off, ctx->h_tree[hb] + off, len, hipMemcpyHostToDevice, ctx->copy));
+    }
+  }
   CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
   CLOUD_TRY(hipEventRecord(c.ready, ctx->copy));
   const int id = ctx->next_id++;
