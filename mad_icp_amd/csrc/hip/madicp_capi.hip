@@ -1416,19 +1416,21 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
   }
   if (out_walked_per_launch)  // (h_fetch still holds the Jobs madicp_icp_fetch just read)
     for (int s = 0; s < n_scans; ++s) out_walked_per_launch[s] = ctx->h_fetch[s].walked / (uint64_t)n_iters;
-  // icp_final alone, replayed `reps` times as a graph: what is left of a registration is its n_iters icp_round launches
+  // icp_final alone, `reps` of them back to back inside ONE graph (a graph per launch would add the idle queue between two
+  // graph launches, ~10 us, to a 5 us kernel): what is left of a registration is its n_iters icp_round launches
   const Geometry geo = pick_geometry(ctx, [&] { int m = 0; for (int s = 0; s < n_scans; ++s) m = std::max(m, ctx->movings.at(moving_ids[s]).L); return m; }(), K, n_scans);
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  hipLaunchKernelGGL(icp_final, dim3(n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                     (const double*)nullptr, geo.grid, n_scans);
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(icp_final, dim3(n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
+                       (const double*)nullptr, geo.grid, n_scans);
   HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
   HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   {
     hipGraphLaunch(exec, ctx->stream);
     hipEventRecord(ctx->ev_t0, ctx->stream);
-    for (int r = 0; r < reps; ++r) hipGraphLaunch(exec, ctx->stream);
+    hipGraphLaunch(exec, ctx->stream);
     hipEventRecord(ctx->ev_t1, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     float ms_final = 0.f;
