@@ -156,8 +156,9 @@ int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, in
 /* What Pipeline::compute does per frame (pipeline.cpp:154-204), as one asynchronous submission: setMoving(leaf_means),
  * init(X0), n_iters rounds against K resident trees, and the read-out of X_, H_adder_, b_adder_, the matched_ flags and
  * their count.  The leaves and the job description are fed on the copy stream (they overlap the registration in
- * flight), the results are written by the registration's last kernel straight into pinned host memory, and
- * madicp_stream_collect waits for ONE event.  Up to 4 tickets may be outstanding; collect them in any order before
+ * flight), the results are written by the registration's last kernel straight into pinned host memory, a sequence
+ * number last, and madicp_stream_collect polls that number (spinning on the calling thread until the registration has
+ * finished; an event instead with option "seq_completion" = 0).  Up to 4 tickets may be outstanding; collect them in any order before
  * their slot is needed again (MADICP_ERR_CAPACITY otherwise).  Bit-identical to madicp_icp_register on the same inputs. */
 int madicp_stream_submit(madicp_ctx* ctx, const double* leaf_means, int32_t L, const int* tree_ids, int K,
                          const double X0[12], const madicp_icp_params* params, int n_iters, int* out_ticket);
