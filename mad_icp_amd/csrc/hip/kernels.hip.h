@@ -247,15 +247,22 @@ __device__ __forceinline__ Screen make_screen(const TreeDesc& td, double q0, dou
   return s;
 }
 
+// the three 21-bit two's-complement fields of a screening record's first 8 bytes (x = low word, y = high word):
+// one signed bit-field extract each (the middle one after a 64-bit funnel shift)
+__device__ __forceinline__ void unpack_k(unsigned int x, unsigned int y, int& k0, int& k1, int& k2) {
+  k0 = __builtin_amdgcn_sbfe((int)x, 0, 21);
+  k1 = __builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(y, x, 21), 0, 21);
+  k2 = __builtin_amdgcn_sbfe((int)y, 10, 21);
+}
+
 // one screened side test: true = go left.  w = the node's 16-byte screening record
 __device__ __forceinline__ bool screened_goes_left(const vu4 w, const Screen& sc, const madicp_node* __restrict__ nodes, int idx,
                                                    double q0, double q1, double q2) {
-  const int k0 = ((int)(w.x << 11)) >> 11;
-  const int k1 = ((int)(((w.y << 22) | (w.x >> 10)) & 0xfffff800u)) >> 11;
-  const int k2 = ((int)(w.y << 1)) >> 11;
+  int k0, k1, k2;
+    unpack_k(w.x, w.y, k0, k1, k2);
   const double c = (double)__uint_as_float(w.z);
-  const double sh = (sc.r0 * (double)k0 + sc.r1 * (double)k1) + sc.r2 * (double)k2 - c;
-  if (fabs(sh) > sc.slack + kScreenC * fabs(c)) return sh < 0.0;
+  const double sh = fma(sc.r0, (double)k0, fma(sc.r1, (double)k1, fma(sc.r2, (double)k2, -c)));  // (fused: see descend_multi)
+  if (fabs(sh) > fma(kScreenC, fabs(c), sc.slack)) return sh < 0.0;
   return exact_goes_left(nodes, idx, q0, q1, q2);
 }
 
@@ -322,12 +329,13 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
   }
   // one screened side test that also lowers the margin; exact fallback -> margin 0
   auto side = [&](const vu4 ww, int j, int node_index) -> bool {
-    const int k0 = ((int)(ww.x << 11)) >> 11;
-    const int k1 = ((int)(((ww.y << 22) | (ww.x >> 10)) & 0xfffff800u)) >> 11;
-    const int k2 = ((int)(ww.y << 1)) >> 11;
+    int k0, k1, k2;
+    unpack_k(ww.x, ww.y, k0, k1, k2);
     const double c = (double)__uint_as_float(ww.z);
-    const double sh = (sc[j].r0 * (double)k0 + sc[j].r1 * (double)k1) + sc[j].r2 * (double)k2 - c;
-    const double slack = sc[j].slack + kScreenC * fabs(c);
+    // (fused: the screening bound E covers the rounding of the UNFUSED evaluation, a fused one errs less; the sign
+    // decision is the same whenever |s^| > E, and the margin stays a lower bound of |S_real|)
+    const double sh = fma(sc[j].r0, (double)k0, fma(sc[j].r1, (double)k1, fma(sc[j].r2, (double)k2, -c)));
+    const double slack = fma(kScreenC, fabs(c), sc[j].slack);
     const double m = fabs(sh) - slack;
     if (m > 0.0) {
       margin[j] = fmin(margin[j], m);
@@ -350,12 +358,11 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         if (intop[j]) {
-          const int k0 = ((int)(w[j].x << 11)) >> 11;
-          const int k1 = ((int)(((w[j].y << 22) | (w[j].x >> 10)) & 0xfffff800u)) >> 11;
-          const int k2 = ((int)(w[j].y << 1)) >> 11;
+          int k0, k1, k2;
+    unpack_k(w[j].x, w[j].y, k0, k1, k2);
           const double c = (double)__uint_as_float(w[j].z);
-          const double sh = (sc[j].r0 * (double)k0 + sc[j].r1 * (double)k1) + sc[j].r2 * (double)k2 - c;
-          const double m = fabs(sh) - (sc[j].slack + kScreenC * fabs(c));
+          const double sh = fma(sc[j].r0, (double)k0, fma(sc[j].r1, (double)k1, fma(sc[j].r2, (double)k2, -c)));
+          const double m = fabs(sh) - fma(kScreenC, fabs(c), sc[j].slack);
           bool left;
           if (m > 0.0) {
             margin[j] = fmin(margin[j], m);
