@@ -99,7 +99,7 @@ struct TreeDesc {
   double rho;            // >= |m - o|_1 for every internal node (sqrt(3) * max |m - o|_2)
   // the hot top of the tree, staged into LDS by icp_round (see "LDS-staged top levels" below)
   const CNode* top;      // n_top records, breadth-first over the first kTopLevels levels (internal nodes only)
-  const int2* top_exit;  // per top entry: node index of its left / right child
+  const int2* top_exit;  // per top entry: node index of its left child, leaves of its left sub-tree
   const int* top_dfs;    // per top entry: its own node index (only the exact-path fallback reads it)
   int32_t n_top;
   int32_t pad_;
@@ -110,14 +110,21 @@ struct TreeDesc {
 // same queries costs as much as the first).  LDS serves the same gather in ~15 cycles.  Each workgroup works on ONE
 // tree, so it copies the first kTopLevels levels of that tree's screening records (<= 2047 x 16 B, plus 8 B of
 // child indices each = 48 KiB, three workgroups per CU) into LDS once and walks them there; only the last few
-// levels and the leaf record come from L1/L2.  A top entry's `right` word is re-purposed:
-//   bits 0..11 index of its first child that is itself in the top array | bit 12 left child in top |
-//   bit 13 right child in top | bit 14 left child is a leaf | bit 15 right child is a leaf
+// levels and the leaf record come from L1/L2.  A top entry's `right` word is re-purposed (the walk of these levels is
+// bound by the instructions it issues, so the word is laid out for the fewest of them):
+//   bits 0..10 the top entry of the LEFT child | bits 11..21 the top entry of the RIGHT child (kTopNone: that child is
+//   not in the top array: a leaf, or below the staged levels) | bit 22 left child is a leaf | bit 23 right child is a leaf
+// and its `top_exit` pair holds the node index of the left child and the number of leaves of the left sub-tree (the
+// right child's node index is left + 2 x leaves - 1; going right adds `leaves` to the running leaf ordinal).
 constexpr int kTopLevels = 11;
 constexpr int kTopMax = 2048;
 constexpr int kTopLdsBytes = kTopMax * (16 + 8);
-constexpr unsigned int kTopFirst = 0xfffu, kTopLeftIn = 1u << 12, kTopRightIn = 1u << 13, kTopLeftLeaf = 1u << 14,
-                       kTopRightLeaf = 1u << 15;
+constexpr unsigned int kTopNone = 0x7ffu, kTopLeftLeaf = 1u << 22, kTopRightLeaf = 1u << 23;
+__host__ __device__ __forceinline__ unsigned int top_link_word(int left_entry, int right_entry, bool l_leaf, bool r_leaf) {
+  return (left_entry < 0 ? kTopNone : (unsigned int)left_entry) | ((right_entry < 0 ? kTopNone : (unsigned int)right_entry) << 11) |
+         (l_leaf ? kTopLeftLeaf : 0u) | (r_leaf ? kTopRightLeaf : 0u);
+}
+static_assert(kTopMax - 1 <= (int)kTopNone, "top entries are addressed with 11 bits, the last value means 'none'");
 
 // What one registration hands back, written by icp_final straight into a pinned host block (no D2H copy operation
 // on any stream): the caller waits for the event behind the registration's last kernel and reads it.
@@ -374,13 +381,14 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
           }
           ++depth[j];
           const unsigned int link = w[j].w;
-          const int2 ex = s_exit[e[j]];                       // node indices of the two children
-          if (!left) leaf[j] += (ex.y - ex.x + 1) >> 1;         // leaves of the left sub-tree = (its node count + 1) / 2
-          if (link & (left ? kTopLeftIn : kTopRightIn)) {
-            e[j] = (int)(link & kTopFirst) + ((!left && (link & kTopLeftIn)) ? 1 : 0);
+          const int2 ex = s_exit[e[j]];                       // left child's node index, leaves of the left sub-tree
+          if (!left) leaf[j] += ex.y;
+          const unsigned int nx = (link >> (left ? 0 : 11)) & kTopNone;
+          if (nx != kTopNone) {
+            e[j] = (int)nx;
             any = true;
           } else {
-            idx[j] = left ? ex.x : ex.y;
+            idx[j] = left ? ex.x : ex.x + 2 * ex.y - 1;
             intop[j] = false;
             if (link & (left ? kTopLeftLeaf : kTopRightLeaf)) live[j] = false;  // arrived at a leaf
           }

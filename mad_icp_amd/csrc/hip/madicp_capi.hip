@@ -866,13 +866,11 @@ void layout_top(const madicp_node* nodes, std::vector<int>& dfs, std::vector<uns
     const bool deeper = level[e] + 1 < kTopLevels;
     const bool l_in = !l_leaf && deeper && dfs.size() + 1 <= (size_t)kTopMax - 1;
     const bool r_in = !r_leaf && deeper && dfs.size() + (l_in ? 2 : 1) <= (size_t)kTopMax - 1;
-    unsigned int w = (unsigned int)dfs.size() & kTopFirst;
-    if (l_in) { dfs.push_back(l); level.push_back(level[e] + 1); w |= kTopLeftIn; }
-    if (r_in) { dfs.push_back(r); level.push_back(level[e] + 1); w |= kTopRightIn; }
-    if (l_leaf) w |= kTopLeftLeaf;
-    if (r_leaf) w |= kTopRightLeaf;
-    link.push_back(w);
-    exits.push_back(make_int2(l, r));
+    int le = -1, re = -1;
+    if (l_in) { le = (int)dfs.size(); dfs.push_back(l); level.push_back(level[e] + 1); }
+    if (r_in) { re = (int)dfs.size(); dfs.push_back(r); level.push_back(level[e] + 1); }
+    link.push_back(top_link_word(le, re, l_leaf, r_leaf));
+    exits.push_back(make_int2(l, nodes[i].right >> 1));  // (a left sub-tree of s nodes holds (s + 1) / 2 leaves, s = right - 1)
   }
 }
 

@@ -1439,14 +1439,11 @@ __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restr
     const int next_base = base + ncur;
     if (on) {
       const int first = next_base + excl;
-      unsigned int w = (unsigned int)first & kTopFirst;
-      if (l_in) { s_next[excl] = l; s_next_right[excl] = l_right; w |= kTopLeftIn; }
-      if (r_in) { s_next[excl + (l_in ? 1 : 0)] = r; s_next_right[excl + (l_in ? 1 : 0)] = r_right; w |= kTopRightIn; }
-      if (l_leaf) w |= kTopLeftLeaf;
-      if (r_leaf) w |= kTopRightLeaf;
+      if (l_in) { s_next[excl] = l; s_next_right[excl] = l_right; }
+      if (r_in) { s_next[excl + (l_in ? 1 : 0)] = r; s_next_right[excl + (l_in ? 1 : 0)] = r_right; }
       dfs[base + threadIdx.x] = i;
-      link[base + threadIdx.x] = w;
-      exits[base + threadIdx.x] = make_int2(l, r);
+      link[base + threadIdx.x] = top_link_word(l_in ? first : -1, r_in ? first + (l_in ? 1 : 0) : -1, l_leaf, r_leaf);
+      exits[base + threadIdx.x] = make_int2(l, (r - l + 1) >> 1);
     }
     __syncthreads();
     base = next_base;
