@@ -530,7 +530,7 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   const size_t nt = (size_t)t.n_top;
   const size_t off_nodes = 0;
   const size_t off_exit = align_up(off_nodes + sizeof(madicp_node) * (size_t)n_nodes);
-  const size_t off_dfs = align_up(off_exit + sizeof(int2) * nt);
+  const size_t off_dfs = align_up(off_exit + sizeof(int4) * nt);
   const size_t off_link = align_up(off_dfs + sizeof(int) * nt);
   const size_t up_bytes = align_up(off_link + sizeof(unsigned int) * nt);
   const size_t off_cnodes = up_bytes;
@@ -541,7 +541,7 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   RC_TRY(pool_alloc(ctx, total, s, &blk));
   t.block = static_cast<char*>(blk);
   t.nodes = reinterpret_cast<madicp_node*>(t.block + off_nodes);
-  t.top_exit = nt ? reinterpret_cast<int2*>(t.block + off_exit) : nullptr;
+  t.top_exit = nt ? reinterpret_cast<int4*>(t.block + off_exit) : nullptr;
   t.top_dfs = nt ? reinterpret_cast<int*>(t.block + off_dfs) : nullptr;
   t.top_link = nt ? reinterpret_cast<unsigned int*>(t.block + off_link) : nullptr;
   t.cnodes = reinterpret_cast<CNode*>(t.block + off_cnodes);

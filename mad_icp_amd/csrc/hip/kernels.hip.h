@@ -99,7 +99,8 @@ struct TreeDesc {
   double rho;            // >= |m - o|_1 for every internal node (sqrt(3) * max |m - o|_2)
   // the hot top of the tree, staged into LDS by icp_round (see "LDS-staged top levels" below)
   const CNode* top;      // n_top records, breadth-first over the first kTopLevels levels (internal nodes only)
-  const int2* top_exit;  // per top entry: node index of its left child, leaves of its left sub-tree
+  const int4* top_exit;  // per top entry: node index of its left child, leaves of its left sub-tree, leaf ordinal of its
+                         // left-most leaf, its level (see "LDS-staged top levels")
   const int* top_dfs;    // per top entry: its own node index (only the exact-path fallback reads it)
   int32_t n_top;
   int32_t pad_;
@@ -114,11 +115,13 @@ struct TreeDesc {
 // bound by the instructions it issues, so the word is laid out for the fewest of them):
 //   bits 0..10 the top entry of the LEFT child | bits 11..21 the top entry of the RIGHT child (kTopNone: that child is
 //   not in the top array: a leaf, or below the staged levels) | bit 22 left child is a leaf | bit 23 right child is a leaf
-// and its `top_exit` pair holds the node index of the left child and the number of leaves of the left sub-tree (the
-// right child's node index is left + 2 x leaves - 1; going right adds `leaves` to the running leaf ordinal).
+// and its `top_exit` record holds what only the LAST staged step of a walk needs: x = node index of the left child (the
+// right child's is x + 2y - 1), y = leaves of the left sub-tree, z = leaf ordinal of the entry's left-most leaf (so the
+// running ordinal is not carried through these levels: it is z, plus y when the walk leaves to the right), w = the
+// entry's level (the depth is not counted either: it is w + 1).
 constexpr int kTopLevels = 11;
 constexpr int kTopMax = 2048;
-constexpr int kTopLdsBytes = kTopMax * (16 + 8);
+constexpr int kTopLdsBytes = kTopMax * (16 + 16);
 constexpr unsigned int kTopNone = 0x7ffu, kTopLeftLeaf = 1u << 22, kTopRightLeaf = 1u << 23;
 __host__ __device__ __forceinline__ unsigned int top_link_word(int left_entry, int right_entry, bool l_leaf, bool r_leaf) {
   return (left_entry < 0 ? kTopNone : (unsigned int)left_entry) | ((right_entry < 0 ? kTopNone : (unsigned int)right_entry) << 11) |
@@ -318,7 +321,7 @@ constexpr int kCacheMaxDepth = 63;
 // LDS copy of the tree's top levels (s_top / s_exit, n_top entries), phase 2 continues in global memory.
 // margin[j] (in/out): running minimum of |s^| - E over the levels walked.
 template <int QPT>
-__device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_top, const int2* s_exit, int n_top,
+__device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_top, const int4* s_exit, int n_top,
                                               const double (&q0)[QPT], const double (&q1)[QPT], const double (&q2)[QPT],
                                               const bool (&valid)[QPT], int (&idx)[QPT], int (&leaf)[QPT],
                                               int (&depth)[QPT], double (&margin)[QPT]) {
@@ -379,16 +382,16 @@ __device__ __forceinline__ void descend_multi(const TreeDesc& td, const vu4* s_t
             margin[j] = fmin(margin[j], fmax(fabs(sx) - sc[j].xslack, 0.0));
             left = sx < 0.0;
           }
-          ++depth[j];
           const unsigned int link = w[j].w;
-          const int2 ex = s_exit[e[j]];                       // left child's node index, leaves of the left sub-tree
-          if (!left) leaf[j] += ex.y;
           const unsigned int nx = (link >> (left ? 0 : 11)) & kTopNone;
           if (nx != kTopNone) {
             e[j] = (int)nx;
             any = true;
-          } else {
+          } else {  // the walk leaves the staged levels here: node index, leaf ordinal and depth from the exit record
+            const int4 ex = s_exit[e[j]];
             idx[j] = left ? ex.x : ex.x + 2 * ex.y - 1;
+            leaf[j] = left ? ex.z : ex.z + ex.y;
+            depth[j] = ex.w + 1;
             intop[j] = false;
             if (link & (left ? kTopLeftLeaf : kTopRightLeaf)) live[j] = false;  // arrived at a leaf
           }
@@ -540,14 +543,14 @@ __global__ __launch_bounds__(1024) void nn_descend_top(const TreeDesc td, const 
                                                        double* __restrict__ out_dist, int32_t* __restrict__ out_depth) {
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
-  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
+  int4* s_exit = reinterpret_cast<int4*>(dyn_lds + kTopMax * sizeof(vu4));
   const int n_top = min(td.n_top, kTopMax);
   {
     gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-    const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+    gptr_u4 ge = (gptr_u4)(uintptr_t)td.top_exit;
     for (int e = threadIdx.x; e < n_top; e += blockDim.x) {
       s_top[e] = gt[e];
-      reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+      reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
     }
   }
   __syncthreads();
@@ -1357,7 +1360,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // for the copy)
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
-  int2* s_exit = reinterpret_cast<int2*>(dyn_lds + kTopMax * sizeof(vu4));
+  int4* s_exit = reinterpret_cast<int4*>(dyn_lds + kTopMax * sizeof(vu4));
   int staged_tree = -1;
   __shared__ double s_hint;
   if (round > 0 && !totals) {
@@ -1371,11 +1374,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     if (s_hint > 0.0 && n_top_first > 0) {  // (workgroup-uniform)
       if (threadIdx.x >= 64) {
         gptr_u4 gt = (gptr_u4)(uintptr_t)s_td.top;
-        const __attribute__((address_space(1))) long long* ge =
-            (const __attribute__((address_space(1))) long long*)(uintptr_t)s_td.top_exit;
+        gptr_u4 ge = (gptr_u4)(uintptr_t)s_td.top_exit;
         for (int e = threadIdx.x - 64; e < n_top_first; e += kBlock - 64) {
           s_top[e] = gt[e];
-          reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+          reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
         }
       }
       staged_tree = k_first;  // visible to everybody after the barrier that ends the prologue
@@ -1538,10 +1540,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         if (n_top_avail > 0 && k != staged_tree && stage_hint) {  // (workgroup-uniform condition) copy the top levels into LDS
           if (staged_tree >= 0) __syncthreads();  // nobody may still be walking the previous tree's copy
           gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-          const long long* ge = reinterpret_cast<const long long*>(td.top_exit);
+          gptr_u4 ge = (gptr_u4)(uintptr_t)td.top_exit;
           for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
             s_top[e] = gt[e];
-            reinterpret_cast<long long*>(s_exit)[e] = ge[e];
+            reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
           }
           __syncthreads();
           staged_tree = k;

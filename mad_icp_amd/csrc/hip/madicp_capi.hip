@@ -78,7 +78,7 @@ struct DevTree {
   CNode* cnodes = nullptr;    // 16-byte screening records, same indexing
   LeafRec* leaves = nullptr;  // dense 64-byte leaf records, by leaf ordinal
   CNode* top = nullptr;       // top levels, breadth first (staged into LDS by icp_round)
-  int2* top_exit = nullptr;
+  int4* top_exit = nullptr;
   int* top_dfs = nullptr;
   unsigned int* top_link = nullptr;
   int32_t n_top = 0;
@@ -852,25 +852,26 @@ int validate_nodes(const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, 
 
 // Breadth-first layout of the internal nodes of the first kTopLevels levels (structure only; depends on the tree's
 // topology, so it is made once at upload).  See "LDS-staged top levels" in kernels.hip.h for the link word.
-void layout_top(const madicp_node* nodes, std::vector<int>& dfs, std::vector<unsigned int>& link, std::vector<int2>& exits) {
+void layout_top(const madicp_node* nodes, std::vector<int>& dfs, std::vector<unsigned int>& link, std::vector<int4>& exits) {
   dfs.clear();
   link.clear();
   exits.clear();
   if (nodes[0].right == 0) return;
-  std::vector<int> level{0};
+  std::vector<int> level{0}, first_leaf{0};  // per entry: its level, the leaf ordinal of its left-most leaf
   dfs.push_back(0);
   for (size_t e = 0; e < dfs.size(); ++e) {
     const int i = dfs[e];
     const int l = i + 1, r = i + nodes[i].right;
+    const int left_leaves = nodes[i].right >> 1;  // (a left sub-tree of s nodes holds (s + 1) / 2 leaves, s = right - 1)
     const bool l_leaf = nodes[l].right == 0, r_leaf = nodes[r].right == 0;
     const bool deeper = level[e] + 1 < kTopLevels;
     const bool l_in = !l_leaf && deeper && dfs.size() + 1 <= (size_t)kTopMax - 1;
     const bool r_in = !r_leaf && deeper && dfs.size() + (l_in ? 2 : 1) <= (size_t)kTopMax - 1;
     int le = -1, re = -1;
-    if (l_in) { le = (int)dfs.size(); dfs.push_back(l); level.push_back(level[e] + 1); }
-    if (r_in) { re = (int)dfs.size(); dfs.push_back(r); level.push_back(level[e] + 1); }
+    if (l_in) { le = (int)dfs.size(); dfs.push_back(l); level.push_back(level[e] + 1); first_leaf.push_back(first_leaf[e]); }
+    if (r_in) { re = (int)dfs.size(); dfs.push_back(r); level.push_back(level[e] + 1); first_leaf.push_back(first_leaf[e] + left_leaves); }
     link.push_back(top_link_word(le, re, l_leaf, r_leaf));
-    exits.push_back(make_int2(l, nodes[i].right >> 1));  // (a left sub-tree of s nodes holds (s + 1) / 2 leaves, s = right - 1)
+    exits.push_back(make_int4(l, left_leaves, first_leaf[e], level[e]));
   }
 }
 
@@ -917,14 +918,14 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   RC_TRY(validate_nodes(nodes, n_nodes, n_leaves, &t.rho2));
   std::vector<int> top_dfs;
   std::vector<unsigned int> top_link;
-  std::vector<int2> top_exit;
+  std::vector<int4> top_exit;
   layout_top(nodes, top_dfs, top_link, top_exit);
   t.n_top = static_cast<int32_t>(top_dfs.size());
   // one device block: what is uploaded first (contiguous, one copy), what the device derives from it behind
   const size_t nt = (size_t)t.n_top;
   const size_t off_nodes = 0;
   const size_t off_exit = align_up(off_nodes + sizeof(madicp_node) * (size_t)n_nodes);
-  const size_t off_dfs = align_up(off_exit + sizeof(int2) * nt);
+  const size_t off_dfs = align_up(off_exit + sizeof(int4) * nt);
   const size_t off_link = align_up(off_dfs + sizeof(int) * nt);
   const size_t up_bytes = align_up(off_link + sizeof(unsigned int) * nt);
   const size_t off_cnodes = up_bytes;
@@ -946,7 +947,7 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   char* hs = ctx->h_tree[hb];
   std::memcpy(hs + off_nodes, nodes, sizeof(madicp_node) * (size_t)n_nodes);
   if (nt) {
-    std::memcpy(hs + off_exit, top_exit.data(), sizeof(int2) * nt);
+    std::memcpy(hs + off_exit, top_exit.data(), sizeof(int4) * nt);
     std::memcpy(hs + off_dfs, top_dfs.data(), sizeof(int) * nt);
     std::memcpy(hs + off_link, top_link.data(), sizeof(unsigned int) * nt);
   }
@@ -954,7 +955,7 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   RC_TRY(pool_alloc(ctx, total, ctx->copy, &blk));
   t.block = static_cast<char*>(blk);
   t.nodes = reinterpret_cast<madicp_node*>(t.block + off_nodes);
-  t.top_exit = nt ? reinterpret_cast<int2*>(t.block + off_exit) : nullptr;
+  t.top_exit = nt ? reinterpret_cast<int4*>(t.block + off_exit) : nullptr;
   t.top_dfs = nt ? reinterpret_cast<int*>(t.block + off_dfs) : nullptr;
   t.top_link = nt ? reinterpret_cast<unsigned int*>(t.block + off_link) : nullptr;
   t.cnodes = reinterpret_cast<CNode*>(t.block + off_cnodes);

@@ -1392,11 +1392,12 @@ __global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, 
 // ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---
 // one workgroup of 1024 threads; a level has at most 1024 internal nodes
 __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restrict__ nodes, int top_levels, int top_max,
-                                                      int* __restrict__ dfs, unsigned int* __restrict__ link, int2* __restrict__ exits,
+                                                      int* __restrict__ dfs, unsigned int* __restrict__ link, int4* __restrict__ exits,
                                                       int* __restrict__ out_n_top) {
   // (node index, its `right` offset) of the current level's entries, in breadth-first order: the offset of an entry was
   // read by its PARENT's step (to tell whether the child is a leaf), so a level costs one dependent memory hop, not two
   __shared__ int s_cur[1024], s_next[1024], s_cur_right[1024], s_next_right[1024];
+  __shared__ int s_cur_leaf[1024], s_next_leaf[1024];  // leaf ordinal of the entry's left-most leaf
   __shared__ int s_w[16];
   __shared__ int s_total;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1404,17 +1405,18 @@ __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restr
   const int root_right = nodes[0].right;
   if (root_right != 0) {
     ncur = 1;
-    if (threadIdx.x == 0) { s_cur[0] = 0; s_cur_right[0] = root_right; }
+    if (threadIdx.x == 0) { s_cur[0] = 0; s_cur_right[0] = root_right; s_cur_leaf[0] = 0; }
   }
   __syncthreads();
   for (int lev = 0; lev < top_levels && ncur > 0; ++lev) {
     const bool on = (int)threadIdx.x < ncur && base + (int)threadIdx.x < top_max - 1;
-    int i = 0, l = 0, r = 0, l_right = 0, r_right = 0;
+    int i = 0, l = 0, r = 0, l_right = 0, r_right = 0, first_leaf = 0;
     bool l_leaf = false, r_leaf = false, l_in = false, r_in = false;
     if (on) {
       i = s_cur[threadIdx.x];
       l = i + 1;
       r = i + s_cur_right[threadIdx.x];
+      first_leaf = s_cur_leaf[threadIdx.x];
       l_right = nodes[l].right;
       r_right = nodes[r].right;
       l_leaf = l_right == 0;
@@ -1439,16 +1441,24 @@ __global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restr
     const int next_base = base + ncur;
     if (on) {
       const int first = next_base + excl;
-      if (l_in) { s_next[excl] = l; s_next_right[excl] = l_right; }
-      if (r_in) { s_next[excl + (l_in ? 1 : 0)] = r; s_next_right[excl + (l_in ? 1 : 0)] = r_right; }
+      const int left_leaves = (r - l + 1) >> 1;
+      if (l_in) { s_next[excl] = l; s_next_right[excl] = l_right; s_next_leaf[excl] = first_leaf; }
+      if (r_in) {
+        const int at = excl + (l_in ? 1 : 0);
+        s_next[at] = r; s_next_right[at] = r_right; s_next_leaf[at] = first_leaf + left_leaves;
+      }
       dfs[base + threadIdx.x] = i;
       link[base + threadIdx.x] = top_link_word(l_in ? first : -1, r_in ? first + (l_in ? 1 : 0) : -1, l_leaf, r_leaf);
-      exits[base + threadIdx.x] = make_int2(l, (r - l + 1) >> 1);
+      exits[base + threadIdx.x] = make_int4(l, left_leaves, first_leaf, lev);
     }
     __syncthreads();
     base = next_base;
     ncur = s_total;
-    if ((int)threadIdx.x < ncur) { s_cur[threadIdx.x] = s_next[threadIdx.x]; s_cur_right[threadIdx.x] = s_next_right[threadIdx.x]; }
+    if ((int)threadIdx.x < ncur) {
+      s_cur[threadIdx.x] = s_next[threadIdx.x];
+      s_cur_right[threadIdx.x] = s_next_right[threadIdx.x];
+      s_cur_leaf[threadIdx.x] = s_next_leaf[threadIdx.x];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) *out_n_top = base;
