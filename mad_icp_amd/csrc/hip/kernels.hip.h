@@ -109,8 +109,8 @@ struct TreeDesc {
 // LDS-staged top levels.  The descent is bound by the L1 address path: a 64-lane gather of 16-byte records costs
 // ~80 cycles of the CU's vector-memory pipe however hot the lines are (measured: a second, cache-warm pass over the
 // same queries costs as much as the first).  LDS serves the same gather in ~15 cycles.  Each workgroup works on ONE
-// tree, so it copies the first kTopLevels levels of that tree's screening records (<= 2047 x 16 B, plus 8 B of
-// child indices each = 48 KiB, three workgroups per CU) into LDS once and walks them there; only the last few
+// tree, so it copies the first kTopLevels levels of that tree's screening records (<= 2047 x 16 B, plus a 16-byte exit
+// record each = 64 KiB; icp_round runs one workgroup per CU) into LDS once and walks them there; only the last few
 // levels and the leaf record come from L1/L2.  A top entry's `right` word is re-purposed (the walk of these levels is
 // bound by the instructions it issues, so the word is laid out for the fewest of them):
 //   bits 0..10 the top entry of the LEFT child | bits 11..21 the top entry of the RIGHT child (kTopNone: that child is
@@ -535,7 +535,7 @@ __global__ void nn_descend(const TreeDesc td, const double* __restrict__ q, long
 }
 
 // The same with the tree's top levels staged in LDS (as icp_round does): each workgroup copies the first kTopLevels
-// levels (<= 48 KiB) once and walks them there — ~15 cycles per level instead of an L1/L2 gather — then continues in
+// levels (<= 64 KiB) once and walks them there — ~15 cycles per level instead of an L1/L2 gather — then continues in
 // global memory.  Same descent, same results (descend_multi is the routine the registration uses); pays when a
 // workgroup walks many queries, i.e. for searchCloud-sized batches.  Dynamic LDS: kTopLdsBytes.
 __global__ __launch_bounds__(1024) void nn_descend_top(const TreeDesc td, const double* __restrict__ q, long long n,
