@@ -35,8 +35,10 @@ extern "C" {
 #define MADICP_OK 0
 #define MADICP_ERR_INVALID (-1)   /* bad argument / unknown id            */
 #define MADICP_ERR_DEVICE (-2)    /* HIP runtime error (no device, OOM …) */
-#define MADICP_ERR_COMM (-3)      /* RCCL error                           */
+#define MADICP_ERR_COMM (-3)      /* collective error: RCCL failure, a host transport's error, or a collective that did
+                                     not complete within "comm_timeout_ms" (the communicator is then aborted)      */
 #define MADICP_ERR_CAPACITY (-4)  /* more trees / scans than the ABI caps */
+#define MADICP_ERR_TIMEOUT (-5)   /* a bounded host wait ("wait_timeout_ms") ran out; the work is still in flight */
 
 #define MADICP_MAX_TREES 128 /* keyframe trees one registration may reference (reference README suggests 16) */
 #define MADICP_MAX_BATCH 64  /* scans in flight in one batched registration                                  */
@@ -84,7 +86,12 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * "seq_completion" (0/1, default 1: a streamed registration publishes its completion through a sequence number in the
  * pinned result block that madicp_stream_collect polls, instead of an event on the stream), "host_feed_wait" (0/1,
  * default 1: while another registration is in flight the HOST waits for a streamed scan's upload before it launches the
- * rounds, so no barrier packet sits between two registrations)}. */
+ * rounds, so no barrier packet sits between two registrations), "wait_mode" (how madicp_stream_collect and
+ * madicp_tree_build wait for the device's sequence number: 0 = spin on the calling core (default: lowest latency), 1 =
+ * sched_yield between polls, 2 = sleep ~50 us between polls (a drop-in odometry process that has other threads to run)),
+ * "wait_timeout_ms" (0 = unbounded, default; otherwise such a wait returns MADICP_ERR_TIMEOUT when it runs out — the
+ * ticket stays collectable), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
+ * registration's collectives before it aborts the communicator and returns MADICP_ERR_COMM)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
 
 /* ---- MAD-tree (fixed side) ---------------------------------------------------------------------- */
@@ -243,6 +250,20 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
 int madicp_comm_unique_id(uint8_t out_id[128]);
 int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks, int rank);
 int madicp_comm_destroy(madicp_ctx* ctx);
+
+/* The same sharded registration over a HOST-STAGED transport supplied by the caller (MPI, gloo, a socket ...) instead of
+ * RCCL: after every round's icp_reduce the library copies this rank's [H(21) b(6) n v w] per scan to pinned host memory,
+ * waits for it (bounded: "comm_timeout_ms"), calls `fn` — which must leave the element-wise reduction over all ranks in
+ * `buf` on every rank — and copies the totals back in front of the next round; the matched flags go through the same
+ * call once with MADICP_REDUCE_MAX_U8.  Kernel sequence, summation order inside a rank and the K = 0 rank are exactly
+ * those of the RCCL path: it is the way to run (and test) the multi-rank product path where RCCL cannot form a
+ * communicator — e.g. two ranks sharing one GPU — and a fallback where there is no xGMI/RDMA path between the ranks.
+ * One host round trip per round, so not capturable in a hipGraph and slower than RCCL (tens of microseconds per round).
+ * `fn` returns 0 on success; anything else fails the registration with MADICP_ERR_COMM.  madicp_comm_destroy ends it. */
+#define MADICP_REDUCE_SUM_F64 0
+#define MADICP_REDUCE_MAX_U8 1
+typedef int (*madicp_host_allreduce_fn)(void* user, void* buf, int64_t count, int kind);
+int madicp_comm_init_host(madicp_ctx* ctx, int n_ranks, int rank, madicp_host_allreduce_fn fn, void* user);
 
 #ifdef __cplusplus
 }

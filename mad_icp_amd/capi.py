@@ -36,6 +36,10 @@ _i32p = C.POINTER(C.c_int32)
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
 
+# madicp_host_allreduce_fn: int (*)(void* user, void* buf, int64_t count, int kind)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+REDUCE_SUM_F64, REDUCE_MAX_U8 = 0, 1
+
 _hip = None
 _host = None
 
@@ -100,6 +104,7 @@ def hip_lib():
         L.madicp_comm_unique_id.argtypes = [_u8p]
         L.madicp_comm_init.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
         L.madicp_comm_destroy.argtypes = [C.c_void_p]
+        L.madicp_comm_init_host.argtypes = [C.c_void_p, C.c_int, C.c_int, HOST_ALLREDUCE_FN, C.c_void_p]
         _hip = L
     return _hip
 
@@ -478,6 +483,22 @@ class Context:
     def comm_init(self, unique_id, n_ranks, rank):
         buf = (C.c_uint8 * 128)(*unique_id)
         _check(hip_lib().madicp_comm_init(self._h, buf, n_ranks, rank))
+
+    def comm_init_host(self, n_ranks, rank, all_reduce):
+        """Host-staged transport (madicp_comm_init_host): `all_reduce(array, kind)` must reduce the numpy array IN PLACE
+        over all ranks (kind REDUCE_SUM_F64: float64 sum; REDUCE_MAX_U8: uint8 max).  Exceptions become MADICP_ERR_COMM."""
+        def _cb(_user, buf, count, kind):
+            try:
+                ctype = C.c_double if kind == REDUCE_SUM_F64 else C.c_uint8
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(ctype)), shape=(count,))
+                all_reduce(arr, kind)
+                return 0
+            except Exception as e:  # noqa: BLE001 — must not unwind through the C frame
+                self._host_ar_error = e
+                return 1
+
+        self._host_ar_cb = HOST_ALLREDUCE_FN(_cb)  # (kept alive as long as the library may call it)
+        _check(hip_lib().madicp_comm_init_host(self._h, n_ranks, rank, self._host_ar_cb, None))
 
     def comm_destroy(self):
         _check(hip_lib().madicp_comm_destroy(self._h))

@@ -412,9 +412,16 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
   hipLaunchKernelGGL(fe::deskew_apply, dim3(tiles), dim3(256), 0, ctx->copy, (const double*)c->xyz, (const uint32_t*)fs->idx[1], (long)n,
                      (const int32_t*)fs->g, (const int32_t*)fs->tile_min, (const double*)(fs->table + kDeskewTableMax), n_poses,
                      static_cast<double*>(fresh), d_chunks);
-  HIP_TRY(hipGetLastError());
   EventRef after;
-  RC_TRY(fence_event(ctx, &after));
+  {  // a failure from here on must not leak the fresh buffer: the cloud keeps its old points
+    const hipError_t le = hipGetLastError();
+    const int frc = le == hipSuccess ? fence_event(ctx, &after) : MADICP_OK;
+    if (le != hipSuccess || frc != MADICP_OK) {
+      hipStreamSynchronize(ctx->copy);
+      pool_free(ctx, fresh, nullptr);
+      return le != hipSuccess ? fail(MADICP_ERR_DEVICE, std::string("deskew: ") + hipGetErrorString(le)) : frc;
+    }
+  }
   pool_free(ctx, c->xyz, after);
   c->xyz = static_cast<double*>(fresh);
   HIP_TRY(hipEventRecord(c->ready, ctx->copy));
@@ -475,8 +482,9 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
       hipLaunchKernelGGL(tb::tb_finish_a, dim3(n_tiles + 64), dim3(256), 0, s, P, kTopLevels, n_tiles);
       hipLaunchKernelGGL(tb::tb_finish_b, dim3(n_tiles), dim3(256), 0, s, P, n_tiles, next_step, fs->h_line, seq);
       HIP_TRY(hipGetLastError());
+      const unsigned check_mask = ctx->wait_mode == 0 ? 0x3ffu : 0xfu;  // (option "wait_mode": spin / yield / sleep)
       for (unsigned spins = 1; __atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
-        if ((spins & 0x3ff) == 0) {  // every few tens of microseconds: is the stream still alive?
+        if ((spins & check_mask) == 0) {  // every few tens of microseconds: is the stream still alive?
           const hipError_t q = hipStreamQuery(s);
           if (q == hipSuccess) {
             if (__atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) == seq) break;
@@ -484,7 +492,7 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
           }
           if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("tree build: ") + hipGetErrorString(q));
         }
-        __builtin_ia32_pause();
+        wait_pause(ctx);
       }
       return MADICP_OK;
     }

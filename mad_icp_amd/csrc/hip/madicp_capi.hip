@@ -13,7 +13,10 @@
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +24,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -199,9 +203,19 @@ struct madicp_ctx {
 
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // measurement entry points
 
-  // multi-GPU
+  // multi-GPU: RCCL communicator, or a host-staged transport supplied by the caller (madicp_comm_init_host)
   ncclComm_t comm = nullptr;
+  madicp_host_allreduce_fn host_ar = nullptr;
+  void* host_ar_user = nullptr;
+  char* h_comm = nullptr;       // pinned staging of the host transport (grow-only)
+  size_t h_comm_cap = 0;
   int n_ranks = 1, rank = 0;
+  int comm_timeout_ms = 60000;  // bounded host wait behind a registration's collectives
+  bool sharded() const { return comm != nullptr || host_ar != nullptr; }
+
+  // how the host waits for a sequence number the device publishes (stream_collect, tree_build)
+  int wait_mode = 0;        // 0 spin, 1 sched_yield, 2 sleep ~50 us
+  int wait_timeout_ms = 0;  // 0: unbounded
 
   // device front-end (frontend_capi.inc.h): resident clouds + builder scratch, created on first use
   struct Front;
@@ -295,6 +309,80 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
   return MADICP_OK;
 }
 
+// one poll of a host wait loop, by option "wait_mode"
+inline void wait_pause(const madicp_ctx* ctx) {
+  if (ctx->wait_mode == 1)
+    sched_yield();
+  else if (ctx->wait_mode == 2)
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  else
+    __builtin_ia32_pause();
+}
+
+// Host wait for everything enqueued on `s`.  Without a communicator this is hipStreamSynchronize.  With one, a peer
+// that never joins a collective would park this rank's stream for ever: poll instead, ask RCCL for asynchronous errors,
+// and after "comm_timeout_ms" abort the communicator — the hang becomes MADICP_ERR_COMM.
+int bounded_sync(madicp_ctx* ctx, hipStream_t s) {
+  if (!ctx->comm) {
+    HIP_TRY(hipStreamSynchronize(s));
+    return MADICP_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return MADICP_OK;
+    if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("stream: ") + hipGetErrorString(q));
+    if ((spins & 63) == 63) {
+      ncclResult_t ar = ncclSuccess;
+      const bool bad = ncclCommGetAsyncError(ctx->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress;
+      const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (bad || ms > ctx->comm_timeout_ms) {
+        const std::string why = bad ? std::string("RCCL asynchronous error: ") + ncclGetErrorString(ar)
+                                    : "a collective did not complete within " + std::to_string(ctx->comm_timeout_ms) +
+                                          " ms (a rank did not join?)";
+        for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+        ctx->graphs.clear();
+        ncclCommAbort(ctx->comm);  // releases the kernels parked on the stream
+        ctx->comm = nullptr;
+        ctx->n_ranks = 1;
+        ctx->rank = 0;
+        return fail(MADICP_ERR_COMM, why + "; communicator aborted");
+      }
+    }
+    if (spins < 256)
+      __builtin_ia32_pause();
+    else
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+
+// element-wise reduction of a DEVICE buffer over the ranks, stream-ordered on the compute stream: RCCL, or the caller's
+// host transport (copy out, wait, callback, copy back)
+int all_reduce(madicp_ctx* ctx, void* d_buf, size_t count, int kind) {
+  if (ctx->comm) {
+    if (kind == MADICP_REDUCE_SUM_F64)
+      NCCL_TRY(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+    else
+      NCCL_TRY(ncclAllReduce(d_buf, d_buf, count, ncclUint8, ncclMax, ctx->comm, ctx->stream));
+    return MADICP_OK;
+  }
+  const size_t bytes = count * (kind == MADICP_REDUCE_SUM_F64 ? sizeof(double) : 1);
+  if (ctx->h_comm_cap < bytes) {
+    if (ctx->h_comm) HIP_TRY(hipHostFree(ctx->h_comm));
+    ctx->h_comm = nullptr;
+    ctx->h_comm_cap = 0;
+    const size_t cap = std::max<size_t>(bytes + bytes / 4, 4096);
+    HIP_TRY(hipHostMalloc(&ctx->h_comm, cap, hipHostMallocDefault));
+    ctx->h_comm_cap = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->h_comm, d_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const int rc = ctx->host_ar(ctx->host_ar_user, ctx->h_comm, (int64_t)count, kind);
+  if (rc != 0) return fail(MADICP_ERR_COMM, "host all-reduce callback failed with code " + std::to_string(rc));
+  HIP_TRY(hipMemcpyAsync(d_buf, ctx->h_comm, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return MADICP_OK;
+}
+
 // launch geometry: 8 XCDs x slots workgroups per scan, about blocks_per_cu * n_cus in total over the batch, and
 // one (tree, range) unit per workgroup so that every workgroup gets the same number of leaves
 Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
@@ -329,26 +417,25 @@ void launch_round(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int round, cons
 int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vector<int>& moving_ids) {
   const int grid = l.grid, batch = l.batch, iters = l.iters;
   for (int it = 0; it < iters; ++it) {
-    launch_round(ctx, l, d_jobs, it, (ctx->comm && it > 0) ? ctx->d_totals : nullptr);
-    if (ctx->comm) {
+    launch_round(ctx, l, d_jobs, it, (ctx->sharded() && it > 0) ? ctx->d_totals : nullptr);
+    if (ctx->sharded()) {
       // this rank's share of the adders (a rank that owns no tree contributes zeros) -> one all-reduce of
       // [H(21) b(6) n v] per scan over xGMI: the serial sum of mad_icp.cpp:106-109
       hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_partials, grid, batch, it,
                          ctx->d_totals);
-      NCCL_TRY(ncclAllReduce(ctx->d_totals, ctx->d_totals, (size_t)batch * kAcc, ncclDouble, ncclSum, ctx->comm,
-                             ctx->stream));
+      RC_TRY(all_reduce(ctx, ctx->d_totals, (size_t)batch * kAcc, MADICP_REDUCE_SUM_F64));
     }
   }
-  if (ctx->comm) {
+  if (ctx->sharded()) {
     // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204)
     for (int s = 0; s < batch; ++s) {
       const DevMoving& mv = ctx->movings.at(moving_ids[s]);
-      NCCL_TRY(ncclAllReduce(mv.matched, mv.matched, (size_t)mv.L, ncclUint8, ncclMax, ctx->comm, ctx->stream));
+      RC_TRY(all_reduce(ctx, mv.matched, (size_t)mv.L, MADICP_REDUCE_MAX_U8));
     }
   }
   // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
   hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials,
-                     ctx->comm ? ctx->d_totals : nullptr, grid, batch);
+                     ctx->sharded() ? ctx->d_totals : nullptr, grid, batch);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -361,7 +448,9 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vec
 int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const std::vector<int>& moving_ids, bool queued_behind) {
   // with a communicator the RCCL calls are captured only on request (option "comm_graph"): it could not be
   // exercised on more than one rank where this was developed
-  const bool graph_ok = ctx->use_graph && (!ctx->comm || ctx->comm_graph) && !(queued_behind && ctx->eager_when_busy && !ctx->comm);
+  // (a host-staged transport makes a host round trip per round: never capturable)
+  const bool graph_ok = ctx->use_graph && !ctx->host_ar && (!ctx->comm || ctx->comm_graph) &&
+                        !(queued_behind && ctx->eager_when_busy && !ctx->comm);
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
   // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
@@ -373,11 +462,14 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
       HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       const int rc = enqueue_rounds(ctx, l, jobs, moving_ids);
       hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
-      if (rc != MADICP_OK) return rc;
-      if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      if (rc != MADICP_OK || e != hipSuccess) {
+        if (graph) hipGraphDestroy(graph);
+        return rc != MADICP_OK ? rc : fail(MADICP_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+      }
       hipGraphExec_t exec = nullptr;
-      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
       hipGraphDestroy(graph);
+      if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
       ctx->graphs.emplace(k, exec);
       return MADICP_OK;
     };
@@ -426,7 +518,7 @@ int reserve_moving(madicp_ctx* ctx, DevMoving& m, int L, hipStream_t user) {
   m.xyzn = nullptr; m.matched = nullptr; m.cache_leaf = nullptr; m.cache_margin = nullptr;
   m.cache_cap = 0;
   m.cap_L = 0;
-  if (ctx->comm) {  // a captured sequence with collectives bakes the matched-flag buffer's address
+  if (ctx->sharded()) {  // a captured sequence with collectives bakes the matched-flag buffer's address
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
     ctx->graphs.clear();
   }
@@ -572,7 +664,7 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
 int check_reg_args(madicp_ctx* ctx, const void* a, const void* b, const void* c, int K, int n_iters) {
   if (!ctx || !a || !b || !c) return fail(MADICP_ERR_INVALID, "null argument");
   // a rank that owns no keyframe tree still has to join the collectives (with zero adders): K == 0 is legal there
-  if (K < (ctx->comm ? 0 : 1)) return fail(MADICP_ERR_INVALID, "K must be >= 1");
+  if (K < (ctx->sharded() ? 0 : 1)) return fail(MADICP_ERR_INVALID, "K must be >= 1");
   if (K > MADICP_MAX_TREES) return fail(MADICP_ERR_CAPACITY, "K exceeds MADICP_MAX_TREES");
   if (n_iters < 1) return fail(MADICP_ERR_INVALID, "n_iters must be >= 1");
   return MADICP_OK;
@@ -666,7 +758,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   }
   // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
   const int saved = ctx->use_graph;
-  if (ctx->comm) ctx->use_graph = 0;
+  if (ctx->sharded()) ctx->use_graph = 0;
   const bool queued_behind = ctx->use_graph && ctx->eager_when_busy && hipStreamQuery(ctx->stream) == hipErrorNotReady;
   const int rc = run_rounds(ctx, launch, ctx->d_jobs, -1, ctx->last_moving, queued_behind);
   ctx->use_graph = saved;
@@ -733,6 +825,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->copy) hipStreamSynchronize(ctx->copy);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
+  if (ctx->h_comm) hipHostFree(ctx->h_comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
   front_destroy(ctx);
   for (auto& t : ctx->trees)
@@ -776,8 +869,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
 int madicp_ctx_synchronize(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   HIP_TRY(hipStreamSynchronize(ctx->copy));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return MADICP_OK;
+  return bounded_sync(ctx, ctx->stream);
 }
 
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
@@ -801,6 +893,15 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->seq_completion = value ? 1 : 0;
   } else if (k == "host_feed_wait") {
     ctx->host_feed_wait = value ? 1 : 0;
+  } else if (k == "wait_mode") {
+    if (value < 0 || value > 2) return fail(MADICP_ERR_INVALID, "wait_mode must be 0 (spin), 1 (yield) or 2 (sleep)");
+    ctx->wait_mode = (int)value;
+  } else if (k == "wait_timeout_ms") {
+    if (value < 0) return fail(MADICP_ERR_INVALID, "wait_timeout_ms must be >= 0");
+    ctx->wait_timeout_ms = (int)std::min<int64_t>(value, 1 << 30);
+  } else if (k == "comm_timeout_ms") {
+    if (value < 1) return fail(MADICP_ERR_INVALID, "comm_timeout_ms must be >= 1");
+    ctx->comm_timeout_ms = (int)std::min<int64_t>(value, 1 << 30);
   } else if (k == "nn_lds_top") {
     ctx->nn_lds_top = value ? 1 : 0;
   } else if (k == "queries_per_lane") {
@@ -1249,21 +1350,42 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
   if (!sl.pending || sl.ticket != ticket) return fail(MADICP_ERR_INVALID, "unknown or already collected ticket");
   if (sl.by_seq) {
     // icp_final releases HostResult::seq after everything else it writes to the pinned block (kernels.hip.h)
+    // (terminal errors give the slot back: a later submission must not find it "pending" for ever)
     const int32_t want = ticket + 1;
     const int32_t* seq = &sl.h_out->seq;
+    const unsigned check_mask = ctx->wait_mode == 0 ? 0x3ffu : 0xfu;  // stream health: every few tens of microseconds
+    const bool bounded = ctx->wait_timeout_ms > 0 || ctx->comm;
+    const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != want; ++spins) {
-      if ((spins & 0x3ff) == 0) {  // every few tens of microseconds: is the stream still alive?
+      if ((spins & check_mask) == 0) {
         const hipError_t q = hipStreamQuery(ctx->stream);
         if (q == hipSuccess) {
           if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) break;
+          sl.pending = false;
           return fail(MADICP_ERR_DEVICE, "registration finished without publishing its results");
         }
-        if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("registration failed: ") + hipGetErrorString(q));
+        if (q != hipErrorNotReady) {
+          sl.pending = false;
+          return fail(MADICP_ERR_DEVICE, std::string("registration failed: ") + hipGetErrorString(q));
+        }
+        if (bounded) {
+          const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+          if (ctx->comm && ms > ctx->comm_timeout_ms) {
+            sl.pending = false;
+            return bounded_sync(ctx, ctx->stream);  // (already over its limit: aborts the communicator, MADICP_ERR_COMM)
+          }
+          if (ctx->wait_timeout_ms > 0 && ms > ctx->wait_timeout_ms)
+            return fail(MADICP_ERR_TIMEOUT, "registration still in flight after wait_timeout_ms; collect the ticket again");
+        }
       }
-      __builtin_ia32_pause();
+      wait_pause(ctx);
     }
   } else {
-    HIP_TRY(hipEventSynchronize(sl.ev_done));
+    const hipError_t e = hipEventSynchronize(sl.ev_done);
+    if (e != hipSuccess) {
+      sl.pending = false;
+      return fail(MADICP_ERR_DEVICE, std::string("registration failed: ") + hipGetErrorString(e));
+    }
   }
   const HostResult& r = *sl.h_out;
   if (out_X) std::memcpy(out_X, r.X, sizeof(r.X));
@@ -1290,7 +1412,7 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
   HIP_TRY(hipSetDevice(ctx->device));
   for (int s = 0; s < n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->h_fetch + s, ctx->d_jobs + s, offsetof(Job, trees), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  RC_TRY(bounded_sync(ctx, ctx->stream));
   for (int s = 0; s < n_scans; ++s) {
     const Job& j = ctx->h_fetch[s];
     if (out_X) std::memcpy(out_X + 12 * s, j.X, 12 * sizeof(double));
@@ -1310,7 +1432,7 @@ int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, in
   if (L != it->second.L) return fail(MADICP_ERR_INVALID, "L mismatch");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(out_matched, it->second.matched, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  RC_TRY(bounded_sync(ctx, ctx->stream));
   return MADICP_OK;
 }
 
@@ -1390,7 +1512,7 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
                                  double* out_linearize_avg_us, double* out_solve_avg_us, uint64_t* out_visits_per_launch,
                                  uint64_t* out_walked_per_launch) {
   if (!ctx || reps < 1 || n_iters < 1) return fail(MADICP_ERR_INVALID, "bad argument");
-  if (ctx->comm) return fail(MADICP_ERR_INVALID, "not available with a communicator");
+  if (ctx->sharded()) return fail(MADICP_ERR_INVALID, "not available with a communicator");
   HIP_TRY(hipSetDevice(ctx->device));
   if (!ctx->ev_t0) {
     HIP_TRY(hipEventCreate(&ctx->ev_t0));
@@ -1549,7 +1671,7 @@ int madicp_comm_unique_id(uint8_t out_id[128]) {
 int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks, int rank) {
   if (!ctx || !unique_id) return fail(MADICP_ERR_INVALID, "null argument");
   if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MADICP_ERR_INVALID, "bad rank / n_ranks");
-  if (ctx->comm) return fail(MADICP_ERR_INVALID, "communicator already initialised");
+  if (ctx->sharded()) return fail(MADICP_ERR_INVALID, "communicator already initialised");
   HIP_TRY(hipSetDevice(ctx->device));
   ncclUniqueId id;
   std::memcpy(&id, unique_id, 128);
@@ -1562,8 +1684,30 @@ int madicp_comm_init(madicp_ctx* ctx, const uint8_t unique_id[128], int n_ranks,
   return MADICP_OK;
 }
 
+int madicp_comm_init_host(madicp_ctx* ctx, int n_ranks, int rank, madicp_host_allreduce_fn fn, void* user) {
+  if (!ctx || !fn) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MADICP_ERR_INVALID, "bad rank / n_ranks");
+  if (ctx->sharded()) return fail(MADICP_ERR_INVALID, "communicator already initialised");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->host_ar = fn;
+  ctx->host_ar_user = user;
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);  // captured without the join over ranks
+  ctx->graphs.clear();
+  return MADICP_OK;
+}
+
 int madicp_comm_destroy(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (ctx->host_ar) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->host_ar = nullptr;
+    ctx->host_ar_user = nullptr;
+    ctx->n_ranks = 1;
+    ctx->rank = 0;
+  }
   if (ctx->comm) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);

@@ -6,10 +6,15 @@ sharded across ranks — round-robin by keyframe index — the moving leaves and
 round ends with ONE small all-reduce of [H, b]; the matched flags are OR-ed (MAX) once, after the last round.
 Every rank then solves the 6x6 redundantly and holds the same pose.
 
-Two transports:
+Three transports:
   * native  — `init_native_comm(ctx)`: the all-reduces are RCCL calls enqueued by libmadicp_hip.so on its own HIP
               stream between the kernels of a round (no host round trip); torch.distributed only carries the
               128-byte ncclUniqueId once.  This is what bench.py --gpus N uses.
+  * host    — `init_host_comm(ctx)`: the SAME launch sequence inside the library (icp_reduce -> all-reduce -> icp_round
+              reading the reduced totals, a rank without trees joining with zeros), but the all-reduce is a callback
+              into torch.distributed on host memory (madicp_comm_init_host).  Works with any backend and with ranks
+              that share one GPU — which RCCL refuses — so it is how the multi-rank product path is tested on a
+              1-GPU box, and a fallback where no xGMI/RDMA path connects the ranks.
   * staged  — `StagedShardedRegistration`: one madicp_icp_linearize per round, (H,b) all-reduced through
               torch.distributed (any backend: nccl on GPUs, gloo in the CPU tests), host-side updateState.  Slower
               (host round trip per round) but backend-agnostic; the CPU tests drive it with an injected linearise
@@ -39,6 +44,28 @@ def init_native_comm(ctx, group=None, device=None):
         uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
     dist.broadcast(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+    return rank, world
+
+
+def init_host_comm(ctx, group=None):
+    """Give `ctx` a host-staged transport over `group` (any torch.distributed backend): see madicp_comm_init_host."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+
+    def all_reduce(arr, kind):
+        t = torch.from_numpy(arr)  # shares the library's pinned staging buffer
+        op = dist.ReduceOp.SUM if kind == capi.REDUCE_SUM_F64 else dist.ReduceOp.MAX
+        if on_gpu:
+            g = t.cuda()
+            dist.all_reduce(g, op=op, group=group)
+            t.copy_(g.cpu())
+        else:
+            dist.all_reduce(t, op=op, group=group)
+
+    ctx.comm_init_host(world, rank, all_reduce)
     return rank, world
 
 

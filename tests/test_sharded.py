@@ -231,3 +231,187 @@ def test_native_rccl_path_two_ranks(ctx, tmp_path, K, graph):
     for t in tids:
         ctx.tree_release(t)
     ctx.moving_release(mid)
+
+
+# ---- the PRODUCT's sharded path with two ranks on ONE GPU (gloo processes sharing device 0) -------------------------------
+def _product_worker(rank, world, port, K, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fixtures import PARAMS
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = capi.Context(0)
+    try:
+        pb = street_problem(max(K, 1))
+        mine = sharded.shard_keyframes(K, world, rank)
+        tids = []
+        for k in mine:
+            T = pb["keyframe_poses"][k]
+            ht = capi.HostTree(pb["keyframe_scans"][k], B_MAX, B_MIN, 2)
+            ht.transform(T[:3, :3], T[:3, 3])
+            tids.append(ctx.upload(ht))
+        qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+        lm = qh.leaf_means()
+        L = qh.num_leaves
+        mid = ctx.moving_upload(lm)
+        guess = pb["query_guess"][0]
+
+        # (i) the staged driver with THE PRODUCT as this rank's lineariser (a rank without trees contributes zeros)
+        def linearize(X):
+            if not tids:
+                return np.zeros((6, 6)), np.zeros(6), np.zeros(L, np.uint8)
+            r = ctx.icp_linearize(mid, tids, capi.pose44(X), PARAMS, L, want_corr=False)
+            return r["H"], r["b"], r["matched"]
+
+        st = sharded.StagedShardedRegistration(linearize, L).register(guess, 15)
+
+        # (ii) the library's own sharded launch sequence — icp_reduce, all-reduce, icp_round / icp_final reading the
+        # reduced totals, K = 0 on a rank without trees — over the host-staged transport (RCCL refuses two ranks on one GPU)
+        sharded.init_host_comm(ctx)
+        nat = ctx.icp_register(mid, tids, guess, PARAMS, 15, L)
+        tk = ctx.stream_submit(lm, tids, guess, PARAMS, 15)
+        sm = ctx.stream_collect(tk, L)
+        mid2 = ctx.moving_upload(lm[: L // 2])
+        X0 = np.stack([capi.pose12(guess), capi.pose12(guess)])
+        bt = ctx.icp_register_batch([mid, mid2], tids, X0, PARAMS, 15)
+        ctx.comm_destroy()
+        np.savez(out % rank, st_X=st["X"], st_H=st["H"], st_matched=st["matched"], nat_X=nat["X"], nat_H=nat["H"],
+                 nat_matched=nat["matched"], nat_Xi=nat["X_iters"], sm_X=sm["X"], sm_H=sm["H"], sm_matched=sm["matched"],
+                 sm_n=sm["n_matched"], bt_X=bt["X"], bt_n=bt["n_matched"], n_local=len(tids))
+    finally:
+        ctx.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [4, 1])
+def test_product_sharded_two_ranks_one_gpu(ctx, tmp_path, K):
+    """BASELINE configs[3]'s split executed by the product with TWO ranks: keyframe trees sharded k % 2 between two
+    processes (each its own capi.Context on device 0), (H, b) joined over gloo every round, matched flags OR-ed once.
+    Both the staged driver (ctx.icp_linearize per round) and the library's own launch sequence (host-staged transport:
+    the RCCL path's kernels and ordering, only the all-reduce itself differs) must give every rank the same pose bit for
+    bit, agree with the single-context registration to 1e-9 and with the oracle to 1e-5 (mad_icp.cpp:106-109,
+    pipeline.cpp:180-183).  K = 1: rank 1 owns no tree and still joins every collective."""
+    from fixtures import PARAMS
+
+    world = 2
+    out = str(tmp_path / "rank%d.npz")
+    port = 29500 + ((os.getpid() + 7 * K) % 2000)
+    mp.spawn(_product_worker, args=(world, port, K, out), nprocs=world, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert int(r0["n_local"]) + int(r1["n_local"]) == K
+    for key in ("st_X", "st_H", "st_matched", "nat_X", "nat_H", "nat_matched", "nat_Xi", "sm_X", "sm_H", "sm_matched", "sm_n",
+                "bt_X", "bt_n"):
+        assert np.array_equal(r0[key], r1[key]), key  # every rank holds the same state, bit for bit
+    # the streamed submission is the same registration
+    assert np.array_equal(r0["sm_X"], r0["nat_X"]) and np.array_equal(r0["sm_matched"], r0["nat_matched"])
+    assert int(r0["sm_n"]) == int(r0["nat_matched"].sum())
+    assert np.array_equal(r0["bt_X"][0], r0["nat_X"])  # and so is scan 0 of a batch of two
+
+    # the single-context registration (all K trees on one rank, fused join)
+    pb = street_problem(max(K, 1))
+    tids, otrees = [], []
+    for k in range(K):
+        T = pb["keyframe_poses"][k]
+        ht = capi.HostTree(pb["keyframe_scans"][k], B_MAX, B_MIN, 2)
+        ht.transform(T[:3, :3], T[:3, 3])
+        tids.append(ctx.upload(ht))
+        ot = O.Tree(pb["keyframe_scans"][k], B_MAX, B_MIN, 2)
+        ot.transform(T[:3, :3], T[:3, 3])
+        otrees.append(ot)
+    qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+    qo = O.Tree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+    mid = ctx.moving_upload(qh.leaf_means())
+    one = ctx.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+    orc = O.icp_register(qo, otrees, pb["query_guess"][0], 15, B_MAX, RHO_KER, B_RATIO, num_threads=1)
+
+    def close(Xa, Tb, tol):
+        d = np.linalg.inv(Tb) @ capi.pose44(Xa)
+        return np.linalg.norm(d[:3, 3]) <= tol and np.abs(d[:3, :3] - np.eye(3)).max() <= tol
+
+    for name in ("st_X", "nat_X"):
+        assert close(r0[name], one["T"], 1e-9), name
+        assert close(r0[name], orc["T"], 1e-5), name
+    for name in ("st_matched", "nat_matched"):
+        assert (r0[name] != one["matched"]).sum() <= 1, name
+        assert (r0[name] != orc["matched"]).sum() <= 1, name
+    assert np.allclose(r0["nat_H"], one["H"], rtol=1e-9, atol=1e-9 * np.abs(one["H"]).max())
+    # the pose before every round, too (the reduced totals fed every solve)
+    for it in range(15):
+        assert close(r0["nat_Xi"][it], capi.pose44(one["X_iters"][it]), 1e-9), it
+    for t in tids:
+        ctx.tree_release(t)
+    ctx.moving_release(mid)
+
+
+@pytest.mark.gpu
+def test_host_transport_failure_is_comm_error(natives):
+    """A transport that fails must surface as MADICP_ERR_COMM (-3), not hang or crash, and leave the context usable."""
+    from fixtures import PARAMS
+
+    pb = street_problem(2)
+    c = capi.Context(0)
+    try:
+        tids = []
+        for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+            ht = capi.HostTree(s, B_MAX, B_MIN, 2)
+            ht.transform(T[:3, :3], T[:3, 3])
+            tids.append(c.upload(ht))
+        qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+        mid = c.moving_upload(qh.leaf_means())
+        ref = c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+        calls = []
+
+        def broken(arr, kind):
+            calls.append(kind)
+            if len(calls) == 3:
+                raise RuntimeError("link down")
+
+        c.comm_init_host(1, 0, broken)
+        with pytest.raises(capi.MadIcpError, match="error -3"):
+            c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+        assert len(calls) == 3
+        c.comm_destroy()
+        c.synchronize()
+        again = c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+        assert np.array_equal(again["X"], ref["X"])
+        # a world of one over an identity transport is the fused path, bit for bit
+        c.comm_init_host(1, 0, lambda arr, kind: None)
+        solo = c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+        c.comm_destroy()
+        assert np.array_equal(solo["X"], ref["X"]) and np.array_equal(solo["H"], ref["H"])
+        assert np.array_equal(solo["matched"], ref["matched"])
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_stream_collect_wait_modes(natives, mode):
+    """Option "wait_mode": spinning, yielding and sleeping collections return the same registration; a bounded wait
+    that runs out says MADICP_ERR_TIMEOUT (-5) and the ticket can be collected again."""
+    from fixtures import PARAMS
+
+    pb = street_problem(2)
+    c = capi.Context(0)
+    try:
+        tids = []
+        for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+            ht = capi.HostTree(s, B_MAX, B_MIN, 2)
+            ht.transform(T[:3, :3], T[:3, 3])
+            tids.append(c.upload(ht))
+        qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+        lm, L = qh.leaf_means(), qh.num_leaves
+        mid = c.moving_upload(lm)
+        ref = c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, L)
+        c.set_option("wait_mode", mode)
+        c.set_option("wait_timeout_ms", 5000)
+        for _ in range(3):
+            tk = c.stream_submit(lm, tids, pb["query_guess"][0], PARAMS, 15)
+            r = c.stream_collect(tk, L)
+            assert np.array_equal(r["X"], ref["X"]) and np.array_equal(r["matched"], ref["matched"])
+        with pytest.raises(capi.MadIcpError):
+            c.set_option("wait_mode", 3)
+    finally:
+        c.close()
