@@ -141,7 +141,7 @@ struct HostResult {
   int32_t n_matched;
   int32_t iter;
   int32_t seq;    // written LAST (system-scope release): Job::seq of the registration these results belong to
-  int32_t pad_;
+  int32_t error;  // Job::error (icp_persist: an in-launch wait ran out)
 };
 
 // One registration in flight; lives in device memory, written by the host before each launch sequence
@@ -172,6 +172,8 @@ struct Job {
   int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
   int32_t lds_top;          // 1 when the launch carries kTopLdsBytes of dynamic LDS
   int32_t seq;              // streamed registrations: what icp_final leaves in HostResult::seq when everything is written
+  uint32_t epoch;           // icp_persist: distinguishes this launch's exchange granules from every earlier launch's (host counter)
+  int32_t error;            // icp_persist: non-zero when a bounded in-launch wait ran out (results invalid)
 #ifdef MADICP_ABLATE
   unsigned long long* dbg;  // profiling builds: per-workgroup phase time stamps of the last launch
 #endif
@@ -1064,10 +1066,9 @@ __device__ __forceinline__ void wave_lds_order() {
 //     zero) gives dx = 0 on both sides.
 // total: the joined adders in LDS (packed lower triangle, column by column: entry (r,c), r >= c, at 6c - c(c-1)/2 + r - c;
 // b at 21..26).  Whole wave, identical `total` -> identical dx in every lane.
-__device__ __forceinline__ void gn_solve_lanes(const double* total /*LDS*/, double (&dx)[6]) {
+__device__ __forceinline__ void gn_solve_lanes(const double* total /*LDS*/, double (&dx)[6], const int lane /* threadIdx.x & 63 */) {
 #pragma clang fp contract(fast)
   __shared__ double s_dx[8];
-  const int lane = threadIdx.x & 63;
   unsigned int P;  // perm[r] = original row that goes to position r, 4 bits each
   {
     const int ci = min(lane / 6, 5), cj = lane % 6;
@@ -1111,8 +1112,10 @@ __device__ __forceinline__ void gn_solve_lanes(const double* total /*LDS*/, doub
 // `moved[2]`: upper bounds of the update's rotation angle and translation length — what the correspondence reuse needs
 // to bound how far any leaf moves: |X_next p - X p| <= |R|_2 (|dR - I|_2 |p| + |dt|) <= (1+1e-6)(moved[0] |p| + moved[1])
 // (|expSO3(w) - I|_2 = 2 sin(|w|/2) <= |w|, and = |w| for the first-order branch; |R|_2 <= 1 + 1e-7 after 15 updates).
+// `lane`: the caller's lane index — a parameter so that a caller looping over rounds (icp_persist) can hand in a copy the
+// compiler cannot hoist the solve's per-lane index arithmetic out of its loop with
 __device__ __forceinline__ void solve_pose(const double* total, const double (&X)[12], bool update, double (&Xn)[12],
-                                           double (&H)[36], double (&b)[6], double (&moved)[2]) {
+                                           double (&H)[36], double (&b)[6], double (&moved)[2], const int lane) {
   moved[0] = 0.0;
   moved[1] = 0.0;
   {
@@ -1133,8 +1136,9 @@ __device__ __forceinline__ void solve_pose(const double* total, const double (&X
   if (update) {
     double dx[6], dR[9];
 #ifndef MADICP_EXACT_SOLVE
-    gn_solve_lanes(total, dx);
+    gn_solve_lanes(total, dx, lane);
 #else
+    (void)lane;
     double nb[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) nb[r] = -b[r];
@@ -1206,15 +1210,29 @@ __device__ __forceinline__ void join_stage1(const double* __restrict__ partials,
   }
   __syncthreads();
 }
-// stage 2 (wave 0 only): the group sums in sequence -> total[kAcc] in LDS, visible to wave 0
+// stage 2 (wave 0 only): the group sums -> total[kAcc] in LDS, visible to wave 0.  THE summation order of a round's
+// adders, shared by every route (icp_round's prologue, icp_final, icp_reduce, and icp_persist, whose workgroups exchange
+// their rows inside the launch): with x = row & 7 (the workgroup's XCD under the observed dispatch rule — a name for the
+// group, nothing depends on the placement),
+//     seg[G]  = 0 + row[G] + row[G + 48] + row[G + 96] + ...      G = 0..47          (stage 1)
+//     F[x]    = seg[x] + seg[x + 8] + ... + seg[x + 40]           x = 0..7           (the fold of one XCD's rows)
+//     total   = F[0] + F[1] + ... + F[7]
+// — 14 dependent additions here instead of 47, and the two levels are what icp_persist's XCD leaders / consumers compute.
+constexpr int kFoldGroups = 8;                          // row & 7
+constexpr int kFoldChains = kJoinGroups / kFoldGroups;  // 6 interleaved chains per group
 __device__ __forceinline__ void join_stage2_wave0(const JoinSeg& seg, double* total /*LDS kAcc*/) {
   if (threadIdx.x < kAcc) {
     double r[kJoinGroups];
 #pragma unroll
     for (int k = 0; k < kJoinGroups; ++k) r[k] = seg[k][threadIdx.x];  // all LDS reads in flight before the first add
-    double a = r[0];
+    double a = 0.0;
 #pragma unroll
-    for (int k = 1; k < kJoinGroups; ++k) a += r[k];
+    for (int x = 0; x < kFoldGroups; ++x) {
+      double f = r[x];
+#pragma unroll
+      for (int q = 1; q < kFoldChains; ++q) f += r[x + kFoldGroups * q];
+      a = (x == 0) ? f : a + f;
+    }
     total[threadIdx.x] = a;
   }
   wave_lds_order();
@@ -1395,7 +1413,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       }
       MADICP_STAMP(1);
       double H[36], b[6];
-      solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved);
+      solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved, threadIdx.x & 63);
       if (blockIdx.x == 0 && threadIdx.x == 0) {  // bookkeeping of the finished round, once per scan
 #pragma unroll
         for (int i = 0; i < 36; ++i) jout->H[i] = H[i];
@@ -1451,241 +1469,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const bool stage_hint = round == 0 || wave_uniform(s_X[14]) > 0.0;
 
 
-  int k = k_first, r = r_first;
-  for (int u = u_first; u < hi; u += nslots, r += nslots) {
-    while (r >= RPT) {  // (k, r) follow u without a division
-      r -= RPT;
-      ++k;
-    }
-    const int i_end = min(L, (r + 1) * S);
-    if (k != desc_tree) {  // (workgroup-uniform; only workgroups with several units get here)
-      __syncthreads();     // nobody still reads the previous descriptor
-      if (threadIdx.x < 11)
-        reinterpret_cast<long long*>(&s_td)[threadIdx.x] =
-            ((const __attribute__((address_space(1))) long long*)(uintptr_t)&job->trees[k])[threadIdx.x];
-      __syncthreads();
-      desc_tree = k;
-    }
-    const TreeDesc& td = s_td;
-    // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
-    // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
-    const int n_top_avail = (opt_lds_top && i_end - r * S >= opt_stage_min) ? min(td.n_top, kTopMax) : 0;
-
-    for (int base = r * S; base < i_end; base += QPT * kBlock) {
-      double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
-      bool valid[QPT], walk[QPT];
-      int leaf[QPT], depth[QPT];
-      // every load of this pass that does not depend on another one is issued first — the leaf's coordinates and
-      // its cached correspondence — so a walk-free pass is two memory round trips (these, then the leaf record)
-      vd4 pv[QPT];
-      float cmar[QPT];
-      unsigned int cword[QPT];
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * kBlock + threadIdx.x;
-        valid[j] = i < i_end;
-        pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
-        cmar[j] = 0.f;
-        cword[j] = 0u;
-        if (u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
-          pv[j] = pv0[j];
-          cmar[j] = cmar0[j];
-          cword[j] = cword0[j];
-        } else if (valid[j]) {
-          pv[j] = ((gptr_d4)(uintptr_t)moving)[i];
-          if (reuse) {
-            const long long ci = (long long)k * L + i;
-            cmar[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
-            cword[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
-          }
-        }
-      }
-#ifdef MADICP_STAMPS
-      if (u == u_first && base == r * S) { MADICP_STAMP(7); }
-      if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP_WAIT(); MADICP_STAMP(10); }
-#endif
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * kBlock + threadIdx.x;
-        const vd4 p = pv[j];
-        px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
-        // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
-        q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
-        q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
-        q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
-        walk[j] = valid[j];
-        margin[j] = 3.0e38;
-        leaf[j] = 0;
-        depth[j] = 0;
-        if (reuse && valid[j]) {
-          // how far can this leaf have moved since the previous round?  (bound from the update itself, see solve_pose;
-          // the 1e-11 term covers the rounding of the two computed queries)
-          const double moved = moved_rot * p.w + moved_trans;
-          const double left_over = (double)cmar[j] - moved * (1.0 + 1e-12) -
-                                   1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
-                                            fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
-          if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
-            leaf[j] = (int)(cword[j] & kCacheIdxMask);
-            depth[j] = (int)(cword[j] >> 26);
-            cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
-            walk[j] = false;
-          }
-        }
-      }
-      if (u == u_first && base == r * S) { MADICP_STAMP(3); }
-      if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP(11); }
-      {
-#pragma unroll
-        for (int j = 0; j < QPT; ++j) walked |= walk[j];
-        if (n_top_avail > 0 && k != staged_tree && stage_hint) {  // (workgroup-uniform condition) copy the top levels into LDS
-          if (staged_tree >= 0) __syncthreads();  // nobody may still be walking the previous tree's copy
-          gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-          gptr_u4 ge = (gptr_u4)(uintptr_t)td.top_exit;
-          for (int e = threadIdx.x; e < n_top_avail; e += kBlock) {
-            s_top[e] = gt[e];
-            reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
-          }
-          __syncthreads();
-          staged_tree = k;
-        }
-        const int n_top = (k == staged_tree) ? n_top_avail : 0;
-        // The lane's QPT leaves share their LOADS (coordinates, cache, leaf record: issued together above and below),
-        // but they are WALKED one after the other: interleaved walks make every step wait for the slowest of
-        // 64*QPT lanes and were measured slower than back-to-back ones.
-        int widx[QPT], wleaf[QPT], wdepth[QPT];
-#pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-          const double a0[1] = {q0[j]}, a1[1] = {q1[j]}, a2[1] = {q2[j]};
-          const bool wv[1] = {walk[j]};
-          int xi[1], xl[1], xd[1];
-          double xm[1] = {margin[j]};
-          bool any_walk = walk[j];
-          if (QPT > 1) any_walk = __any(walk[j]);  // skip the whole (wave-uniform) call when nobody in the wave walks
-          if (any_walk) {
-            descend_multi<1>(td, s_top, s_exit, n_top, a0, a1, a2, wv, xi, xl, xd, xm);
-            widx[j] = xi[0]; wleaf[j] = xl[0]; wdepth[j] = xd[0]; margin[j] = xm[0];
-          } else {
-            widx[j] = 0; wleaf[j] = 0; wdepth[j] = 0;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-          if (walk[j]) {
-            leaf[j] = wleaf[j];
-            depth[j] = wdepth[j];
-            walked_visits += (unsigned int)wdepth[j];
-            if (cache_leaf) {
-              const long long ci = (long long)k * L + (base + j * kBlock + threadIdx.x);
-              const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
-              cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
-              cache_margin[ci] = cacheable ? __double2float_rd(margin[j]) : 0.f;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < QPT; ++j)
-        if (valid[j]) visits += (unsigned int)depth[j];
-      if (u == u_first && base == r * S) { MADICP_STAMP(4); }
-
-#pragma unroll
-      for (int j = 0; j < QPT; ++j) {
-        if (!valid[j]) continue;
-        const int i = base + j * kBlock + threadIdx.x;
-        // the matched leaf's record: one 64-byte line, its four 16-byte loads issued together (one round trip)
-        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + leaf[j]);
-        const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
-#ifdef MADICP_STAMPS
-        if (u == u_first && base == r * S) { MADICP_STAMP_WAIT(); MADICP_STAMP(8); }
-        if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP_WAIT(); MADICP_STAMP(12); }
-#endif
-        // gate (mad_icp.cpp:81-83)
-        const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
-        const double src_ball = min_ball + b_ratio * pn[j];
-        const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-        if (TRACE && corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
-        if (rejected) continue;
-        if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
-
-        const double bbox0 = ld.x;
-        const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
-#ifndef MADICP_EXACT_SOLVE
-        // From here on nothing decides a branch of the reference (the gate above was the last decision; the Huber
-        // switch below is continuous in e), and the kernel is bound by the INSTRUCTIONS its twelve waves issue: the
-        // residual, the Jacobian and the 27 accumulations use fused multiply-adds (one instruction where the
-        // reference's order needs two), the zero columns of skew(p) are not multiplied out, and the two quotients use
-        // the refined reciprocal (1/min_ball once per kernel).  (H, b) differ from the reference-order sums in the last
-        // bits — they already do by the order of the reduction; the pose contract is 1e-5.
-        {
-#pragma clang fp contract(fast)
-          // errorAndJacobian (mad_icp.cpp:59-72)
-          const double e = g0 * n0 + g1 * n1 + g2 * n2;
-          double J[6];
-          J[0] = n0 * R[0] + n1 * R[3] + n2 * R[6];
-          J[1] = n0 * R[1] + n1 * R[4] + n2 * R[7];
-          J[2] = n0 * R[2] + n1 * R[5] + n2 * R[8];
-          // -J[0:3] * skew(p)
-          J[3] = J[2] * py[j] - J[1] * pz[j];
-          J[4] = J[0] * pz[j] - J[2] * px[j];
-          J[5] = J[1] * px[j] - J[0] * py[j];
-          // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
-          double scale = 1.0;
-          const double chi = fabs(e);
-          if (chi > rho) scale = fast_div(rho, chi, fast_rcp(chi));
-          const double w = 1.0 - fast_div(bbox0, min_ball, inv_min_ball);
-          scale *= w * w;
-          double sJ[6];
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
-          int v = 0;
-#pragma unroll
-          for (int cc = 0; cc < 6; ++cc)
-#pragma unroll
-            for (int rr = cc; rr < 6; ++rr) {
-              acc[v] = __builtin_fma(sJ[rr], J[cc], acc[v]);
-              ++v;
-            }
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) acc[21 + rr] = __builtin_fma(sJ[rr], e, acc[21 + rr]);
-        }
-#else
-
-        // errorAndJacobian (mad_icp.cpp:59-72)
-        const double e = dotc(g0, g1, g2, n0, n1, n2);
-        double J[6];
-        J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
-        J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
-        J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
-        // -J[0:3] * skew(p): columns of skew(p) are (0,pz,-py), (-pz,0,px), (py,-px,0)
-        const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
-        J[3] = dotc(a0, a1, a2, 0.0, pz[j], -py[j]);
-        J[4] = dotc(a0, a1, a2, -pz[j], 0.0, px[j]);
-        J[5] = dotc(a0, a1, a2, py[j], -px[j], 0.0);
-
-        // Huber x planarity weight (mad_icp.cpp:92-98; `abs` there is fabs — SURVEY fact 4)
-        double scale = 1.0;
-        const double chi = fabs(e);
-        if (chi > rho) scale = rho / chi;
-        const double w = 1.0 - bbox0 / min_ball;
-        scale *= w * w;
-
-        double sJ[6];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
-        int v = 0;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc)
-#pragma unroll
-          for (int rr = cc; rr < 6; ++rr) acc[v++] += sJ[rr] * J[cc];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
-#endif
-        acc[27] += 1.0;
-      }
-      if (u == u_first && base == r * S) { MADICP_STAMP(9); }
-    }
-  }
-
+#define MADICP_TID threadIdx.x
+#include "icp_linearize_body.inc.h"
+#undef MADICP_TID
 
   MADICP_STAMP(5);
   // deterministic reduction: lanes (halving butterfly) -> waves (LDS, fixed order) -> partial
@@ -1704,6 +1490,316 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   }
   if (threadIdx.x == 0) hints[(round & 1) * hint_stride + hint_slot] = static_cast<double>(n_walked);
   MADICP_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ALL Gauss-Newton rounds of a registration as ONE launch (single GPU, every workgroup resident: one per CU).
+//
+// What a kernel boundary per round costs icp_round (stamps): ~1.3 us between two dependent launches, then
+// ~2.7 us until the 256 partial rows of the previous round (61 KB per reader, seven eighths of them from other XCDs) have
+// arrived, with every pose-independent quantity (leaf coordinates, options, descriptors, the LDS copy of the tree's top)
+// fetched again.  Here the workgroups stay resident and exchange their adders inside the launch, in two levels that
+// are exactly the two levels of join_stage2_wave0's summation order:
+//   level 1  every workgroup publishes its row of kAcc sums; the LEADER of its group x = blockIdx.x & 7 (the workgroup
+//            with blockIdx.x == x) folds the group's rows in the fixed order  F[x] = sum_q (0 + sum_i row[x + 8(q + 6i)])
+//   level 2  the leaders publish F[x]; wave 0 of EVERY workgroup reads the eight F[x] (3.8 KB instead of 61 KB), adds
+//            them in order and solves — all workgroups get the bit-identical pose, as in icp_round.
+// Transport (the guide's "data IS the flag" form for payloads <= 4 KB): every double travels as two 8-byte granules
+// {tag, 32 data bits}, each written by ONE relaxed agent-scope atomic store (write-through, sc1) and polled with relaxed
+// agent-scope atomic loads until the tag matches; tag = (Job::epoch << 8) + round + 1, so a granule left by an earlier
+// round, registration or launch geometry never matches and nothing has to be cleared between launches.  No fence, no
+// counter, no acquire: the only words another workgroup reads are granules.  Rows are double-buffered by round parity;
+// nobody can run two rounds ahead of a reader (publishing round r + 1 needs every workgroup's row of round r, hence
+// everybody past their reads of round r - 1).  Correctness never depends on which CU or XCD a workgroup runs on; the
+// group = XCD coincidence only makes level 1 cheap.  Every spin is bounded by the 100 MHz wall clock: a launch whose
+// workgroups are not all resident ends with Job::error set instead of hanging.
+// The matched_ flags are cleared with write-through stores before the first row is published (mad_icp.cpp:85 sets
+// them in the last round only, from other workgroups; pipeline.cpp:172-176).
+// After the last round the leaders fold once more and icp_final (next launch) reads the eight F[x] of round n - 1.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long* gptr_g64;
+constexpr int kRowGranules = 2 * kAcc;  // 480 bytes per row
+__host__ __device__ constexpr size_t xch_level1(int n_scans, int grid) { return (size_t)2 * n_scans * grid * kRowGranules; }
+__host__ __device__ constexpr size_t xch_granules(int n_scans, int grid) {
+  return xch_level1(n_scans, grid) + (size_t)2 * n_scans * kFoldGroups * kRowGranules;
+}
+__device__ __forceinline__ void granule_store(gptr_g64 g, unsigned tag, double v) {
+  const unsigned long long t = (unsigned long long)tag << 32;
+  __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one poll: true when both halves carry `tag`
+__device__ __forceinline__ bool granule_try(gptr_g64 g, unsigned tag, double& v) {
+  const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+  return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+}
+constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
+
+template <int QPT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_persist(
+    const Job* __restrict__ jobs, Job* __restrict__ jobs_out, unsigned long long* __restrict__ xch, int n_iters, int K_arg,
+    int RPT_arg) {
+  constexpr bool TRACE = false;
+  typedef const __attribute__((address_space(1))) unsigned int* gptr_u1;
+  typedef const __attribute__((address_space(1))) float* gptr_f1;
+  typedef const __attribute__((address_space(1))) double* gptr_d1;
+
+  __shared__ __attribute__((aligned(16))) TreeDesc s_td;
+  __shared__ double s_total[kAcc];
+  __shared__ double s_X[15];      // the pose of the current round + the bounds of the last update: lives here between rounds
+  __shared__ JoinSeg s_rows;      // leader: the group's rows [slot][value]; everybody (wave 0): the eight F[x]
+  __shared__ double red[kWaves][32];
+  __shared__ unsigned long long s_cnt[2];  // visits / walked of the rounds joined so far
+  __shared__ int s_abort;
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  vu4* s_top = reinterpret_cast<vu4*>(dyn_lds);
+  int4* s_exit = reinterpret_cast<int4*>(dyn_lds + kTopMax * sizeof(vu4));
+
+  int desc_tree, staged_tree = -1;
+  bool stage_hint_next = true;
+  {
+    const Job* job = jobs + blockIdx.y;
+    const int U = K_arg * RPT_arg;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int lo = (xcd * U) >> 3, hi = ((xcd + 1) * U) >> 3;
+    const int u_first = lo + slot;
+    const int k_first = u_first < hi ? u_first / RPT_arg : 0;
+    if (threadIdx.x < 11)
+      reinterpret_cast<long long*>(&s_td)[threadIdx.x] =
+          ((const __attribute__((address_space(1))) long long*)(uintptr_t)&job->trees[k_first])[threadIdx.x];
+    desc_tree = k_first;
+    if (threadIdx.x < 12) s_X[threadIdx.x] = ((gptr_d1)(uintptr_t)job->Xring[0])[threadIdx.x];
+    if (threadIdx.x >= 12 && threadIdx.x < 15) s_X[threadIdx.x] = 0.0;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) s_abort = 0;
+    // matched_ flags: cleared here, write-through, before anything of this workgroup is published
+    gptr_g64 m8 = (gptr_g64)(uintptr_t)job->matched;  // hipMalloc'ed: 256-byte aligned, padded by 16 bytes
+    const int L = job->L;
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ((L + 7) >> 3); i += stride)
+      __hip_atomic_store(m8 + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the flag stores have left before the first row does)
+  }
+  __syncthreads();
+
+  for (int round = 0; round < n_iters; ++round) {
+    // Everything below is derived afresh every round from values the compiler cannot prove loop-invariant — exactly what
+    // a launch of icp_round derives: left to itself the compiler hoists ~30 per-lane addresses and ~60 uniform values
+    // out of the round loop and spills them (168 VGPRs + 270 bytes of scratch against 151 + 0).
+    int tid = threadIdx.x, bx = blockIdx.x, by = blockIdx.y, K = K_arg, RPT = RPT_arg;
+    const Job* jbase = jobs;
+    asm volatile("" : "+v"(tid), "+s"(bx), "+s"(by), "+s"(K), "+s"(RPT), "+s"(jbase));
+    const Job* job = jbase + by;
+    const int U = K * RPT;
+    const int xcd = bx & 7;
+    const int slot = bx >> 3;
+    const int nslots = gridDim.x >> 3;
+    const int lo = (xcd * U) >> 3;
+    const int hi = ((xcd + 1) * U) >> 3;
+    const int u_first = lo + slot;
+    const bool have_first = u_first < hi;
+    const int k_first = have_first ? u_first / RPT : 0;
+    const int r_first = have_first ? u_first - k_first * RPT : 0;
+    const int opt_lds_top = job->lds_top;
+    const int opt_stage_min = job->stage_min_leaves;
+    const int L = job->L;
+    const int flags = job->flags;
+    const unsigned tag0 = job->epoch << 8;
+    const double* __restrict__ moving = job->moving;
+    uint8_t* __restrict__ matched = job->matched;
+    uint32_t* __restrict__ corr = nullptr;
+    const double min_ball = job->min_ball, rho = job->rho, b_ratio = job->b_ratio;
+#ifndef MADICP_EXACT_SOLVE
+    const double inv_min_ball = fast_rcp(min_ball);
+#endif
+    uint32_t* __restrict__ cache_leaf = job->cache_leaf;
+    float* __restrict__ cache_margin = job->cache_margin;
+    const int S = (L + RPT - 1) / RPT;
+    const bool leader = slot == 0;
+    const bool last_round = (round == n_iters - 1);
+    const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
+    const unsigned tag_prev = tag0 + (unsigned)round;  // rows of round - 1 carry (round - 1) + 1
+    const unsigned tag_now = tag_prev + 1u;
+    // exchange rows of this scan
+    const size_t l1_stride = (size_t)gridDim.y * gridDim.x * kRowGranules;  // one parity of level 1
+    const size_t l2_stride = (size_t)gridDim.y * kFoldGroups * kRowGranules;
+    gptr_g64 l1 = (gptr_g64)(uintptr_t)xch + (size_t)by * gridDim.x * kRowGranules;
+    gptr_g64 l2 = (gptr_g64)(uintptr_t)xch + xch_level1(gridDim.y, gridDim.x) + (size_t)by * kFoldGroups * kRowGranules;
+
+    // the first pass's pose-independent loads (leaf coordinates, cached correspondence: L1/L2 hits from the second round
+    // on): in flight during the wait below
+    vd4 pv0[QPT];
+    float cmar0[QPT];
+    unsigned int cword0[QPT];
+    {
+      const int i_end0 = have_first ? min(L, (r_first + 1) * S) : 0;
+      const int i_last0 = max(i_end0 - 1, 0);
+#pragma unroll
+      for (int j = 0; j < QPT; ++j) {
+        const int i = min(r_first * S + j * kBlock + tid, i_last0);
+        pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
+        cmar0[j] = 0.f;
+        cword0[j] = 0u;
+        if (reuse) {  // (uniform)
+          const long long ci = (long long)k_first * L + i;
+          cmar0[j] = ((gptr_f1)(uintptr_t)cache_margin)[ci];
+          cword0[j] = ((gptr_u1)(uintptr_t)cache_leaf)[ci];
+        }
+      }
+    }
+    MADICP_STAMP(0);
+    // ---- the pose of this round: wave 0 reads the eight folded rows of round - 1, adds them, solves ---------------
+    if (tid < 64 && round > 0) {
+      gptr_g64 src = l2 + ((round - 1) & 1) * l2_stride;
+      double v[4];
+      bool ok[4];
+      bool expired = false;
+      const unsigned long long t_start = wall_clock64();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ok[j] = tid >= 60;  // 60 lanes x 4 values = 8 rows x 30
+      // (Measured and dropped: polling ONE granule per row first and sweeping all 240 values only then — it takes the
+      // waiting workgroups off the stragglers' memory channels, but adds a dependent round trip per hop: -9 %.)
+      for (unsigned spins = 1;; ++spins) {
+        bool all_ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!ok[j]) {
+            const int idx = tid + 60 * j;  // = 30 x + c
+            const int x = idx / kAcc, c = idx - x * kAcc;
+            ok[j] = granule_try(src + x * kRowGranules + 2 * c, tag_prev, v[j]);
+          }
+          all_ok &= ok[j];
+        }
+        if (__all(all_ok)) break;
+        if ((spins & 63u) == 0u && wall_clock64() - t_start > kSpinLimitTicks) { expired = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      expired = __any(expired);
+      if (expired) {
+        if (tid == 0) s_abort = 1;
+      } else {
+        if (tid < 60) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int idx = tid + 60 * j;
+            const int x = idx / kAcc, c = idx - x * kAcc;
+            s_rows[x][c] = v[j];
+          }
+        }
+        wave_lds_order();
+        MADICP_STAMP(1);
+        if (tid < kAcc) {
+          double a = s_rows[0][tid];
+#pragma unroll
+          for (int x = 1; x < kFoldGroups; ++x) a += s_rows[x][tid];
+          s_total[tid] = a;
+        }
+        wave_lds_order();
+        double Xp[12], Xn[12], H[36], b[6], moved[2];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Xp[i] = s_X[i];
+        solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved, tid);
+        wave_lds_order();  // (every lane has read the old pose)
+        if (tid == 0) {
+          s_cnt[0] += static_cast<unsigned long long>(s_total[28]);
+          s_cnt[1] += static_cast<unsigned long long>(s_total[29]);
+#pragma unroll
+          for (int i = 0; i < 12; ++i) s_X[i] = Xn[i];
+          s_X[12] = moved[0];
+          s_X[13] = moved[1];
+        }
+      }
+    }
+    if (tid < 12 && bx == 0 && job->x_iters) {  // the pose this round linearises at (wave 0: behind its own LDS stores)
+      wave_lds_order();
+      job->x_iters[(long long)round * 12 + tid] = s_X[tid];
+    }
+    double acc[kAcc];
+#pragma unroll
+    for (int v = 0; v < kAcc; ++v) acc[v] = 0.0;
+    unsigned int visits = 0, walked_visits = 0;
+    bool walked = false;
+    __syncthreads();
+    MADICP_STAMP(2);
+    if (s_abort) break;  // (uniform)
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = wave_uniform(s_X[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = wave_uniform(s_X[9 + k]);
+    const double moved_rot = wave_uniform(s_X[12]), moved_trans = wave_uniform(s_X[13]);
+    const bool stage_hint = stage_hint_next;
+
+#define MADICP_TID tid
+#include "icp_linearize_body.inc.h"
+#undef MADICP_TID
+
+    MADICP_STAMP(5);
+    // ---- reduction: lanes -> waves -> this workgroup's row, published for the leader of its group -------------------
+    acc[28] = static_cast<double>(visits);
+    acc[29] = static_cast<double>(walked_visits);
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    wave_reduce_scatter(acc, lane, red[wave]);
+    const int n_walked = __syncthreads_count(walked ? 1 : 0);
+    stage_hint_next = n_walked > 0;
+    if (tid < kAcc) {
+      double s = red[0][tid];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) s += red[w][tid];
+      granule_store(l1 + (round & 1) * l1_stride + (size_t)bx * kRowGranules + 2 * tid, tag_now, s);
+    }
+    MADICP_STAMP(6);
+    // ---- level 1: the leader folds its group's rows and publishes F[x] ---------------------------------------------
+    if (leader) {  // (workgroup-uniform)
+      gptr_g64 src = l1 + (round & 1) * l1_stride + (size_t)xcd * kRowGranules;
+      const int n_vals = nslots * kAcc;
+      bool expired = false;
+      const unsigned long long t_start = wall_clock64();
+      for (int idx = tid; idx < n_vals; idx += kBlock) {
+        const int sl = idx / kAcc, c = idx - sl * kAcc;
+        gptr_g64 g = src + (size_t)sl * kFoldGroups * kRowGranules + 2 * c;  // row x + 8 sl
+        double v = 0.0;
+        for (unsigned spins = 1; !granule_try(g, tag_now, v); ++spins) {
+          if ((spins & 63u) == 0u && wall_clock64() - t_start > kSpinLimitTicks) { expired = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        s_rows[sl][c] = v;
+      }
+      MADICP_STAMP(15);
+      if (__syncthreads_or(expired ? 1 : 0)) {
+        if (tid == 0) s_abort = 1;
+      } else if (tid < kAcc) {
+        double rv[kJoinGroups];  // (every LDS read in flight before the first addition; rows the group does not have: +0.0)
+#pragma unroll
+        for (int sl = 0; sl < kJoinGroups; ++sl) rv[sl] = sl < nslots ? s_rows[sl][tid] : 0.0;
+        double f = 0.0;
+#pragma unroll
+        for (int q = 0; q < kFoldChains; ++q) {
+          double sg = 0.0;
+#pragma unroll
+          for (int sl = q; sl < kJoinGroups; sl += kFoldChains) sg += rv[sl];
+          f = (q == 0) ? sg : f + sg;
+        }
+        granule_store(l2 + (round & 1) * l2_stride + (size_t)xcd * kRowGranules + 2 * tid, tag_now, f);
+      }
+      __syncthreads();  // s_rows is reused by wave 0 at the top of the next round; s_abort published
+      MADICP_STAMP(14);
+      if (s_abort) break;
+    }
+  }
+  // bookkeeping of the rounds joined in this launch (icp_final adds the last round's)
+  Job* jout = jobs_out + blockIdx.y;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    jout->visits += s_cnt[0];
+    jout->walked += s_cnt[1];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) jout->Xring[(n_iters - 1) & 1][i] = s_X[i];  // the pose the last round linearised at
+    jout->iter = n_iters - 1;
+  }
+  if (threadIdx.x == 0 && s_abort) jout->error = 1;
 }
 
 // matched-leaf count (pipeline.cpp:197-204), whole workgroup; valid once the last round's linearisation is done
@@ -1736,12 +1832,34 @@ __device__ __forceinline__ void count_matched(Job* job) {
 // after the last round: join + solve once more -> final pose, H, b of the last round, counters, matched-leaf count
 // (pipeline.cpp:195-204,223).  grid = n_scans, block = kBlock (the join order depends on it).  nblocks = workgroups per scan of icp_round.
 __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, const double* __restrict__ partials,
-                                                          const double* __restrict__ totals, int nblocks, int n_scans) {
+                                                          const double* __restrict__ totals, int nblocks, int n_scans,
+                                                          const unsigned long long* __restrict__ xch) {
   __shared__ double s_total[kAcc];
   Job* job = jobs + blockIdx.x;
   const int n = job->n_iters;
   if (totals) {
     if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.x * kAcc + threadIdx.x];
+    __syncthreads();
+  } else if (xch) {
+    // behind icp_persist: the eight folded rows F[x] of the last round, left by the group leaders (level 2 of the
+    // exchange; the kernel boundary made them visible, the tags are checked all the same)
+    __shared__ double s_f[kFoldGroups][kAcc];
+    const unsigned tag = (job->epoch << 8) + (unsigned)n;
+    if (threadIdx.x < kFoldGroups * kAcc) {
+      const int x = threadIdx.x / kAcc, c = threadIdx.x - x * kAcc;
+      gptr_g64 src = (gptr_g64)(uintptr_t)xch + xch_level1(n_scans, nblocks) +
+                     ((size_t)((n - 1) & 1) * n_scans + blockIdx.x) * kFoldGroups * kRowGranules;
+      double v;
+      if (!granule_try(src + x * kRowGranules + 2 * c, tag, v)) job->error = 2;  // (a round never published: icp_persist gave up)
+      s_f[x][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAcc) {
+      double a = s_f[0][threadIdx.x];
+#pragma unroll
+      for (int x = 1; x < kFoldGroups; ++x) a += s_f[x][threadIdx.x];
+      s_total[threadIdx.x] = a;
+    }
     __syncthreads();
   } else {
     const int prows = join_rows(nblocks);
@@ -1754,7 +1872,7 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
 #pragma unroll
     for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(n - 1) & 1][i];
     double moved[2];
-    solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b, moved);
+    solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b, moved, threadIdx.x & 63);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int i = 0; i < 36; ++i) job->H[i] = H[i];
@@ -1785,6 +1903,7 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
         ho->visits = job->visits;
         ho->walked = job->walked;
         ho->iter = n;
+        ho->error = job->error;
       }
     }
   }

@@ -111,10 +111,10 @@ struct DevMoving {
 };
 
 struct GraphKey {  // everything a captured launch sequence bakes in
-  int grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot;
+  int grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot, persist;
   bool operator<(const GraphKey& o) const {
-    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot) <
-           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt, o.trace, o.slot);
+    return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot, persist) <
+           std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt, o.trace, o.slot, o.persist);
   }
 };
 struct Geometry {
@@ -170,6 +170,8 @@ struct madicp_ctx {
   size_t partials_cap = 0;     // doubles
   int partials_grid = -1, partials_batch = -1;  // geometry the zero padding rows of d_partials are valid for
   double* d_totals = nullptr;  // [MADICP_MAX_BATCH][kAcc]
+  unsigned long long* d_xch = nullptr;  // icp_persist's exchange granules (kernels.hip.h), sized for every admissible geometry
+  uint32_t epoch = 0;          // one per enqueued registration: Job::epoch
   int last_batch = 0;
   std::vector<int> last_moving;
 
@@ -197,6 +199,7 @@ struct madicp_ctx {
   int eager_when_busy = 1; // a registration queued behind another is launched kernel by kernel, not as a graph (run_rounds)
   int seq_completion = 1;  // streamed registrations publish completion through HostResult::seq instead of an event
   int host_feed_wait = 1;  // ... and the host, not the stream, waits for their feed while another one is in flight
+  int persistent = 0;      // all rounds of a registration as ONE launch (icp_persist) where the geometry admits it
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -405,6 +408,16 @@ struct Launch {  // one registration's launch shape
   int grid, batch, iters, qpt, lds, K, rpt, trace;
 };
 
+constexpr size_t kXchRowsMax = 1024 + 8 * MADICP_MAX_BATCH;  // level-1 rows + level-2 rows of the largest admissible launch
+
+// May this registration run as ONE launch?  icp_persist needs every workgroup resident at once (one 768-thread workgroup
+// per CU is all a CU holds), no collective between rounds, and tags of 8 bits of round.
+bool use_persist(const madicp_ctx* ctx, const Launch& l) {
+  return ctx->persistent && !ctx->sharded() && !l.trace && l.iters >= 2 && l.iters <= 250 && ctx->blocks_per_cu == 1 &&
+         (long long)l.grid * l.batch <= ctx->n_cus && (l.grid >> 3) <= kJoinGroups && l.K >= 1 &&
+         madicp::xch_granules(l.batch, l.grid) <= kXchRowsMax * 2 * madicp::kRowGranules;
+}
+
 void launch_round(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
   void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int) =
@@ -416,6 +429,15 @@ void launch_round(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int round, cons
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
 int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vector<int>& moving_ids) {
   const int grid = l.grid, batch = l.batch, iters = l.iters;
+  if (use_persist(ctx, l)) {
+    dim3 g(grid, batch), b(kBlock);
+    void (*kern)(const Job*, Job*, unsigned long long*, int, int, int) = l.qpt == 2 ? icp_persist<2> : icp_persist<1>;
+    hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)d_jobs, d_jobs, ctx->d_xch, iters, l.K, l.rpt);
+    hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials, (const double*)nullptr,
+                       grid, batch, (const unsigned long long*)ctx->d_xch);
+    HIP_TRY(hipGetLastError());
+    return MADICP_OK;
+  }
   for (int it = 0; it < iters; ++it) {
     launch_round(ctx, l, d_jobs, it, (ctx->sharded() && it > 0) ? ctx->d_totals : nullptr);
     if (ctx->sharded()) {
@@ -435,7 +457,7 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vec
   }
   // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
   hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials,
-                     ctx->sharded() ? ctx->d_totals : nullptr, grid, batch);
+                     ctx->sharded() ? ctx->d_totals : nullptr, grid, batch, (const unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -454,7 +476,7 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
   // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
-  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot};
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot, use_persist(ctx, l) ? 1 : 0};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     auto instantiate = [&](Job* jobs, const GraphKey& k) -> int {
@@ -644,6 +666,9 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
   j.K = K;
   j.n_iters = n_iters;
   j.iter = 0;
+  j.epoch = ++ctx->epoch;  // (24 bits of it reach the granule tags: a tag recurs after 16 M registrations, far beyond
+                           // the life of any granule of a geometry in use)
+  j.error = 0;
   j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse);
   std::memcpy(j.X, X0, 12 * sizeof(double));
   std::memcpy(j.Xring[0], X0, 12 * sizeof(double));
@@ -747,7 +772,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
     // fold the last launch's partials (round parity 0) into job->visits / H / b: icp_final with n_iters = 1 semantics
     hipLaunchKernelGGL(icp_final, dim3(a.n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                       (const double*)nullptr, grid, a.n_scans);
+                       (const double*)nullptr, grid, a.n_scans, (const unsigned long long*)nullptr);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
@@ -803,6 +828,8 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->h_tree_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc(&ctx->h_fetch, sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(&ctx->d_totals, sizeof(double) * kAcc * MADICP_MAX_BATCH);
+  if (e == hipSuccess) e = hipMalloc(&ctx->d_xch, kXchRowsMax * 2 * madicp::kRowGranules * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(ctx->d_xch, 0, kXchRowsMax * 2 * madicp::kRowGranules * sizeof(unsigned long long));
   for (int i = 0; i < madicp_ctx::kStreamSlots && e == hipSuccess; ++i) {
     StreamSlot& sl = ctx->slots[i];
     e = hipMalloc(&sl.d_job, sizeof(Job));
@@ -860,6 +887,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->h_fetch) hipHostFree(ctx->h_fetch);
   if (ctx->d_partials) hipFree(ctx->d_partials);
   if (ctx->d_totals) hipFree(ctx->d_totals);
+  if (ctx->d_xch) hipFree(ctx->d_xch);
   if (ctx->copy) hipStreamDestroy(ctx->copy);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -893,6 +921,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->seq_completion = value ? 1 : 0;
   } else if (k == "host_feed_wait") {
     ctx->host_feed_wait = value ? 1 : 0;
+  } else if (k == "persistent") {
+    ctx->persistent = value ? 1 : 0;
   } else if (k == "wait_mode") {
     if (value < 0 || value > 2) return fail(MADICP_ERR_INVALID, "wait_mode must be 0 (spin), 1 (yield) or 2 (sleep)");
     ctx->wait_mode = (int)value;
@@ -1388,6 +1418,10 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
     }
   }
   const HostResult& r = *sl.h_out;
+  if (r.error) {
+    sl.pending = false;
+    return fail(MADICP_ERR_DEVICE, "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(r.error) + ")");
+  }
   if (out_X) std::memcpy(out_X, r.X, sizeof(r.X));
   if (out_H) std::memcpy(out_H, r.H, sizeof(r.H));
   if (out_b) std::memcpy(out_b, r.b, sizeof(r.b));
@@ -1415,6 +1449,7 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
   RC_TRY(bounded_sync(ctx, ctx->stream));
   for (int s = 0; s < n_scans; ++s) {
     const Job& j = ctx->h_fetch[s];
+    if (j.error) return fail(MADICP_ERR_DEVICE, "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(j.error) + ")");
     if (out_X) std::memcpy(out_X + 12 * s, j.X, 12 * sizeof(double));
     if (out_H) std::memcpy(out_H + 36 * s, j.H, 36 * sizeof(double));
     if (out_b) std::memcpy(out_b + 6 * s, j.b, 6 * sizeof(double));
@@ -1545,7 +1580,7 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
   HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   for (int r = 0; r < reps; ++r)
     hipLaunchKernelGGL(icp_final, dim3(n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                       (const double*)nullptr, geo.grid, n_scans);
+                       (const double*)nullptr, geo.grid, n_scans, (const unsigned long long*)nullptr);
   HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
   HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   {
