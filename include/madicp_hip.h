@@ -100,6 +100,14 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
  * range): a malformed array is MADICP_ERR_INVALID, never an out-of-bounds access.  Returns once `nodes` has been
  * staged; the copy and the build of the screening records run on the context's copy stream. */
 int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id);
+/* The same for an array whose structure the PRODUCER guarantees — madicp_host_tree_build's output (csrc/host/
+ * tree_builder.cpp), which is what the host MADtree / Pipeline classes upload once per scan — so that the O(n) host
+ * validation pass (0.25 ms of a 2.9 ms drop-in frame at 45 k nodes) is not paid per frame.  rho2 = max |mean_i - mean_0|_2
+ * over the internal nodes with finite means (madicp_tree_upload computes it while validating; the builder while
+ * numbering the leaves).  No check beyond n_nodes == 2 n_leaves - 1: a malformed array here is undefined behaviour
+ * on the device.  Arrays from anywhere else go through madicp_tree_upload. */
+int madicp_tree_upload_trusted(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, double rho2,
+                               int* out_tree_id);
 int madicp_tree_release(madicp_ctx* ctx, int tree_id);
 int madicp_tree_download(madicp_ctx* ctx, int tree_id, madicp_node* out_nodes, int32_t n_nodes);
 /* MADtree::applyTransform (mad_tree.cpp:165-172): mean <- R mean + t, dir <- R dir on every node.  Stream-ordered

@@ -39,6 +39,18 @@ void madicp_host_gn_update(const double H[36], const double b[6], double X[12]);
 /* det(H^-1), the keyframe weight of pipeline.cpp:223 */
 double madicp_host_det_of_inverse6(const double H[36]);
 
+/* max |mean_i - mean_0|_2 over the internal nodes with finite means — the rho2 argument of madicp_tree_upload_trusted */
+double madicp_host_tree_rho2(const madicp_host_tree* t);
+
+/* The thread budget of the host tree builder (the caller included), process-wide — what Pipeline's num_threads
+ * argument sets, like the reference's omp_set_num_threads(num_threads) (pipeline.cpp:64-65). */
+void madicp_host_set_threads(int n);
+
+/* Test hook: `split` of utils.h:37-52 about the plane (mean, normal) applied to points (n,3) IN PLACE, by the
+ * reference's own loop (impl 0) or by the builder's flag-driven closed form (impl 1); returns the split position
+ * (first point of the right part), -1 on bad arguments.  Both must leave the same permutation. */
+int64_t madicp_host_debug_partition(double* points, int64_t n, const double mean[3], const double normal[3], int impl);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,7 @@ def hip_lib():
         L.madicp_ctx_synchronize.argtypes = [C.c_void_p]
         L.madicp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.madicp_tree_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _ip]
+        L.madicp_tree_upload_trusted.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, _ip]
         L.madicp_tree_release.argtypes = [C.c_void_p, C.c_int]
         L.madicp_tree_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32]
         L.madicp_tree_transform.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
@@ -129,6 +130,11 @@ def host_lib():
         L.madicp_host_gn_update.argtypes = [_dp, _dp, _dp]
         L.madicp_host_det_of_inverse6.restype = C.c_double
         L.madicp_host_det_of_inverse6.argtypes = [_dp]
+        L.madicp_host_set_threads.argtypes = [C.c_int]
+        L.madicp_host_tree_rho2.restype = C.c_double
+        L.madicp_host_tree_rho2.argtypes = [C.c_void_p]
+        L.madicp_host_debug_partition.restype = C.c_int64
+        L.madicp_host_debug_partition.argtypes = [_dp, C.c_int64, _dp, _dp, C.c_int]
         _host = L
     return _host
 
@@ -212,6 +218,10 @@ class HostTree:
         t = _f64(t, (3,))
         host_lib().madicp_host_tree_transform(self._h, R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
 
+    @property
+    def rho2(self):
+        return host_lib().madicp_host_tree_rho2(self._h)
+
 
 class Context:
     """One device + one stream (include/madicp_hip.h)."""
@@ -244,8 +254,18 @@ class Context:
                                             C.byref(tid)))
         return tid.value
 
-    def upload(self, host_tree):
+    def upload(self, host_tree, trusted=False):
+        if trusted:
+            return self.tree_upload_trusted(host_tree.nodes, host_tree.num_leaves, host_tree.rho2)
         return self.tree_upload(host_tree.nodes, host_tree.num_leaves)
+
+    def tree_upload_trusted(self, nodes, n_leaves, rho2):
+        """madicp_tree_upload_trusted: no validation pass (arrays from the product's own builder only)."""
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        tid = C.c_int(0)
+        _check(hip_lib().madicp_tree_upload_trusted(self._h, nodes.ctypes.data_as(C.c_void_p), nodes.shape[0], n_leaves,
+                                                    float(rho2), C.byref(tid)))
+        return tid.value
 
     def tree_release(self, tid):
         _check(hip_lib().madicp_tree_release(self._h, tid))

@@ -1038,7 +1038,21 @@ void release_tree(madicp_ctx* ctx, DevTree& t, const EventRef& after) {
 
 }  // namespace
 
+namespace {
+int tree_upload_impl(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, bool trusted, double rho2,
+                     int* out_tree_id);
+}
 int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, int* out_tree_id) {
+  return tree_upload_impl(ctx, nodes, n_nodes, n_leaves, false, 0.0, out_tree_id);
+}
+int madicp_tree_upload_trusted(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, double rho2,
+                               int* out_tree_id) {
+  if (!(rho2 >= 0.0) || !std::isfinite(rho2)) return fail(MADICP_ERR_INVALID, "rho2 must be finite and >= 0");
+  return tree_upload_impl(ctx, nodes, n_nodes, n_leaves, true, rho2, out_tree_id);
+}
+namespace {
+int tree_upload_impl(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_nodes, int32_t n_leaves, bool trusted, double rho2,
+                     int* out_tree_id) {
   if (!ctx || !nodes || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
   if (n_nodes < 1 || n_leaves < 1 || n_nodes != 2 * n_leaves - 1)
     return fail(MADICP_ERR_INVALID, "a MAD-tree has n_nodes == 2*n_leaves-1 >= 1");
@@ -1046,7 +1060,10 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   DevTree t;
   t.n_nodes = n_nodes;
   t.n_leaves = n_leaves;
-  RC_TRY(validate_nodes(nodes, n_nodes, n_leaves, &t.rho2));
+  if (trusted)
+    t.rho2 = rho2;
+  else
+    RC_TRY(validate_nodes(nodes, n_nodes, n_leaves, &t.rho2));
   std::vector<int> top_dfs;
   std::vector<unsigned int> top_link;
   std::vector<int4> top_exit;
@@ -1109,6 +1126,7 @@ int madicp_tree_upload(madicp_ctx* ctx, const madicp_node* nodes, int32_t n_node
   *out_tree_id = id;
   return MADICP_OK;
 }
+}  // namespace
 
 int madicp_tree_release(madicp_ctx* ctx, int tree_id) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");

@@ -4,6 +4,7 @@
 
 #include "linalg.h"
 #include "madicp_host.h"
+#include "task_pool.h"
 #include "tree_builder.h"
 
 struct madicp_host_tree {
@@ -49,5 +50,13 @@ void madicp_host_gn_update(const double H[36], const double b[6], double X[12]) 
   std::memcpy(X + 9, out.t, sizeof(out.t));
 }
 double madicp_host_det_of_inverse6(const double H[36]) { return madicp_host::det_of_inverse6(H); }
+
+double madicp_host_tree_rho2(const madicp_host_tree* t) { return t ? t->tree.rho2 : -1.0; }
+void madicp_host_set_threads(int n) { madicp_host::TaskPool::instance().set_limit(n); }
+
+int64_t madicp_host_debug_partition(double* points, int64_t n, const double mean[3], const double normal[3], int impl) {
+  if (!points || n < 0 || !mean || !normal) return -1;
+  return madicp_host::debug_partition(points, n, mean, normal, impl);
+}
 
 }  // extern "C"

@@ -114,7 +114,13 @@ int MADtree::deviceId() {
     if (!host_copy_) throw std::runtime_error("MADtree: device-built tree lost with its context");
     flushTransform();
     madicp_ctx* c = Device::ctx();
-    check(madicp_tree_upload(c, tree_.nodes.data(), tree_.num_nodes(), tree_.num_leaves(), &dev_id_), "madicp_tree_upload");
+    // a tree from this library's own builder needs no structure check; anything else (a downloaded / caller-made
+    // array: rho2 < 0) goes through the validating entry
+    if (tree_.rho2 >= 0.0)
+      check(madicp_tree_upload_trusted(c, tree_.nodes.data(), tree_.num_nodes(), tree_.num_leaves(), tree_.rho2, &dev_id_),
+            "madicp_tree_upload_trusted");
+    else
+      check(madicp_tree_upload(c, tree_.nodes.data(), tree_.num_nodes(), tree_.num_leaves(), &dev_id_), "madicp_tree_upload");
     dev_gen_ = Device::generation();
   }
   return dev_id_;

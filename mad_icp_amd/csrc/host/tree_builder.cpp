@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -21,6 +22,11 @@ struct Ctx {
   double* pts;  // xyz triples
   double b_max, b_min;
   int max_parallel_level;  // levels above this depth run as tasks (0: everything on the calling thread)
+  // scratch, one entry per point, indexed like pts: a node only touches the entries of its own range [b, e), so the
+  // sub-trees built by different threads never share one
+  uint8_t* side;    // 1: the point lies on the negative side of its node's split plane (goes left)
+  int32_t* reject;  // partition_from_flags: positions of the points that go right, ascending
+  bool reference_loop;  // development A/B (environment MADICP_HOST_PARTITION=loop): partition with the reference's swap loop
 };
 
 // Task policy.  The reference forks two std::async threads per node above `max_parallel_level` and the parent waits
@@ -28,9 +34,21 @@ struct Ctx {
 // Here the same argument buys 4x as many, smaller tasks (two more levels), the parent builds one child itself, a
 // range below kTaskMinPoints is never forked, and the order-independent pass of a big node (the bounding box) is cut
 // over idle threads.  None of this can change a bit of the result: every sum keeps its sequential order.
-constexpr int kExtraTaskLevels = 2;
-constexpr int64_t kTaskMinPoints = 4096;
-constexpr int64_t kBboxSliceMinPoints = 1 << 20;  // (measured: at 120 k points handing slices to the pool costs more than the pass)
+int env_int(const char* name, int dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : dflt;
+}
+// (development overrides: MADICP_HOST_EXTRA_LEVELS, MADICP_HOST_TASK_MIN)
+const int kExtraTaskLevels = env_int("MADICP_HOST_EXTRA_LEVELS", 2);
+const int64_t kTaskMinPoints = env_int("MADICP_HOST_TASK_MIN", 4096);
+// a range of fewer points is not cut (development override: environment MADICP_HOST_BBOX_SLICE_MIN)
+int64_t bbox_slice_min_points() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("MADICP_HOST_BBOX_SLICE_MIN");
+    return e ? std::atoll(e) : (int64_t(1) << 20);
+  }();
+  return v;
+}
 
 // what a leaf may need from its ancestors (reference mad_tree.cpp:64-74)
 struct Inherited {
@@ -93,8 +111,13 @@ void mean_cov(const Ctx& c, int64_t b, int64_t e, double* mean, double* cov /*ro
 
 // utils.h:75-97: extents of the points in the eigen frame, 0 included; min/max keep the running value on NaN.
 // min and max do not depend on the order of the points, so a big range is cut into slices.
+// The third projection IS the value the split predicate tests: `(p - mean).dot(eigenvectors.col(2)) < 0`
+// (mad_tree.cpp:95-97) and row 2 of `R * (p - mean)` (utils.h:89) are the same three products added in the same order —
+// so this pass also records every point's side of the split plane (NaN: false, like the reference's `< 0`), and the
+// partition that follows for an internal node needs no floating-point arithmetic at all.
 void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V, double* lo, double* hi) {
-#if defined(__SSE2__)
+  uint8_t* side = c.side;
+#if defined(__SSE2__) && !defined(MADICP_REDUX_SCALAR_ONLY)
   // two of the three projections per instruction; every lane does exactly the scalar sequence
   // (c_a0 d0 + c_a1 d1) + c_a2 d2, and min_pd/max_pd keep their SECOND operand on NaN or equality — the running value,
   // like the `if (v < lo) lo = v` of the scalar loop below
@@ -108,7 +131,9 @@ void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const dou
     const double d0 = p[0] - m0, d1 = p[1] - m1, d2 = p[2] - m2;
     const __m128d v01 = _mm_add_pd(_mm_add_pd(_mm_mul_pd(A0, _mm_set1_pd(d0)), _mm_mul_pd(A1, _mm_set1_pd(d1))),
                                    _mm_mul_pd(A2, _mm_set1_pd(d2)));
-    const __m128d v2 = _mm_set_sd((c20 * d0 + c21 * d1) + c22 * d2);
+    const double s2 = (c20 * d0 + c21 * d1) + c22 * d2;
+    side[i] = s2 < 0.0 ? 1 : 0;
+    const __m128d v2 = _mm_set_sd(s2);
     lo01 = _mm_min_pd(v01, lo01);
     hi01 = _mm_max_pd(v01, hi01);
     lo2 = _mm_min_sd(v2, lo2);
@@ -125,6 +150,7 @@ void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const dou
     const double* p = P(c, i);
     const double d[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
     const double v[3] = {dot3c(c0, d), dot3c(c1, d), dot3c(c2, d)};
+    side[i] = v[2] < 0.0 ? 1 : 0;
     for (int a = 0; a < 3; ++a) {
       if (v[a] < lo[a]) lo[a] = v[a];
       if (hi[a] < v[a]) hi[a] = v[a];
@@ -136,7 +162,7 @@ void bbox_lohi(const Ctx& c, int64_t b, int64_t e, const double* mean, const dou
 void bbox_extents(const Ctx& c, int64_t b, int64_t e, const double* mean, const double* V /*row-major, cols = eigvecs*/,
                   double* ext, int slices) {
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  if (slices <= 1 || e - b < kBboxSliceMinPoints) {
+  if (slices <= 1 || e - b < bbox_slice_min_points()) {
     bbox_lohi(c, b, e, mean, V, lo, hi);
   } else {
     struct LoHi { double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}; };
@@ -178,6 +204,66 @@ int64_t partition_by_plane(const Ctx& c, int64_t b, int64_t e, const double* mea
     hi -= keep ? 0 : 1;
   }
   return hi;
+}
+
+// The same permutation as partition_by_plane, from the side flags the bounding-box pass left behind — without the
+// reference loop's dependency chain (every step of `split` needs the previous decision to know which element it looks
+// at next: load -> subtract -> dot -> compare -> cursor, ~27 cycles per point, 1 ms for the root of a 120 k-point scan).
+//
+// What utils.h:37-52 does, in closed form.  The lower cursor walks the front of the range; whenever it meets a point
+// that has to go right (a "hole"), that point is swapped to the top of the not yet examined back part and the point
+// that was there is examined in its place, again and again until one of them stays.  Hence, with the holes h_1 < h_2 <
+// ... (front points that go right) and the back points that go left k_1 > k_2 > ... (descending positions):
+//   * hole h_r ends up holding the point of k_r;
+//   * every back point that goes right ends up ONE position lower (the swap that examined it put it there);
+//   * the point of hole h_r ends up at the top of "its" run: position e - 1 for r = 1, k_{r-1} - 1 after that;
+//   * it ends when the cursors meet: at k_m if the front has no hole left below it, else at the hole h_{m+1} that no
+//     back point is left to fill.
+// One descending sweep over the back part does all of it: `carry` is what has to be written at the position the sweep
+// stands on — the hole's point at the top of a run, the shifted point below it.  Bit-identical by construction and
+// checked against the loop above on exhaustive small and random large flag patterns (tests/test_host_builder.py).
+int64_t partition_from_flags(const Ctx& c, int64_t b, int64_t e) {
+  const uint8_t* side = c.side;
+  int32_t* rej = c.reject + b;
+  // positions that go right, ascending (branch-free compaction: the slot is written every step, kept when it counts)
+  int64_t n_rej = 0;
+  for (int64_t p = b; p < e; ++p) {
+    rej[n_rej] = static_cast<int32_t>(p);
+    n_rej += side[p] ? 0 : 1;
+  }
+  if (n_rej == 0) return e;  // everything stays
+  // (points as three 64-bit words: the selects below become conditional moves — the side of a point is a coin flip to
+  // the branch predictor, and a mispredicted branch per point is what the sweep would otherwise cost)
+  struct P3 { uint64_t x, y, z; };
+  static_assert(sizeof(P3) == 24, "a point is three doubles");
+  P3* pts = reinterpret_cast<P3*>(c.pts);
+  P3 sink;
+  int64_t r = 0;
+  int64_t hole = rej[0];
+  int64_t q = e - 1;
+  P3 carry = pts[hole];
+  for (;;) {
+    if (q == hole) {  // the back part is used up: the hole is where the two parts meet
+      pts[q] = carry;
+      return hole;
+    }
+    const P3 y = pts[q];
+    pts[q] = carry;
+    const bool left = side[q] != 0;
+    // goes left: it fills the hole, and the next hole's point opens the next run one position down; goes right: it is
+    // what the next position down receives
+    P3* dst = left ? &pts[hole] : &sink;
+    *dst = y;
+    r += left ? 1 : 0;
+    const int64_t next = r < n_rej ? rej[r] : e;
+    if (left && next >= q) return q;  // no hole left below q: the front walks up to q undisturbed
+    hole = left ? next : hole;
+    const P3 nc = pts[hole];
+    carry.x = left ? nc.x : y.x;
+    carry.y = left ? nc.y : y.y;
+    carry.z = left ? nc.z : y.z;
+    --q;
+  }
 }
 
 // one node: statistics, leaf test, and — for an internal node — the partition.  Returns true for a leaf.
@@ -224,7 +310,7 @@ bool make_node(const Ctx& c, int64_t b, int64_t e, Inherited& inh, madicp_node& 
   if (!inh.plane_normal && ext[0] < c.b_min) inh.plane_normal = col0;  // mad_tree.cpp:90-93
   if (n_pts >= 3 || !inh.small_normal) inh.small_normal = col0;         // mad_tree.cpp:68-72, walked top-down
 
-  mid = partition_by_plane(c, b, e, mean, col2);
+  mid = c.reference_loop ? partition_by_plane(c, b, e, mean, col2) : partition_from_flags(c, b, e);  // (same permutation)
 
   std::memcpy(nd.mean, mean, sizeof(nd.mean));
   std::memcpy(nd.dir, col2, sizeof(nd.dir));
@@ -305,16 +391,28 @@ void layout(const Piece& p, size_t node_off, size_t& leaf_off, madicp_node* out,
   layout(*p.right, node_off + 1 + p.left->size, leaf_off, out, chunks);
 }
 
-// copy one chunk into place and number its leaves (getLeafs() order == order of appearance in preorder)
-void place_chunk(const ChunkRef& r, madicp_node* out, int32_t* leaf_nodes) {
+// |mean - origin|_2 of an internal node, 0 when it is not finite (like madicp_tree_upload's validation pass)
+inline double spread_of(const madicp_node& nd, const double* o) {
+  const double e0 = nd.mean[0] - o[0], e1 = nd.mean[1] - o[1], e2 = nd.mean[2] - o[2];
+  const double r = std::sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+  return std::isfinite(r) ? r : 0.0;
+}
+
+// copy one chunk into place and number its leaves (getLeafs() order == order of appearance in preorder); returns the
+// largest spread_of() among its internal nodes
+double place_chunk(const ChunkRef& r, madicp_node* out, int32_t* leaf_nodes, const double* origin) {
   const NodeVec& ch = r.piece->chunk;
   std::memcpy(out + r.node_off, ch.data(), ch.size() * sizeof(madicp_node));
   size_t leaf = r.leaf_off;
+  double rho = 0.0;
   for (size_t i = 0; i < ch.size(); ++i)
     if (ch[i].right == 0) {
       out[r.node_off + i].leaf_id = static_cast<int32_t>(leaf);
       leaf_nodes[leaf++] = static_cast<int32_t>(r.node_off + i);
+    } else {
+      rho = std::max(rho, spread_of(ch[i], origin));
     }
+  return rho;
 }
 
 }  // namespace
@@ -325,18 +423,26 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
   const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
   int levels = max_parallel_level > 0 ? max_parallel_level + kExtraTaskLevels : 0;
   while (levels > 0 && (1 << (levels - 1)) > 2 * hw) --levels;  // never far more leaf tasks than cores
-  Ctx c{points, b_max, b_min, levels};
+  // per-point scratch of the partition (uninitialised: every node writes its own range before it reads it)
+  std::unique_ptr<uint8_t[]> side(new uint8_t[static_cast<size_t>(n)]);
+  std::unique_ptr<int32_t[]> reject(new int32_t[static_cast<size_t>(n)]);
+  const char* how = std::getenv("MADICP_HOST_PARTITION");
+  Ctx c{points, b_max, b_min, levels, side.get(), reject.get(), how && std::strcmp(how, "loop") == 0};
   if (levels == 0) {
     t.nodes.reserve(static_cast<size_t>(2 * n));
     build_sequential(c, 0, n, Inherited{nullptr, nullptr}, t.nodes);
     t.nodes.shrink_to_fit();
     // getLeafs() order == order of appearance in the preorder array (mad_tree.cpp:154-163)
     t.leaf_nodes.reserve((t.nodes.size() + 1) / 2);
+    double rho = 0.0;
     for (size_t i = 0; i < t.nodes.size(); ++i)
       if (t.nodes[i].right == 0) {
         t.nodes[i].leaf_id = static_cast<int32_t>(t.leaf_nodes.size());
         t.leaf_nodes.push_back(static_cast<int32_t>(i));
+      } else {
+        rho = std::max(rho, spread_of(t.nodes[i], t.nodes[0].mean));
       }
+    t.rho2 = rho;
     return t;
   }
   const int slices = std::min(hw, 1 << std::min(levels, 4));
@@ -352,6 +458,11 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
   std::vector<TaskPool::Handle> jobs;
   madicp_node* out = t.nodes.data();
   int32_t* leaf_nodes = t.leaf_nodes.data();
+  // (the root is a forked node unless the whole tree is one chunk: either way its mean is final before any copy task
+  // starts — layout() wrote it, or it is element 0 of the only chunk)
+  double origin[3];
+  std::memcpy(origin, top->chunk.empty() ? top->nd.mean : top->chunk[0].mean, sizeof(origin));
+  std::vector<double> rho_part(n_tasks + 1, 0.0);
   size_t first = 0;
   for (size_t k = 0; k < n_tasks; ++k) {
     const size_t want = top->size * (k + 1) / n_tasks;  // nodes up to which this task copies
@@ -360,17 +471,48 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
     if (last == first) continue;
     const ChunkRef* cb = chunks.data() + first;
     const ChunkRef* ce = chunks.data() + last;
-    auto run = [cb, ce, out, leaf_nodes] {
-      for (const ChunkRef* r = cb; r != ce; ++r) place_chunk(*r, out, leaf_nodes);
+    double* rho_out = &rho_part[k];
+    auto run = [cb, ce, out, leaf_nodes, rho_out, &origin] {
+      double rho = 0.0;
+      for (const ChunkRef* r = cb; r != ce; ++r) rho = std::max(rho, place_chunk(*r, out, leaf_nodes, origin));
+      *rho_out = rho;
     };
     if (k + 1 == n_tasks) run(); else jobs.push_back(pool.submit(run));
     first = last;
   }
   for (const TaskPool::Handle& j : jobs) pool.wait(j);
+  // the forked nodes (a few dozen) were written by layout()
+  {
+    std::vector<const Piece*> stack{top.get()};
+    while (!stack.empty()) {
+      const Piece* p = stack.back();
+      stack.pop_back();
+      if (!p->chunk.empty()) continue;
+      rho_part[n_tasks] = std::max(rho_part[n_tasks], spread_of(p->nd, origin));
+      stack.push_back(p->left.get());
+      stack.push_back(p->right.get());
+    }
+  }
+  t.rho2 = *std::max_element(rho_part.begin(), rho_part.end());
   return t;
 }
 
+// test hook (madicp_host_debug_partition): one partition of `pts` about the plane (mean, normal), by the reference's
+// loop (impl 0) or by flags + closed form (impl 1); returns the split position
+int64_t debug_partition(double* pts, int64_t n, const double* mean, const double* normal, int impl) {
+  std::vector<uint8_t> side(static_cast<size_t>(std::max<int64_t>(n, 1)));
+  std::vector<int32_t> reject(static_cast<size_t>(std::max<int64_t>(n, 1)));
+  Ctx c{pts, 0.0, 0.0, 0, side.data(), reject.data(), false};
+  if (impl == 0) return partition_by_plane(c, 0, n, mean, normal);
+  for (int64_t i = 0; i < n; ++i) {
+    const double d[3] = {pts[3 * i] - mean[0], pts[3 * i + 1] - mean[1], pts[3 * i + 2] - mean[2]};
+    side[static_cast<size_t>(i)] = dot3c(d, normal) < 0.0 ? 1 : 0;
+  }
+  return partition_from_flags(c, 0, n);
+}
+
 void transform_tree(LinearTree& tree, const double* R, const double* t) {
+  if (tree.rho2 >= 0.0) tree.rho2 *= (1.0 + 1e-12);  // rotation invariant up to rounding
   auto run = [&tree, R, t](size_t b, size_t e) {
     for (size_t k = b; k < e; ++k) {
       madicp_node& nd = tree.nodes[k];

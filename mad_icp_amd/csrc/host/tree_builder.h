@@ -38,6 +38,9 @@ using IndexVec = std::vector<int32_t, DefaultInitAllocator<int32_t>>;
 struct LinearTree {
   NodeVec nodes;        // DFS preorder; left child = i + 1, right child = i + nodes[i].right
   IndexVec leaf_nodes;  // node index of leaf `leaf_id`, i.e. getLeafs() order
+  // max |mean_i - mean_0|_2 over the internal nodes with finite means (what the device's screening bound needs,
+  // madicp_tree_upload computes it while it validates the array): -1 = not known.  Rotation invariant up to rounding.
+  double rho2 = -1.0;
   int32_t num_leaves() const { return static_cast<int32_t>(leaf_nodes.size()); }
   int32_t num_nodes() const { return static_cast<int32_t>(nodes.size()); }
 };
@@ -47,6 +50,9 @@ struct LinearTree {
 // `level >= max_parallel_level` test at mad_tree.cpp:99; here the same argument forks two levels deeper, smaller
 // tasks, see tree_builder.cpp "Task policy").  The result does not depend on it.
 LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int max_parallel_level);
+
+// test hook: see tree_builder.cpp
+int64_t debug_partition(double* pts, int64_t n, const double* mean, const double* normal, int impl);
 
 // MADtree::applyTransform (mad_tree.cpp:165-172) on the linear form; R row-major.
 void transform_tree(LinearTree& tree, const double* R, const double* t);

@@ -388,6 +388,31 @@ def test_persistent_rounds_are_bit_identical(ctx, K):
     _teardown(ctx, tids, mids)
 
 
+def test_trusted_upload_equals_validated_upload(ctx):
+    """madicp_tree_upload_trusted (no host validation pass; rho2 from the builder) must give the tree madicp_tree_upload
+    gives: same node array back, same registration bit for bit."""
+    pb = street_problem(2)
+    L = None
+    res = []
+    for trusted in (False, True):
+        tids = []
+        for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+            ht = capi.HostTree(s, B_MAX, B_MIN, 2)
+            ht.transform(T[:3, :3], T[:3, 3])
+            tids.append(ctx.upload(ht, trusted=trusted))
+        qh = capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+        L = qh.num_leaves
+        mid = ctx.moving_upload(qh.leaf_means())
+        res.append((ctx.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, L), ctx.tree_download(tids[0], ht.num_nodes if False else capi.HostTree(pb["keyframe_scans"][0], B_MAX, B_MIN, 2).num_nodes)))
+        _teardown(ctx, tids, [mid])
+    for key in ("X", "H", "b", "matched", "X_iters"):
+        assert np.array_equal(res[0][0][key], res[1][0][key]), key
+    assert res[0][0]["visits"] == res[1][0]["visits"]
+    assert res[0][1].tobytes() == res[1][1].tobytes()
+    with pytest.raises(capi.MadIcpError):
+        ctx.tree_upload_trusted(capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 0).nodes, 3, 1.0)  # n_nodes != 2 n_leaves - 1
+
+
 def test_pairwise_registration_known_answer(ctx):
     """apps/utils/tools/mad_registration.py:51-68 — query = copy of reference, guess = euler-xyz(0.1,0.1,0.1)
     + rand(3) translation drawn after the cloud; ground truth is the identity."""

@@ -110,3 +110,59 @@ def test_concurrent_builds_share_the_task_pool():
         t.join()
     for a, b in zip(want, got):
         assert a.tobytes() == b.tobytes()
+
+
+def _partition(points, mean, normal, impl):
+    import ctypes as C
+
+    pts = np.ascontiguousarray(points, dtype=np.float64).copy()
+    dp = C.POINTER(C.c_double)
+    m = np.ascontiguousarray(mean, dtype=np.float64)
+    nv = np.ascontiguousarray(normal, dtype=np.float64)
+    mid = capi.host_lib().madicp_host_debug_partition(pts.ctypes.data_as(dp), pts.shape[0], m.ctypes.data_as(dp),
+                                                      nv.ctypes.data_as(dp), impl)
+    return mid, pts
+
+
+def test_partition_closed_form_equals_reference_loop_exhaustively(natives):
+    """utils.h:37-52 `split`: the builder derives the permutation from per-point side flags in one descending sweep
+    (tree_builder.cpp partition_from_flags) instead of running the reference's data-dependent swap loop.  Every
+    left/right pattern of up to 12 points, tagged points so that the full permutation is compared, not just the sides."""
+    mean, normal = np.zeros(3), np.array([1.0, 0.0, 0.0])
+    for n in range(0, 13):
+        for pattern in range(1 << n):
+            x = np.array([-1.0 if (pattern >> i) & 1 else 1.0 for i in range(n)])
+            pts = np.column_stack([x, np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64) * 7 + 1]) if n else np.zeros((0, 3))
+            m0, p0 = _partition(pts, mean, normal, 0)
+            m1, p1 = _partition(pts, mean, normal, 1)
+            assert m0 == m1 == int((x < 0).sum()), (n, pattern)
+            assert np.array_equal(p0, p1), (n, pattern)
+
+
+def test_partition_closed_form_equals_reference_loop_on_large_random_inputs(natives):
+    rng = np.random.default_rng(5)
+    for n, p_left in [(1000, 0.5), (4097, 0.03), (4097, 0.97), (120000, 0.5), (50001, 0.0), (50001, 1.0)]:
+        pts = rng.normal(size=(n, 3))
+        pts[:, 0] = np.where(rng.random(n) < p_left, -np.abs(pts[:, 0]) - 1e-3, np.abs(pts[:, 0]))
+        # on-plane and NaN points go right, like `dot < 0` says
+        pts[rng.integers(0, n, 5), 0] = 0.0
+        pts[rng.integers(0, n, 3), 1] = np.nan
+        mean, normal = np.zeros(3), np.array([1.0, 0.0, 0.0])
+        m0, p0 = _partition(pts, mean, normal, 0)
+        m1, p1 = _partition(pts, mean, normal, 1)
+        assert m0 == m1
+        assert np.array_equal(p0, p1, equal_nan=True)
+
+
+@pytest.mark.parametrize("par", [0, 3])
+def test_builder_reports_the_spread_the_device_bound_needs(par):
+    """rho2 = max |mean_i - mean_0|_2 over the internal nodes (what madicp_tree_upload computes while validating and
+    madicp_tree_upload_trusted takes from the builder)."""
+    pb = street_problem(2)
+    ht = capi.HostTree(pb["keyframe_scans"][0], 0.2, 0.1, par)
+    nodes = ht.nodes
+    internal = nodes["right"] != 0
+    want = np.sqrt(((nodes["mean"][internal] - nodes["mean"][0]) ** 2).sum(axis=1)).max()
+    assert abs(ht.rho2 - want) <= 1e-12 * want
+    one = capi.HostTree(np.array([[1.0, 2.0, 3.0]]), 0.2, 0.1, 0)
+    assert one.rho2 == 0.0
