@@ -56,16 +56,34 @@ class Scene:
                 y = o[1] + t * d[:, 1]
                 ok = (t > 0) & (z >= 0) & (z <= self.facade_height) & (np.abs(y) <= self.half_width)
                 t_best = np.where(ok & (t < t_best), t, t_best)
-            # boxes (slab method)
+            # boxes (slab method).  Only the rays whose heading lies inside the box's angular extent as seen from the
+            # sensor can hit it (a conservative superset, margin 1e-6 rad; every ray when the sensor stands over the
+            # footprint): the result is that of testing every ray against every box, at a tenth of the work.
+            heading = np.arctan2(d[:, 1], d[:, 0])
             for cx, cy, sx, sy, h in self.boxes:
                 lo = np.array([cx - sx / 2, cy - sy / 2, 0.0])
                 hi = np.array([cx + sx / 2, cy + sy / 2, h])
-                t1 = (lo - o) / d
-                t2 = (hi - o) / d
-                tn = np.nanmax(np.minimum(t1, t2), axis=1)
-                tf = np.nanmin(np.maximum(t1, t2), axis=1)
+                if lo[0] - 1e-9 <= o[0] <= hi[0] + 1e-9 and lo[1] - 1e-9 <= o[1] <= hi[1] + 1e-9:
+                    idx = np.arange(d.shape[0])
+                else:
+                    ca = np.arctan2(np.array([lo[1], lo[1], hi[1], hi[1]]) - o[1], np.array([lo[0], hi[0], lo[0], hi[0]]) - o[0])
+                    mid = np.arctan2(cy - o[1], cx - o[0])
+                    rel = np.angle(np.exp(1j * (ca - mid)))  # corner headings relative to the centre's: within (-pi/2, pi/2)
+                    dh = np.angle(np.exp(1j * (heading - mid)))
+                    idx = np.nonzero((dh >= rel.min() - 1e-6) & (dh <= rel.max() + 1e-6))[0]
+                if idx.size == 0:
+                    continue
+                tn = tf = None
+                for a in range(3):
+                    da = d[idx, a]
+                    t1 = (lo[a] - o[a]) / da
+                    t2 = (hi[a] - o[a]) / da
+                    mn, mx = np.minimum(t1, t2), np.maximum(t1, t2)
+                    tn = mn if tn is None else np.fmax(tn, mn)  # (fmax / fmin: NaN from 0/0 ignored, as nanmax / nanmin)
+                    tf = mx if tf is None else np.fmin(tf, mx)
                 ok = (tn <= tf) & (tn > 0)
-                t_best = np.where(ok & (tn < t_best), tn, t_best)
+                cur = t_best[idx]
+                t_best[idx] = np.where(ok & (tn < cur), tn, cur)
         return t_best
 
 
