@@ -90,7 +90,11 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * madicp_tree_build wait for the device's sequence number: 0 = spin on the calling core (default: lowest latency), 1 =
  * sched_yield between polls, 2 = sleep ~50 us between polls (a drop-in odometry process that has other threads to run)),
  * "wait_timeout_ms" (0 = unbounded, default; otherwise such a wait returns MADICP_ERR_TIMEOUT when it runs out — the
- * ticket stays collectable), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
+ * ticket stays collectable), "match_all_rounds" (0/1, default 0: the matched flags of a registration are
+ * the OR over ALL its rounds instead of the last round's — what the reference's Pipeline leaves behind when its realtime
+ * check ends the loop before iteration MAX_ICP_ITS - 1, the only one that resets them: pipeline.cpp:167-176),
+ * "persistent" (0/1, default 0: all rounds of a single-GPU registration as ONE launch; bit-identical, measured slower —
+ * profiles/r3_b_persist_negative.md), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
  * registration's collectives before it aborts the communicator and returns MADICP_ERR_COMM)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
 

@@ -4,7 +4,7 @@
 // launch) so that both kernels run the same instructions in the same order; not a translation unit of its own.
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
-// s_td; per round: round, reuse, last_round, stage_hint, R[9], t[3], moved_rot, moved_trans, pv0 / cmar0 / cword0 (the
+// s_td; per round: round, reuse, mark_matched, stage_hint, R[9], t[3], moved_rot, moved_trans, pv0 / cmar0 / cword0 (the
 // first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
@@ -162,7 +162,7 @@
         const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
         if (TRACE && corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
-        if (last_round) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
+        if (mark_matched) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 
         const double bbox0 = ld.x;
         const double n0 = lb.y, n1 = lc.x, n2 = lc.y;

@@ -183,6 +183,9 @@ struct Job {
 };
 constexpr int kFlagNoUpdate = 1;
 constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (option cache_correspondences = 0)
+constexpr int kFlagMatchAll = 1024;  // matched_ flags are the OR over ALL rounds (the host cleared them), not the last round's:
+                                     // what the reference leaves behind when its realtime check ends the loop before
+                                     // iteration MAX_ICP_ITS - 1, the only one that resets them (pipeline.cpp:167-176)
 
 // ---------------------------------------------------------------------------------------------------
 // fp64 helpers with the reference's evaluation order (see oracle/linalg.h for the derivation).
@@ -1331,6 +1334,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int L = job->L;
   const int flags = job->flags;
   const bool last_round = (round == n_iters - 1);
+  const bool mark_matched = last_round || (flags & kFlagMatchAll);
   const double* __restrict__ moving = job->moving;
   uint8_t* __restrict__ matched = job->matched;
   uint32_t* __restrict__ corr = TRACE ? job->corr : nullptr;
@@ -1446,7 +1450,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // Pose-independent set-up goes here, BEFORE the barrier that ends the prologue: eleven of the twelve waves reach this
   // point ~2 us before wave 0 has solved, and whatever they do now they do for free.
   // the matched_ flags are cleared before the last round (pipeline.cpp:172-176); all workgroups share the work
-  if (round == n_iters - 2) {
+  if (round == n_iters - 2 && !(flags & kFlagMatchAll)) {
     uint4* m16 = reinterpret_cast<uint4*>(matched);  // hipMalloc'ed: 256-byte aligned
     const int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (L >> 4); i += stride) m16[i] = make_uint4(0, 0, 0, 0);
@@ -1619,6 +1623,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const int S = (L + RPT - 1) / RPT;
     const bool leader = slot == 0;
     const bool last_round = (round == n_iters - 1);
+    const bool mark_matched = last_round || (flags & kFlagMatchAll);
     const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
     const unsigned tag_prev = tag0 + (unsigned)round;  // rows of round - 1 carry (round - 1) + 1
     const unsigned tag_now = tag_prev + 1u;

@@ -199,6 +199,7 @@ struct madicp_ctx {
   int eager_when_busy = 1; // a registration queued behind another is launched kernel by kernel, not as a graph (run_rounds)
   int seq_completion = 1;  // streamed registrations publish completion through HostResult::seq instead of an event
   int host_feed_wait = 1;  // ... and the host, not the stream, waits for their feed while another one is in flight
+  int match_all = 0;       // option "match_all_rounds": the matched flags a registration returns are the OR over all its rounds
   int persistent = 0;      // all rounds of a registration as ONE launch (icp_persist) where the geometry admits it
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
@@ -669,7 +670,7 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
   j.epoch = ++ctx->epoch;  // (24 bits of it reach the granule tags: a tag recurs after 16 M registrations, far beyond
                            // the life of any granule of a geometry in use)
   j.error = 0;
-  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse);
+  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse) | (ctx->match_all ? kFlagMatchAll : 0);
   std::memcpy(j.X, X0, 12 * sizeof(double));
   std::memcpy(j.Xring[0], X0, 12 * sizeof(double));
   std::memcpy(j.Xring[1], X0, 12 * sizeof(double));
@@ -737,7 +738,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     j.x_iters = (s == 0) ? a.d_x_iters : nullptr;
     max_L = std::max(max_L, mv.L);
     // flags are cleared on the device before the last round; with a single round that is "now"
-    if (a.n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
+    if (a.n_iters == 1 || ctx->match_all) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
   }
   const Geometry geo = pick_geometry(ctx, max_L, a.K, a.n_scans);
   const int grid = geo.grid;
@@ -921,6 +922,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->seq_completion = value ? 1 : 0;
   } else if (k == "host_feed_wait") {
     ctx->host_feed_wait = value ? 1 : 0;
+  } else if (k == "match_all_rounds") {
+    ctx->match_all = value ? 1 : 0;
   } else if (k == "persistent") {
     ctx->persistent = value ? 1 : 0;
   } else if (k == "wait_mode") {
@@ -1363,7 +1366,7 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
     HIP_TRY(hipEventSynchronize(sl.ev_up));
   else
     HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.ev_up, 0));
-  if (n_iters == 1) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)L, ctx->stream));
+  if (n_iters == 1 || ctx->match_all) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)L, ctx->stream));
   RC_TRY(prepare_partials(ctx, geo.grid, 1));
   const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
   const std::vector<int> ids{sl.moving_id};

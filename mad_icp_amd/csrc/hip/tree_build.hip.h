@@ -9,8 +9,9 @@
 // at the centroid along the largest eigenvector (:95-97) — but NOT the same bits: the reference adds a node's points
 // one after the other in the order its in-place partition left them, a serial chain that no parallel machine can
 // follow, and the eigen-solver's atan2 / cos / sin come from a different math library.  Every sum here has a FIXED
-// shape (lane-strided partial sums, xor butterfly, chunk partials in chunk order), the partition is stable, so a build
-// is bit-reproducible run to run and independent of scheduling; against the host builder it agrees node for node
+// shape (lane-strided partial sums, xor butterfly, chunk partials in chunk order) and the partition is deterministic
+// (chip regime: stable; wave and quad regimes: lefts in order from the front, rights in REVERSE order from the end of the
+// node's range), so a build is bit-reproducible run to run and independent of scheduling; against the host builder it agrees node for node
 // except where a decision sits within rounding of its threshold (tests/test_gpu_frontend.py states the measured
 // rates and the pose bound).
 //
@@ -20,11 +21,11 @@
 // levels deep.  So the design is level-synchronous — every node of a level at once, one launch sequence per level, the
 // points ping-ponging between two buffers so that a stable partition is an out-of-place scatter inside the node's own
 // range — and the only question per node is how many lanes share its chain:
-//   chip  (n > 4096, first levels): the node's points are cut into 2048-point chunks, one workgroup per chunk; three
+//   chip  (n > kChipMin = 512, first levels): the node's points are cut into 2048-point chunks, one workgroup per chunk; three
 //          kernels per level (sums | statistics + extents + left counts | scatter); every workgroup recombines the
 //          per-chunk partials of its node in chunk order (loaded in parallel, added in order), so nothing waits for a
 //          single combiner and the result does not depend on scheduling;
-//   wave  (32 < n <= 4096, or larger past the chip levels): one wavefront per node, no barrier — 4-deep unrolled
+//   wave  (32 < n <= 512, or larger past the chip levels): one wavefront per node, no barrier — 4-deep unrolled
 //          strided sums, xor butterfly, wave-uniform eigen-solve, ballot-based stable scatter;
 //   quad  (n <= 32): FOUR lanes per node, 16 nodes per wavefront (most nodes of a MAD-tree hold a handful of points; a
 //          wave-uniform eigen-solve per such node would spend 64 lanes on one, a single lane per node makes the sweep a

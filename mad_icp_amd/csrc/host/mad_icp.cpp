@@ -30,12 +30,29 @@ void MADicp::setMoving(MADtree& scan_tree) {
   matched_.assign(L_, 0);
 }
 
-void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters) {
+void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated) {
   if (L_ <= 0) throw std::runtime_error("MADicp::compute: setMoving was not called");
   if (fixed.empty()) throw std::runtime_error("MADicp::compute: no fixed tree");
   if (n_iters < 1) return;
   DeviceLock lock(Device::mutex());
   madicp_ctx* ctx = Device::ctx();
+  // A loop the caller cut short (Pipeline's realtime budget): the reference only resets matched_ in iteration
+  // MAX_ICP_ITS - 1, so after an early break the flags are the OR of every round that ran (pipeline.cpp:167-176); and a
+  // round count that changes from frame to frame must not instantiate hipGraphs inside a time-critical frame.
+  struct Restore {
+    madicp_ctx* c;
+    bool on;
+    ~Restore() {
+      if (on) {
+        madicp_ctx_set_option(c, "match_all_rounds", 0);
+        madicp_ctx_set_option(c, "use_graph", 1);
+      }
+    }
+  } restore{ctx, truncated};
+  if (truncated) {
+    check(madicp_ctx_set_option(ctx, "match_all_rounds", 1), "madicp_ctx_set_option");
+    check(madicp_ctx_set_option(ctx, "use_graph", 0), "madicp_ctx_set_option");
+  }
   std::vector<int> ids;
   ids.reserve(fixed.size());
   for (MADtree* t : fixed) ids.push_back(t->deviceId());

@@ -28,7 +28,9 @@ class MADicp {
 
   // n_iters rounds of {resetAdders; update(tree) for every fixed tree; updateState} on the device.
   // matched flags are those of the last round (cleared before it: pipeline.cpp:172-176).
-  void compute(const std::vector<MADtree*>& fixed, int n_iters);
+  // truncated: the caller cut the loop short of MAX_ICP_ITS (Pipeline's realtime budget): matched flags are the OR over
+  // the rounds that ran, like the reference's after an early break (pipeline.cpp:167-176)
+  void compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated = false);
 
   int numMoving() const { return L_; }
   int numMatched() const { return n_matched_; }

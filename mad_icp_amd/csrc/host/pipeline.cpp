@@ -129,6 +129,7 @@ void Pipeline::initialize(const double& curr_stamp, ContainerType& cloud) {
 
 void Pipeline::prefetch(ContainerType next_cloud) {
   if (next_cloud.empty()) return;
+  if (device_frontend_) return;  // the tree is built on the GPU: a host build would only compete for the CPU
   // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it
   if (deskew_ && is_initialized_) return;
   if (prefetched_.valid()) prefetched_.wait();  // one look-ahead at a time
@@ -252,23 +253,26 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
 
   const float preprocessing_time = float(now_ms() - t_pre);
   const double t_icp = now_ms();
-  // The reference re-checks its wall-clock budget before every round and stops when preprocessing + the rounds run so
-  // far exceed it (pipeline.cpp:167-169).  The device loop is one submission, so the same budget is turned into a round
-  // count BEFORE it starts: the rounds that fit, at the per-round time the previous frame measured (all MAX_ICP_ITS
-  // of them unless the budget is nearly spent: a round is ~0.02 ms here).  As in the reference, the matched flags are
-  // those of the last round that ran.
+  // The reference re-checks its wall-clock budget before every round: round k runs iff preprocessing + the k rounds run
+  // so far + ONE MORE round's time (its `icp_time` term: the duration of the round before, counted a second time) still
+  // fit loop_time - 5 ms (pipeline.cpp:167-169).  The device loop is one submission, so the same test is turned into a
+  // round count BEFORE it starts, at the per-round time the previous frame measured: with budget B and round time t,
+  // rounds = 0 if B < 0, else max(1, floor(B / t)) (round 0 is tested with icp_time = 0), capped at MAX_ICP_ITS — all of
+  // them unless the budget is nearly spent: a round is ~0.02 ms here.
   int rounds = MAX_ICP_ITS;
   if (realtime_) {
     const double remaining = double(loop_time_) - 5.0 - double(preprocessing_time);
-    // the reference runs round r iff the time spent before it is <= the budget: rounds = 1 + floor(remaining / round)
-    rounds = remaining < 0 ? 0 : int(std::min<double>(MAX_ICP_ITS, 1.0 + std::floor(remaining / std::max(round_ms_estimate_, 1e-3))));
+    rounds = remaining < 0 ? 0
+                           : int(std::min<double>(MAX_ICP_ITS, std::max(1.0, std::floor(remaining / std::max(round_ms_estimate_, 1e-3)))));
   }
   int matched_leaves = 0;
   if (rounds > 0) {
     std::vector<MADtree*> fixed;
     fixed.reserve(keyframes_.size());
     for (auto& f : keyframes_) fixed.push_back(f->tree_.get());
-    icp_.compute(fixed, rounds);
+    // (cut short: the matched flags are the OR over the rounds that ran — the reference resets them in iteration
+    // MAX_ICP_ITS - 1 only — and the launch goes kernel by kernel, no graph is instantiated for an odd round count)
+    icp_.compute(fixed, rounds, rounds < MAX_ICP_ITS);
     matched_leaves = icp_.numMatched();
   }
   last_icp_ms_ = now_ms() - t_icp;

@@ -11,8 +11,12 @@
 // incoming scan, deskew, the constant-velocity predictor, keyframe selection.
 //
 // Additive: prefetch(next_cloud) starts building the NEXT scan's tree on another thread — the build does not depend
-// on the current pose (pipeline.cpp:140-141 builds in the sensor frame) — so a caller that has scan i+1 in hand
-// (bin_runner / the launcher reading a dataset) overlaps that build with frame i.
+// on the current pose (pipeline.cpp:140-141 builds in the sensor frame).  compute() itself is synchronous, so what the
+// build overlaps is the CALLER's own work between two compute() calls (reading / decoding the next scan); call order is
+// compute(i), prefetch(i + 1), ..., compute(i + 1) — one look-ahead, matched to its scan by size and end points, a
+// prefetch() issued before the compute() of the scan in hand replaces it.  Measured gain on the synthetic drive, where the
+// caller does nothing between frames: ~1 % (tests/test_gpu_pipeline_fullsize.py).  A no-op with the device front-end on
+// (the tree is built on the GPU) and for deskewed datasets (the tree needs the previous pose).
 #pragma once
 #include <cstddef>
 #include <deque>
@@ -66,7 +70,9 @@ class Pipeline {
   // deskew (pipeline.cpp:79-123) and MADtree::build (mad_tree.cpp:47-130) run on the MI355X; the tree never exists on
   // the host unless currentLeaves() / modelLeaves() ask for it.  Default: the MAD_ICP_GPU_BUILD environment variable
   // ("1" = on), else off.  Device-built trees agree with host-built ones statistically, not bitwise
-  // (mad_icp_amd/csrc/hip/tree_build.hip.h), so poses differ from the host path's at the 1e-4 m level.
+  // (mad_icp_amd/csrc/hip/tree_build.hip.h): over the full-size test drives poses differ from the host path's by up to
+  // 1e-3 m / 3e-5 rad (3e-3 m / 1.4e-4 rad with deskew), while the error against GROUND TRUTH is the same for both
+  // (tests/test_gpu_frontend.py states and asserts the bars).
   void setDeviceFrontEnd(bool on) { device_frontend_ = on; }
   bool deviceFrontEnd() const { return device_frontend_; }
   // additive: one frame straight from sensor records — float32 (x, y, z, intensity ...) `stride_floats` apart, range

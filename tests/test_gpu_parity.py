@@ -413,6 +413,33 @@ def test_trusted_upload_equals_validated_upload(ctx):
         ctx.tree_upload_trusted(capi.HostTree(pb["query_scans"][0], B_MAX, B_MIN, 0).nodes, 3, 1.0)  # n_nodes != 2 n_leaves - 1
 
 
+def test_match_all_rounds_is_the_or_over_the_rounds(ctx):
+    """Option "match_all_rounds" (what Pipeline uses when its realtime budget cuts the loop short): the reference resets
+    matched_ only in iteration MAX_ICP_ITS - 1 (pipeline.cpp:172-176), so after an early break a leaf counts as matched if
+    ANY round that ran matched it.  Checked against the oracle's per-round flags at the poses the device reports."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 2)
+    L = qh[0].num_leaves
+    T0 = pb["query_guess"][0]
+    last_only = ctx.icp_register(mids[0], tids, T0, PARAMS, 5, L)
+    ctx.set_option("match_all_rounds", 1)
+    try:
+        g = ctx.icp_register(mids[0], tids, T0, PARAMS, 5, L)
+        tk = ctx.stream_submit(qh[0].leaf_means(), tids, T0, PARAMS, 5)
+        st = ctx.stream_collect(tk, L)
+    finally:
+        ctx.set_option("match_all_rounds", 0)
+    assert np.array_equal(g["X"], last_only["X"]) and np.array_equal(g["H"], last_only["H"])  # only the flags differ
+    want = np.zeros(L, np.uint8)
+    for r in range(5):
+        for k in range(len(ots)):
+            _, _, _, _, mat, _ = O.icp_linearize(qo[0], ots[k], capi.pose44(g["X_iters"][r]), B_MAX, RHO_KER, B_RATIO)
+            want |= mat
+    assert np.array_equal(g["matched"], want)
+    assert np.array_equal(st["matched"], want) and st["n_matched"] == int(want.sum())
+    assert (want != last_only["matched"]).any()  # (the first rounds, half a metre off, match other leaves than the last)
+    _teardown(ctx, tids, mids)
+
+
 def test_pairwise_registration_known_answer(ctx):
     """apps/utils/tools/mad_registration.py:51-68 — query = copy of reference, guess = euler-xyz(0.1,0.1,0.1)
     + rand(3) translation drawn after the cloud; ground truth is the identity."""
