@@ -724,6 +724,10 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
 
 // One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
 // 256 threads = 4 wavefronts.
+// (Round 3, measured at compile time and not kept: the eigen-solve as ONE out-of-line function shared by the wave and quad
+// regimes — arguments and results in registers — does not free the registers it was hoped to: the caller's live state has
+// to survive the call, 230 VGPRs + 168 bytes of scratch at two waves per SIMD, 168 + 392 bytes at three, against 256 + 96
+// inlined.  The kernel's registers are the sweep's, not the solver's.)
 #ifndef MADICP_TB_WPE
 #define MADICP_TB_WPE 2
 #endif
