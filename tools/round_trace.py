@@ -26,6 +26,10 @@ def run(n):
     pb = synth.make_problem(K, seed=1, n_queries=1)
     scans, gts, gs = synth.make_query_streams(K, seed=1, n_streams=8)
     ctx = capi.Context(0)
+    for kv in os.environ.get("MADICP_OPTIONS", "").split(","):  # development: library options for an A/B trace, "key=value,..."
+        if "=" in kv:
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
     tids = []
     for s, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
         ht = capi.HostTree(s, 0.2, 0.1, 3)
