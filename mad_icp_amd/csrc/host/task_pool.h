@@ -66,7 +66,7 @@ class TaskPool {
       // nothing queued: the job is running on another thread.  Poll for a while — a fork's join is usually tens of
       // microseconds away, a condition-variable round trip costs more than that — then sleep.
       bool seen = false;
-      for (int s = 0; s < kSpins; ++s) {
+      for (int s = 0; s < kJoinSpins; ++s) {
         if (j->done.load(std::memory_order_acquire) || queued_.load(std::memory_order_acquire) > 0) {
           seen = true;
           break;
@@ -95,12 +95,37 @@ class TaskPool {
       limit_.store(std::max(1, n), std::memory_order_release);
     }
     cv_.notify_all();
+    cv_parked_.notify_all();
+  }
+
+  // several jobs at once: one lock, one wake-up (a build ends with a dozen 10-microsecond copy tasks: submitted one by
+  // one, each paid its own notify)
+  std::vector<Handle> submit_batch(std::vector<std::function<void()>> fns) {
+    std::vector<Handle> out;
+    out.reserve(fns.size());
+    for (auto& f : fns) {
+      Handle j = std::make_shared<Job>();
+      j->fn = std::move(f);
+      out.push_back(std::move(j));
+    }
+    bool wake;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      for (const Handle& j : out) q_.push_back(j);
+      queued_.store(static_cast<int>(q_.size()), std::memory_order_release);
+      wake = sleepers_ > 0;
+    }
+    if (wake) cv_.notify_all();
+    return out;
   }
 
  private:
   // how long an idle thread polls before it sleeps: ~100 us — longer than the gap between two forks of one tree build,
   // far shorter than the gap between two scans
   static constexpr int kSpins = 4000;
+  // a JOIN polls longer (~1 ms): the joins of a build form its critical path — one thread per fork level — and a wake-up
+  // through the condition variable at each of six levels was ~0.1 ms of a 2 ms build
+  static constexpr int kJoinSpins = 40000;
   static void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -223,14 +248,23 @@ class TaskPool {
         if (seen) continue;
       }
       std::unique_lock<std::mutex> lk(m_);
+      if (index >= limit_.load(std::memory_order_relaxed) - 1) {
+        // over the caller's thread budget: parked on a condition variable of its own, which only set_limit() signals —
+        // on the queue's one, every submit would wake these threads just to send them back to sleep (with a budget of
+        // 16 on a pool of 31 that thundering herd was ~14 us per submit, 0.2 ms at the end of every build)
+        cv_parked_.wait(lk, [this, index] { return index < limit_.load(std::memory_order_relaxed) - 1; });
+        continue;
+      }
+      if (!q_.empty()) continue;
       ++sleepers_;
-      cv_.wait(lk, [this, index] { return !q_.empty() && index < limit_.load(std::memory_order_relaxed) - 1; });
+      cv_.wait(lk);
       --sleepers_;
     }
   }
 
   std::mutex m_;
   std::condition_variable cv_;
+  std::condition_variable cv_parked_;  // workers beyond the thread budget
   std::deque<Handle> q_;
   std::atomic<int> queued_{0};  // q_.size(), readable without the mutex
   int sleepers_ = 0;            // threads inside cv_.wait (under m_)

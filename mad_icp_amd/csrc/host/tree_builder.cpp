@@ -5,7 +5,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <chrono>
+#include <cstdio>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #if defined(__SSE2__)
@@ -17,6 +21,27 @@
 
 namespace madicp_host {
 namespace {
+
+// development timeline (environment MADICP_HOST_TRACE=<file>): one line per forked node / sequential chunk of the LAST
+// build: kind level points t_start_us t_end_us thread — where the parallel build's wall time goes
+struct TraceEv {
+  char kind;
+  int level;
+  int64_t n;
+  double t0, t1;
+  size_t tid;
+};
+std::mutex g_trace_mu;
+std::vector<TraceEv> g_trace;
+const char* g_trace_path = std::getenv("MADICP_HOST_TRACE");
+std::chrono::steady_clock::time_point g_trace_t0;
+inline double trace_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_trace_t0).count(); }
+inline void trace_add(char kind, int level, int64_t n, double t0) {
+  if (!g_trace_path) return;
+  const double t1 = trace_now();
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace.push_back(TraceEv{kind, level, n, t0, t1, std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000});
+}
 
 struct Ctx {
   double* pts;  // xyz triples
@@ -40,7 +65,7 @@ int env_int(const char* name, int dflt) {
 }
 // (development overrides: MADICP_HOST_EXTRA_LEVELS, MADICP_HOST_TASK_MIN)
 const int kExtraTaskLevels = env_int("MADICP_HOST_EXTRA_LEVELS", 2);
-const int64_t kTaskMinPoints = env_int("MADICP_HOST_TASK_MIN", 4096);
+const int64_t kTaskMinPoints = env_int("MADICP_HOST_TASK_MIN", 2048);  // (4096: 1.80 ms, 2048: 1.67 ms, 1024: 1.68 ms per 120 k scan)
 // a range of fewer points is not cut (development override: environment MADICP_HOST_BBOX_SLICE_MIN)
 int64_t bbox_slice_min_points() {
   static const int64_t v = [] {
@@ -347,28 +372,43 @@ struct Piece {
 std::unique_ptr<Piece> build_forked(const Ctx& c, int64_t b, int64_t e, int level, Inherited inh, int bbox_slices) {
   auto piece = std::make_unique<Piece>();
   if (level >= c.max_parallel_level || e - b < kTaskMinPoints) {
+    const double t0 = g_trace_path ? trace_now() : 0.0;
     piece->chunk.reserve(static_cast<size_t>(std::min<int64_t>(2 * (e - b), 1 << 16)));
     build_sequential(c, b, e, inh, piece->chunk);
     piece->size = piece->chunk.size();
+    trace_add('S', level, e - b, t0);
     return piece;
   }
   double col0[3];  // lives until both children are done (they may point at it through `inh`)
   int64_t mid = 0;
-  if (make_node(c, b, e, inh, piece->nd, col0, mid, bbox_slices)) {
+  const double t_node = g_trace_path ? trace_now() : 0.0;
+  const bool is_leaf = make_node(c, b, e, inh, piece->nd, col0, mid, bbox_slices);
+  trace_add('N', level, e - b, t_node);
+  if (is_leaf) {
     piece->chunk.push_back(piece->nd);
     piece->size = 1;
     return piece;
   }
-  // left child as a pool task, right child here; a level down there are twice as many busy threads, so the
-  // bounding-box pass gets half the slices
+  // the SMALLER child as a pool task, the larger one here: the points were just written by this core, a child that
+  // moves to another core (another L3 on the hosts this runs on) reads them at half the speed (timeline: 347 us against
+  // 155 us for the two halves of a 120 k-point root), so the cold start is given to the half with less to read.  A level
+  // down there are twice as many busy threads, so the bounding-box pass gets half the slices.
   const int child_slices = std::max(1, bbox_slices / 2);
   TaskPool& pool = TaskPool::instance();
   Piece* self = piece.get();
-  const TaskPool::Handle jl = pool.submit([&c, self, b, mid, level, inh, child_slices] {
-    self->left = build_forked(c, b, mid, level + 1, inh, child_slices);
-  });
-  piece->right = build_forked(c, mid, e, level + 1, inh, child_slices);
-  pool.wait(jl);
+  TaskPool::Handle j_other;
+  if (mid - b <= e - mid) {
+    j_other = pool.submit([&c, self, b, mid, level, inh, child_slices] {
+      self->left = build_forked(c, b, mid, level + 1, inh, child_slices);
+    });
+    piece->right = build_forked(c, mid, e, level + 1, inh, child_slices);
+  } else {
+    j_other = pool.submit([&c, self, e, mid, level, inh, child_slices] {
+      self->right = build_forked(c, mid, e, level + 1, inh, child_slices);
+    });
+    piece->left = build_forked(c, b, mid, level + 1, inh, child_slices);
+  }
+  pool.wait(j_other);
   piece->size = 1 + piece->left->size + piece->right->size;
   piece->nd.right = static_cast<int32_t>(1 + piece->left->size);
   return piece;
@@ -446,16 +486,24 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
     return t;
   }
   const int slices = std::min(hw, 1 << std::min(levels, 4));
+  if (g_trace_path) {
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    g_trace.clear();
+    g_trace_t0 = std::chrono::steady_clock::now();
+  }
   const std::unique_ptr<Piece> top = build_forked(c, 0, n, 0, Inherited{nullptr, nullptr}, slices);
+  const double t_forked = g_trace_path ? trace_now() : 0.0;
   t.nodes.resize(top->size);  // (uninitialised: every element is written below)
   t.leaf_nodes.resize((top->size + 1) / 2);
   std::vector<ChunkRef> chunks;
   size_t n_leaves = 0;
   layout(*top, 0, n_leaves, t.nodes.data(), chunks);
+  trace_add('L', 0, static_cast<int64_t>(chunks.size()), t_forked);  // allocation + layout
   // a handful of copy tasks, each a contiguous run of chunks of about the same number of nodes
   TaskPool& pool = TaskPool::instance();
-  const size_t n_tasks = std::min<size_t>(8, chunks.size());
-  std::vector<TaskPool::Handle> jobs;
+  const size_t n_tasks = std::min<size_t>(16, chunks.size());
+  std::vector<std::function<void()>> copy_fns;
+  std::function<void()> own_copy;
   madicp_node* out = t.nodes.data();
   int32_t* leaf_nodes = t.leaf_nodes.data();
   // (the root is a forked node unless the whole tree is one chunk: either way its mean is final before any copy task
@@ -473,13 +521,21 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
     const ChunkRef* ce = chunks.data() + last;
     double* rho_out = &rho_part[k];
     auto run = [cb, ce, out, leaf_nodes, rho_out, &origin] {
+      const double t0 = g_trace_path ? trace_now() : 0.0;
       double rho = 0.0;
-      for (const ChunkRef* r = cb; r != ce; ++r) rho = std::max(rho, place_chunk(*r, out, leaf_nodes, origin));
+      int64_t nn = 0;
+      for (const ChunkRef* r = cb; r != ce; ++r) {
+        rho = std::max(rho, place_chunk(*r, out, leaf_nodes, origin));
+        nn += static_cast<int64_t>(r->piece->chunk.size());
+      }
       *rho_out = rho;
+      trace_add('P', 0, nn, t0);
     };
-    if (k + 1 == n_tasks) run(); else jobs.push_back(pool.submit(run));
+    if (k + 1 == n_tasks) own_copy = run; else copy_fns.push_back(run);
     first = last;
   }
+  const std::vector<TaskPool::Handle> jobs = pool.submit_batch(std::move(copy_fns));  // one lock, one wake-up
+  if (own_copy) own_copy();
   for (const TaskPool::Handle& j : jobs) pool.wait(j);
   // the forked nodes (a few dozen) were written by layout()
   {
@@ -494,6 +550,14 @@ LinearTree build_tree(double* points, int64_t n, double b_max, double b_min, int
     }
   }
   t.rho2 = *std::max_element(rho_part.begin(), rho_part.end());
+  if (g_trace_path) {
+    trace_add('C', 0, static_cast<int64_t>(top->size), t_forked);  // layout + copy tasks
+    std::lock_guard<std::mutex> lk(g_trace_mu);
+    if (std::FILE* f = std::fopen(g_trace_path, "w")) {
+      for (const TraceEv& ev : g_trace) std::fprintf(f, "%c %d %lld %.1f %.1f %zu\n", ev.kind, ev.level, (long long)ev.n, ev.t0, ev.t1, ev.tid);
+      std::fclose(f);
+    }
+  }
   return t;
 }
 
