@@ -1266,11 +1266,36 @@ __device__ unsigned long long g_stamps[16 * 256 * 16];
 #define MADICP_STAMP_WAIT()
 #endif
 
+// exchange granules (icp_persist, and icp_round's FOLD variant): see icp_persist for the protocol
+typedef __attribute__((address_space(1))) unsigned long long* gptr_g64;
+constexpr int kRowGranules = 2 * kAcc;  // 480 bytes per row
+__host__ __device__ constexpr size_t xch_level1(int n_scans, int grid) { return (size_t)2 * n_scans * grid * kRowGranules; }
+__host__ __device__ constexpr size_t xch_granules(int n_scans, int grid) {
+  return xch_level1(n_scans, grid) + (size_t)2 * n_scans * kFoldGroups * kRowGranules;
+}
+__device__ __forceinline__ void granule_store(gptr_g64 g, unsigned tag, double v) {
+  const unsigned long long t = (unsigned long long)tag << 32;
+  __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one poll: true when both halves carry `tag`
+__device__ __forceinline__ bool granule_try(gptr_g64 g, unsigned tag, double& v) {
+  const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+  return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+}
+constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
+
 // TRACE: also write the per-pair correspondence trace (Job::corr) — the single-round debugging entry point only
-template <int QPT, bool TRACE>
+// FOLD (option "xcd_fold", an experiment kept for its measurement — profiles/r3_j_xcd_fold.md): the XCD-hierarchical join
+// WITHOUT the persistent launch.  Every workgroup publishes its row as granules; the leader of each group x = blockIdx.x & 7
+// waits for the group's rows at the END of the launch, folds them in the canonical order and publishes F[x]; the next
+// launch's wave 0 reads eight rows (3.8 KB) instead of every workgroup joining 256 (61 KB).
+template <int QPT, bool TRACE, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
     const Job* __restrict__ jobs, Job* __restrict__ jobs_out, double* __restrict__ partials,
-    const double* __restrict__ totals, int round, int n_iters, int K, int RPT) {
+    const double* __restrict__ totals, int round, int n_iters, int K, int RPT, unsigned long long* __restrict__ xch) {
   // (n_iters, K and ranges_per_tree are the same for every scan of the launch: as kernel arguments they are known
   // one memory round trip before anything read through `job`)
   // `jobs` and `jobs_out` are the SAME array: everything this kernel reads goes through the const restrict view, the
@@ -1293,7 +1318,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const double* __restrict__ prev_partials = partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * prows * kAcc;
   double Xp[12];
   JoinLoads jl;
-  if (round > 0 && !totals) join_issue(prev_partials, jl);
+  if (!FOLD && round > 0 && !totals) join_issue(prev_partials, jl);
+  // FOLD: the eight folded rows of the previous round (level 2 of the exchange), four values per lane of wave 0
+  double fv[4] = {0.0, 0.0, 0.0, 0.0};
+  bool fold_ok = true;
+  if (FOLD && round > 0 && threadIdx.x < 60) {
+    const unsigned tag_prev = (job->epoch << 8) + (unsigned)round;
+    gptr_g64 src = (gptr_g64)(uintptr_t)xch + xch_level1(gridDim.y, gridDim.x) +
+                   ((size_t)((round - 1) & 1) * gridDim.y + blockIdx.y) * kFoldGroups * kRowGranules;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = threadIdx.x + 60 * j;
+      const int x = idx / kAcc, c = idx - x * kAcc;
+      fold_ok &= granule_try(src + x * kRowGranules + 2 * c, tag_prev, fv[j]);
+    }
+  }
   MADICP_STAMP(14);
   // walk hint: how many lanes of THIS workgroup had to walk in the previous round (written at the end of that round,
   // behind the two partial buffers); decides — without a vote, i.e. without a barrier per pass — whether the tree's
@@ -1387,7 +1426,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   __shared__ double s_hint;
   if (round > 0 && !totals) {
     if (threadIdx.x == 0) s_hint = prev_hint;
-    join_stage1(prev_partials, prows, jl, s_seg);
+    if (FOLD) {
+      if (threadIdx.x < 60) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = threadIdx.x + 60 * j;
+          const int x = idx / kAcc, c = idx - x * kAcc;
+          s_seg[x][c] = fv[j];
+        }
+      }
+      if (threadIdx.x < 64 && !__all(fold_ok) && threadIdx.x == 0) jout->error = 3;  // (a leader gave up: its row never came)
+      __syncthreads();
+    } else {
+      join_stage1(prev_partials, prows, jl, s_seg);
+    }
     // The barrier above also published the first unit's descriptor and the walk hint.  While wave 0 solves (2-3 us),
     // the other eleven waves have nothing to do: if lanes of this workgroup had to walk last round they copy the
     // tree's top levels into LDS NOW instead of after the prologue (~1 us of every walking round).
@@ -1411,6 +1463,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     if (round > 0) {
       if (totals) {
         if (threadIdx.x < kAcc) s_total[threadIdx.x] = totals[blockIdx.y * kAcc + threadIdx.x];
+        wave_lds_order();
+      } else if (FOLD) {
+        if (threadIdx.x < kAcc) {
+          double a = s_seg[0][threadIdx.x];
+#pragma unroll
+          for (int x = 1; x < kFoldGroups; ++x) a += s_seg[x][threadIdx.x];
+          s_total[threadIdx.x] = a;
+        }
         wave_lds_order();
       } else {
         join_stage2_wave0(s_seg, s_total);
@@ -1486,14 +1546,52 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int wave = threadIdx.x >> 6;
   wave_reduce_scatter(acc, lane, red[wave]);
   const int n_walked = __syncthreads_count(walked ? 1 : 0);
+  const unsigned tag_now = FOLD ? (job->epoch << 8) + (unsigned)round + 1u : 0u;
   if (threadIdx.x < kAcc) {
     double s = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
-    partials[(round & 1) * pstride + ((long long)blockIdx.y * prows + blockIdx.x) * kAcc + threadIdx.x] = s;
+    if (FOLD)
+      granule_store((gptr_g64)(uintptr_t)xch + ((size_t)((round & 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kRowGranules +
+                        2 * threadIdx.x, tag_now, s);
+    else
+      partials[(round & 1) * pstride + ((long long)blockIdx.y * prows + blockIdx.x) * kAcc + threadIdx.x] = s;
   }
   if (threadIdx.x == 0) hints[(round & 1) * hint_stride + hint_slot] = static_cast<double>(n_walked);
   MADICP_STAMP(6);
+  if (FOLD && slot == 0) {  // (workgroup-uniform) the leader of group `xcd`: wait for the group's rows, fold, publish F[x]
+    gptr_g64 src = (gptr_g64)(uintptr_t)xch + ((size_t)((round & 1) * gridDim.y + blockIdx.y) * gridDim.x + xcd) * kRowGranules;
+    bool expired = false;
+    const unsigned long long t_start = wall_clock64();
+    for (int idx = threadIdx.x; idx < nslots * kAcc; idx += kBlock) {
+      const int sl = idx / kAcc, c = idx - sl * kAcc;
+      gptr_g64 g = src + (size_t)sl * kFoldGroups * kRowGranules + 2 * c;  // row xcd + 8 sl
+      double v = 0.0;
+      for (unsigned spins = 1; !granule_try(g, tag_now, v); ++spins) {
+        if ((spins & 63u) == 0u && wall_clock64() - t_start > kSpinLimitTicks) { expired = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      s_seg[sl][c] = v;
+    }
+    if (__syncthreads_or(expired ? 1 : 0)) {
+      if (threadIdx.x == 0) jout->error = 1;
+    } else if (threadIdx.x < kAcc) {
+      double rv[kJoinGroups];
+#pragma unroll
+      for (int sl = 0; sl < kJoinGroups; ++sl) rv[sl] = sl < nslots ? s_seg[sl][threadIdx.x] : 0.0;
+      double f = 0.0;
+#pragma unroll
+      for (int q = 0; q < kFoldChains; ++q) {
+        double sg = 0.0;
+#pragma unroll
+        for (int sl = q; sl < kJoinGroups; sl += kFoldChains) sg += rv[sl];
+        f = (q == 0) ? sg : f + sg;
+      }
+      granule_store((gptr_g64)(uintptr_t)xch + xch_level1(gridDim.y, gridDim.x) +
+                        ((size_t)((round & 1) * gridDim.y + blockIdx.y) * kFoldGroups + xcd) * kRowGranules + 2 * threadIdx.x,
+                    tag_now, f);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1521,26 +1619,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 // them in the last round only, from other workgroups; pipeline.cpp:172-176).
 // After the last round the leaders fold once more and icp_final (next launch) reads the eight F[x] of round n - 1.
 // ---------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned long long* gptr_g64;
-constexpr int kRowGranules = 2 * kAcc;  // 480 bytes per row
-__host__ __device__ constexpr size_t xch_level1(int n_scans, int grid) { return (size_t)2 * n_scans * grid * kRowGranules; }
-__host__ __device__ constexpr size_t xch_granules(int n_scans, int grid) {
-  return xch_level1(n_scans, grid) + (size_t)2 * n_scans * kFoldGroups * kRowGranules;
-}
-__device__ __forceinline__ void granule_store(gptr_g64 g, unsigned tag, double v) {
-  const unsigned long long t = (unsigned long long)tag << 32;
-  __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(g + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// one poll: true when both halves carry `tag`
-__device__ __forceinline__ bool granule_try(gptr_g64 g, unsigned tag, double& v) {
-  const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
-  return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
-}
-constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
-
 template <int QPT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_persist(
     const Job* __restrict__ jobs, Job* __restrict__ jobs_out, unsigned long long* __restrict__ xch, int n_iters, int K_arg,

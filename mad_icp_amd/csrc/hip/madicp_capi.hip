@@ -111,7 +111,7 @@ struct DevMoving {
 };
 
 struct GraphKey {  // everything a captured launch sequence bakes in
-  int grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot, persist;
+  int grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot, persist;  // persist: 0 per-round launches, 1 icp_persist, 2 xcd_fold
   bool operator<(const GraphKey& o) const {
     return std::tie(grid, batch, iters, qpt, comm, lds, K, rpt, trace, slot, persist) <
            std::tie(o.grid, o.batch, o.iters, o.qpt, o.comm, o.lds, o.K, o.rpt, o.trace, o.slot, o.persist);
@@ -201,6 +201,7 @@ struct madicp_ctx {
   int host_feed_wait = 1;  // ... and the host, not the stream, waits for their feed while another one is in flight
   int match_all = 0;       // option "match_all_rounds": the matched flags a registration returns are the OR over all its rounds
   int persistent = 0;      // all rounds of a registration as ONE launch (icp_persist) where the geometry admits it
+  int xcd_fold = 0;        // per-round launches whose group leaders fold their XCD's rows at the end of the launch (experiment)
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -419,12 +420,23 @@ bool use_persist(const madicp_ctx* ctx, const Launch& l) {
          madicp::xch_granules(l.batch, l.grid) <= kXchRowsMax * 2 * madicp::kRowGranules;
 }
 
+bool use_fold(const madicp_ctx* ctx, const Launch& l);
+
 void launch_round(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
-  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int) =
+  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int, unsigned long long*) =
       l.trace ? (l.qpt == 2 ? icp_round<2, true> : icp_round<1, true>) : (l.qpt == 2 ? icp_round<2, false> : icp_round<1, false>);
+  if (use_fold(ctx, l)) kern = icp_round<1, false, true>;
   hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)d_jobs, d_jobs, ctx->d_partials, totals, round, l.iters, l.K,
-                     l.rpt);
+                     l.rpt, ctx->d_xch);
+}
+
+// (experiment, option "xcd_fold") per-round launches with the XCD-hierarchical join: same admission rules as icp_persist
+// except residency — the leaders only wait for workgroups of their own launch, which all run to completion
+bool use_fold(const madicp_ctx* ctx, const Launch& l) {
+  return ctx->xcd_fold && !ctx->persistent && !ctx->sharded() && !l.trace && l.qpt == 1 && l.iters >= 2 && l.iters <= 250 &&
+         (l.grid >> 3) <= kJoinGroups && l.K >= 1 &&
+         madicp::xch_granules(l.batch, l.grid) <= kXchRowsMax * 2 * madicp::kRowGranules;
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
@@ -458,7 +470,8 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vec
   }
   // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
   hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials,
-                     ctx->sharded() ? ctx->d_totals : nullptr, grid, batch, (const unsigned long long*)nullptr);
+                     ctx->sharded() ? ctx->d_totals : nullptr, grid, batch,
+                     use_fold(ctx, l) ? (const unsigned long long*)ctx->d_xch : (const unsigned long long*)nullptr);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -477,7 +490,7 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
   // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
-  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot, use_persist(ctx, l) ? 1 : 0};
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot, use_persist(ctx, l) ? 1 : (use_fold(ctx, l) ? 2 : 0)};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     auto instantiate = [&](Job* jobs, const GraphKey& k) -> int {
@@ -922,6 +935,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->seq_completion = value ? 1 : 0;
   } else if (k == "host_feed_wait") {
     ctx->host_feed_wait = value ? 1 : 0;
+  } else if (k == "xcd_fold") {
+    ctx->xcd_fold = value ? 1 : 0;
   } else if (k == "match_all_rounds") {
     ctx->match_all = value ? 1 : 0;
   } else if (k == "persistent") {

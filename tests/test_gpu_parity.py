@@ -355,26 +355,29 @@ def test_register_is_deterministic_and_graph_equals_eager(ctx):
     _teardown(ctx, tids, mids)
 
 
+@pytest.mark.parametrize("option", ["persistent", "xcd_fold"])
 @pytest.mark.parametrize("K", [1, 3])
-def test_persistent_rounds_are_bit_identical(ctx, K):
+def test_persistent_rounds_are_bit_identical(ctx, K, option):
     """Option "persistent": all GN rounds of a registration as ONE launch (icp_persist — the workgroups exchange their
     adders inside the launch, in the two levels of the canonical summation order) must give the bits of the per-round
     launches: pose before every round, final pose, H, b, matched flags, visit counter — single scan, a batch, streamed —
-    and agree with the oracle like them (mad_icp.cpp:105-117).  Speed is another matter (profiles/r3_b_persist_negative.md)."""
+    and agree with the oracle like them (mad_icp.cpp:105-117).  Speed is another matter (profiles/r3_b_persist_negative.md).
+    Option "xcd_fold" — per-round launches whose group leaders fold their XCD's rows at the end of the launch — likewise
+    (profiles/r3_j_xcd_fold_negative.md)."""
     pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K, n_queries=3)
     L = qh[0].num_leaves
     T0 = pb["query_guess"][0]
     X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
     res = {}
     for persist in (0, 1):
-        ctx.set_option("persistent", persist)
+        ctx.set_option(option, persist)
         one = ctx.icp_register(mids[0], tids, T0, PARAMS, 15, L)
         two = ctx.icp_register(mids[0], tids, T0, PARAMS, 2, L)
         bat = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
         tk = ctx.stream_submit(qh[0].leaf_means(), tids, T0, PARAMS, 15)
         stm = ctx.stream_collect(tk, L)
         res[persist] = (one, two, bat, stm)
-    ctx.set_option("persistent", 0)
+    ctx.set_option(option, 0)
     for a, b in zip(res[0], res[1]):
         for key in a:
             if isinstance(a[key], np.ndarray):
