@@ -628,16 +628,20 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
 
     # ---- the headline: streamed registrations, a different scan every step (measured after the secondary figures:
     # the W warm-up steps below are then the only thing between a busy device and the timed region) --------------
-    # (at least 8 untimed steps whatever W says: every stream slot's graph, the kernel-by-kernel route a busy stream
-    # takes, and the pinned staging of all four slots have then been used before the timed region)
-    streamed_loop(ctx, capi, leaves, guesses, tids, max(args.warmup, 8))
-    fence()
-    results = []
+    # (at least 40 untimed steps — 9 ms — whatever W says: every stream slot's graph, the kernel-by-kernel route a busy stream
+    # takes, the pinned staging of all four slots have then been used, and the device clocks are where a long run keeps them:
+    # the driver's --steps 20 --warmup 5 then reports 4 420 against 4 540 for 400 steps — what is left is the one registration
+    # of pipeline drain in twenty — instead of 4 150)
     # the host is only one submission ahead of the device here, so a generational garbage collection over the
     # interpreter's (torch-sized) heap would stall the device for tens of milliseconds: keep it out of the timed region,
-    # like timeit does
+    # like timeit does — and collect BEFORE the warm-up, so that nothing but the fence separates the warm-up's last
+    # registration from the timed region's first (tens of milliseconds of idle device in between showed as a slow start of a
+    # 20-step run)
     gc.collect()
     gc.disable()
+    streamed_loop(ctx, capi, leaves, guesses, tids, max(args.warmup, 40))
+    fence()
+    results = []
     t0 = time.perf_counter()
     stamps = [] if os.environ.get("MADICP_BENCH_DEBUG") else None
     streamed_loop(ctx, capi, leaves, guesses, tids, args.steps, results, stamps)
