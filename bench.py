@@ -754,6 +754,11 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
         elapsed, last = batched(B, tids, args.steps, args.warmup, mids)
         value = args.steps * B / elapsed
         terr = max(pose_error(pb["query_gt"][q], capi.pose44(last[1]["X"][s])) for s, q in enumerate(last[0]))
+        out_extra["shard_note"] = (
+            "keyframe sharding was developed on ONE GPU (RCCL with one rank; two ranks through a host-staged transport): this line "
+            "is the first multi-GPU measurement of it.  A round is ~14 us of device work per scan and every sharded round adds "
+            "icp_reduce (~4 us) and one %d-byte RCCL all-reduce, so the shard keys are bound by all-reduce latency, not by "
+            "xGMI bandwidth; `replica` (no collective) is the key that scales with the GPU count" % (240 * (args.scans if args.scans > 0 else world)))
         out_extra["all_reduces_per_registration"] = N_ITERS + 1
         out_extra["all_reduce_payload_bytes_per_round"] = 240 * B
         out_extra["max_translation_error_m"] = round(terr, 5)
