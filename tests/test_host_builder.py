@@ -166,3 +166,19 @@ def test_builder_reports_the_spread_the_device_bound_needs(par):
     assert abs(ht.rho2 - want) <= 1e-12 * want
     one = capi.HostTree(np.array([[1.0, 2.0, 3.0]]), 0.2, 0.1, 0)
     assert one.rho2 == 0.0
+
+
+def test_thread_budget_changes_nothing_but_time(natives):
+    """madicp_host_set_threads (Pipeline's num_threads; the reference's omp_set_num_threads, pipeline.cpp:64-65): workers over
+    the budget park, workers under it pick up tasks again when it is raised — and the tree is the same bits for every
+    budget and every forking depth (the result is schedule-independent, like the reference's std::async recursion)."""
+    pb = street_problem(2)
+    scan = pb["keyframe_scans"][0]
+    ref = capi.HostTree(scan, 0.2, 0.1, 0).nodes.tobytes()
+    try:
+        for threads in (1, 2, 5, 16, 64, 3):
+            capi.host_lib().madicp_host_set_threads(threads)
+            for par in (1, 4, 6):
+                assert capi.HostTree(scan, 0.2, 0.1, par).nodes.tobytes() == ref, (threads, par)
+    finally:
+        capi.host_lib().madicp_host_set_threads(1 << 20)
