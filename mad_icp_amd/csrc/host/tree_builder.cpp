@@ -66,7 +66,10 @@ int env_int(const char* name, int dflt) {
 // (development overrides: MADICP_HOST_EXTRA_LEVELS, MADICP_HOST_TASK_MIN)
 const int kExtraTaskLevels = env_int("MADICP_HOST_EXTRA_LEVELS", 2);
 const int64_t kTaskMinPoints = env_int("MADICP_HOST_TASK_MIN", 2048);  // (4096: 1.80 ms, 2048: 1.67 ms, 1024: 1.68 ms per 120 k scan)
-// a range of fewer points is not cut (development override: environment MADICP_HOST_BBOX_SLICE_MIN)
+// a range of fewer points is not cut (development override: environment MADICP_HOST_BBOX_SLICE_MIN).  Cutting the
+// 120 k-point root's pass over the pool — order-independent, so legal — was measured again in round 3 with the pool fixed
+// and the workers pre-woken: the root goes from 0.34 to 0.46-0.70 ms.  The slices leave the points in other cores' caches in
+// shared state and the partition that follows WRITES them: every written line first has to be taken back across the fabric.
 int64_t bbox_slice_min_points() {
   static const int64_t v = [] {
     const char* e = std::getenv("MADICP_HOST_BBOX_SLICE_MIN");
