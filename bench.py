@@ -607,12 +607,16 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in range(10)]
         threads = min(os.cpu_count() or 1, 16)
         pipe = {"frames": len(drive), "points_per_scan": int(drive[0].shape[0]), "host_threads": threads}
-        for key, dev in (("host_path", False), ("device_front_end", True)):
+        for key, dev, ahead in (("host_path", False, False), ("host_path_lookahead", False, True), ("device_front_end", True, False)):
             pl = pm.Pipeline(10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)
             pl.setDeviceFrontEnd(dev)
             ts = []
+            if ahead:
+                pl.prefetch(drive[0])
             for i, sc in enumerate(drive):
                 t1 = time.perf_counter()
+                if ahead and i + 1 < len(drive):
+                    pl.prefetch(drive[i + 1])  # the next scan's tree is built while this one is registered
                 pl.compute(0.1 * i, sc)
                 ts.append(time.perf_counter() - t1)
             gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(1.0 * (len(drive) - 1))
@@ -621,8 +625,9 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                          "tree_ms": round(pl.lastBuildMs(), 3), "registration_ms": round(pl.lastIcpMs(), 3),
                          "end_translation_error_m": round(float(np.linalg.norm(np.asarray(pl.currentPose())[:3, 3] - gt[:3, 3])), 4)}
         pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: host_path = the default (host tree builder, "
-                        "bit-identical to the oracle's, + upload); device_front_end = setDeviceFrontEnd(True): upload, MAD-tree "
-                        "build and registration on the GPU")
+                        "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(next scan) issued "
+                        "before compute(this scan): the frame PERIOD of a caller that has the next scan in hand, same poses; "
+                        "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU")
     except Exception as e:  # noqa: BLE001
         pipe = {"error": str(e)[:200]}
 

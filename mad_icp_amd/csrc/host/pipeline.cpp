@@ -58,9 +58,12 @@ Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, 
   if (const char* e = std::getenv("MAD_ICP_GPU_BUILD")) device_frontend_ = (e[0] == '1');
 }
 
-Pipeline::~Pipeline() {
-  if (prefetched_.valid()) prefetched_.wait();
-}  // Frames own their trees; trees release their HBM copies
+void Pipeline::waitPrefetched() {
+  for (Prefetched& p : prefetched_)
+    if (p.tree.valid()) p.tree.wait();
+}
+
+Pipeline::~Pipeline() { waitPrefetched(); }  // Frames own their trees; trees release their HBM copies
 
 const std::vector<Matrix4d> Pipeline::trajectory() const {
   std::vector<Matrix4d> out;
@@ -132,15 +135,20 @@ void Pipeline::prefetch(ContainerType next_cloud) {
   if (device_frontend_) return;  // the tree is built on the GPU: a host build would only compete for the CPU
   // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it
   if (deskew_ && is_initialized_) return;
-  if (prefetched_.valid()) prefetched_.wait();  // one look-ahead at a time
-  prefetched_n_ = next_cloud.size();
-  prefetched_first_ = next_cloud.front();
-  prefetched_last_ = next_cloud.back();
+  while (prefetched_.size() >= 2) {  // two look-aheads at most: the oldest one makes room (its build is waited for)
+    if (prefetched_.front().tree.valid()) prefetched_.front().tree.wait();
+    prefetched_.pop_front();
+  }
+  Prefetched p;
+  p.n = next_cloud.size();
+  p.first = next_cloud.front();
+  p.last = next_cloud.back();
   const double b_max = b_max_, b_min = b_min_;
   const int levels = max_parallel_levels_;
-  prefetched_ = std::async(std::launch::async, [cloud = std::move(next_cloud), b_max, b_min, levels]() mutable {
+  p.tree = std::async(std::launch::async, [cloud = std::move(next_cloud), b_max, b_min, levels]() mutable {
     return build_tree(cloud.front().data(), static_cast<int64_t>(cloud.size()), b_max, b_min, levels);
   });
+  prefetched_.push_back(std::move(p));
 }
 
 // the device front-end for one frame: the cloud is resident; deskew when the reference would (pipeline.cpp:138-139),
@@ -169,7 +177,7 @@ void Pipeline::computeRecords(const double& curr_stamp, const float* records, si
   is_map_updated_ = false;
   if (!records || n_records == 0) throw std::invalid_argument("Pipeline::computeRecords: no records");
   const double t_pre = now_ms();
-  if (prefetched_.valid()) prefetched_.wait();
+  waitPrefetched();
   int cloud_id = -1;
   {
     DeviceLock lock(Device::mutex());
@@ -189,7 +197,7 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   std::unique_ptr<MADtree> current_tree;
   const double t_pre = now_ms();
   if (device_frontend_) {
-    if (prefetched_.valid()) prefetched_.wait();
+    waitPrefetched();
     int cloud_id = -1;
     {
       DeviceLock lock(Device::mutex());
@@ -197,13 +205,22 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
             "madicp_cloud_upload");
     }
     current_tree = buildOnDevice(cloud_id);
-  } else if (prefetched_.valid()) {
-    const bool same = prefetched_n_ == curr_cloud.size() &&
-                      std::memcmp(prefetched_first_.data(), curr_cloud.front().data(), 24) == 0 &&
-                      std::memcmp(prefetched_last_.data(), curr_cloud.back().data(), 24) == 0 &&
-                      !(deskew_ && is_initialized_ && trajectory_.size() > 1);
-    LinearTree built = prefetched_.get();  // (waits for the builder thread either way)
-    if (same) current_tree = std::make_unique<MADtree>(std::move(built));
+  } else if (!prefetched_.empty() && !(deskew_ && is_initialized_ && trajectory_.size() > 1)) {
+    // the look-ahead built for exactly this scan, if there is one; older look-aheads are for scans that never came
+    for (size_t q = 0; q < prefetched_.size(); ++q) {
+      const Prefetched& p = prefetched_[q];
+      if (p.n == curr_cloud.size() && std::memcmp(p.first.data(), curr_cloud.front().data(), 24) == 0 &&
+          std::memcmp(p.last.data(), curr_cloud.back().data(), 24) == 0) {
+        for (size_t d = 0; d < q; ++d) {
+          if (prefetched_.front().tree.valid()) prefetched_.front().tree.wait();
+          prefetched_.pop_front();
+        }
+        LinearTree built = prefetched_.front().tree.get();  // (waits for the builder thread)
+        prefetched_.pop_front();
+        current_tree = std::make_unique<MADtree>(std::move(built));
+        break;
+      }
+    }
   }
   computeWithTree(curr_stamp, std::move(current_tree), &curr_cloud, t_pre);
 }

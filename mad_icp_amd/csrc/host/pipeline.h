@@ -12,11 +12,12 @@
 //
 // Additive: prefetch(next_cloud) starts building the NEXT scan's tree on another thread — the build does not depend
 // on the current pose (pipeline.cpp:140-141 builds in the sensor frame).  compute() itself is synchronous, so what the
-// build overlaps is the CALLER's own work between two compute() calls (reading / decoding the next scan); call order is
-// compute(i), prefetch(i + 1), ..., compute(i + 1) — one look-ahead, matched to its scan by size and end points, a
-// prefetch() issued before the compute() of the scan in hand replaces it.  Measured gain on the synthetic drive, where the
-// caller does nothing between frames: ~1 % (tests/test_gpu_pipeline_fullsize.py).  A no-op with the device front-end on
-// (the tree is built on the GPU) and for deskewed datasets (the tree needs the previous pose).
+// build overlaps is whatever runs until the compute() of that scan: with the call order prefetch(i + 1), compute(i) — two
+// look-aheads are kept, each matched to its scan by size and end points — the build of scan i + 1 runs during the whole
+// frame step of scan i (upload, registration, bookkeeping), and the frame period of a caller that has the next scan in hand
+// (bin_runner / the launcher reading a dataset) drops from build + registration to about the build alone
+// (tests/test_gpu_pipeline_fullsize.py prints both).  A no-op with the device front-end on (the tree is built on the GPU)
+// and for deskewed datasets (the tree needs the previous pose).
 #pragma once
 #include <cstddef>
 #include <deque>
@@ -106,10 +107,15 @@ class Pipeline {
   std::vector<Pose> trajectory_;
   MADtree* current_tree_view_ = nullptr;  // the last scan's tree (owned by a Frame in frames_ / keyframes_)
   size_t current_num_leaves_ = 0;
-  // look-ahead build: the tree of the next scan and what identifies that scan
-  std::future<LinearTree> prefetched_;
-  size_t prefetched_n_ = 0;
-  Vector3d prefetched_first_{}, prefetched_last_{};
+  // look-ahead builds: up to two scans ahead, each identified by its size and end points (a prefetch(i + 1) issued BEFORE
+  // compute(i) must not cost scan i its tree)
+  struct Prefetched {
+    size_t n = 0;
+    Vector3d first{}, last{};
+    std::future<LinearTree> tree;
+  };
+  std::deque<Prefetched> prefetched_;
+  void waitPrefetched();  // every look-ahead build has finished (their trees stay available)
   double round_ms_estimate_ = 0.05;  // device time of one GN round, from the previous frame (realtime budget)
   bool device_frontend_ = false;
   bool deskew_, realtime_;

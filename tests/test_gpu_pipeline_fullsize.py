@@ -65,9 +65,9 @@ def test_pipeline_fullsize_matches_oracle_and_reports_rate(pypeline, drive, caps
     ga.prefetch(clouds[0])
     for i in range(N_FRAMES):
         t = time.perf_counter()
-        ga.compute(0.1 * i, clouds[i])
         if i + 1 < N_FRAMES:
-            ga.prefetch(clouds[i + 1])
+            ga.prefetch(clouds[i + 1])  # BEFORE compute(i): the build of scan i + 1 runs during the whole frame step of scan i
+        ga.compute(0.1 * i, clouds[i])
         t_ahead.append(time.perf_counter() - t)
     assert np.array_equal(np.asarray(ga.trajectory()), np.asarray(gp.trajectory()))
     assert np.asarray(gp.currentLeaves()).shape == op.currentLeaves().shape if ORACLE_FRAMES == N_FRAMES else True
