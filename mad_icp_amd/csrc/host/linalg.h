@@ -86,7 +86,7 @@ inline void exp_so3(const double* w, double* R) {
 
 // lie_algebra.h:54-89 (reference) — only used by deskew
 inline void log_so3(const double* R, double* w) {
-  const double tr = R[0] + R[4] + R[8];
+  const double tr = R[0] + (R[4] + R[8]);  // Matrix3d::trace(): strided 3-term redux, a + (b + c) (oracle/linalg.h trace3)
   if (tr + 1.0 < 1e-10) {
     double f;
     if (std::fabs(R[8] + 1.0) > 1e-5) {

@@ -1,0 +1,435 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  THIS IS NOT EIGEN.
+//
+// A stand-in for the few dozen Eigen names the reference's hot path uses (mad_icp/src/tools/{mad_tree,utils,
+// lie_algebra,frame}.h, mad_tree.cpp, odometry/{mad_icp,vel_estimator,pipeline}.{h,cpp}), so that the reference's OWN
+// translation units can be compiled from where they lie under /root/reference in an image that has no Eigen
+// (oracle/build_ref_standin.sh -> oracle/_ref/libmad_ref_standin.so) and run next to the restatement in oracle/.
+//
+// What that pins and what it does not:
+//   * every arithmetic primitive here IS the oracle's (oracle/linalg.h: eig3_compute_direct, ldlt6_solve, inverse6 / det6,
+//     the 3-term reduction) — so if the reference's sources compiled against this header reproduce the oracle's node
+//     arrays, correspondences, (H, b), poses and keyframe decisions BIT FOR BIT (tests/test_reference_structure_pin.py),
+//     then the oracle's CONTROL FLOW is the reference's: split() and its swap order, the leaf representative, the
+//     plane-predecessor rule, getLeafs order, the gate, the per-thread adders and their join, updateState, deskew,
+//     the velocity estimator, the frame window and keyframe promotion.  That is the part a restatement can get wrong
+//     silently, and it is checked mechanically here instead of by reading.
+//   * it does NOT pin Eigen's own arithmetic (computeDirect, LDLT, PartialPivLU, the association order of fixed-size
+//     reductions): both sides use the same restatement of those.  The oracle stays "parity unpinned" for that part
+//     until oracle/build_ref.sh finds real Eigen headers.
+//
+// One evaluation order only: every 3-term inner product is a0*b0 + (a1*b1 + a2*b2) (Eigen's scalar unrolled redux).  The
+// oracle's default build distinguishes contiguous from strided operands (linalg.h:11-19), which a value-semantics stand-in
+// cannot see, so this header requires -DMADICP_REDUX_SCALAR_ONLY and the test compares against the oracle built the same
+// way; control flow does not depend on that switch.
+#pragma once
+#ifndef MADICP_REDUX_SCALAR_ONLY
+#error "the Eigen stand-in implements the scalar reduction order only: compile with -DMADICP_REDUX_SCALAR_ONLY"
+#endif
+// the standard headers Eigen/Core itself pulls in (unqualified abs / sqrt / sin in the reference resolve as they would)
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <climits>
+#include <cmath>
+#include <complex>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <iosfwd>
+#include <limits>
+#include <string>
+#include <vector>
+// Eigen/Core (src/Core/util/ConfigureVectorization.h) includes the SSE intrinsics headers on x86-64, and GCC's xmmintrin.h
+// reaches <stdlib.h> through mm_malloc.h — in C++ that is libstdc++'s wrapper, which brings std::abs(double) into the
+// GLOBAL namespace.  That chain is what makes the unqualified `abs(e)` of mad_icp.cpp:93 (and lie_algebra.h:69,71) the
+// floating-point one in a real build: with <cmath> / <cstdlib> alone g++ 11 picks ::abs(int) and the robust kernel
+// sees chi = 0 for every |e| < 1 (measured here: H changes in its second digit).  Same chain, same outcome:
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
+#include "../linalg.h"
+
+namespace Eigen {
+
+enum TransformTraits { Isometry = 1, Affine = 2 };
+
+template <typename S, int R, int C>
+class Matrix;
+
+namespace standin {
+
+// inner product of K terms, a strided by sa, b strided by sb
+template <int K>
+inline double inner(const double* a, int sa, const double* b, int sb) {
+  if constexpr (K == 1) return a[0] * b[0];
+  else if constexpr (K == 3) return a[0] * b[0] + (a[sa] * b[sb] + a[2 * sa] * b[2 * sb]);
+  else {
+    // 6-term sums only occur with J = delta_t * I (vel_estimator.cpp:61,77-78): one non-zero term, any order is exact
+    double s = a[0] * b[0];
+    for (int k = 1; k < K; ++k) s += a[k * sa] * b[k * sb];
+    return s;
+  }
+}
+
+template <typename M, int BR, int BC>
+class Block;
+template <typename M>
+class Segment3;
+
+}  // namespace standin
+
+template <typename S, int R, int C>
+class Matrix {
+  static_assert(sizeof(S) == sizeof(double), "stand-in: double only");
+
+ public:
+  enum { Rows = R, Cols = C, Size = R * C };
+  double d[R * C];  // column-major, like Eigen's default
+
+  Matrix() {}
+  Matrix(double x, double y, double z) {
+    static_assert(R * C == 3, "three-coefficient constructor is for 3-vectors");
+    d[0] = x, d[1] = y, d[2] = z;
+  }
+
+  double& operator()(int r, int c) { return d[c * R + r]; }
+  const double& operator()(int r, int c) const { return d[c * R + r]; }
+  double& operator()(int i) { return d[i]; }
+  const double& operator()(int i) const { return d[i]; }
+  double& operator[](int i) { return d[i]; }
+  const double& operator[](int i) const { return d[i]; }
+  const double& x() const { return d[0]; }
+  const double& y() const { return d[1]; }
+  const double& z() const { return d[2]; }
+
+  Matrix& setZero() {
+    for (double& v : d) v = 0.0;
+    return *this;
+  }
+  Matrix& setIdentity() {
+    setZero();
+    for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = 1.0;
+    return *this;
+  }
+  static Matrix Zero() {
+    Matrix m;
+    m.setZero();
+    return m;
+  }
+  static Matrix Identity() {
+    Matrix m;
+    m.setIdentity();
+    return m;
+  }
+
+  Matrix<S, C, R> transpose() const {
+    Matrix<S, C, R> t;
+    for (int r = 0; r < R; ++r)
+      for (int c = 0; c < C; ++c) t(c, r) = (*this)(r, c);
+    return t;
+  }
+
+  Matrix operator-() const {
+    Matrix m;
+    for (int i = 0; i < Size; ++i) m.d[i] = -d[i];
+    return m;
+  }
+  Matrix& operator+=(const Matrix& o) {
+    for (int i = 0; i < Size; ++i) d[i] += o.d[i];
+    return *this;
+  }
+  Matrix& operator-=(const Matrix& o) {
+    for (int i = 0; i < Size; ++i) d[i] -= o.d[i];
+    return *this;
+  }
+  Matrix& operator*=(double s) {
+    for (int i = 0; i < Size; ++i) d[i] *= s;
+    return *this;
+  }
+
+  double dot(const Matrix& o) const {
+    static_assert(Size == 3, "stand-in: dot of 3-vectors");
+    return standin::inner<3>(d, 1, o.d, 1);
+  }
+  double squaredNorm() const {
+    if constexpr (Size == 3) {
+      return standin::inner<3>(d, 1, d, 1);
+    } else {
+      // contiguous 6-vector (vel_estimator.cpp:72): the order of oracle/mad_oracle.cpp VelEstimator::update
+      static_assert(Size == 6, "stand-in: squaredNorm of 3- and 6-vectors");
+      const double p0 = d[0] * d[0] + (d[2] * d[2] + d[4] * d[4]);
+      const double p1 = d[1] * d[1] + (d[3] * d[3] + d[5] * d[5]);
+      return p0 + p1;
+    }
+  }
+  double norm() const { return std::sqrt(squaredNorm()); }
+  double trace() const {
+    static_assert(R == 3 && C == 3, "stand-in: trace of 3x3");
+    return oracle::trace3(d[0], d[4], d[8]);
+  }
+
+  // columns
+  Matrix<S, R, 1> col(int c) const {
+    Matrix<S, R, 1> v;
+    for (int r = 0; r < R; ++r) v[r] = (*this)(r, c);
+    return v;
+  }
+  standin::Block<Matrix, R, 1> col(int c) { return standin::Block<Matrix, R, 1>(*this, 0, c); }
+
+  // fixed blocks
+  template <int BR, int BC>
+  standin::Block<Matrix, BR, BC> block(int r, int c) {
+    return standin::Block<Matrix, BR, BC>(*this, r, c);
+  }
+  template <int BR, int BC>
+  Matrix<S, BR, BC> block(int r, int c) const {
+    Matrix<S, BR, BC> m;
+    for (int i = 0; i < BR; ++i)
+      for (int j = 0; j < BC; ++j) m(i, j) = (*this)(r + i, c + j);
+    return m;
+  }
+
+  // head(3) / tail(3) of a 6-vector
+  standin::Segment3<Matrix> head(int n) {
+    assert(n == 3);
+    (void)n;
+    return standin::Segment3<Matrix>(*this, 0);
+  }
+  standin::Segment3<Matrix> tail(int n) {
+    assert(n == 3);
+    (void)n;
+    return standin::Segment3<Matrix>(*this, Size - 3);
+  }
+  Matrix<S, 3, 1> head(int n) const {
+    assert(n == 3);
+    (void)n;
+    return Matrix<S, 3, 1>(d[0], d[1], d[2]);
+  }
+  Matrix<S, 3, 1> tail(int n) const {
+    assert(n == 3);
+    (void)n;
+    return Matrix<S, 3, 1>(d[Size - 3], d[Size - 2], d[Size - 1]);
+  }
+
+  // 6x6 only: LDLT solve, inverse, determinant — the oracle's restatements
+  struct Ldlt {
+    const Matrix& A;
+    Matrix<S, 6, 1> solve(const Matrix<S, 6, 1>& rhs) const {
+      oracle::Mat6 a;
+      oracle::Vec6 b;
+      std::memcpy(a.m, A.d, sizeof(a.m));
+      std::memcpy(b.v, rhs.d, sizeof(b.v));
+      const oracle::Vec6 x = oracle::ldlt6_solve(a, b);
+      Matrix<S, 6, 1> out;
+      std::memcpy(out.d, x.v, sizeof(x.v));
+      return out;
+    }
+  };
+  Ldlt ldlt() const {
+    static_assert(R == 6 && C == 6, "stand-in: ldlt of 6x6");
+    return Ldlt{*this};
+  }
+  Matrix inverse() const {
+    static_assert(R == 6 && C == 6, "stand-in: inverse of 6x6 (Isometry3d has its own)");
+    oracle::Mat6 a;
+    std::memcpy(a.m, d, sizeof(a.m));
+    const oracle::Mat6 inv = oracle::inverse6(a);
+    Matrix out;
+    std::memcpy(out.d, inv.m, sizeof(inv.m));
+    return out;
+  }
+  double determinant() const {
+    static_assert(R == 6 && C == 6, "stand-in: determinant of 6x6");
+    oracle::Mat6 a;
+    std::memcpy(a.m, d, sizeof(a.m));
+    return oracle::det6(a);
+  }
+};
+
+template <typename S, int R, int C>
+inline Matrix<S, R, C> operator+(const Matrix<S, R, C>& a, const Matrix<S, R, C>& b) {
+  Matrix<S, R, C> m;
+  for (int i = 0; i < R * C; ++i) m.d[i] = a.d[i] + b.d[i];
+  return m;
+}
+template <typename S, int R, int C>
+inline Matrix<S, R, C> operator-(const Matrix<S, R, C>& a, const Matrix<S, R, C>& b) {
+  Matrix<S, R, C> m;
+  for (int i = 0; i < R * C; ++i) m.d[i] = a.d[i] - b.d[i];
+  return m;
+}
+template <typename S, int R, int C>
+inline Matrix<S, R, C> operator*(double s, const Matrix<S, R, C>& a) {
+  Matrix<S, R, C> m;
+  for (int i = 0; i < R * C; ++i) m.d[i] = s * a.d[i];
+  return m;
+}
+template <typename S, int R, int C>
+inline Matrix<S, R, C> operator*(const Matrix<S, R, C>& a, double s) {
+  Matrix<S, R, C> m;
+  for (int i = 0; i < R * C; ++i) m.d[i] = a.d[i] * s;
+  return m;
+}
+template <typename S, int R, int C>
+inline Matrix<S, R, C> operator/(const Matrix<S, R, C>& a, double s) {
+  Matrix<S, R, C> m;
+  for (int i = 0; i < R * C; ++i) m.d[i] = a.d[i] / s;
+  return m;
+}
+// (R x K) * (K x C), coefficient by coefficient
+template <typename S, int R, int K, int C>
+inline Matrix<S, R, C> operator*(const Matrix<S, R, K>& a, const Matrix<S, K, C>& b) {
+  Matrix<S, R, C> m;
+  for (int c = 0; c < C; ++c)
+    for (int r = 0; r < R; ++r) m(r, c) = standin::inner<K>(&a.d[r], R, &b.d[c * K], 1);
+  return m;
+}
+
+namespace standin {
+
+// writable view of a fixed block (col(), block<>()): assignment from a value, conversion to a value, and the handful
+// of expressions the reference forms directly on a view (-view * M, scalar * view)
+template <typename M, int BR, int BC>
+class Block {
+  M& m_;
+  int r_, c_;
+
+ public:
+  using Value = Matrix<double, BR, BC>;
+  Block(M& m, int r, int c) : m_(m), r_(r), c_(c) {}
+  Value eval() const {
+    Value v;
+    for (int i = 0; i < BR; ++i)
+      for (int j = 0; j < BC; ++j) v(i, j) = m_(r_ + i, c_ + j);
+    return v;
+  }
+  operator Value() const { return eval(); }
+  Block& operator=(const Value& v) {
+    for (int i = 0; i < BR; ++i)
+      for (int j = 0; j < BC; ++j) m_(r_ + i, c_ + j) = v(i, j);
+    return *this;
+  }
+  Block& operator=(const Block& o) { return *this = o.eval(); }
+  Value operator-() const { return -eval(); }
+  Matrix<double, BC, BR> transpose() const { return eval().transpose(); }
+  double dot(const Value& o) const { return eval().dot(o); }
+};
+template <typename M, int BR, int BC>
+inline Matrix<double, BR, BC> operator*(double s, const Block<M, BR, BC>& b) {
+  return s * b.eval();
+}
+
+template <typename M>
+class Segment3 {
+  M& m_;
+  int o_;
+
+ public:
+  using Value = Matrix<double, 3, 1>;
+  Segment3(M& m, int o) : m_(m), o_(o) {}
+  operator Value() const { return Value(m_[o_], m_[o_ + 1], m_[o_ + 2]); }
+  Segment3& operator=(const Value& v) {
+    for (int i = 0; i < 3; ++i) m_[o_ + i] = v[i];
+    return *this;
+  }
+};
+
+struct CommaInit {  // S << a, b, c, ... fills row by row
+  double* d;
+  int rows, cols, k;
+  CommaInit& operator,(double v) {
+    d[(k % cols) * rows + k / cols] = v;
+    ++k;
+    return *this;
+  }
+};
+
+}  // namespace standin
+
+template <typename S, int R, int C>
+inline standin::CommaInit operator<<(Matrix<S, R, C>& m, double v) {
+  standin::CommaInit ci{m.d, R, C, 0};
+  ci, v;
+  return ci;
+}
+
+using Vector3d = Matrix<double, 3, 1>;
+using Matrix3d = Matrix<double, 3, 3>;
+using Matrix4d = Matrix<double, 4, 4>;
+
+// SelfAdjointEigenSolver<Matrix3d>::computeDirect (call site mad_tree.cpp:59-61): the oracle's restatement
+template <typename M>
+class SelfAdjointEigenSolver {
+  Matrix3d vecs_;
+  Vector3d vals_;
+
+ public:
+  SelfAdjointEigenSolver& computeDirect(const Matrix3d& A) {
+    oracle::Mat3 a, v;
+    std::memcpy(a.m, A.d, sizeof(a.m));
+    oracle::eig3_compute_direct(a, vals_.d, v);
+    std::memcpy(vecs_.d, v.m, sizeof(v.m));
+    return *this;
+  }
+  const Matrix3d& eigenvectors() const { return vecs_; }
+  const Vector3d& eigenvalues() const { return vals_; }
+};
+
+// Transform<double, 3, Isometry> as (linear, translation); products and inverse are oracle::compose / apply / inverse
+template <typename S, int Dim, int Mode>
+class Transform {
+  static_assert(Dim == 3 && Mode == Isometry, "stand-in: Isometry3d only");
+  Matrix3d R_;
+  Vector3d t_;
+
+  oracle::Iso3 iso() const {
+    oracle::Iso3 x;
+    std::memcpy(x.R.m, R_.d, sizeof(x.R.m));
+    std::memcpy(x.t.v, t_.d, sizeof(x.t.v));
+    return x;
+  }
+  static Transform from(const oracle::Iso3& x) {
+    Transform T;
+    std::memcpy(T.R_.d, x.R.m, sizeof(x.R.m));
+    std::memcpy(T.t_.d, x.t.v, sizeof(x.t.v));
+    return T;
+  }
+
+ public:
+  Transform() {}
+  void setIdentity() {
+    R_.setIdentity();
+    t_.setZero();
+  }
+  static Transform Identity() {
+    Transform T;
+    T.setIdentity();
+    return T;
+  }
+  Matrix3d& linear() { return R_; }
+  const Matrix3d& linear() const { return R_; }
+  Vector3d& translation() { return t_; }
+  const Vector3d& translation() const { return t_; }
+  Transform inverse() const { return from(oracle::inverse(iso())); }
+  Transform operator*(const Transform& o) const { return from(oracle::compose(iso(), o.iso())); }
+  Vector3d operator*(const Vector3d& p) const {
+    oracle::Vec3 q;
+    std::memcpy(q.v, p.d, sizeof(q.v));
+    const oracle::Vec3 r = oracle::apply(iso(), q);
+    return Vector3d(r[0], r[1], r[2]);
+  }
+  Matrix4d matrix() const {
+    Matrix4d m;
+    m.setIdentity();
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) m(r, c) = R_(r, c);
+      m(r, 3) = t_[r];
+    }
+    return m;
+  }
+};
+using Isometry3d = Transform<double, 3, Isometry>;
+
+}  // namespace Eigen

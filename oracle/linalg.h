@@ -50,6 +50,9 @@ inline double dotc(const Vec3& a, const Vec3& b) {
   return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
 #endif
 }
+// Matrix3d::trace() = diagonal().sum(): the diagonal is a STRIDED 3-coefficient expression -> scalar unrolled redux,
+// split in halves like dots():  a + (b + c)   (call site lie_algebra.h:60)
+inline double trace3(double a, double b, double c) { return a + (b + c); }
 inline double sqnorm(const Vec3& a) { return dotc(a, a); }
 inline double norm(const Vec3& a) { return std::sqrt(sqnorm(a)); }
 inline Vec3 cross(const Vec3& a, const Vec3& b) {
@@ -431,7 +434,7 @@ inline Vec3 logMapSO3(const Mat3& R) {  // lie_algebra.h:54-89 (only used by des
   const double R11 = R(0, 0), R12 = R(0, 1), R13 = R(0, 2);
   const double R21 = R(1, 0), R22 = R(1, 1), R23 = R(1, 2);
   const double R31 = R(2, 0), R32 = R(2, 1), R33 = R(2, 2);
-  const double tr = R11 + R22 + R33;
+  const double tr = trace3(R11, R22, R33);
   const double pi = M_PI, two = 2.0;
   Vec3 omega;
   if (tr + 1.0 < 1e-10) {

@@ -1,7 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  PARITY UNPINNED: the reference ships no
 // tests/golden vectors for this path and cannot be compiled here (Eigen absent), so this restatement is
-// pinned only by the reference's two example-script properties (tests/test_oracle_known_answers.py) and
-// by independent numpy checks of the restated Eigen routines.
+// pinned only by the reference's two example-script properties (tests/test_oracle_known_answers.py), by
+// independent numpy checks of the restated Eigen routines, and — for everything that is not Eigen arithmetic —
+// by the reference's own translation units compiled against an Eigen stand-in and compared with this
+// restatement bit for bit (oracle/eigen_standin/standin.h, tests/test_reference_structure_pin.py).
 //
 // CPU restatement of the MAD-ICP hot path, following the reference files function by function and
 // keeping the reference's data structure and threading (heap-allocated pointer tree, std::async build,

@@ -19,6 +19,9 @@ c_u8p = C.POINTER(C.c_uint8)
 
 
 def build(force=False):
+    so = os.environ.get("MADICP_ORACLE_SO")  # another implementation of the same ABI (tests/test_reference_structure_pin.py:
+    if so:                                   # the reference's own sources behind it)
+        return so
     out = os.environ.get("MADICP_ORACLE_DIR")  # a second build with other defines (tests/test_redux_variant.py)
     so = os.path.join(out or _DIR, "libmad_oracle.so")
     if force or not os.path.exists(so):

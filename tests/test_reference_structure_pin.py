@@ -1,0 +1,207 @@
+"""Structure pin of the oracle: the REFERENCE'S OWN translation units (tools/mad_tree.cpp, odometry/mad_icp.cpp,
+vel_estimator.cpp, pipeline.cpp and the headers they include), compiled from where they lie under /root/reference against
+the Eigen stand-in of oracle/eigen_standin, must reproduce the oracle BIT FOR BIT — node arrays, leaf order, nearest
+neighbours, gate decisions, (H, b), the pose before every round, matched flags, deskewed clouds, pipeline poses and
+keyframe decisions.
+
+Both libraries export the oracle's C ABI, so the SAME script (run in two subprocesses, one per library) produces the
+arrays that are compared.  The stand-in's arithmetic primitives are the oracle's own restatements of Eigen
+(oracle/linalg.h), so what this pins is everything that is NOT Eigen: control flow, operation order at the reference's
+call sites, bookkeeping.  Eigen's arithmetic itself stays unpinned (oracle/build_ref.sh + tests/test_reference_pin.py are
+the recipe for that, for an image that has Eigen).  The stand-in knows one reduction order only, so the oracle side is
+the -DMADICP_REDUX_SCALAR_ONLY build (tests/test_redux_variant.py shows the switch does not touch control flow).
+
+The library is built here (oracle/build_ref_standin.sh, needs /root/reference) and travels to the GPU box as a file; where
+neither the file nor the reference exists the tests skip."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libmad_ref_standin.so")
+FLAG = "-DMADICP_REDUX_SCALAR_ONLY"
+
+SCRIPT = r"""
+import sys
+import numpy as np
+import oracle_lib as O
+from fixtures import B_MAX, B_MIN, B_RATIO, RHO_KER, four_walls, street_problem
+from mad_icp_amd import synth
+
+out = {}
+rng = np.random.default_rng(5)
+
+# ---- restated Eigen routines through the reference's call forms (plumbing of the stand-in) ----
+for i in range(20):
+    A = rng.normal(size=(3, 3)); A = A @ A.T
+    w, V = O.eig3(A)
+    out["eig3_w_%d" % i], out["eig3_V_%d" % i] = w, V
+    M = rng.normal(size=(6, 6)); M = M @ M.T + 0.1 * np.eye(6)
+    out["ldlt_%d" % i] = O.ldlt6_solve(M, rng.normal(size=6))
+    out["detinv_%d" % i] = np.array(O.det_inverse6(M))
+    om = rng.normal(size=3) * (10.0 ** rng.integers(-6, 1))
+    R = O.expmap_so3(om)
+    out["exp_%d" % i], out["log_%d" % i] = R, O.logmap_so3(R)
+out["log_pi"] = O.logmap_so3(np.diag([1.0, -1.0, -1.0]))
+
+# ---- MADtree::build / getLeafs / applyTransform / bestMatchingLeafFast (mad_tree.cpp:47-172, utils.h:37-97) ----
+pb = street_problem(3)
+np.random.seed(42)
+walls = four_walls(600)
+g = np.random.default_rng(11)
+clouds = {
+    "street": pb["keyframe_scans"][0],
+    "walls": walls,
+    "one": np.array([[0.5, -1.0, 2.0]]),
+    "two": np.array([[0.0, 0, 0], [3.0, 1, 0]]),
+    "three_collinear": np.array([[0.0, 0, 0], [1.0, 1, 1], [2.0, 2, 2]]),
+    "duplicates": np.repeat(g.normal(size=(7, 3)), 9, axis=0),
+    "planar": np.column_stack([g.uniform(-5, 5, 800), g.uniform(-5, 5, 800), np.zeros(800)]),
+    "line": np.column_stack([np.linspace(0, 50, 500), np.zeros(500), np.zeros(500)]),
+    "huge_coords": g.normal(size=(1000, 3)) + 1e6,
+}
+for name, c in clouds.items():
+    for b_max, par in ((B_MAX, 0), (B_MAX, 2), (1e-5, 1)):
+        t = O.Tree(c, b_max, B_MIN, par)
+        ex = t.export()
+        for k, v in ex.items():
+            out["tree_%s_%g_%d_%s" % (name, b_max, par, k)] = v
+        q = np.vstack([c[:: max(1, len(c) // 300)] + 0.013, c[:50]])
+        leaf, _, dist = t.search(q, want_dist=True)
+        out["nn_%s_%g_%d_leaf" % (name, b_max, par)] = leaf
+        out["nn_%s_%g_%d_dist" % (name, b_max, par)] = dist
+T = pb["keyframe_poses"][1]
+t = O.Tree(pb["keyframe_scans"][1], B_MAX, B_MIN, 2)
+t.transform(T[:3, :3], T[:3, 3])
+for k, v in t.export().items():
+    out["transformed_" + k] = v
+
+# ---- MADicp::update / updateState and the round loop of pipeline.cpp:166-193 ----
+fixed = []
+for s, Tk in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+    f = O.Tree(s, B_MAX, B_MIN, 2)
+    f.transform(Tk[:3, :3], Tk[:3, 3])
+    fixed.append(f)
+moving = O.Tree(pb["query_scans"][0], B_MAX, B_MIN, 2)
+guess = pb["query_guess"][0]
+H, b, corr, rej, mat, _ = O.icp_linearize(moving, fixed[0], guess, B_MAX, RHO_KER, B_RATIO)
+out["lin_H"], out["lin_b"], out["lin_corr"], out["lin_rej"], out["lin_mat"] = H, b, corr, rej, mat
+for threads in (1, 3, 4):
+    r = O.icp_register(moving, fixed, guess, 15, B_MAX, RHO_KER, B_RATIO, threads)
+    for k in ("T", "H", "b", "matched", "X_iters"):
+        out["reg%d_%s" % (threads, k)] = r[k]
+r = O.icp_register(moving, fixed[:1], np.eye(4), 3, B_MAX, RHO_KER, B_RATIO, 2)  # far guess: gate rejects, kernel saturates
+for k in ("T", "H", "b", "matched", "X_iters"):
+    out["regfar_%s" % k] = r[k]
+
+# ---- Pipeline::deskew on its own (pipeline.cpp:79-123) ----
+Tp, Tn = synth.path_pose(3.0), synth.path_pose(4.0)
+c, vel = O.deskew(pb["query_scans"][0], Tp, Tn, 10.0)
+out["deskew_cloud"], out["deskew_vel"] = c, vel
+
+# ---- Pipeline::compute (pipeline.cpp:125-262) with VelEstimator, frame window and keyframe promotion ----
+scene = synth.Scene(0)
+for tag, deskew, p_th, kf, step in (("plain", False, 0.8, 4, 1.0), ("deskew", True, 0.8, 4, 1.0), ("promote", False, 0.95, 2, 2.5)):
+    pl = O.Pipeline(10.0, deskew, B_MAX, RHO_KER, p_th, B_MIN, B_RATIO, kf, 4, False)
+    poses, kposes, ids, kids, upd, nk, ratio = [], [], [], [], [], [], []
+    for i in range(14):
+        sc = synth.render_scan(scene, synth.path_pose(step * i), 100 + i, n_beams=16, n_azimuth=400)
+        pl.compute(0.1 * i, sc)
+        poses.append(pl.currentPose()); kposes.append(pl.keyframePose()); ids.append(pl.currentID())
+        kids.append(pl.keyframeID()); upd.append(pl.isMapUpdated()); nk.append(pl.numKeyframes())
+        ratio.append(pl.lastInliersRatio())
+    out["pipe_%s_poses" % tag] = np.array(poses)
+    out["pipe_%s_kposes" % tag] = np.array(kposes)
+    out["pipe_%s_ids" % tag] = np.array(ids)
+    out["pipe_%s_kids" % tag] = np.array(kids)
+    out["pipe_%s_upd" % tag] = np.array(upd)
+    out["pipe_%s_nk" % tag] = np.array(nk)
+    out["pipe_%s_ratio" % tag] = np.array(ratio[1:])
+    out["pipe_%s_leaves" % tag] = pl.currentLeaves()
+    out["pipe_%s_model" % tag] = pl.modelLeaves()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _env(**extra):
+    return dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")] + sys.path), **extra)
+
+
+def _run(env, args):
+    r = subprocess.run([sys.executable] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.fixture(scope="module")
+def both(tmp_path_factory):
+    if os.path.isdir("/root/reference/mad_icp/src"):
+        subprocess.check_call([os.path.join(ROOT, "oracle", "build_ref_standin.sh")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref/libmad_ref_standin.so not built and /root/reference not on this machine")
+    tmp = tmp_path_factory.mktemp("structure_pin")
+    script = tmp / "script.py"
+    script.write_text(SCRIPT)
+    orc_dir = tmp / "oracle_scalar"
+    orc_dir.mkdir()
+    env_o = _env(MADICP_ORACLE_DIR=str(orc_dir), MADICP_EXTRA_DEFINES=FLAG)
+    _run(env_o, ["-c", "import oracle_lib as O; O.build()"])
+    _run(env_o, [str(script), str(tmp / "oracle.npz")])
+    _run(_env(MADICP_ORACLE_SO=REF_SO), [str(script), str(tmp / "reference.npz")])
+    return np.load(tmp / "oracle.npz"), np.load(tmp / "reference.npz")
+
+
+def _same(a, b, keys):
+    assert keys, "nothing to compare"
+    bad = [k for k in keys if not np.array_equal(a[k], b[k], equal_nan=True)]
+    assert not bad, "reference sources and oracle differ in: %s" % ", ".join(bad[:12])
+
+
+def _keys(npz, prefix):
+    return [k for k in npz.files if k.startswith(prefix)]
+
+
+def test_both_sides_ran_the_same_script(both):
+    orc, ref = both
+    assert sorted(orc.files) == sorted(ref.files) and len(orc.files) > 300
+
+
+def test_stand_in_plumbing(both):
+    orc, ref = both
+    _same(orc, ref, [k for p in ("eig3_", "ldlt_", "detinv_", "exp_", "log_") for k in _keys(orc, p)])
+
+
+def test_tree_build_leaf_order_and_transform(both):
+    """mad_tree.cpp:47-130 (split, leaf representative, plane predecessor, small-leaf normal), :154-163, :165-172"""
+    orc, ref = both
+    _same(orc, ref, _keys(orc, "tree_") + _keys(orc, "transformed_"))
+    assert orc["tree_street_0.2_2_left"].size > 1000  # a real tree, not a stub
+
+
+def test_nearest_neighbour_search(both):
+    """mad_tree.cpp:143-152 + mad_tree_wrapper.h:48-67"""
+    orc, ref = both
+    _same(orc, ref, _keys(orc, "nn_"))
+
+
+def test_linearisation_and_rounds(both):
+    """mad_icp.cpp:58-117 and the loop of pipeline.cpp:166-193, one / three / four OpenMP threads"""
+    orc, ref = both
+    _same(orc, ref, _keys(orc, "lin_") + _keys(orc, "reg"))
+    assert orc["lin_mat"].sum() > 100 and orc["lin_rej"].sum() > 0
+
+
+def test_deskew(both):
+    """pipeline.cpp:79-123"""
+    orc, ref = both
+    _same(orc, ref, _keys(orc, "deskew_"))
+
+
+def test_pipeline_poses_and_keyframe_decisions(both):
+    """pipeline.cpp:125-262, vel_estimator.cpp:32-97"""
+    orc, ref = both
+    _same(orc, ref, _keys(orc, "pipe_"))
+    assert orc["pipe_promote_upd"][1:].any(), "the promotion drive must promote at least one keyframe"
