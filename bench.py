@@ -738,40 +738,59 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
     shard_ok = backend == "nccl"
     value = elapsed = None
     n_local = 0
+    shard_error = None
     if shard_ok and args.mode in ("auto", "shard"):
-        my = [k for k in range(K) if k % world == rank]
-        tids, n_nodes = upload_map(ctx, capi, pb, my)
-        n_local = len(tids)
-        uid = torch.zeros(128, dtype=torch.uint8, device=small)
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
-        if os.environ.get("MADICP_COMM_GRAPH") == "1":
-            ctx.set_option("comm_graph", 1)
-        B = args.scans if args.scans > 0 else world
-        mids = [ctx.moving_upload(leaves[s % N_DISTINCT]) for s in range(B)]
-        # strong scaling first (ONE scan in flight over all the GPUs): a secondary figure, and the communicator's first
-        # few hundred collectives (channel set-up) are out of the way before the headline is timed
-        e1, _ = batched(1, tids, max(20, args.steps // 4), 5, mids[:1])
-        out_extra["shard_one_scan"] = {"registrations_per_s": round(max(20, args.steps // 4) / e1, 1), "scaling": "strong",
-                                       "note": "one scan in flight, 16 trees over %d GPUs, %d all-reduces of 240 B" % (world, N_ITERS)}
-        elapsed, last = batched(B, tids, args.steps, args.warmup, mids)
-        value = args.steps * B / elapsed
-        terr = max(pose_error(pb["query_gt"][q], capi.pose44(last[1]["X"][s])) for s, q in enumerate(last[0]))
-        out_extra["shard_note"] = (
-            "keyframe sharding was developed on ONE GPU (RCCL with one rank; two ranks through a host-staged transport): this line "
-            "is the first multi-GPU measurement of it.  A round is ~14 us of device work per scan and every sharded round adds "
-            "icp_reduce (~4 us) and one %d-byte RCCL all-reduce, so the shard keys are bound by all-reduce latency, not by "
-            "xGMI bandwidth; `replica` (no collective) is the key that scales with the GPU count" % (240 * (args.scans if args.scans > 0 else world)))
-        out_extra["all_reduces_per_registration"] = N_ITERS + 1
-        out_extra["all_reduce_payload_bytes_per_round"] = 240 * B
-        out_extra["max_translation_error_m"] = round(terr, 5)
-        for m in mids:
-            ctx.moving_release(m)
-        for t in tids:
-            ctx.tree_release(t)
-        ctx.comm_destroy()
+        # a failure of the sharded path (communicator set-up, a collective that does not complete: MADICP_ERR_COMM after the
+        # library's bounded wait) must not cost the run its line: every rank catches, the ranks agree, the line then reports
+        # the replica figure and says why
+        try:
+            my = [k for k in range(K) if k % world == rank]
+            tids, n_nodes = upload_map(ctx, capi, pb, my)
+            n_local = len(tids)
+            uid = torch.zeros(128, dtype=torch.uint8, device=small)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+            if os.environ.get("MADICP_BENCH_FAIL_SHARD") == "1":  # (development: exercises the fall-back below)
+                raise RuntimeError("injected failure of the sharded path")
+            if os.environ.get("MADICP_COMM_GRAPH") == "1":
+                ctx.set_option("comm_graph", 1)
+            B = args.scans if args.scans > 0 else world
+            mids = [ctx.moving_upload(leaves[s % N_DISTINCT]) for s in range(B)]
+            # strong scaling first (ONE scan in flight over all the GPUs): a secondary figure, and the communicator's first
+            # few hundred collectives (channel set-up) are out of the way before the headline is timed
+            e1, _ = batched(1, tids, max(20, args.steps // 4), 5, mids[:1])
+            out_extra["shard_one_scan"] = {"registrations_per_s": round(max(20, args.steps // 4) / e1, 1), "scaling": "strong",
+                                           "note": "one scan in flight, 16 trees over %d GPUs, %d all-reduces of 240 B" % (world, N_ITERS)}
+            elapsed, last = batched(B, tids, args.steps, args.warmup, mids)
+            value = args.steps * B / elapsed
+            terr = max(pose_error(pb["query_gt"][q], capi.pose44(last[1]["X"][s])) for s, q in enumerate(last[0]))
+            out_extra["shard_note"] = (
+                "keyframe sharding was developed on ONE GPU (RCCL with one rank; two ranks through a host-staged transport): this line "
+                "is the first multi-GPU measurement of it.  A round is ~14 us of device work per scan and every sharded round adds "
+                "icp_reduce (~4 us) and one %d-byte RCCL all-reduce, so the shard keys are bound by all-reduce latency, not by "
+                "xGMI bandwidth; `replica` (no collective) is the key that scales with the GPU count" % (240 * (args.scans if args.scans > 0 else world)))
+            out_extra["all_reduces_per_registration"] = N_ITERS + 1
+            out_extra["all_reduce_payload_bytes_per_round"] = 240 * B
+            out_extra["max_translation_error_m"] = round(terr, 5)
+            for m in mids:
+                ctx.moving_release(m)
+            for t in tids:
+                ctx.tree_release(t)
+            ctx.comm_destroy()
+        except Exception as e:  # noqa: BLE001
+            shard_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+        failed = torch.tensor([1.0 if shard_error else 0.0], device=small)
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if failed.item() > 0:
+            value = elapsed = None
+            out_extra.pop("shard_one_scan", None)
+            out_extra["shard_error"] = shard_error or "the sharded path failed on another rank"
+            try:
+                ctx.comm_destroy()
+            except Exception:  # noqa: BLE001
+                pass
 
     # replicas: the whole map on every GPU, every rank streams its own scans, no collective
     tids, n_nodes = upload_map(ctx, capi, pb, list(range(K)))
@@ -794,7 +813,8 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                             "note": "every rank holds all %d trees and streams its own scans; no data-path collective" % K}
     if value is None or args.mode == "replica":
         value, elapsed = replica, r_elapsed
-        workload = ("replicas of BASELINE configs[2] (no shard figure: %s)" % ("--mode replica" if shard_ok else "gloo backend"))
+        why = "the sharded path failed, see shard_error" if "shard_error" in out_extra else ("--mode replica" if shard_ok else "gloo backend")
+        workload = "replicas of BASELINE configs[2] (no shard figure: %s)" % why
         par = "replicas"
     else:
         B = args.scans if args.scans > 0 else world
