@@ -613,20 +613,23 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
             ts = []
             if ahead:
                 pl.prefetch(drive[0])
+                pl.prefetch(drive[1])
             for i, sc in enumerate(drive):
                 t1 = time.perf_counter()
-                if ahead and i + 1 < len(drive):
-                    pl.prefetch(drive[i + 1])  # the next scan's tree is built while this one is registered
+                if ahead and i + 2 < len(drive):
+                    pl.prefetch(drive[i + 2])  # the trees of the next two scans are built while this one is registered
                 pl.compute(0.1 * i, sc)
                 ts.append(time.perf_counter() - t1)
+            if ahead:
+                ts = ts[:-2]  # (the last two frames have nothing left to look ahead to)
             gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(1.0 * (len(drive) - 1))
             pipe[key] = {"ms_per_frame": round(float(np.median(ts[2:])) * 1e3, 3),
                          "frames_per_s": round(1.0 / float(np.median(ts[2:])), 1),
                          "tree_ms": round(pl.lastBuildMs(), 3), "registration_ms": round(pl.lastIcpMs(), 3),
                          "end_translation_error_m": round(float(np.linalg.norm(np.asarray(pl.currentPose())[:3, 3] - gt[:3, 3])), 4)}
         pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: host_path = the default (host tree builder, "
-                        "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(next scan) issued "
-                        "before compute(this scan): the frame PERIOD of a caller that has the next scan in hand, same poses; "
+                        "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(scan i + 2) issued "
+                        "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "
                         "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU")
     except Exception as e:  # noqa: BLE001
         pipe = {"error": str(e)[:200]}

@@ -135,7 +135,7 @@ void Pipeline::prefetch(ContainerType next_cloud) {
   if (device_frontend_) return;  // the tree is built on the GPU: a host build would only compete for the CPU
   // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it
   if (deskew_ && is_initialized_) return;
-  while (prefetched_.size() >= 2) {  // two look-aheads at most: the oldest one makes room (its build is waited for)
+  while (prefetched_.size() >= kMaxLookAhead) {  // the oldest one makes room (its build is waited for)
     if (prefetched_.front().tree.valid()) prefetched_.front().tree.wait();
     prefetched_.pop_front();
   }

@@ -12,12 +12,13 @@
 //
 // Additive: prefetch(next_cloud) starts building the NEXT scan's tree on another thread — the build does not depend
 // on the current pose (pipeline.cpp:140-141 builds in the sensor frame).  compute() itself is synchronous, so what the
-// build overlaps is whatever runs until the compute() of that scan: with the call order prefetch(i + 1), compute(i) — two
-// look-aheads are kept, each matched to its scan by size and end points — the build of scan i + 1 runs during the whole
-// frame step of scan i (upload, registration, bookkeeping), and the frame period of a caller that has the next scan in hand
-// (bin_runner / the launcher reading a dataset) drops from build + registration to about the build alone
-// (tests/test_gpu_pipeline_fullsize.py prints both).  A no-op with the device front-end on (the tree is built on the GPU)
-// and for deskewed datasets (the tree needs the previous pose).
+// build overlaps is whatever runs until the compute() of that scan.  Up to three look-aheads are kept beside the scan being
+// consumed, each matched to its scan by size and end points, so a caller that reads ahead (bin_runner / the launcher on a
+// dataset) issues prefetch(i + d) before compute(i): with d = 1 the build of the next scan runs during the whole frame
+// step of this one (frame period 2.4-2.8 -> 1.6-1.7 ms at 120 k points); with d = 2 two builds share the builder's threads —
+// one's serial top levels beside the other's parallel bottom — and the period is 0.95 ms, 1 050 frames/s, with the
+// reference's own trees bit for bit (tools/lookahead_probe.py; d = 3 adds nothing: the 16 threads are then busy).  A no-op
+// with the device front-end on (the tree is built on the GPU) and for deskewed datasets (the tree needs the previous pose).
 #pragma once
 #include <cstddef>
 #include <deque>
@@ -114,6 +115,7 @@ class Pipeline {
     Vector3d first{}, last{};
     std::future<LinearTree> tree;
   };
+  static constexpr size_t kMaxLookAhead = 4;  // scan i being consumed, up to three more building
   std::deque<Prefetched> prefetched_;
   void waitPrefetched();  // every look-ahead build has finished (their trees stay available)
   double round_ms_estimate_ = 0.05;  // device time of one GN round, from the previous frame (realtime budget)

@@ -70,14 +70,28 @@ def test_pipeline_fullsize_matches_oracle_and_reports_rate(pypeline, drive, caps
         ga.compute(0.1 * i, clouds[i])
         t_ahead.append(time.perf_counter() - t)
     assert np.array_equal(np.asarray(ga.trajectory()), np.asarray(gp.trajectory()))
+    # two scans ahead: the builds of scans i + 1 and i + 2 share the builder's threads (one's serial top levels run beside the
+    # other's parallel bottom)
+    g2 = pypeline.Pipeline(*args)
+    t_ahead2 = []
+    g2.prefetch(clouds[0])
+    g2.prefetch(clouds[1])
+    for i in range(N_FRAMES):
+        t = time.perf_counter()
+        if i + 2 < N_FRAMES:
+            g2.prefetch(clouds[i + 2])
+        g2.compute(0.1 * i, clouds[i])
+        t_ahead2.append(time.perf_counter() - t)
+    assert np.array_equal(np.asarray(g2.trajectory()), np.asarray(gp.trajectory()))
     assert np.asarray(gp.currentLeaves()).shape == op.currentLeaves().shape if ORACLE_FRAMES == N_FRAMES else True
     gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(1.0 * (N_FRAMES - 1))
     assert np.linalg.norm(np.asarray(gp.currentPose())[:3, 3] - gt[:3, 3]) < 0.1
     with capsys.disabled():
         print("\n[pipeline @ %d pts/scan, %d host threads] compute: median %.2f ms/frame = %.0f frames/s (build %.2f ms, "
-              "registration %.3f ms); with prefetch(next): %.2f ms per frame period = %.0f frames/s"
+              "registration %.3f ms); with prefetch(next): %.2f ms per frame period = %.0f frames/s; two scans ahead: %.2f ms = %.0f frames/s"
               % (drive[0].shape[0], threads, 1e3 * np.median(t_plain[2:]), 1.0 / np.median(t_plain[2:]), gp.lastBuildMs(),
-                 gp.lastIcpMs(), 1e3 * np.median(t_ahead[2:]), 1.0 / np.median(t_ahead[2:])))
+                 gp.lastIcpMs(), 1e3 * np.median(t_ahead[2:]), 1.0 / np.median(t_ahead[2:]), 1e3 * np.median(t_ahead2[2:-2]),
+                 1.0 / np.median(t_ahead2[2:-2])))
 
 
 def test_two_pipelines_share_the_context(pypeline, drive):

@@ -1,0 +1,36 @@
+"""Frame period of Pipeline.compute on the host path against the look-ahead depth (prefetch(i + d) before compute(i)).
+Usage: python tools/lookahead_probe.py [frames]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mad_icp_amd import _build, synth  # noqa: E402
+
+_build.build_pybind()
+from mad_icp.src.pybind import pypeline  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+scene = synth.Scene(0)
+drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in range(N)]
+clouds = [pypeline.VectorEigen3d(s) for s in drive]
+threads = min(os.cpu_count() or 1, 16)
+ref = None
+for depth in (0, 1, 2, 3):
+    pl = pypeline.Pipeline(10.0, False, 0.2, 0.1, 0.8, 0.1, 0.02, 16, threads, False)
+    for d in range(depth):
+        pl.prefetch(clouds[d])
+    ts = []
+    for i in range(N):
+        t = time.perf_counter()
+        if depth and i + depth < N:
+            pl.prefetch(clouds[i + depth])
+        pl.compute(0.1 * i, clouds[i])
+        ts.append(time.perf_counter() - t)
+    traj = np.asarray(pl.trajectory())
+    if ref is None:
+        ref = traj
+    assert np.array_equal(traj, ref)
+    print("look-ahead %d: median %.2f ms per frame period = %.0f frames/s" % (depth, 1e3 * np.median(ts[3:N - 3]), 1.0 / np.median(ts[3:N - 3])))
