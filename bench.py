@@ -607,21 +607,21 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in range(10)]
         threads = min(os.cpu_count() or 1, 16)
         pipe = {"frames": len(drive), "points_per_scan": int(drive[0].shape[0]), "host_threads": threads}
-        for key, dev, ahead in (("host_path", False, False), ("host_path_lookahead", False, True), ("device_front_end", True, False)):
+        for key, dev, ahead in (("host_path", False, 0), ("host_path_lookahead", False, 2), ("device_front_end", True, 0),
+                                ("device_front_end_lookahead", True, 1)):
             pl = pm.Pipeline(10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)
             pl.setDeviceFrontEnd(dev)
             ts = []
-            if ahead:
-                pl.prefetch(drive[0])
-                pl.prefetch(drive[1])
+            for d in range(ahead):
+                pl.prefetch(drive[d])
             for i, sc in enumerate(drive):
                 t1 = time.perf_counter()
-                if ahead and i + 2 < len(drive):
-                    pl.prefetch(drive[i + 2])  # the trees of the next two scans are built while this one is registered
+                if ahead and i + ahead < len(drive):
+                    pl.prefetch(drive[i + ahead])  # the trees of the next scans are built while this one is registered
                 pl.compute(0.1 * i, sc)
                 ts.append(time.perf_counter() - t1)
             if ahead:
-                ts = ts[:-2]  # (the last two frames have nothing left to look ahead to)
+                ts = ts[:-ahead]  # (the last frames have nothing left to look ahead to)
             gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(1.0 * (len(drive) - 1))
             pipe[key] = {"ms_per_frame": round(float(np.median(ts[2:])) * 1e3, 3),
                          "frames_per_s": round(1.0 / float(np.median(ts[2:])), 1),
@@ -630,7 +630,9 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: host_path = the default (host tree builder, "
                         "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(scan i + 2) issued "
                         "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "
-                        "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU")
+                        "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU; "
+                        "device_front_end_lookahead = the same with prefetch(scan i + 1) before compute(scan i): the next scan's "
+                        "construction runs on the library's build stream beside this scan's registration, same poses bit for bit")
     except Exception as e:  # noqa: BLE001
         pipe = {"error": str(e)[:200]}
 

@@ -249,6 +249,18 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
  * eigen-solver's trigonometry comes from the device library (mad_icp_amd/csrc/hip/tree_build.hip.h); bit-reproducible
  * run to run.  The cloud is left untouched.  Synchronises the copy stream once (the leaf count sizes the tree). */
 int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves);
+/* The same construction as a look-ahead, for a caller that has the NEXT scan in hand while the current one registers
+ * (what Pipeline::prefetch does with the device front-end on).  _begin copies the (n,3) float64 scan to the device and
+ * enqueues the whole level loop on a stream of its own — the library's BUILD stream, so that neither the registration on
+ * the compute stream nor its feed on the copy stream queues behind it — and returns without waiting; _end waits for the
+ * leaf count, sizes and emits the tree and returns its id.  One look-ahead per context: a second _begin, or
+ * madicp_tree_build / madicp_cloud_ingest_f32 / madicp_cloud_deskew / madicp_tree_build_stats before the _end, return
+ * MADICP_ERR_CAPACITY (they share the builder's scratch).  Registrations, uploads, transforms, searches and releases are
+ * free to run in between.  The tree is the one madicp_cloud_upload + madicp_tree_build give for the same scan, bit for bit. */
+int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, double b_max, double b_min);
+int madicp_tree_build_end(madicp_ctx* ctx, int* out_tree_id, int32_t* out_n_leaves);
+/* drops a look-ahead whose scan never came (waits for the device work, frees the copy of the scan); no-op without one */
+int madicp_tree_build_cancel(madicp_ctx* ctx);
 int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t* out_n_leaves);
 /* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] nodes handled one-per-lane, out[2..65] nodes handled one-per-wavefront per level, out[66..129] nodes handled chip-wide per level */
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);

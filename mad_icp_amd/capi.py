@@ -100,6 +100,9 @@ def hip_lib():
                                               C.c_int, _ip, _i64p]
         L.madicp_cloud_deskew.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double, _i32p]
         L.madicp_tree_build.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _ip, _i32p]
+        L.madicp_tree_build_begin.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_double, C.c_double]
+        L.madicp_tree_build_end.argtypes = [C.c_void_p, _ip, _i32p]
+        L.madicp_tree_build_cancel.argtypes = [C.c_void_p]
         L.madicp_tree_info.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
         L.madicp_tree_build_stats.argtypes = [C.c_void_p, _i32p]
         L.madicp_comm_unique_id.argtypes = [_u8p]
@@ -343,6 +346,20 @@ class Context:
         tid, nl = C.c_int(0), C.c_int32(0)
         _check(hip_lib().madicp_tree_build(self._h, cid, float(b_max), float(b_min), C.byref(tid), C.byref(nl)))
         return tid.value, nl.value
+
+    def tree_build_begin(self, xyz, b_max, b_min):
+        """Look-ahead: copy the scan and enqueue its construction on the library's build stream; returns at once."""
+        a = _f64(xyz)
+        _check(hip_lib().madicp_tree_build_begin(self._h, a.ctypes.data_as(_dp), a.shape[0], float(b_max), float(b_min)))
+
+    def tree_build_end(self):
+        """... and collect it.  Returns (tree id, leaves)."""
+        tid, nl = C.c_int(0), C.c_int32(0)
+        _check(hip_lib().madicp_tree_build_end(self._h, C.byref(tid), C.byref(nl)))
+        return tid.value, nl.value
+
+    def tree_build_cancel(self):
+        _check(hip_lib().madicp_tree_build_cancel(self._h))
 
     def tree_info(self, tid):
         nn, nl = C.c_int32(0), C.c_int32(0)

@@ -1,7 +1,9 @@
 // Part of madicp_capi.hip (included at its end): the device front-end — scans resident in HBM (madicp_cloud_*), ingest
 // and deskew, MAD-tree construction on the device (row f-1).  Everything runs on the context's copy
 // stream: like a tree upload it feeds the registrations, so the front-end of scan i+1 overlaps the registration of scan i,
-// and the compute stream is only made to wait (by event) where it reads the result.
+// and the compute stream is only made to wait (by event) where it reads the result.  The one exception is the look-ahead
+// build (madicp_tree_build_begin / _end): it runs on a stream of its own, so that a registration's feed — which IS on the
+// copy stream — never queues behind half a millisecond of level kernels.
 //
 // One host synchronisation per build: after the last level the host reads 1 KB of counters (leaf count, top size,
 // rho, error flags) because the launch geometry and the buffer sizes of everything downstream need the leaf count.
@@ -36,6 +38,18 @@ struct FrontScratch {
   bool state_stale = false;      // h_state is older than the device State
   double* h_table = nullptr;     // pinned, same layout as `table`
   hipEvent_t h_table_read = nullptr;
+  // a construction between its two halves (tree_build_begin_on / tree_build_end_on)
+  struct InFlight {
+    bool active = false;
+    bool lookahead = false;  // begun by madicp_tree_build_begin: owns `cloud`
+    hipStream_t s = nullptr;
+    tb::Params P{};
+    int64_t n = 0;
+    bool chip = false;
+    int chip_grid = 0, level_grid = 0, n_tiles = 0, levels_done = 0;
+    int seq = 0;           // what tb_finish_b will publish (direct scan path)
+    DevCloud cloud;        // look-ahead only
+  } fly;
 };
 
 constexpr int kDeskewTableMax = 1040;  // > CHUNKS + a few: thresholds fall below -pi after ~1024 steps
@@ -57,6 +71,13 @@ madicp_ctx::Front& front_of(madicp_ctx* ctx) {
 
 size_t sort_temp_bytes(int64_t n);  // (defined below, needs rocPRIM)
 
+// the builder's scratch has one owner at a time: between madicp_tree_build_begin and _end it is the look-ahead
+int busy_with_lookahead(madicp_ctx* ctx) {
+  if (ctx->front && ctx->front->scratch.fly.active)
+    return fail(MADICP_ERR_CAPACITY, "a look-ahead tree build is in flight on this context: madicp_tree_build_end (or _cancel) first");
+  return MADICP_OK;
+}
+
 int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   FrontScratch& fs = front_of(ctx).scratch;
   *out = &fs;
@@ -71,6 +92,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   if (fs.block) {
     HIP_TRY(hipStreamSynchronize(ctx->copy));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->build) HIP_TRY(hipStreamSynchronize(ctx->build));
     HIP_TRY(hipFree(fs.block));
     fs.block = nullptr;
     fs.cap = 0;
@@ -188,11 +210,11 @@ int drop_cloud(madicp_ctx* ctx, DevCloud& c, int rc) {
     if (e_ != hipSuccess) return drop_cloud(ctx, c, fail(MADICP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
   } while (0)
 
-int scan_marks(madicp_ctx* ctx, FrontScratch& fs, const uint32_t* marks, int64_t n, int32_t* d_total) {
+int scan_marks(hipStream_t s, FrontScratch& fs, const uint32_t* marks, int64_t n, int32_t* d_total) {
   const int tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
-  hipLaunchKernelGGL(tb::tb_scan_tiles, dim3(tiles), dim3(256), 0, ctx->copy, marks, (int)n, fs.tile_sums);
-  hipLaunchKernelGGL(tb::tb_scan_top, dim3(1), dim3(256), 0, ctx->copy, fs.tile_sums, tiles, d_total);
-  hipLaunchKernelGGL(tb::tb_scan_apply, dim3(tiles), dim3(256), 0, ctx->copy, marks, (int)n, (const uint32_t*)fs.tile_sums, fs.S);
+  hipLaunchKernelGGL(tb::tb_scan_tiles, dim3(tiles), dim3(256), 0, s, marks, (int)n, fs.tile_sums);
+  hipLaunchKernelGGL(tb::tb_scan_top, dim3(1), dim3(256), 0, s, fs.tile_sums, tiles, d_total);
+  hipLaunchKernelGGL(tb::tb_scan_apply, dim3(tiles), dim3(256), 0, s, marks, (int)n, (const uint32_t*)fs.tile_sums, fs.S);
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -274,6 +296,7 @@ int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_rec
   if (!ctx || !records || !out_cloud_id || !out_n) return fail(MADICP_ERR_INVALID, "null argument");
   if (n_records < 1 || n_records > 0x3fffffff) return fail(MADICP_ERR_INVALID, "1 .. 2^30 records");
   if (stride_floats < 3) return fail(MADICP_ERR_INVALID, "a record holds at least x, y, z");
+  RC_TRY(busy_with_lookahead(ctx));
   HIP_TRY(hipSetDevice(ctx->device));
   FrontScratch* fs = nullptr;
   // the raw records go through the pinned staging into buf[0] of the scratch (a KITTI record is 16 bytes, a point of the
@@ -301,7 +324,7 @@ int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_rec
   const int blocks = static_cast<int>(std::min<int64_t>((n_records + 255) / 256, (int64_t)ctx->n_cus * 8));
   hipLaunchKernelGGL(fe::ingest_mark, dim3(blocks), dim3(256), 0, ctx->copy, (const float*)d_rec, (long)n_records, stride_floats,
                      min_range, max_range, keep);
-  RC_TRY(scan_marks(ctx, *fs, keep, n_records, &fs->P.st->n_leaves));
+  RC_TRY(scan_marks(ctx->copy, *fs, keep, n_records, &fs->P.st->n_leaves));
   HIP_TRY(hipMemcpyAsync(&fs->h_state->n_leaves, &fs->P.st->n_leaves, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->copy));
   HIP_TRY(hipStreamSynchronize(ctx->copy));  // the size of the result decides the allocation
   const int64_t kept = fs->h_state->n_leaves;
@@ -343,6 +366,7 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
   DevCloud* c = find_cloud(ctx, cloud_id);
   if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
   if (!(sensor_hz > 0.0)) return fail(MADICP_ERR_INVALID, "sensor_hz must be positive");
+  RC_TRY(busy_with_lookahead(ctx));
   HIP_TRY(hipSetDevice(ctx->device));
   FrontScratch* fs = nullptr;
   RC_TRY(ensure_scratch(ctx, c->n, &fs));
@@ -432,95 +456,123 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
   return MADICP_OK;
 }
 
+}  // extern "C"
+
 // ---- MAD-tree construction on the device ------------------------------------------------------------------------------
-int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves) {
-  if (!ctx || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
-  DevCloud* c = find_cloud(ctx, cloud_id);
-  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
-  HIP_TRY(hipSetDevice(ctx->device));
-  FrontScratch* fs = nullptr;
-  RC_TRY(ensure_scratch(ctx, c->n, &fs));
-  const int64_t n = c->n;
-  tb::Params P = fs->P;
-  P.cloud = c->xyz;
-  P.n_points = static_cast<int32_t>(n);
-  P.b_max = b_max;
-  P.b_min = b_min;
-  hipStream_t s = ctx->copy;
-  const bool chip = n > tb::kChipMin;
-  P.first_step = chip ? tb::kChipLevels : 0;
+namespace {
+
+// the level kernels of steps [from, to) of the construction in flight, on its stream
+void tb_run_levels(FrontScratch::InFlight& f, int from, int to) {
+  const tb::Params& P = f.P;
+  hipStream_t s = f.s;
+  for (int level = from; level < to; ++level) {
+    if (f.chip && level < tb::kChipLevels) {
+      if (level == 0) hipLaunchKernelGGL(tb::tb_chip_sums, dim3(f.chip_grid), dim3(256), 0, s, P, level);
+      hipLaunchKernelGGL(tb::tb_chip_stats, dim3(f.chip_grid), dim3(256), 0, s, P, level);
+      hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(f.chip_grid), dim3(256), 0, s, P, level);
+    }
+    if (level < P.first_step) continue;  // (wave / quad nodes born up here wait for step first_step: tree_build.hip.h)
+    // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
+    // workgroups that only look at an empty queue still cost their dispatch)
+    const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, f.n) : f.n;
+    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1)));
+    hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
+  }
+}
+
+// What the host needs before it can size the tree — leaf count (scan of the leaf starts), root mean, rho, size of the
+// LDS-staged top, error flags, whether a queue is still waiting — arrives in fs.h_line.  Two halves: the kernels that
+// produce it (direct scan path only; huge clouds do everything in the second half) ...
+int tb_summary_enqueue(FrontScratch& fs, int next_step, bool again) {
+  FrontScratch::InFlight& f = fs.fly;
+  if (again)  // (a fresh State is all zero; a second summary must not add to the first)
+    HIP_TRY(hipMemsetAsync(&f.P.st->n_leaves, 0, offsetof(tb::State, q_count) - offsetof(tb::State, n_leaves), f.s));  // the results line
+  if (f.n_tiles > tb::kScanDirectMax) return MADICP_OK;
+  f.seq = ++fs.build_seq;
+  hipLaunchKernelGGL(tb::tb_finish_a, dim3(f.n_tiles + 64), dim3(256), 0, f.s, f.P, kTopLevels, f.n_tiles);
+  hipLaunchKernelGGL(tb::tb_finish_b, dim3(f.n_tiles), dim3(256), 0, f.s, f.P, f.n_tiles, next_step, fs.h_line, f.seq);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
+}
+// ... and the wait for it
+int tb_summary_wait(madicp_ctx* ctx, FrontScratch& fs, int next_step) {
+  FrontScratch::InFlight& f = fs.fly;
+  tb::HostLine& hl = *fs.h_line;
+  if (f.n_tiles <= tb::kScanDirectMax) {
+    const int seq = f.seq;
+    const unsigned check_mask = ctx->wait_mode == 0 ? 0x3ffu : 0xfu;  // (option "wait_mode": spin / yield / sleep)
+    for (unsigned spins = 1; __atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
+      if ((spins & check_mask) == 0) {  // every few tens of microseconds: is the stream still alive?
+        const hipError_t q = hipStreamQuery(f.s);
+        if (q == hipSuccess) {
+          if (__atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) == seq) break;
+          return fail(MADICP_ERR_DEVICE, "tree build: finished without publishing its summary");
+        }
+        if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("tree build: ") + hipGetErrorString(q));
+      }
+      wait_pause(ctx);
+    }
+    return MADICP_OK;
+  }
+  // huge clouds: three-kernel scan, summary, the State copied back
+  RC_TRY(scan_marks(f.s, fs, f.P.leaf_start, f.n, &f.P.st->n_leaves));
+  hipLaunchKernelGGL(tb::tb_summary, dim3(64), dim3(256), 0, f.s, f.P, kTopLevels);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(fs.h_state, f.P.st, sizeof(tb::State), hipMemcpyDeviceToHost, f.s));
+  HIP_TRY(hipStreamSynchronize(f.s));
+  const tb::State& h = *fs.h_state;
+  hl.n_nodes = h.n_nodes.v; hl.error = h.n_nodes.error; hl.n_leaves = h.n_leaves; hl.n_top = h.n_top;
+  hl.max_level = h.max_level; hl.n_valid = h.n_valid; hl.rho_bits = h.rho_bits;
+  hl.pending_wave = h.q_count[next_step].v; hl.pending_quad = h.small_count[next_step].v;
+  for (int i = 0; i < 3; ++i) hl.origin[i] = h.origin[i];
+  return MADICP_OK;
+}
+
+// first half of a construction: everything up to the summary of step 20 is enqueued on `s`; nothing is waited for
+int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, int64_t n, double b_max, double b_min, hipStream_t s) {
+  FrontScratch::InFlight& f = fs.fly;
+  f.s = s;
+  f.n = n;
+  f.P = fs.P;
+  f.P.cloud = d_xyz;
+  f.P.n_points = static_cast<int32_t>(n);
+  f.P.b_max = b_max;
+  f.P.b_min = b_min;
+  f.chip = n > tb::kChipMin;
+  f.P.first_step = f.chip ? tb::kChipLevels : 0;
   // (State and leaf-start marks are cleared by tb_init itself)
-  hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, P);
-  const int chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
+  hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, f.P);
+  f.chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
   // one wave per wave-regime node (at most n / 33 of them on a level) and four lanes per small node (most levels hold far
   // fewer than the n of them this bound allows for: the queues are walked with a stride)
-  const int level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + n / 256 + 1)));
-  auto run_levels = [&](int from, int to) {
-    for (int level = from; level < to; ++level) {
-      if (chip && level < tb::kChipLevels) {
-        if (level == 0) hipLaunchKernelGGL(tb::tb_chip_sums, dim3(chip_grid), dim3(256), 0, s, P, level);
-        hipLaunchKernelGGL(tb::tb_chip_stats, dim3(chip_grid), dim3(256), 0, s, P, level);
-        hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(chip_grid), dim3(256), 0, s, P, level);
-      }
-      if (level < P.first_step) continue;  // (wave / quad nodes born up here wait for step first_step: tree_build.hip.h)
-      // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
-      // workgroups that only look at an empty queue still cost their dispatch)
-      const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, n) : n;
-      const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1)));
-      hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
-    }
-  };
-  // What the host needs before it can size the tree — leaf count (scan of the leaf starts), root mean, rho, size of the
-  // LDS-staged top, error flags, whether a queue is still waiting — arrives in fs->h_line.
-  tb::HostLine& hl = *fs->h_line;
-  const int n_tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
-  auto finish = [&](int next_step, bool again) -> int {
-    if (again)  // (a fresh State is all zero; a second summary must not add to the first)
-      HIP_TRY(hipMemsetAsync(&P.st->n_leaves, 0, offsetof(tb::State, q_count) - offsetof(tb::State, n_leaves), s));  // the results line
-    if (n_tiles <= tb::kScanDirectMax) {
-      const int seq = ++fs->build_seq;
-      hipLaunchKernelGGL(tb::tb_finish_a, dim3(n_tiles + 64), dim3(256), 0, s, P, kTopLevels, n_tiles);
-      hipLaunchKernelGGL(tb::tb_finish_b, dim3(n_tiles), dim3(256), 0, s, P, n_tiles, next_step, fs->h_line, seq);
-      HIP_TRY(hipGetLastError());
-      const unsigned check_mask = ctx->wait_mode == 0 ? 0x3ffu : 0xfu;  // (option "wait_mode": spin / yield / sleep)
-      for (unsigned spins = 1; __atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) != seq; ++spins) {
-        if ((spins & check_mask) == 0) {  // every few tens of microseconds: is the stream still alive?
-          const hipError_t q = hipStreamQuery(s);
-          if (q == hipSuccess) {
-            if (__atomic_load_n(&hl.seq, __ATOMIC_ACQUIRE) == seq) break;
-            return fail(MADICP_ERR_DEVICE, "tree build: finished without publishing its summary");
-          }
-          if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("tree build: ") + hipGetErrorString(q));
-        }
-        wait_pause(ctx);
-      }
-      return MADICP_OK;
-    }
-    // huge clouds: three-kernel scan, summary, the State copied back
-    RC_TRY(scan_marks(ctx, *fs, P.leaf_start, n, &P.st->n_leaves));
-    hipLaunchKernelGGL(tb::tb_summary, dim3(64), dim3(256), 0, s, P, kTopLevels);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(fs->h_state, P.st, sizeof(tb::State), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const tb::State& h = *fs->h_state;
-    hl.n_nodes = h.n_nodes.v; hl.error = h.n_nodes.error; hl.n_leaves = h.n_leaves; hl.n_top = h.n_top;
-    hl.max_level = h.max_level; hl.n_valid = h.n_valid; hl.rho_bits = h.rho_bits;
-    hl.pending_wave = h.q_count[next_step].v; hl.pending_quad = h.small_count[next_step].v;
-    for (int i = 0; i < 3; ++i) hl.origin[i] = h.origin[i];
-    return MADICP_OK;
-  };
-  // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop below
-  int levels_done = 20;
-  run_levels(0, levels_done);
-  RC_TRY(finish(levels_done, false));
+  f.level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + n / 256 + 1)));
+  f.n_tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
+  // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop in the second half
+  f.levels_done = 20;
+  tb_run_levels(f, 0, f.levels_done);
+  HIP_TRY(hipGetLastError());
+  RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
+  f.active = true;
+  return MADICP_OK;
+}
+
+// second half: the host learns the leaf count (deeper trees: more levels first), the tree is sized, emitted, compacted
+int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32_t* out_n_leaves) {
+  FrontScratch::InFlight& f = fs.fly;
+  hipStream_t s = f.s;
+  const tb::Params& P = f.P;
+  tb::HostLine& hl = *fs.h_line;
+  f.active = false;  // (whatever happens below, the scratch is free again: every error path leaves the stream drained or dead)
+  RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
   auto pending = [&]() { return hl.pending_wave > 0 || hl.pending_quad > 0; };
-  while (hl.error == 0 && levels_done < tb::kMaxLevels && pending()) {
-    const int to = std::min(levels_done + 8, tb::kMaxLevels);
-    run_levels(levels_done, to);
-    levels_done = to;
-    RC_TRY(finish(levels_done, true));
+  while (hl.error == 0 && f.levels_done < tb::kMaxLevels && pending()) {
+    const int to = std::min(f.levels_done + 8, tb::kMaxLevels);
+    tb_run_levels(f, f.levels_done, to);
+    f.levels_done = to;
+    RC_TRY(tb_summary_enqueue(fs, f.levels_done, true));
+    RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
   }
-  fs->state_stale = true;
+  fs.state_stale = true;
   if (hl.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
   if (hl.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
   const int32_t n_leaves = hl.n_leaves, n_nodes = 2 * hl.n_leaves - 1;
@@ -556,7 +608,7 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   t.leaves = reinterpret_cast<LeafRec*>(t.block + off_leaves);
   t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
   set_desc(t, st.origin);
-  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256), dim3(256), 0, s, (const tb::BNode*)P.nodes, n_nodes, (const uint32_t*)fs->S,
+  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256), dim3(256), 0, s, (const tb::BNode*)P.nodes, n_nodes, (const uint32_t*)fs.S,
                      t.nodes, n_nodes);
   if (nt)
     hipLaunchKernelGGL(tb::tb_layout_top, dim3(1), dim3(1024), 0, s, (const madicp_node*)t.nodes, kTopLevels, kTopMax, t.top_dfs,
@@ -566,6 +618,9 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   if (e == hipSuccess) rc = compact_tree(t, s);
   if (e == hipSuccess && rc == MADICP_OK) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
   if (e == hipSuccess && rc == MADICP_OK) e = hipEventRecord(t.ready, s);
+  // a tree from the build stream: the copy stream feeds registrations from trees it believes it produced itself
+  // (moving_from_leaves, transforms' staging), so it is put behind the event once, here
+  if (e == hipSuccess && rc == MADICP_OK && s != ctx->copy) e = hipStreamWaitEvent(ctx->copy, t.ready, 0);
   if (e != hipSuccess || rc != MADICP_OK) {
     hipStreamSynchronize(s);
     release_tree(ctx, t, nullptr);
@@ -575,6 +630,106 @@ int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min,
   ctx->trees[id] = t;
   *out_tree_id = id;
   if (out_n_leaves) *out_n_leaves = n_leaves;
+  return MADICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves) {
+  if (!ctx || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
+  DevCloud* c = find_cloud(ctx, cloud_id);
+  if (!c) return fail(MADICP_ERR_INVALID, "unknown cloud id");
+  RC_TRY(busy_with_lookahead(ctx));
+  HIP_TRY(hipSetDevice(ctx->device));
+  FrontScratch* fs = nullptr;
+  RC_TRY(ensure_scratch(ctx, c->n, &fs));
+  fs->fly.lookahead = false;
+  RC_TRY(tree_build_begin_on(ctx, *fs, c->xyz, c->n, b_max, b_min, ctx->copy));
+  return tree_build_end_on(ctx, *fs, out_tree_id, out_n_leaves);
+}
+
+int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, double b_max, double b_min) {
+  if (!ctx || !xyz) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n < 1 || n > 0x3fffffff) return fail(MADICP_ERR_INVALID, "a cloud holds 1 .. 2^30 points");
+  RC_TRY(busy_with_lookahead(ctx));
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->build) HIP_TRY(hipStreamCreateWithFlags(&ctx->build, hipStreamNonBlocking));
+  FrontScratch* fs = nullptr;
+  RC_TRY(ensure_scratch(ctx, n, &fs));
+  hipStream_t s = ctx->build;
+  // the scratch's previous users ran on the copy stream (ingest, deskew, a synchronous build's tail): behind them
+  {
+    EventRef ev;
+    RC_TRY(fence_event(ctx, &ev));
+    HIP_TRY(hipStreamWaitEvent(s, ev->ev_copy, 0));
+  }
+  // the scan: staged through the pinned buffers the uploads share, copied on the BUILD stream
+  DevCloud c;
+  {
+    void* p = nullptr;
+    RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)n, s, &p));
+    c.xyz = static_cast<double*>(p);
+    c.n = n;
+  }
+  const size_t bytes = sizeof(double) * 3 * (size_t)n;
+  const int hb = ctx->h_tree_next;
+  ctx->h_tree_next ^= 1;
+  CLOUD_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
+  if (ctx->h_tree_cap[hb] < bytes) {
+    if (ctx->h_tree[hb]) CLOUD_TRY(hipHostFree(ctx->h_tree[hb]));
+    ctx->h_tree[hb] = nullptr;
+    ctx->h_tree_cap[hb] = 0;
+    const size_t cap = bytes + bytes / 4;
+    CLOUD_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
+    ctx->h_tree_cap[hb] = cap;
+  }
+  {
+    const size_t piece = std::max<size_t>(align_up(bytes / 4), 256 << 10);
+    for (size_t off = 0; off < bytes; off += piece) {
+      const size_t len = std::min(piece, bytes - off);
+      std::memcpy(ctx->h_tree[hb] + off, reinterpret_cast<const char*>(xyz) + off, len);
+      CLOUD_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c.xyz) + off, ctx->h_tree[hb] + off, len, hipMemcpyHostToDevice, s));
+    }
+  }
+  CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], s));
+  fs->fly.lookahead = true;
+  const int rc = tree_build_begin_on(ctx, *fs, c.xyz, n, b_max, b_min, s);
+  if (rc != MADICP_OK) {
+    hipStreamSynchronize(s);
+    return drop_cloud(ctx, c, rc);
+  }
+  fs->fly.cloud = c;
+  return MADICP_OK;
+}
+
+int madicp_tree_build_end(madicp_ctx* ctx, int* out_tree_id, int32_t* out_n_leaves) {
+  if (!ctx || !out_tree_id) return fail(MADICP_ERR_INVALID, "null argument");
+  if (!ctx->front || !ctx->front->scratch.fly.active || !ctx->front->scratch.fly.lookahead)
+    return fail(MADICP_ERR_INVALID, "no look-ahead tree build in flight");
+  HIP_TRY(hipSetDevice(ctx->device));
+  FrontScratch& fs = ctx->front->scratch;
+  const int rc = tree_build_end_on(ctx, fs, out_tree_id, out_n_leaves);
+  // the level kernels — the only readers of the scan — are behind the summary the host has just seen (or the stream is drained)
+  DevCloud c = fs.fly.cloud;
+  fs.fly.cloud = DevCloud{};
+  if (rc != MADICP_OK) hipStreamSynchronize(fs.fly.s);
+  return drop_cloud(ctx, c, rc);
+}
+
+int madicp_tree_build_cancel(madicp_ctx* ctx) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (!ctx->front || !ctx->front->scratch.fly.active || !ctx->front->scratch.fly.lookahead) return MADICP_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  FrontScratch& fs = ctx->front->scratch;
+  const hipError_t e = hipStreamSynchronize(fs.fly.s);
+  fs.fly.active = false;
+  fs.state_stale = true;
+  DevCloud c = fs.fly.cloud;
+  fs.fly.cloud = DevCloud{};
+  drop_cloud(ctx, c, MADICP_OK);
+  if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("tree build: ") + hipGetErrorString(e));
   return MADICP_OK;
 }
 
@@ -592,6 +747,7 @@ int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
   if (!ctx || !out) return fail(MADICP_ERR_INVALID, "null argument");
   if (!ctx->front || !ctx->front->scratch.h_state || !ctx->front->scratch.block) return fail(MADICP_ERR_INVALID, "no build yet");
+  RC_TRY(busy_with_lookahead(ctx));
   FrontScratch& fs = ctx->front->scratch;
   if (fs.state_stale) {  // (a build publishes one line to the host; the per-level counters are fetched when asked for)
     HIP_TRY(hipSetDevice(ctx->device));

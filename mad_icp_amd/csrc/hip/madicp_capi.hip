@@ -64,9 +64,11 @@ int fail(int code, const std::string& msg) {
 struct EventHolder {
   hipEvent_t ev = nullptr;       // behind everything enqueued on the compute stream
   hipEvent_t ev_copy = nullptr;  // behind everything enqueued on the copy stream
+  hipEvent_t ev_build = nullptr; // behind everything enqueued on the build stream (only while a look-ahead build has used it)
   ~EventHolder() {
     if (ev) hipEventDestroy(ev);
     if (ev_copy) hipEventDestroy(ev_copy);
+    if (ev_build) hipEventDestroy(ev_build);
   }
 };
 using EventRef = std::shared_ptr<EventHolder>;
@@ -146,6 +148,7 @@ struct madicp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // compute
   hipStream_t copy = nullptr;    // feeds: uploads, record builds, next scan's leaves
+  hipStream_t build = nullptr;   // look-ahead tree construction (madicp_tree_build_begin); created on first use
   bool own_stream = false;
   int n_cus = 256;
 
@@ -245,6 +248,7 @@ int pool_alloc(madicp_ctx* ctx, size_t bytes, hipStream_t user, void** out) {
     if (it->second.after) {
       if (it->second.after->ev) HIP_TRY(hipStreamWaitEvent(user, it->second.after->ev, 0));
       if (it->second.after->ev_copy) HIP_TRY(hipStreamWaitEvent(user, it->second.after->ev_copy, 0));
+      if (it->second.after->ev_build) HIP_TRY(hipStreamWaitEvent(user, it->second.after->ev_build, 0));
     }
     *out = it->second.ptr;
     ctx->pool_bytes -= it->first;
@@ -277,6 +281,10 @@ int fence_event(madicp_ctx* ctx, EventRef* out) {
   HIP_TRY(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(h->ev, ctx->stream));
   HIP_TRY(hipEventRecord(h->ev_copy, ctx->copy));
+  if (ctx->build) {
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_build, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->ev_build, ctx->build));
+  }
   *out = h;
   return MADICP_OK;
 }
@@ -290,6 +298,7 @@ void pool_free(madicp_ctx* ctx, void* p, const EventRef& after) {
   if (ctx->pool_bytes + cap > kPoolMax) {
     if (after && after->ev) hipEventSynchronize(after->ev);
     if (after && after->ev_copy) hipEventSynchronize(after->ev_copy);
+    if (after && after->ev_build) hipEventSynchronize(after->ev_build);
     ctx->alloc_bytes.erase(it);
     hipFree(p);
     return;
@@ -865,6 +874,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->copy) hipStreamSynchronize(ctx->copy);
+  if (ctx->build) hipStreamSynchronize(ctx->build);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   if (ctx->h_comm) hipHostFree(ctx->h_comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
@@ -903,6 +913,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->d_totals) hipFree(ctx->d_totals);
   if (ctx->d_xch) hipFree(ctx->d_xch);
   if (ctx->copy) hipStreamDestroy(ctx->copy);
+  if (ctx->build) hipStreamDestroy(ctx->build);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return MADICP_OK;
@@ -911,6 +922,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
 int madicp_ctx_synchronize(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   HIP_TRY(hipStreamSynchronize(ctx->copy));
+  if (ctx->build) HIP_TRY(hipStreamSynchronize(ctx->build));
   return bounded_sync(ctx, ctx->stream);
 }
 

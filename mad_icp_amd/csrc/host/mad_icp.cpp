@@ -30,7 +30,7 @@ void MADicp::setMoving(MADtree& scan_tree) {
   matched_.assign(L_, 0);
 }
 
-void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated) {
+void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated, const std::function<void()>& while_in_flight) {
   if (L_ <= 0) throw std::runtime_error("MADicp::compute: setMoving was not called");
   if (fixed.empty()) throw std::runtime_error("MADicp::compute: no fixed tree");
   if (n_iters < 1) return;
@@ -69,6 +69,15 @@ void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool trunc
     check(madicp_stream_submit(ctx, moving_.front().data(), L_, ids.data(), static_cast<int>(ids.size()), X, &p, n_iters,
                                &ticket),
           "madicp_stream_submit");
+  }
+  if (while_in_flight) {
+    try {
+      while_in_flight();
+    } catch (...) {  // the registration is in flight: its slot must be collected whatever the caller's work did
+      int32_t nm = 0;
+      madicp_stream_collect(ctx, ticket, X, H_adder_, b_adder_, matched_.data(), &nm, &visits_);
+      throw;
+    }
   }
   int32_t n_matched = 0;
   check(madicp_stream_collect(ctx, ticket, X, H_adder_, b_adder_, matched_.data(), &n_matched, &visits_),

@@ -5,6 +5,7 @@
 // the whole loop runs on the device without host round trips: one streamed submission (madicp_stream_submit /
 // madicp_stream_collect), no device allocation, free or synchronisation per scan.
 #pragma once
+#include <functional>
 #include <cstdint>
 #include <vector>
 
@@ -30,7 +31,10 @@ class MADicp {
   // matched flags are those of the last round (cleared before it: pipeline.cpp:172-176).
   // truncated: the caller cut the loop short of MAX_ICP_ITS (Pipeline's realtime budget): matched flags are the OR over
   // the rounds that ran, like the reference's after an early break (pipeline.cpp:167-176)
-  void compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated = false);
+  // `while_in_flight` (optional) runs on the calling thread between the submission of the registration and the wait for its
+  // results — host work that has nothing to do with this registration (Pipeline: staging the next scan's look-ahead build)
+  void compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated = false,
+               const std::function<void()>& while_in_flight = {});
 
   int numMoving() const { return L_; }
   int numMatched() const { return n_matched_; }

@@ -53,12 +53,57 @@ MADtree::MADtree(ContainerType cloud, double b_max, double b_min, int max_parall
 MADtree::MADtree(DeviceCloud cloud, double b_max, double b_min) {
   DeviceLock lock(Device::mutex());
   madicp_ctx* c = Device::ctx();
+  cancelDeviceBuild(0);  // (a look-ahead of another Pipeline: its owner finds its ticket stale and builds when its scan comes)
   int32_t leaves = 0;
   check(madicp_tree_build(c, cloud.cloud_id, b_max, b_min, &dev_id_, &leaves), "madicp_tree_build");
   dev_gen_ = Device::generation();
   n_leaves_ = leaves;
   n_nodes_ = 2 * leaves - 1;
   host_copy_ = false;
+}
+
+namespace {
+unsigned g_lookahead = 0;       // ticket of the construction in flight on the context's build stream (0: none)
+unsigned g_lookahead_next = 1;
+unsigned g_lookahead_gen = 0;   // context generation it belongs to
+}  // namespace
+
+unsigned MADtree::beginDeviceBuild(const ContainerType& cloud, double b_max, double b_min) {
+  if (cloud.empty()) throw std::invalid_argument("MADtree: empty cloud");
+  DeviceLock lock(Device::mutex());
+  madicp_ctx* c = Device::ctx();
+  if (g_lookahead && g_lookahead_gen != Device::generation()) g_lookahead = 0;  // (went down with its context)
+  if (g_lookahead) return 0;  // another Pipeline of this process is looking ahead: build when the scan comes
+  const int rc = madicp_tree_build_begin(c, cloud.front().data(), static_cast<int64_t>(cloud.size()), b_max, b_min);
+  if (rc == MADICP_ERR_CAPACITY) return 0;
+  check(rc, "madicp_tree_build_begin");
+  g_lookahead = g_lookahead_next++;
+  if (g_lookahead_next == 0) g_lookahead_next = 1;
+  g_lookahead_gen = Device::generation();
+  return g_lookahead;
+}
+
+void MADtree::cancelDeviceBuild(unsigned ticket) {
+  DeviceLock lock(Device::mutex());
+  if (!g_lookahead || (ticket && ticket != g_lookahead)) return;
+  g_lookahead = 0;
+  if (madicp_ctx* c = Device::current(g_lookahead_gen)) madicp_tree_build_cancel(c);
+}
+
+std::unique_ptr<MADtree> MADtree::collectDeviceBuild(unsigned ticket) {
+  DeviceLock lock(Device::mutex());
+  if (!ticket || ticket != g_lookahead) return nullptr;  // cancelled in between (a synchronous build needed the scratch)
+  g_lookahead = 0;
+  madicp_ctx* c = Device::current(g_lookahead_gen);
+  if (!c) return nullptr;
+  std::unique_ptr<MADtree> t(new MADtree());
+  int32_t leaves = 0;
+  check(madicp_tree_build_end(c, &t->dev_id_, &leaves), "madicp_tree_build_end");
+  t->dev_gen_ = g_lookahead_gen;
+  t->n_leaves_ = leaves;
+  t->n_nodes_ = 2 * leaves - 1;
+  t->host_copy_ = false;
+  return t;
 }
 
 MADtree::MADtree(LinearTree&& built) : tree_(std::move(built)) {

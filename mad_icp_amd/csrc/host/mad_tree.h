@@ -4,6 +4,7 @@
 // runs on the GPU (madicp_nn_search).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "linalg.h"
@@ -31,6 +32,14 @@ class MADtree {
     int cloud_id;
   };
   MADtree(DeviceCloud cloud, double b_max, double b_min);
+  // ... as a look-ahead (madicp_tree_build_begin / _end): beginDeviceBuild() copies the scan and starts its construction on
+  // the library's build stream and returns a ticket (0: the one slot of the process-wide device context is taken);
+  // collectDeviceBuild(ticket) waits for it and returns the tree — or null when somebody cancelled it in between;
+  // cancelDeviceBuild(ticket) drops it (ticket 0: whatever is in flight — what a synchronous device build does first, the
+  // builder's scratch has one owner at a time)
+  static unsigned beginDeviceBuild(const ContainerType& cloud, double b_max, double b_min);
+  static std::unique_ptr<MADtree> collectDeviceBuild(unsigned ticket);
+  static void cancelDeviceBuild(unsigned ticket);
   ~MADtree();
   MADtree(const MADtree&) = delete;
   MADtree& operator=(const MADtree&) = delete;
@@ -52,6 +61,7 @@ class MADtree {
   bool resident() const { return dev_id_ >= 0; }
 
  private:
+  MADtree() = default;    // (collectDeviceBuild fills one in)
   void flushTransform();
   void fetchHostCopy();   // device-built trees: download the node array on first host-side use
   LinearTree tree_;

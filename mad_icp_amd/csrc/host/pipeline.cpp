@@ -63,7 +63,47 @@ void Pipeline::waitPrefetched() {
     if (p.tree.valid()) p.tree.wait();
 }
 
-Pipeline::~Pipeline() { waitPrefetched(); }  // Frames own their trees; trees release their HBM copies
+bool Pipeline::DevKey::matches(const ContainerType& c) const {
+  return n == c.size() && std::memcmp(first.data(), c.front().data(), 24) == 0 && std::memcmp(last.data(), c.back().data(), 24) == 0;
+}
+
+void Pipeline::collectDeviceLookAhead() {
+  if (!dev_pending_) return;
+  const unsigned ticket = dev_pending_;
+  dev_pending_ = 0;
+  dev_ready_.reset();  // (an older collected tree whose scan never came)
+  dev_ready_ = MADtree::collectDeviceBuild(ticket);  // (null: cancelled by a synchronous build of another Pipeline)
+  dev_ready_key_ = dev_pending_key_;
+}
+
+void Pipeline::beginStagedLookAhead() {
+  if (dev_next_cloud_.empty()) return;
+  ContainerType cloud = std::move(dev_next_cloud_);
+  dev_next_cloud_.clear();
+  collectDeviceLookAhead();  // (the one slot: whatever was in flight is collected first)
+  dev_pending_ = MADtree::beginDeviceBuild(cloud, b_max_, b_min_);
+  if (!dev_pending_) return;
+  dev_pending_key_.n = cloud.size();
+  dev_pending_key_.first = cloud.front();
+  dev_pending_key_.last = cloud.back();
+}
+
+void Pipeline::dropDeviceLookAhead(bool staged_too) {
+  if (staged_too) dev_next_cloud_.clear();
+  if (dev_pending_) {
+    MADtree::cancelDeviceBuild(dev_pending_);
+    dev_pending_ = 0;
+  }
+  dev_ready_.reset();
+}
+
+Pipeline::~Pipeline() {  // Frames own their trees; trees release their HBM copies
+  waitPrefetched();
+  try {
+    dropDeviceLookAhead();
+  } catch (...) {
+  }
+}
 
 const std::vector<Matrix4d> Pipeline::trajectory() const {
   std::vector<Matrix4d> out;
@@ -132,7 +172,14 @@ void Pipeline::initialize(const double& curr_stamp, ContainerType& cloud) {
 
 void Pipeline::prefetch(ContainerType next_cloud) {
   if (next_cloud.empty()) return;
-  if (device_frontend_) return;  // the tree is built on the GPU: a host build would only compete for the CPU
+  if (device_frontend_) {
+    // the tree is built on the GPU — a host build would only compete for the CPU — and the look-ahead is the library's:
+    // collect the construction in flight (the scan about to be consumed), start this one beside the coming registration
+    if (deskew_) return;  // (the tree needs the previous pose)
+    dev_next_cloud_ = std::move(next_cloud);  // begun by the next compute(), behind its registration's submission
+    if (!is_initialized_ || (!dev_pending_ && !dev_ready_)) beginStagedLookAhead();  // (nothing to hide behind yet)
+    return;
+  }
   // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it
   if (deskew_ && is_initialized_) return;
   while (prefetched_.size() >= kMaxLookAhead) {  // the oldest one makes room (its build is waited for)
@@ -156,6 +203,7 @@ void Pipeline::prefetch(ContainerType next_cloud) {
 std::unique_ptr<MADtree> Pipeline::buildOnDevice(int cloud_id) {
   DeviceLock lock(Device::mutex());
   madicp_ctx* ctx = Device::ctx();
+  MADtree::cancelDeviceBuild(0);  // deskew and build need the builder's scratch: a look-ahead of another Pipeline gives way
   std::unique_ptr<MADtree> tree;
   try {
     if (is_initialized_ && deskew_ && trajectory_.size() > 1) {
@@ -178,6 +226,8 @@ void Pipeline::computeRecords(const double& curr_stamp, const float* records, si
   if (!records || n_records == 0) throw std::invalid_argument("Pipeline::computeRecords: no records");
   const double t_pre = now_ms();
   waitPrefetched();
+  dropDeviceLookAhead();          // (ingest shares the builder's scratch ...
+  MADtree::cancelDeviceBuild(0);  //  ... with every Pipeline of the process)
   int cloud_id = -1;
   {
     DeviceLock lock(Device::mutex());
@@ -198,13 +248,22 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
   const double t_pre = now_ms();
   if (device_frontend_) {
     waitPrefetched();
-    int cloud_id = -1;
-    {
-      DeviceLock lock(Device::mutex());
-      check(madicp_cloud_upload(Device::ctx(), curr_cloud.front().data(), static_cast<int64_t>(curr_cloud.size()), &cloud_id),
-            "madicp_cloud_upload");
+    if (dev_ready_ && dev_ready_key_.matches(curr_cloud)) {
+      current_tree = std::move(dev_ready_);  // collected when the next look-ahead was begun
+    } else if (dev_pending_ && dev_pending_key_.matches(curr_cloud)) {
+      collectDeviceLookAhead();
+      current_tree = std::move(dev_ready_);
     }
-    current_tree = buildOnDevice(cloud_id);
+    if (!current_tree) {
+      dropDeviceLookAhead(false);  // whatever was looked ahead for is not this scan (the scan staged for the NEXT frame stays)
+      int cloud_id = -1;
+      {
+        DeviceLock lock(Device::mutex());
+        check(madicp_cloud_upload(Device::ctx(), curr_cloud.front().data(), static_cast<int64_t>(curr_cloud.size()), &cloud_id),
+              "madicp_cloud_upload");
+      }
+      current_tree = buildOnDevice(cloud_id);
+    }
   } else if (!prefetched_.empty() && !(deskew_ && is_initialized_ && trajectory_.size() > 1)) {
     // the look-ahead built for exactly this scan, if there is one; older look-aheads are for scans that never came
     for (size_t q = 0; q < prefetched_.size(); ++q) {
@@ -289,7 +348,9 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
     for (auto& f : keyframes_) fixed.push_back(f->tree_.get());
     // (cut short: the matched flags are the OR over the rounds that ran — the reference resets them in iteration
     // MAX_ICP_ITS - 1 only — and the launch goes kernel by kernel, no graph is instantiated for an odd round count)
-    icp_.compute(fixed, rounds, rounds < MAX_ICP_ITS);
+    icp_.compute(fixed, rounds, rounds < MAX_ICP_ITS, [this]() {
+      if (device_frontend_) beginStagedLookAhead();
+    });
     matched_leaves = icp_.numMatched();
   }
   last_icp_ms_ = now_ms() - t_icp;

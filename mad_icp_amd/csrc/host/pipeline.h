@@ -17,8 +17,11 @@
 // dataset) issues prefetch(i + d) before compute(i): with d = 1 the build of the next scan runs during the whole frame
 // step of this one (frame period 2.4-2.8 -> 1.6-1.7 ms at 120 k points); with d = 2 two builds share the builder's threads —
 // one's serial top levels beside the other's parallel bottom — and the period is 0.95 ms, 1 050 frames/s, with the
-// reference's own trees bit for bit (tools/lookahead_probe.py; d = 3 adds nothing: the 16 threads are then busy).  A no-op
-// with the device front-end on (the tree is built on the GPU) and for deskewed datasets (the tree needs the previous pose).
+// reference's own trees bit for bit (tools/lookahead_probe.py; d = 3 adds nothing: the 16 threads are then busy).  With the
+// device front-end on, prefetch(i + 1) before compute(i) hands over the NEXT scan; compute(i) starts its construction on the
+// library's build stream (madicp_tree_build_begin) as soon as its own registration is submitted, so that both the host side
+// (staging, launches) and the device side of that build run beside the registration of this scan; one look-ahead there.  A no-op for
+// deskewed datasets (the tree needs the previous pose).
 #pragma once
 #include <cstddef>
 #include <deque>
@@ -75,7 +78,10 @@ class Pipeline {
   // (mad_icp_amd/csrc/hip/tree_build.hip.h): over the full-size test drives poses differ from the host path's by up to
   // 1e-3 m / 3e-5 rad (3e-3 m / 1.4e-4 rad with deskew), while the error against GROUND TRUTH is the same for both
   // (tests/test_gpu_frontend.py states and asserts the bars).
-  void setDeviceFrontEnd(bool on) { device_frontend_ = on; }
+  void setDeviceFrontEnd(bool on) {
+    if (!on) dropDeviceLookAhead();
+    device_frontend_ = on;
+  }
   bool deviceFrontEnd() const { return device_frontend_; }
   // additive: one frame straight from sensor records — float32 (x, y, z, intensity ...) `stride_floats` apart, range
   // filter and optional KITTI correction as in apps/cpp_runners/bin_runner.cpp:126-166 — ingest, deskew, build and
@@ -118,6 +124,23 @@ class Pipeline {
   static constexpr size_t kMaxLookAhead = 4;  // scan i being consumed, up to three more building
   std::deque<Prefetched> prefetched_;
   void waitPrefetched();  // every look-ahead build has finished (their trees stay available)
+  // device front-end: ONE construction in flight on the library's build stream (`dev_pending_`), and the tree of the scan
+  // before it, collected when the next look-ahead was begun (`dev_ready_`) — with the call order prefetch(i + 1),
+  // compute(i) the tree of scan i is collected at prefetch(i + 1) and scan i + 1 is built while scan i registers
+  struct DevKey {
+    size_t n = 0;
+    Vector3d first{}, last{};
+    bool matches(const ContainerType& c) const;
+  };
+  unsigned dev_pending_ = 0;  // ticket (MADtree::beginDeviceBuild), 0: none
+  ContainerType dev_next_cloud_;  // the scan prefetch() was given, staged and begun by compute() WHILE its registration is in
+                                  // flight (the host side of a begin — 3 MB into pinned memory, ~60 launches — is a third of
+                                  // a millisecond that would otherwise sit in front of the registration)
+  void beginStagedLookAhead();
+  DevKey dev_pending_key_, dev_ready_key_;
+  std::unique_ptr<MADtree> dev_ready_;
+  void collectDeviceLookAhead();  // dev_pending_ -> dev_ready_
+  void dropDeviceLookAhead(bool staged_too = true);  // forget both (and the scan staged for the next frame)
   double round_ms_estimate_ = 0.05;  // device time of one GN round, from the previous frame (realtime budget)
   bool device_frontend_ = false;
   bool deskew_, realtime_;

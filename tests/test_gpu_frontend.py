@@ -406,3 +406,110 @@ def test_deskew_is_bit_identical_without_azimuth_ties(ctx):
     out = ctx.cloud_download(cid)
     assert np.array_equal(out, ref)
     ctx.cloud_release(cid)
+
+
+# ---- the look-ahead form of the device build (madicp_tree_build_begin / _end) -----------------------------------------------
+def test_look_ahead_build_is_the_synchronous_build(ctx):
+    """madicp_tree_build_begin .. _end give the tree of madicp_cloud_upload + madicp_tree_build bit for bit — with
+    registrations, uploads, transforms and searches of OTHER trees running on the context between the two calls (the
+    construction is on a stream of its own).  The builder's scratch has one owner: a second _begin, a synchronous build, an
+    ingest or a deskew in between are refused with the library's message, and a cancelled look-ahead leaves no trace."""
+    pb = street_problem(2)
+    scan = pb["query_scans"][0]
+    other = pb["keyframe_scans"][0]
+    cid = ctx.cloud_upload(scan)
+    t_sync, nl_sync = ctx.tree_build(cid, B_MAX, B_MIN)
+    ref = ctx.tree_download(t_sync, 2 * nl_sync - 1)
+    # a resident map to keep the device busy in between
+    kf = capi.HostTree(other, B_MAX, B_MIN, 2)
+    Tk = pb["keyframe_poses"][0]
+    tk = ctx.upload(kf)
+    ctx.tree_transform(tk, Tk[:3, :3], Tk[:3, 3])
+    moving = capi.HostTree(scan, B_MAX, B_MIN, 2).leaf_means()
+    tick = ctx.stream_submit(moving, [tk], pb["query_guess"][0], PARAMS, 15)
+    base = ctx.stream_collect(tick, moving.shape[0])
+
+    for rep in range(3):
+        ctx.tree_build_begin(scan, B_MAX, B_MIN)
+        with pytest.raises(capi.MadIcpError, match="look-ahead tree build is in flight"):
+            ctx.tree_build_begin(scan, B_MAX, B_MIN)
+        with pytest.raises(capi.MadIcpError, match="look-ahead tree build is in flight"):
+            ctx.tree_build(cid, B_MAX, B_MIN)
+        with pytest.raises(capi.MadIcpError, match="look-ahead tree build is in flight"):
+            ctx.cloud_deskew(cid, np.zeros(6), 10.0)
+        with pytest.raises(capi.MadIcpError, match="look-ahead tree build is in flight"):
+            ctx.cloud_ingest_f32(np.ones((10, 4), np.float32), 0.7, 120.0, 0)
+        # everything else goes on
+        tick = ctx.stream_submit(moving, [tk], pb["query_guess"][0], PARAMS, 15)
+        ctx.nn_search(tk, scan[:1000], want=("leaf",))
+        r = ctx.stream_collect(tick, moving.shape[0])
+        assert np.array_equal(r["X"], base["X"]) and np.array_equal(r["H"], base["H"])
+        c3 = ctx.cloud_upload(other)
+        ctx.cloud_release(c3)
+        if rep == 1:
+            ctx.tree_build_cancel()
+            ctx.tree_build_cancel()  # (no-op without one)
+            with pytest.raises(capi.MadIcpError, match="no look-ahead tree build in flight"):
+                ctx.tree_build_end()
+            continue
+        t_la, nl_la = ctx.tree_build_end()
+        assert nl_la == nl_sync
+        got = ctx.tree_download(t_la, 2 * nl_la - 1)
+        assert got.tobytes() == ref.tobytes()
+        # and it is a tree like any other: searched, registered against, released
+        l2 = ctx.nn_search(t_la, scan[:1000], want=("leaf",))["leaf"]
+        l1 = ctx.nn_search(t_sync, scan[:1000], want=("leaf",))["leaf"]
+        assert np.array_equal(l1, l2)
+        ctx.tree_release(t_la)
+    # the synchronous entry works again
+    t4, nl4 = ctx.tree_build(cid, B_MAX, B_MIN)
+    assert ctx.tree_download(t4, 2 * nl4 - 1).tobytes() == ref.tobytes()
+    for t in (t4, t_sync, tk):
+        ctx.tree_release(t)
+    ctx.cloud_release(cid)
+
+
+def test_pipeline_device_front_end_look_ahead(natives, drive, capsys):
+    """Pipeline with the device front-end on, prefetch(i + 1) issued before compute(i): the construction of the next scan's
+    tree runs on the build stream beside the registration of this one.  Device builds are bit-reproducible, so the
+    trajectory is the one of the same Pipeline without look-ahead, bit for bit; a second Pipeline of the process that builds
+    synchronously in between takes the scratch (the first one's ticket goes stale and it builds when its scan comes) and
+    both still produce their own trajectories."""
+    import time
+
+    from mad_icp.src.pybind import pypeline as m
+
+    args = (10.0, False, B_MAX, 0.1, 0.8, B_MIN, 0.02, 16, 8, False)
+    plain, ahead = m.Pipeline(*args), m.Pipeline(*args)
+    for p in (plain, ahead):
+        p.setDeviceFrontEnd(True)
+    t_plain, t_ahead = [], []
+    for i, s in enumerate(drive):
+        t = time.perf_counter()
+        plain.compute(0.1 * i, s)
+        t_plain.append(time.perf_counter() - t)
+    ahead.prefetch(drive[0])
+    for i, s in enumerate(drive):
+        t = time.perf_counter()
+        if i + 1 < len(drive):
+            ahead.prefetch(drive[i + 1])
+        ahead.compute(0.1 * i, s)
+        t_ahead.append(time.perf_counter() - t)
+    assert np.array_equal(np.asarray(ahead.trajectory()), np.asarray(plain.trajectory()))
+    assert ahead.keyframeID() == plain.keyframeID()
+    # two Pipelines, one looking ahead, the other building synchronously in between
+    a, b = m.Pipeline(*args), m.Pipeline(*args)
+    a.setDeviceFrontEnd(True)
+    b.setDeviceFrontEnd(True)
+    a.prefetch(drive[0])
+    for i, s in enumerate(drive[:6]):
+        if i + 1 < 6:
+            a.prefetch(drive[i + 1])
+        b.compute(0.1 * i, s)  # cancels a's look-ahead
+        a.compute(0.1 * i, s)
+    ref = np.asarray(plain.trajectory())[:6]
+    assert np.array_equal(np.asarray(a.trajectory()), ref) and np.array_equal(np.asarray(b.trajectory()), ref)
+    with capsys.disabled():
+        print("\n[pipeline, device front-end] per frame %.2f ms = %.0f frames/s; with prefetch(next) before compute: %.2f ms per "
+              "frame period = %.0f frames/s" % (1e3 * np.median(t_plain[2:]), 1.0 / np.median(t_plain[2:]),
+                                                1e3 * np.median(t_ahead[2:-1]), 1.0 / np.median(t_ahead[2:-1])))
