@@ -14,10 +14,11 @@
 // on the current pose (pipeline.cpp:140-141 builds in the sensor frame).  compute() itself is synchronous, so what the
 // build overlaps is whatever runs until the compute() of that scan.  Up to three look-aheads are kept beside the scan being
 // consumed, each matched to its scan by size and end points, so a caller that reads ahead (bin_runner / the launcher on a
-// dataset) issues prefetch(i + d) before compute(i): with d = 1 the build of the next scan runs during the whole frame
-// step of this one (frame period 2.4-2.8 -> 1.6-1.7 ms at 120 k points); with d = 2 two builds share the builder's threads —
-// one's serial top levels beside the other's parallel bottom — and the period is 0.95 ms, 1 050 frames/s, with the
-// reference's own trees bit for bit (tools/lookahead_probe.py; d = 3 adds nothing: the 16 threads are then busy).  With the
+// dataset) issues prefetch(i + d) before compute(i).  Averaged over a drive at 120 k points the frame takes 2.5 ms without,
+// 1.67 ms with d = 1, 1.41 ms with d = 2, 1.29 ms with d = 3 (tools/lookahead_probe.py), with the reference's own trees bit
+// for bit.  Individual frames are bimodal — one that waits about a build's length, then d quick ones of 0.7 ms: a build's
+// critical path (2.1-2.6 ms inside the pipeline) does not get shorter with more threads, so depth d buys d builds per build
+// latency until the 16 threads are busy.  With the
 // device front-end on, prefetch(i + 1) before compute(i) hands over the NEXT scan; compute(i) starts its construction on the
 // library's build stream (madicp_tree_build_begin) as soon as its own registration is submitted, so that both the host side
 // (staging, launches) and the device side of that build run beside the registration of this scan; one look-ahead there.  A no-op for

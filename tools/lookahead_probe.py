@@ -1,4 +1,5 @@
-"""Frame period of Pipeline.compute on the host path against the look-ahead depth (prefetch(i + d) before compute(i)).
+"""Frame period of Pipeline.compute against the look-ahead depth (prefetch(i + d) before compute(i)), host path and device
+front-end.
 Usage: python tools/lookahead_probe.py [frames]"""
 import os
 import sys
@@ -18,8 +19,11 @@ drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in ra
 clouds = [pypeline.VectorEigen3d(s) for s in drive]
 threads = min(os.cpu_count() or 1, 16)
 ref = None
-for depth in (0, 1, 2, 3):
+for device, depth in ((False, 0), (False, 1), (False, 2), (False, 3), (True, 0), (True, 1)):
+    if device and depth == 0:
+        ref = None  # (device-built trees: their own reference trajectory)
     pl = pypeline.Pipeline(10.0, False, 0.2, 0.1, 0.8, 0.1, 0.02, 16, threads, False)
+    pl.setDeviceFrontEnd(device)
     for d in range(depth):
         pl.prefetch(clouds[d])
     ts = []
@@ -33,4 +37,8 @@ for depth in (0, 1, 2, 3):
     if ref is None:
         ref = traj
     assert np.array_equal(traj, ref)
-    print("look-ahead %d: median %.2f ms per frame period = %.0f frames/s" % (depth, 1e3 * np.median(ts[3:N - 3]), 1.0 / np.median(ts[3:N - 3])))
+    if os.environ.get("LOOKAHEAD_SERIES") == "1":
+        print("   ", " ".join("%.2f" % (1e3 * t) for t in ts))
+    print("%s, look-ahead %d: mean %.2f ms per frame = %.0f frames/s (median %.2f: the series is bimodal with a look-ahead)"
+          % ("device front-end" if device else "host path", depth, 1e3 * np.mean(ts[3:N - 3]), 1.0 / np.mean(ts[3:N - 3]),
+             1e3 * np.median(ts[3:N - 3])))
