@@ -46,6 +46,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# This process holds more HIP streams than a runner would (torch's, this script's context with two, the Pipeline block's
+# context with three): with the runtime's default of four hardware queues some of them share a queue and the look-ahead
+# build serialises behind the registration it is meant to run beside (pipeline_end_to_end.device_front_end_lookahead:
+# 0.81 ms per frame with 4 queues, 0.63 with 8; the headline is unchanged within its box-to-box noise).  Read by the HIP
+# runtime when it initialises, so it is set before anything imports torch.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
 PARAMS = (B_MAX, RHO_KER, B_RATIO)

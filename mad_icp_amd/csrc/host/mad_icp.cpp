@@ -30,7 +30,8 @@ void MADicp::setMoving(MADtree& scan_tree) {
   matched_.assign(L_, 0);
 }
 
-void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated, const std::function<void()>& while_in_flight) {
+void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated, const std::function<void()>& while_in_flight,
+                     bool eager) {
   if (L_ <= 0) throw std::runtime_error("MADicp::compute: setMoving was not called");
   if (fixed.empty()) throw std::runtime_error("MADicp::compute: no fixed tree");
   if (n_iters < 1) return;
@@ -41,18 +42,14 @@ void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool trunc
   // round count that changes from frame to frame must not instantiate hipGraphs inside a time-critical frame.
   struct Restore {
     madicp_ctx* c;
-    bool on;
+    bool match_all, no_graph;
     ~Restore() {
-      if (on) {
-        madicp_ctx_set_option(c, "match_all_rounds", 0);
-        madicp_ctx_set_option(c, "use_graph", 1);
-      }
+      if (match_all) madicp_ctx_set_option(c, "match_all_rounds", 0);
+      if (no_graph) madicp_ctx_set_option(c, "use_graph", 1);
     }
-  } restore{ctx, truncated};
-  if (truncated) {
-    check(madicp_ctx_set_option(ctx, "match_all_rounds", 1), "madicp_ctx_set_option");
-    check(madicp_ctx_set_option(ctx, "use_graph", 0), "madicp_ctx_set_option");
-  }
+  } restore{ctx, truncated, truncated || eager};
+  if (truncated) check(madicp_ctx_set_option(ctx, "match_all_rounds", 1), "madicp_ctx_set_option");
+  if (truncated || eager) check(madicp_ctx_set_option(ctx, "use_graph", 0), "madicp_ctx_set_option");
   std::vector<int> ids;
   ids.reserve(fixed.size());
   for (MADtree* t : fixed) ids.push_back(t->deviceId());

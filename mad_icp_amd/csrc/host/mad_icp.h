@@ -33,8 +33,11 @@ class MADicp {
   // the rounds that ran, like the reference's after an early break (pipeline.cpp:167-176)
   // `while_in_flight` (optional) runs on the calling thread between the submission of the registration and the wait for its
   // results — host work that has nothing to do with this registration (Pipeline: staging the next scan's look-ahead build)
+  // `eager`: launch kernel by kernel, never through a hipGraph (a graph is instantiated per launch geometry and keyframe
+  // count — milliseconds, and several of them while another stream of the context is busy: a frame with a look-ahead build
+  // in flight must not pay that)
   void compute(const std::vector<MADtree*>& fixed, int n_iters, bool truncated = false,
-               const std::function<void()>& while_in_flight = {});
+               const std::function<void()>& while_in_flight = {}, bool eager = false);
 
   int numMoving() const { return L_; }
   int numMatched() const { return n_matched_; }

@@ -348,9 +348,10 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
     for (auto& f : keyframes_) fixed.push_back(f->tree_.get());
     // (cut short: the matched flags are the OR over the rounds that ran — the reference resets them in iteration
     // MAX_ICP_ITS - 1 only — and the launch goes kernel by kernel, no graph is instantiated for an odd round count)
+    const bool looking_ahead = device_frontend_ && (dev_pending_ || !dev_next_cloud_.empty());
     icp_.compute(fixed, rounds, rounds < MAX_ICP_ITS, [this]() {
       if (device_frontend_) beginStagedLookAhead();
-    });
+    }, looking_ahead);
     matched_leaves = icp_.numMatched();
   }
   last_icp_ms_ = now_ms() - t_icp;
