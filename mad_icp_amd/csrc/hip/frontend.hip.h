@@ -174,9 +174,15 @@ __global__ __launch_bounds__(256) void deskew_apply(const double* __restrict__ x
     const long src = idx_sorted[j];
     const double x = xyz[3 * src], y = xyz[3 * src + 1], z = xyz[3 * src + 2];
     const double* P = poses + 12 * (long)kd;
+#ifdef MADICP_XFORM_HOMOGENEOUS  // (Isometry3d * Vector3d in the homogeneous-product order: oracle/linalg.h apply())
+    out[3 * j] = ((P[0] * x + P[1] * y) + P[2] * z) + P[9];
+    out[3 * j + 1] = ((P[3] * x + P[4] * y) + P[5] * z) + P[10];
+    out[3 * j + 2] = ((P[6] * x + P[7] * y) + P[8] * z) + P[11];
+#else
     out[3 * j] = P[9] + madicp_host::sum3s(P[0] * x, P[1] * y, P[2] * z);
     out[3 * j + 1] = P[10] + madicp_host::sum3s(P[3] * x, P[4] * y, P[5] * z);
     out[3 * j + 2] = P[11] + madicp_host::sum3s(P[6] * x, P[7] * y, P[8] * z);
+#endif
     if (chunk_of) chunk_of[d] = kd;
   }
 }

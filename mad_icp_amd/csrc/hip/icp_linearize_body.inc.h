@@ -67,9 +67,15 @@
         const vd4 p = pv[j];
         px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
         // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
+#ifdef MADICP_XFORM_HOMOGENEOUS  // (the homogeneous-product order: oracle/linalg.h apply(); same operation count)
+        q0[j] = ((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0];
+        q1[j] = ((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1];
+        q2[j] = ((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2];
+#else
         q0[j] = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
         q1[j] = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
         q2[j] = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+#endif
         walk[j] = valid[j];
         margin[j] = 3.0e38;
         leaf[j] = 0;

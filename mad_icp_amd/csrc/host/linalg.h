@@ -40,10 +40,18 @@ struct Pose {
   }
 };
 // X * p = R p + t (Isometry3d * Vector3d)
+// Isometry3d * Vector3d; -DMADICP_XFORM_HOMOGENEOUS: the homogeneous-product order (oracle/linalg.h apply())
 inline void apply(const Pose& X, const double* p, double* o) {
+#ifdef MADICP_XFORM_HOMOGENEOUS
+  const double x = p[0], y = p[1], z = p[2];
+  double r[3];
+  for (int i = 0; i < 3; ++i) r[i] = ((X.R[3 * i] * x + X.R[3 * i + 1] * y) + X.R[3 * i + 2] * z) + X.t[i];
+  for (int i = 0; i < 3; ++i) o[i] = r[i];
+#else
   double rp[3];
   matvec3(X.R, p, rp);
   for (int i = 0; i < 3; ++i) o[i] = X.t[i] + rp[i];
+#endif
 }
 // A * B = (Ra Rb, Ra tb + ta)
 inline Pose compose(const Pose& A, const Pose& B) {

@@ -17,6 +17,7 @@
 //     Matrix3d * Matrix3d): scalar unrolled redux, split in halves:  a0*b0 + (a1*b1 + a2*b2) -> dots()
 // Compile with -DMADICP_REDUX_SCALAR_ONLY to force the scalar order everywhere (what a build with
 // EIGEN_DONT_VECTORIZE would do); the product code has the same switch so both stay in lock-step.
+// -DMADICP_XFORM_HOMOGENEOUS is a second such switch, for Isometry3d * Vector3d (see apply()).
 //
 // No FMA contraction anywhere: build with -ffp-contract=off (g++ -O3 on baseline x86-64 emits
 // mulsd+addsd anyway; the flag makes that explicit).
@@ -107,9 +108,19 @@ struct Iso3 {
   Vec3 t;
   static Iso3 Identity() { return {Mat3::Identity(), {{0, 0, 0}}}; }
 };
+// Isometry3d * Vector3d (mad_icp.cpp:78, pipeline.cpp:121).  Default: linear() * p + translation(), the product in the
+// scalar order.  -DMADICP_XFORM_HOMOGENEOUS: what Eigen 3.3+'s vector specialisation of transform_right_product_impl would
+// give with SSE2 packets if it multiplies the 4x4 matrix by the homogeneous 4-vector — ((r0 p0 + r1 p1) + r2 p2) + t * 1,
+// row by row (candidate (a)); product and oracle switch together, like MADICP_REDUX_SCALAR_ONLY.
 inline Vec3 apply(const Iso3& X, const Vec3& p) {
+#ifdef MADICP_XFORM_HOMOGENEOUS
+  Vec3 r;
+  for (int i = 0; i < 3; ++i) r[i] = ((X.R(i, 0) * p[0] + X.R(i, 1) * p[1]) + X.R(i, 2) * p[2]) + X.t[i];
+  return r;
+#else
   const Vec3 rp = mul(X.R, p);
   return {{X.t[0] + rp[0], X.t[1] + rp[1], X.t[2] + rp[2]}};
+#endif
 }
 inline Iso3 compose(const Iso3& A, const Iso3& B) {
   Iso3 r;
