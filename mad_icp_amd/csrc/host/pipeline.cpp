@@ -254,8 +254,12 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
       collectDeviceLookAhead();
       current_tree = std::move(dev_ready_);
     }
+    if (current_tree) ++look_ahead_hits_;
     if (!current_tree) {
-      dropDeviceLookAhead(false);  // whatever was looked ahead for is not this scan (the scan staged for the NEXT frame stays)
+      // Nothing looked ahead for THIS scan.  A construction in flight is then most likely for the NEXT one (a caller whose
+      // first scan came without a prefetch stays one ahead from there on): it is collected and kept — the synchronous build
+      // below needs the builder's scratch, so it has to be finished either way — not thrown away.
+      collectDeviceLookAhead();
       int cloud_id = -1;
       {
         DeviceLock lock(Device::mutex());
@@ -277,6 +281,7 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
         LinearTree built = prefetched_.front().tree.get();  // (waits for the builder thread)
         prefetched_.pop_front();
         current_tree = std::make_unique<MADtree>(std::move(built));
+        ++look_ahead_hits_;
         break;
       }
     }

@@ -96,6 +96,7 @@ class Pipeline {
   double lastIcpMs() const { return last_icp_ms_; }
   double lastBuildMs() const { return last_build_ms_; }
   size_t numKeyframes() const { return keyframes_.size(); }
+  size_t lookAheadHits() const { return look_ahead_hits_; }  // frames whose tree had been built ahead (prefetch)
 
   static Matrix4d toMatrix(const Pose& p);
 
@@ -154,6 +155,7 @@ class Pipeline {
   bool is_map_updated_ = false;
   float loop_time_;
   double last_inliers_ratio_ = 0., last_icp_ms_ = 0., last_build_ms_ = 0.;
+  size_t look_ahead_hits_ = 0;
 };
 
 }  // namespace madicp_host

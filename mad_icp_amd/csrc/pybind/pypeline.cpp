@@ -26,6 +26,7 @@ PYBIND11_MODULE(pypeline, m) {
            self.compute(stamp, container_from_array(std::move(cloud)));
          })
     // additive look-ahead: start building the next scan's MAD-tree while this frame is registered
+    .def("lookAheadHits", &Pipeline::lookAheadHits)
     .def("prefetch", &Pipeline::prefetch, py::arg("next_cloud"))
     .def("prefetch",
          [](Pipeline& self, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {

@@ -497,6 +497,26 @@ def test_pipeline_device_front_end_look_ahead(natives, drive, capsys):
         t_ahead.append(time.perf_counter() - t)
     assert np.array_equal(np.asarray(ahead.trajectory()), np.asarray(plain.trajectory()))
     assert ahead.keyframeID() == plain.keyframeID()
+    assert ahead.lookAheadHits() == len(drive) and plain.lookAheadHits() == 0
+    # a caller whose FIRST scan comes without a prefetch is one ahead from there on: the construction in flight at a miss is
+    # for the next scan and must be kept (dropping it left the pipeline permanently one behind: every frame a miss)
+    late = m.Pipeline(*args)
+    late.setDeviceFrontEnd(True)
+    for i, s in enumerate(drive):
+        if i + 1 < len(drive):
+            late.prefetch(drive[i + 1])
+        late.compute(0.1 * i, s)
+    assert np.array_equal(np.asarray(late.trajectory()), np.asarray(plain.trajectory()))
+    assert late.lookAheadHits() == len(drive) - 1
+    # ... and on the host path (keyed look-aheads)
+    hp, hl = m.Pipeline(*args), m.Pipeline(*args)
+    for i, s in enumerate(drive[:8]):
+        hp.compute(0.1 * i, s)
+        if i + 2 < 8:
+            hl.prefetch(drive[i + 2])
+        hl.compute(0.1 * i, s)
+    assert np.array_equal(np.asarray(hl.trajectory()), np.asarray(hp.trajectory()))
+    assert hl.lookAheadHits() == 6
     # two Pipelines, one looking ahead, the other building synchronously in between
     a, b = m.Pipeline(*args), m.Pipeline(*args)
     a.setDeviceFrontEnd(True)

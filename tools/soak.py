@@ -15,14 +15,24 @@ from mad_icp.src.pybind import pypeline as pm  # noqa: E402
 from mad_icp_amd import synth  # noqa: E402
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+MODE = sys.argv[2] if len(sys.argv) > 2 else "deskew"  # deskew (default) | plain (deskew off) | lookahead (deskew off,
+LOOKAHEAD = MODE == "lookahead"                          # prefetch(next) before compute: the build stream's path)
 scene = synth.Scene(0)
 scans = [synth.render_scan(scene, synth.path_pose(0.5 * i), 300 + i) for i in range(24)]
-pl = pm.Pipeline(10.0, True, 0.2, 0.1, 0.8, 0.1, 0.02, 16, 8, False)
+pl = pm.Pipeline(10.0, MODE == "deskew", 0.2, 0.1, 0.8, 0.1, 0.02, 16, 8, False)
 pl.setDeviceFrontEnd(True)
 ts, mem = [], []
+
+
+def scan_of(i):
+    return scans[i % len(scans)] if (i // len(scans)) % 2 == 0 else scans[len(scans) - 1 - i % len(scans)]  # back and forth
+
+
 for i in range(n_frames):
-    s = scans[i % len(scans)] if (i // len(scans)) % 2 == 0 else scans[len(scans) - 1 - i % len(scans)]  # back and forth
+    s = scan_of(i)
     t0 = time.perf_counter()
+    if LOOKAHEAD and i + 1 < n_frames and i % 97 != 96:  # (every 97th frame comes without a look-ahead: the fall-back path)
+        pl.prefetch(scan_of(i + 1))
     pl.compute(0.1 * i, s)
     ts.append(time.perf_counter() - t0)
     if i % 20 == 19:
