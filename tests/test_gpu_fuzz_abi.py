@@ -19,6 +19,10 @@ from mad_icp_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
+DEFAULT_ROUTE = {"use_graph": 1, "eager_when_busy": 1, "seq_completion": 1, "host_feed_wait": 1, "wait_mode": 0, "nn_lds_top": 0,
+                 "persistent": 0, "xcd_fold": 0}  # madicp_capi.hip
+
+
 def descend(nodes, q):
     """bestMatchingLeafFast over a linear node array, the reference's arithmetic: (q - mean) . dir with the contiguous
     3-vector reduction order (oracle/linalg.h dotc), left when negative."""
@@ -143,7 +147,16 @@ def test_random_walk_over_the_abi(ctx, seed):
             mid = ctx.moving_upload(moving)
             want = ctx.icp_register(mid, ids, T, PARAMS, 6, moving.shape[0])
             ctx.moving_release(mid)
+            # every launch route is claimed bit-identical: the streamed twin runs under randomly chosen ones
+            route = {"use_graph": int(rng.integers(2)), "eager_when_busy": int(rng.integers(2)), "seq_completion": int(rng.integers(2)),
+                     "host_feed_wait": int(rng.integers(2)), "wait_mode": int(rng.integers(3)), "nn_lds_top": int(rng.integers(2))}
+            fused = int(rng.integers(3))  # 0 per-round launches, 1 all rounds in one launch, 2 XCD fold
+            route["persistent"], route["xcd_fold"] = int(fused == 1), int(fused == 2)
+            for key, v in route.items():
+                ctx.set_option(key, v)
             tk = ctx.stream_submit(moving, ids, T, PARAMS, 6)
+            for key, v in DEFAULT_ROUTE.items():
+                ctx.set_option(key, v)
             inflight.append((tk, want, moving.shape[0]))
             counts["register"] += 1
         elif op == "collect" and inflight:
