@@ -50,6 +50,13 @@ void madicp_host_set_threads(int n);
  * reference's own loop (impl 0) or by the builder's flag-driven closed form (impl 1); returns the split position
  * (first point of the right part), -1 on bad arguments.  Both must leave the same permutation. */
 int64_t madicp_host_debug_partition(double* points, int64_t n, const double mean[3], const double normal[3], int impl);
+/* Pipeline::deskew (mad_icp/src/odometry/pipeline.cpp:79-123) on its own, in place, output in azimuth order; poses as 12
+ * doubles (R row-major, t).  route 0: the azimuth order from the task pool (unique when the azimuths are distinct), the
+ * reference's serial std::sort of (azimuth, point) pairs when two of them tie; route 1: always the reference's route.
+ * Returns 1 when the parallel order was used, 0 when the serial route ran, < 0 on bad arguments.  out_velocity6 (optional):
+ * naive_vel of pipeline.cpp:82-86. */
+int madicp_host_debug_deskew(double* points, int64_t n, const double T_prev[12], const double T_now[12], double sensor_hz, int route,
+                             double* out_velocity6);
 
 #ifdef __cplusplus
 }

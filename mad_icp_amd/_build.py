@@ -98,7 +98,7 @@ def hip_source_hash():
     return source_hash(_hip_deps(srcs), HIP_FLAGS + EXTRA_HIP_FLAGS)
 
 
-HOST_SRCS = ("tree_builder.cpp", "host_capi.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp", "pipeline.cpp")
+HOST_SRCS = ("tree_builder.cpp", "host_capi.cpp", "mad_tree.cpp", "mad_icp.cpp", "vel_estimator.cpp", "pipeline.cpp", "deskew.cpp")
 
 
 def build_host(force=False):

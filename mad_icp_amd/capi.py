@@ -136,6 +136,7 @@ def host_lib():
         L.madicp_host_set_threads.argtypes = [C.c_int]
         L.madicp_host_tree_rho2.restype = C.c_double
         L.madicp_host_tree_rho2.argtypes = [C.c_void_p]
+        L.madicp_host_debug_deskew.argtypes = [_dp, C.c_int64, _dp, _dp, C.c_double, C.c_int, _dp]
         L.madicp_host_debug_partition.restype = C.c_int64
         L.madicp_host_debug_partition.argtypes = [_dp, C.c_int64, _dp, _dp, C.c_int]
         _host = L
@@ -224,6 +225,18 @@ class HostTree:
     @property
     def rho2(self):
         return host_lib().madicp_host_tree_rho2(self._h)
+
+
+def host_deskew(points, T_prev, T_now, sensor_hz, route=0):
+    """Pipeline::deskew on the host (csrc/host/deskew.h).  Returns (cloud in azimuth order, naive velocity (6,), used_parallel_order)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).copy()
+    vel = np.empty(6)
+    a, b = pose12(T_prev), pose12(T_now)
+    rc = host_lib().madicp_host_debug_deskew(pts.ctypes.data_as(_dp), pts.shape[0], a.ctypes.data_as(_dp), b.ctypes.data_as(_dp),
+                                             float(sensor_hz), int(route), vel.ctypes.data_as(_dp))
+    if rc < 0:
+        raise MadIcpError("madicp_host_debug_deskew: bad arguments")
+    return pts, vel, bool(rc)
 
 
 class Context:

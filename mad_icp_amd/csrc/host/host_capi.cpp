@@ -5,6 +5,7 @@
 #include "linalg.h"
 #include "madicp_host.h"
 #include "task_pool.h"
+#include "deskew.h"
 #include "tree_builder.h"
 
 struct madicp_host_tree {
@@ -57,6 +58,27 @@ void madicp_host_set_threads(int n) { madicp_host::TaskPool::instance().set_limi
 int64_t madicp_host_debug_partition(double* points, int64_t n, const double mean[3], const double normal[3], int impl) {
   if (!points || n < 0 || !mean || !normal) return -1;
   return madicp_host::debug_partition(points, n, mean, normal, impl);
+}
+
+// Pipeline::deskew on its own (csrc/host/deskew.h).  route 0: the parallel azimuth order, the reference's serial sort when
+// two azimuths tie; route 1: the reference's route always.  Returns 1 when the parallel order was used, 0 when the serial
+// route ran, < 0 on bad arguments.
+int madicp_host_debug_deskew(double* points, int64_t n, const double T_prev[12], const double T_now[12], double sensor_hz, int route,
+                             double* out_velocity6) {
+  if (!points || n < 0 || !T_prev || !T_now || !(sensor_hz > 0.0)) return -1;
+  madicp_host::ContainerType cloud(static_cast<size_t>(n));
+  if (n) std::memcpy(static_cast<void*>(cloud.data()), points, sizeof(double) * 3 * static_cast<size_t>(n));
+  madicp_host::Pose a, b;
+  std::memcpy(a.R, T_prev, sizeof(a.R));
+  std::memcpy(a.t, T_prev + 9, sizeof(a.t));
+  std::memcpy(b.R, T_now, sizeof(b.R));
+  std::memcpy(b.t, T_now + 9, sizeof(b.t));
+  madicp_host::DeskewOrder prep = madicp_host::deskew_order(cloud);
+  if (route == 1) prep.ties = true;
+  const int fast = prep.ties ? 0 : 1;
+  madicp_host::deskew_cloud(cloud, a, b, sensor_hz, &prep, out_velocity6);
+  if (n) std::memcpy(points, static_cast<const void*>(cloud.data()), sizeof(double) * 3 * static_cast<size_t>(n));
+  return fast;
 }
 
 }  // extern "C"

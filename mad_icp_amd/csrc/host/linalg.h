@@ -93,6 +93,14 @@ inline void exp_so3(const double* w, double* R) {
 }
 
 // lie_algebra.h:54-89 (reference) — only used by deskew
+// [t; omega] -> (expSO3(omega), t)   (pipeline.cpp:101-104,147-152 of the reference)
+inline Pose motion_from_twist(const double* dx) {
+  Pose p;
+  exp_so3(dx + 3, p.R);
+  p.t[0] = dx[0]; p.t[1] = dx[1]; p.t[2] = dx[2];
+  return p;
+}
+
 inline void log_so3(const double* R, double* w) {
   const double tr = R[0] + (R[4] + R[8]);  // Matrix3d::trace(): strided 3-term redux, a + (b + c) (oracle/linalg.h trace3)
   if (tr + 1.0 < 1e-10) {

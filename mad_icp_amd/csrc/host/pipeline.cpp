@@ -1,5 +1,6 @@
 #include "pipeline.h"
 
+#include "deskew.h"
 #include "device.h"
 #include "task_pool.h"
 
@@ -17,12 +18,6 @@ namespace {
 double now_ms() {
   using clk = std::chrono::steady_clock;
   return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
-}
-Pose motion_from_twist(const double* dx) {  // [t; omega] -> (expSO3(omega), t)
-  Pose p;
-  exp_so3(dx + 3, p.R);
-  p.t[0] = dx[0]; p.t[1] = dx[1]; p.t[2] = dx[2];
-  return p;
 }
 }  // namespace
 
@@ -61,6 +56,8 @@ Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, 
 void Pipeline::waitPrefetched() {
   for (Prefetched& p : prefetched_)
     if (p.tree.valid()) p.tree.wait();
+  for (DeskewAhead& a : deskew_ahead_)
+    if (a.order.valid()) a.order.wait();
 }
 
 bool Pipeline::DevKey::matches(const ContainerType& c) const {
@@ -112,47 +109,15 @@ const std::vector<Matrix4d> Pipeline::trajectory() const {
   return out;
 }
 
-// pipeline.cpp:82-86: [translation; logMapSO3(rotation)] of T_prev^-1 T_now over one scan period
+// pipeline.cpp:82-86
 void Pipeline::naiveVelocity(const Pose& T_prev, const Pose& T_now, double* vel) const {
-  const double ts = 1. / sensor_hz_;
-  const Pose rel = compose(inverse(T_prev), T_now);
-  double w[3];
-  log_so3(rel.R, w);
-  for (int i = 0; i < 3; ++i) {
-    vel[i] = rel.t[i] / ts;
-    vel[3 + i] = w[i] / ts;
-  }
+  naive_velocity(T_prev, T_now, sensor_hz_, vel);
 }
 
-// pipeline.cpp:79-123 — motion compensation in 1024 azimuth chunks, host version (the device front-end runs
-// madicp_cloud_deskew instead)
-void Pipeline::deskew(ContainerType& cloud, const Pose& T_prev, const Pose& T_now) {
-  const double ts = 1. / sensor_hz_;
-  double vel[6];
-  naiveVelocity(T_prev, T_now, vel);
-  using AzimuthPair = std::pair<double, Vector3d>;
-  std::vector<AzimuthPair> sorted(cloud.size());
-  for (size_t i = 0; i < sorted.size(); ++i) sorted[i] = std::make_pair(std::atan2(cloud[i][1], cloud[i][0]), cloud[i]);
-  std::sort(sorted.begin(), sorted.end(),
-            [](const AzimuthPair& a, const AzimuthPair& b) -> bool { return a.first < b.first; });
-
-  const double resolution = 2 * M_PI / double(CHUNKS);
-  const double delta = ts / double(CHUNKS - 1);
-  double t = -ts;
-  auto pose_at = [&](double tt) {
-    const double dx[6] = {vel[0] * tt, vel[1] * tt, vel[2] * tt, vel[3] * tt, vel[4] * tt, vel[5] * tt};
-    return motion_from_twist(dx);
-  };
-  Pose m = pose_at(t);
-  double angle = M_PI - resolution;
-  for (int i = int(sorted.size()) - 1; i >= 0; --i) {
-    if (sorted[i].first < angle) {
-      angle -= resolution;
-      t += delta;
-      m = pose_at(t);
-    }
-    apply(m, sorted[i].second.data(), cloud[i].data());
-  }
+// pipeline.cpp:79-123 — motion compensation in 1024 azimuth chunks, host version (deskew.h; the device front-end runs
+// madicp_cloud_deskew instead).  `prep`: the pose-independent half, when prefetch() computed it ahead.
+void Pipeline::deskew(ContainerType& cloud, const Pose& T_prev, const Pose& T_now, const DeskewOrder* prep) {
+  deskew_cloud(cloud, T_prev, T_now, sensor_hz_, prep, nullptr);
 }
 
 // pipeline.cpp:267-284
@@ -180,8 +145,21 @@ void Pipeline::prefetch(ContainerType next_cloud) {
     if (!is_initialized_ || (!dev_pending_ && !dev_ready_)) beginStagedLookAhead();  // (nothing to hide behind yet)
     return;
   }
-  // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it
-  if (deskew_ && is_initialized_) return;
+  // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it — but the
+  // azimuth of every point and their order do not (deskew.h): that half is started now
+  if (deskew_ && is_initialized_) {
+    while (deskew_ahead_.size() >= kMaxLookAhead) {
+      if (deskew_ahead_.front().order.valid()) deskew_ahead_.front().order.wait();
+      deskew_ahead_.pop_front();
+    }
+    DeskewAhead a;
+    a.key.n = next_cloud.size();
+    a.key.first = next_cloud.front();
+    a.key.last = next_cloud.back();
+    a.order = std::async(std::launch::async, [cloud = std::move(next_cloud)]() { return deskew_order(cloud); });
+    deskew_ahead_.push_back(std::move(a));
+    return;
+  }
   while (prefetched_.size() >= kMaxLookAhead) {  // the oldest one makes room (its build is waited for)
     if (prefetched_.front().tree.valid()) prefetched_.front().tree.wait();
     prefetched_.pop_front();
@@ -314,8 +292,23 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
   }
 
   if (!current_tree) {
-    if (deskew_ && trajectory_.size() > 1)
-      deskew(*cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1]);
+    if (deskew_ && trajectory_.size() > 1) {
+      // the azimuth order computed ahead for exactly this scan, if there is one (older ones: scans that never came)
+      DeskewOrder ahead;
+      bool have = false;
+      for (size_t q = 0; q < deskew_ahead_.size() && !have; ++q) {
+        if (!deskew_ahead_[q].key.matches(*cloud)) continue;
+        for (size_t d = 0; d < q; ++d) {
+          if (deskew_ahead_.front().order.valid()) deskew_ahead_.front().order.wait();
+          deskew_ahead_.pop_front();
+        }
+        ahead = deskew_ahead_.front().order.get();
+        deskew_ahead_.pop_front();
+        have = true;
+        ++look_ahead_hits_;
+      }
+      deskew(*cloud, trajectory_[trajectory_.size() - 2], trajectory_[trajectory_.size() - 1], have ? &ahead : nullptr);
+    }
     current_tree = std::make_unique<MADtree>(std::move(*cloud), b_max_, b_min_, max_parallel_levels_);
   }
   // resident from now on (frame window, maybe keyframe later); the copy runs on the library's copy stream while the

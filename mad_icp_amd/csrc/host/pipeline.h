@@ -22,8 +22,9 @@
 // device front-end on, prefetch(i + 1) before compute(i) hands over the NEXT scan; compute(i) starts its construction on the
 // library's build stream (madicp_tree_build_begin) as soon as its own registration is submitted: the host side of that build
 // (staging, launches, the wait for the leaf count) is hidden behind the registration and the frame becomes device-bound
-// (0.90 -> 0.64 ms; the kernels of the two streams interleave, profiles/r3_o_lookahead_overlap.md); one look-ahead there.  A no-op for
-// deskewed datasets (the tree needs the previous pose).
+// (0.90 -> 0.64 ms; the kernels of the two streams interleave, profiles/r3_o_lookahead_overlap.md); one look-ahead there.  For
+// deskewed datasets the tree needs the previous poses: prefetch() then computes the pose-independent half of deskew ahead —
+// the azimuth of every point and their order (deskew.h).
 #pragma once
 #include <cstddef>
 #include <deque>
@@ -31,6 +32,7 @@
 #include <memory>
 #include <vector>
 
+#include "deskew.h"
 #include "linalg.h"
 #include "mad_icp.h"
 #include "mad_tree.h"
@@ -102,7 +104,7 @@ class Pipeline {
 
  protected:
   void initialize(const double& curr_stamp, ContainerType& curr_cloud);
-  void deskew(ContainerType& curr_cloud, const Pose& T_prev, const Pose& T_now);
+  void deskew(ContainerType& curr_cloud, const Pose& T_prev, const Pose& T_now, const DeskewOrder* prep = nullptr);
   void naiveVelocity(const Pose& T_prev, const Pose& T_now, double* vel6) const;  // pipeline.cpp:82-86
   std::unique_ptr<MADtree> buildOnDevice(int cloud_id);  // deskew (if due) + build + release of the cloud
   void computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree> current_tree, ContainerType* curr_cloud, double t_pre);
@@ -135,6 +137,13 @@ class Pipeline {
     Vector3d first{}, last{};
     bool matches(const ContainerType& c) const;
   };
+  // deskewed datasets: the tree needs the two previous poses, but the azimuth order of the scan does not — that half of
+  // Pipeline::deskew (atan2 per point, the sort: most of a deskewed frame on the host) is what prefetch() computes ahead
+  struct DeskewAhead {
+    DevKey key;
+    std::future<DeskewOrder> order;
+  };
+  std::deque<DeskewAhead> deskew_ahead_;
   unsigned dev_pending_ = 0;  // ticket (MADtree::beginDeviceBuild), 0: none
   ContainerType dev_next_cloud_;  // the scan prefetch() was given, staged and begun by compute() WHILE its registration is in
                                   // flight (the host side of a begin — 3 MB into pinned memory, ~60 launches — is a third of

@@ -140,3 +140,34 @@ def test_cpp_runner_surface(natives, drive, tmp_path):
         assert np.allclose(np.asarray(gp.currentPose())[:3], poses[i], atol=1e-9)
     gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(4.0)
     assert np.linalg.norm(poses[-1][:, 3] - gt[:3, 3]) < 0.05
+
+
+@pytest.mark.gpu
+def test_deskewed_drive_with_the_azimuth_order_computed_ahead(pypeline, drive, capsys):
+    """deskew = True on the host path: the tree needs the two previous poses, the azimuth order of the scan does not —
+    prefetch(i + 1) before compute(i) computes it beside the frame step (csrc/host/deskew.h).  Scans with distinct azimuths
+    (the synthetic ones, which share 64 points per azimuth column, with 1e-7 m of jitter: what a real sensor's noise does)
+    take the parallel order, tied ones the reference's serial route; either way the trajectory is the one without look-ahead
+    bit for bit."""
+    rng = np.random.default_rng(4)
+    threads = min(os.cpu_count() or 1, 16)
+    args = (10.0, True, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, 16, threads, False)
+    for tag, scans in (("distinct azimuths", [s + rng.normal(scale=1e-7, size=s.shape) for s in drive]), ("tied azimuths", drive)):
+        clouds = [pypeline.VectorEigen3d(s) for s in scans]
+        plain, ahead = pypeline.Pipeline(*args), pypeline.Pipeline(*args)
+        t_plain, t_ahead = [], []
+        for i in range(N_FRAMES):
+            t = time.perf_counter()
+            plain.compute(0.1 * i, clouds[i])
+            t_plain.append(time.perf_counter() - t)
+        for i in range(N_FRAMES):
+            t = time.perf_counter()
+            if i + 1 < N_FRAMES:
+                ahead.prefetch(clouds[i + 1])
+            ahead.compute(0.1 * i, clouds[i])
+            t_ahead.append(time.perf_counter() - t)
+        assert np.array_equal(np.asarray(ahead.trajectory()), np.asarray(plain.trajectory()))
+        assert ahead.lookAheadHits() >= N_FRAMES - 3
+        with capsys.disabled():
+            print("\n[pipeline, host path, deskew on, %s] mean %.2f ms per frame; with prefetch(i + 1) before compute(i): %.2f ms"
+                  % (tag, 1e3 * np.mean(t_plain[3:]), 1e3 * np.mean(t_ahead[3:-1])))
