@@ -1,6 +1,7 @@
 #include "deskew.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <functional>
 #include <utility>
@@ -73,19 +74,27 @@ DeskewOrder deskew_order(const ContainerType& cloud) {
   std::vector<uint32_t> other(n);
   double* az = d.azimuth.data();
   uint32_t* buf[2] = {d.order.data(), other.data()};
+  std::atomic<bool> run_tie{false};
   {  // azimuths and sorted runs
     std::vector<std::function<void()>> fns;
     for (int r = 0; r < runs; ++r) {
       const size_t lo = cut[static_cast<size_t>(r)], hi = cut[static_cast<size_t>(r) + 1];
-      fns.emplace_back([&cloud, az, lo, hi, out = buf[0]] {
+      fns.emplace_back([&cloud, &run_tie, az, lo, hi, out = buf[0]] {
         for (size_t i = lo; i < hi; ++i) {
           az[i] = std::atan2(cloud[i][1], cloud[i][0]);  // pipeline.cpp:93
           out[i] = static_cast<uint32_t>(i);
         }
         std::sort(out + lo, out + hi, [az](uint32_t x, uint32_t y) { return az[x] < az[y]; });
+        bool tie = false;  // a tie inside a run is a tie of the scan: the merges would be wasted work
+        for (size_t i = lo; i + 1 < hi; ++i) tie |= !(az[out[i]] < az[out[i + 1]]);
+        if (tie) run_tie.store(true, std::memory_order_relaxed);
       });
     }
     for (const TaskPool::Handle& j : pool.submit_batch(std::move(fns))) pool.wait(j);
+  }
+  if (run_tie.load(std::memory_order_relaxed)) {  // (the order is not used with ties: deskew_cloud takes the serial route)
+    d.ties = true;
+    return d;
   }
   int src = 0;
   for (int width = 1; width < runs; width *= 2) {  // pairwise merges, ping-pong between the two buffers
