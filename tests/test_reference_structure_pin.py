@@ -73,6 +73,26 @@ for name, c in clouds.items():
         leaf, _, dist = t.search(q, want_dist=True)
         out["nn_%s_%g_%d_leaf" % (name, b_max, par)] = leaf
         out["nn_%s_%g_%d_dist" % (name, b_max, par)] = dist
+# random small clouds: mixtures of blobs, sheets and lines at random scales, random thresholds — the corners of the leaf rule,
+# the plane-predecessor rule and the small-leaf normal (mad_tree.cpp:64-93) far more often than a street scan visits them
+r2 = np.random.default_rng(77)
+for i in range(60):
+    n = int(r2.integers(1, 400))
+    kind = int(r2.integers(4))
+    c = r2.normal(size=(n, 3)) * r2.choice([0.01, 0.3, 5.0], size=3)
+    if kind == 1:
+        c[:, 2] = 0.0
+    elif kind == 2:
+        c[:, 1:] = 0.0
+    elif kind == 3:
+        c = np.repeat(c[: max(1, n // 4)], 4, axis=0)
+    c = c + r2.normal(size=3) * 10.0
+    b_max, b_min = float(r2.choice([1e-5, 0.05, 0.2, 1.0])), float(r2.choice([0.01, 0.1, 0.5]))
+    t = O.Tree(c, b_max, b_min, int(r2.integers(3)))
+    for k, v in t.export().items():
+        out["rnd_%d_%s" % (i, k)] = v
+    leaf, _, dist = t.search(c + r2.normal(size=c.shape) * 0.01, want_dist=True)
+    out["rnd_%d_leaf" % i], out["rnd_%d_dist" % i] = leaf, dist
 T = pb["keyframe_poses"][1]
 t = O.Tree(pb["keyframe_scans"][1], B_MAX, B_MIN, 2)
 t.transform(T[:3, :3], T[:3, 3])
@@ -177,7 +197,7 @@ def test_stand_in_plumbing(both):
 def test_tree_build_leaf_order_and_transform(both):
     """mad_tree.cpp:47-130 (split, leaf representative, plane predecessor, small-leaf normal), :154-163, :165-172"""
     orc, ref = both
-    _same(orc, ref, _keys(orc, "tree_") + _keys(orc, "transformed_"))
+    _same(orc, ref, _keys(orc, "tree_") + _keys(orc, "transformed_") + _keys(orc, "rnd_"))
     assert orc["tree_street_0.2_2_left"].size > 1000  # a real tree, not a stub
 
 
