@@ -182,3 +182,23 @@ def test_thread_budget_changes_nothing_but_time(natives):
                 assert capi.HostTree(scan, 0.2, 0.1, par).nodes.tobytes() == ref, (threads, par)
     finally:
         capi.host_lib().madicp_host_set_threads(1 << 20)
+
+
+def test_random_small_clouds():
+    """Sixty random small clouds — blobs, sheets, lines, duplicates at random scales and thresholds, the inputs of
+    tests/test_reference_structure_pin.py's random leg — through the product's builder and the oracle's: the corners of the
+    leaf rule, the plane-predecessor rule and the small-leaf normal (mad_tree.cpp:64-93), bit for bit."""
+    r2 = np.random.default_rng(77)
+    for i in range(60):
+        n = int(r2.integers(1, 400))
+        kind = int(r2.integers(4))
+        c = r2.normal(size=(n, 3)) * r2.choice([0.01, 0.3, 5.0], size=3)
+        if kind == 1:
+            c[:, 2] = 0.0
+        elif kind == 2:
+            c[:, 1:] = 0.0
+        elif kind == 3:
+            c = np.repeat(c[: max(1, n // 4)], 4, axis=0)
+        c = c + r2.normal(size=3) * 10.0
+        b_max, b_min = float(r2.choice([1e-5, 0.05, 0.2, 1.0])), float(r2.choice([0.01, 0.1, 0.5]))
+        assert_same_tree(c, b_max, b_min, int(r2.integers(3)))
