@@ -120,3 +120,46 @@ def test_maximum_number_of_keyframes(ctx):
     for t in tids:
         ctx.tree_release(t)
     ctx.moving_release(mid)
+
+
+@pytest.mark.gpu
+def test_random_small_clouds_nearest_neighbour_and_linearisation(ctx):
+    """The sixty random small clouds of the structure pin and the host-builder test (blobs, sheets, lines, duplicates at random
+    scales and thresholds, 1 .. 400 points) on the device: nearest neighbours and distances against the oracle's, and one
+    linearisation of each cloud's own leaves against its tree — correspondences and gate bit for bit.  Trees of one, two,
+    three leaves, leaves without a normal of their own, NaN-free or not: whatever the reference builds, the kernels walk."""
+    r2 = np.random.default_rng(77)
+    checked = 0
+    for i in range(60):
+        n = int(r2.integers(1, 400))
+        kind = int(r2.integers(4))
+        c = r2.normal(size=(n, 3)) * r2.choice([0.01, 0.3, 5.0], size=3)
+        if kind == 1:
+            c[:, 2] = 0.0
+        elif kind == 2:
+            c[:, 1:] = 0.0
+        elif kind == 3:
+            c = np.repeat(c[: max(1, n // 4)], 4, axis=0)
+        c = c + r2.normal(size=3) * 10.0
+        b_max, b_min = float(r2.choice([1e-5, 0.05, 0.2, 1.0])), float(r2.choice([0.01, 0.1, 0.5]))
+        par = int(r2.integers(3))
+        ht = capi.HostTree(c, b_max, b_min, par)
+        ot = O.Tree(c, b_max, b_min, par)
+        tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+        q = c + r2.normal(size=c.shape) * 0.01
+        got = ctx.nn_search(tid, q, want=("leaf", "dist"))
+        leaf, _, dist = ot.search(q, want_dist=True)
+        assert np.array_equal(got["leaf"], leaf), i
+        assert np.array_equal(got["dist"], dist, equal_nan=True), i
+        mid = ctx.moving_upload(ht.leaf_means())
+        T0 = np.eye(4)
+        T0[:3, 3] = r2.normal(size=3) * 0.02
+        g = ctx.icp_linearize(mid, [tid], T0, (b_max, RHO_KER, B_RATIO), ht.num_leaves)
+        _, _, corr, rej, mat, depth = O.icp_linearize(ot, ot, T0, b_max, RHO_KER, B_RATIO)
+        assert np.array_equal(g["corr"][0] & 0x7FFFFFFF, corr), i
+        assert np.array_equal((g["corr"][0] >> 31).astype(np.uint8), rej), i
+        assert g["visits"] == depth, i
+        ctx.moving_release(mid)
+        ctx.tree_release(tid)
+        checked += 1
+    assert checked == 60
