@@ -100,6 +100,37 @@ def test_device_tree_build_vs_host_builder(ctx, name):
     ctx.cloud_release(cid)
 
 
+def test_device_tree_build_on_random_small_clouds(ctx):
+    """Sixty random small clouds (blobs, sheets, lines, duplicates at random scales and thresholds, 1 .. 400 points) through
+    the device builder: always a valid tree with the exact properties (preorder, leaf ordinals, every leaf mean a member of the
+    cloud and its own nearest neighbour), the leaf count the host builder's to within one leaf in fifty, and the same bytes
+    from the look-ahead entry."""
+    r2 = np.random.default_rng(77)
+    for i in range(60):
+        n = int(r2.integers(1, 400))
+        kind = int(r2.integers(4))
+        c = r2.normal(size=(n, 3)) * r2.choice([0.01, 0.3, 5.0], size=3)
+        if kind == 1:
+            c[:, 2] = 0.0
+        elif kind == 2:
+            c[:, 1:] = 0.0
+        elif kind == 3:
+            c = np.repeat(c[: max(1, n // 4)], 4, axis=0)
+        c = c + r2.normal(size=3) * 10.0
+        b_max, b_min = float(r2.choice([1e-5, 0.05, 0.2, 1.0])), float(r2.choice([0.01, 0.1, 0.5]))
+        r2.integers(3)  # (the host tests' parallel level: keeps the three tests on the same clouds)
+        ht, cid, tid, nodes = build_both(ctx, c, b_max, b_min)
+        check_exact_properties(ctx, c, tid, nodes)
+        nl = (nodes.shape[0] + 1) // 2
+        assert abs(nl - ht.num_leaves) <= max(2, ht.num_leaves // 50), (i, nl, ht.num_leaves)
+        ctx.tree_build_begin(c, b_max, b_min)
+        t2, nl2 = ctx.tree_build_end()
+        assert nl2 == nl and ctx.tree_download(t2, nodes.shape[0]).tobytes() == nodes.tobytes(), i
+        ctx.tree_release(t2)
+        ctx.tree_release(tid)
+        ctx.cloud_release(cid)
+
+
 def test_dense_tree_self_query_is_exact(ctx):
     """apps/utils/tools/nn_search.py:55-61 on a device-built tree: b_max = 1e-5, every point queried, total error 0."""
     pts = street_problem(2)["query_scans"][0]
