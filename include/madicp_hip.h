@@ -264,6 +264,11 @@ int madicp_tree_build_cancel(madicp_ctx* ctx);
 int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t* out_n_leaves);
 /* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] nodes handled one-per-lane, out[2..65] nodes handled one-per-wavefront per level, out[66..129] nodes handled chip-wide per level */
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
+/* diagnostics (tests): the (n,3) points of the last madicp_tree_build on this context in the order the construction left
+ * them — every leaf's members as the splits above it ordered them, i.e. the caller's container after the reference's
+ * MADtree::build (mad_tree.cpp:95-97 with utils.h:37-52; the reference additionally overwrites a leaf's first member with
+ * the leaf's representative, mad_tree.cpp:76-84).  Valid until the next build, ingest or deskew on the context. */
+int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n);
 
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
 /* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte

@@ -50,6 +50,10 @@ void madicp_host_set_threads(int n);
  * reference's own loop (impl 0) or by the builder's flag-driven closed form (impl 1); returns the split position
  * (first point of the right part), -1 on bad arguments.  Both must leave the same permutation. */
 int64_t madicp_host_debug_partition(double* points, int64_t n, const double mean[3], const double normal[3], int impl);
+/* Test hook: MADtree::build on the CALLER's buffer — points (n,3) are permuted in place exactly like the reference permutes
+ * its private copy (utils.h:37-52 at every internal node, and mad_tree.cpp:76-84 at every leaf: the representative is
+ * written over the leaf's first member); returns the number of leaves, -1 on bad arguments. */
+int64_t madicp_host_debug_tree_points(double* points, int64_t n, double b_max, double b_min, int max_parallel_level);
 /* Pipeline::deskew (mad_icp/src/odometry/pipeline.cpp:79-123) on its own, in place, output in azimuth order; poses as 12
  * doubles (R row-major, t).  route 0: the azimuth order from the task pool (unique when the azimuths are distinct), the
  * reference's serial std::sort of (azimuth, point) pairs when two of them tie; route 1: always the reference's route.

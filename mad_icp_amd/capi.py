@@ -105,6 +105,7 @@ def hip_lib():
         L.madicp_tree_build_cancel.argtypes = [C.c_void_p]
         L.madicp_tree_info.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
         L.madicp_tree_build_stats.argtypes = [C.c_void_p, _i32p]
+        L.madicp_debug_tree_build_points.argtypes = [C.c_void_p, _dp, C.c_int64]
         L.madicp_comm_unique_id.argtypes = [_u8p]
         L.madicp_comm_init.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
         L.madicp_comm_destroy.argtypes = [C.c_void_p]
@@ -137,6 +138,8 @@ def host_lib():
         L.madicp_host_tree_rho2.restype = C.c_double
         L.madicp_host_tree_rho2.argtypes = [C.c_void_p]
         L.madicp_host_debug_deskew.argtypes = [_dp, C.c_int64, _dp, _dp, C.c_double, C.c_int, _dp]
+        L.madicp_host_debug_tree_points.restype = C.c_int64
+        L.madicp_host_debug_tree_points.argtypes = [_dp, C.c_int64, C.c_double, C.c_double, C.c_int]
         L.madicp_host_debug_partition.restype = C.c_int64
         L.madicp_host_debug_partition.argtypes = [_dp, C.c_int64, _dp, _dp, C.c_int]
         _host = L
@@ -225,6 +228,17 @@ class HostTree:
     @property
     def rho2(self):
         return host_lib().madicp_host_tree_rho2(self._h)
+
+
+def host_tree_points(points, b_max, b_min, max_parallel_level=0):
+    """The cloud as the host builder's construction leaves it (the reference's container after MADtree::build): every
+    leaf's members in the order the splits produced, the leaf's first member overwritten by its representative."""
+    pts = np.ascontiguousarray(points, dtype=np.float64).copy()
+    nl = host_lib().madicp_host_debug_tree_points(pts.ctypes.data_as(_dp), pts.shape[0], float(b_max), float(b_min),
+                                                  int(max_parallel_level))
+    if nl < 0:
+        raise MadIcpError("madicp_host_debug_tree_points: bad arguments")
+    return pts, int(nl)
 
 
 def host_deskew(points, T_prev, T_now, sensor_hz, route=0):
@@ -383,6 +397,12 @@ class Context:
         out = np.zeros(130, np.int32)
         _check(hip_lib().madicp_tree_build_stats(self._h, out.ctypes.data_as(_i32p)))
         return dict(max_level=int(out[0]), lane_subtrees=int(out[1]), wave_nodes=out[2:66].copy(), chip_nodes=out[66:130].copy())
+
+    def tree_build_points(self, n):
+        """the points of the last synchronous device build in the order the construction left them (diagnostics)"""
+        out = np.empty((int(n), 3))
+        _check(hip_lib().madicp_debug_tree_build_points(self._h, out.ctypes.data_as(_dp), int(n)))
+        return out
 
     # ---- moving ----
     def moving_upload(self, leaf_means):

@@ -121,6 +121,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
   const size_t o_p1 = take(sizeof(double) * 18 * slots * (tb::kChipLevels + 1));
   const size_t o_p2 = take(sizeof(double) * 8 * slots);
+  const size_t o_tab = take(sizeof(int32_t) * ((size_t)nc + 8));
   const size_t o_key0 = take(sizeof(double) * (size_t)nc);
   const size_t o_key1 = take(sizeof(double) * (size_t)nc);
   const size_t o_idx0 = take(sizeof(uint32_t) * (size_t)nc);
@@ -150,6 +151,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.partLR = reinterpret_cast<double*>(b + o_p1);
   fs.P.part_stride = (long)(18 * slots);
   fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
+  fs.P.tab = reinterpret_cast<int32_t*>(b + o_tab);
   fs.S = reinterpret_cast<uint32_t*>(b + o_S);
   fs.tile_sums = reinterpret_cast<uint32_t*>(b + o_tiles);
   fs.P.S = fs.S;
@@ -739,6 +741,31 @@ int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t
   if (it == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
   if (out_n_nodes) *out_n_nodes = it->second.n_nodes;
   if (out_n_leaves) *out_n_leaves = it->second.n_leaves;
+  return MADICP_OK;
+}
+
+// Diagnostics (tests): the points of the last synchronous build on this context in the order the construction left them —
+// every leaf's members in the order the splits above it produced (reference: the caller's container after MADtree::build,
+// mad_tree.cpp:95-97 with utils.h:37-52, except that the reference also overwrites a leaf's first member with its
+// representative, mad_tree.cpp:76-84).  Valid until the next build, ingest or deskew on the context.
+int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n) {
+  if (!ctx || !out_xyz) return fail(MADICP_ERR_INVALID, "null argument");
+  if (!ctx->front || !ctx->front->scratch.block || !ctx->front->scratch.h_line) return fail(MADICP_ERR_INVALID, "no build yet");
+  RC_TRY(busy_with_lookahead(ctx));
+  FrontScratch& fs = ctx->front->scratch;
+  const tb::Params& P = fs.fly.P;
+  if (n != P.n_points) return fail(MADICP_ERR_INVALID, "n is not the size of the last build's cloud");
+  HIP_TRY(hipSetDevice(ctx->device));
+  void* d_out = nullptr;
+  RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)n, ctx->copy, &d_out));
+  const int n_nodes = fs.h_line->n_nodes;
+  hipLaunchKernelGGL(tb::tb_debug_order, dim3((n_nodes + 3) / 4), dim3(256), 0, ctx->copy, P, n_nodes, static_cast<double*>(d_out));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out_xyz, d_out, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->copy);
+  const hipError_t e2 = hipStreamSynchronize(ctx->copy);
+  pool_free(ctx, d_out, nullptr);
+  if (e != hipSuccess || e2 != hipSuccess)
+    return fail(MADICP_ERR_DEVICE, std::string("tree build points: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return MADICP_OK;
 }
 

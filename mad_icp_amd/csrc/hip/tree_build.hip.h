@@ -5,15 +5,18 @@
 // Same decisions as the reference, node by node — mean / sample covariance of the node's points (utils.h:54-73), the
 // closed-form eigen-decomposition (common/eig3.h, the one source the host builder uses), extents in the eigen frame with 0
 // included (utils.h:75-97), leaf rule bbox(2) < b_max, normal inheritance from the top-most flat ancestor or the nearest
-// ancestor with >= 3 points (mad_tree.cpp:64-74), leaf mean snapped to the member nearest the centroid (:76-86), split
-// at the centroid along the largest eigenvector (:95-97) — but NOT the same bits: the reference adds a node's points
-// one after the other in the order its in-place partition left them, a serial chain that no parallel machine can
-// follow, and the eigen-solver's atan2 / cos / sin come from a different math library.  Every sum here has a FIXED
-// shape (lane-strided partial sums, xor butterfly, chunk partials in chunk order) and the partition is deterministic
-// (chip regime: stable; wave and quad regimes: lefts in order from the front, rights in REVERSE order from the end of the
-// node's range), so a build is bit-reproducible run to run and independent of scheduling; against the host builder it agrees node for node
-// except where a decision sits within rounding of its threshold (tests/test_gpu_frontend.py states the measured
-// rates and the pose bound).
+// ancestor with >= 3 points (mad_tree.cpp:64-74), leaf mean snapped to the member nearest the centroid, FIRST member on
+// ties (:76-86), split at the centroid along the largest eigenvector (:95-97) — and the same MEMBER ORDER: every node's
+// points end up in the permutation the reference's in-place `split` (utils.h:37-52) leaves, in all three regimes
+// (common/split_order.h: the closed form per point, from the side flags and two rank tables — pinned against the
+// reference's loop on the CPU, tests/test_split_order.py).  The order decides which member represents a leaf whenever two
+// members tie in distance to the centroid (every two-point leaf does), and with it the device-built tree has the host
+// builder's leaf representatives except where a decision sits within rounding of its threshold.  What is NOT the same
+// bits: the reference adds a node's points one after the other in that order, a serial chain that no parallel machine
+// can follow, and the eigen-solver's atan2 / cos / sin come from a different math library — centroids, split normals and
+// extents differ in their last bits.  Every sum here has a FIXED shape (lane-strided partial sums, xor butterfly, chunk
+// partials in chunk order), so a build is bit-reproducible run to run and independent of scheduling
+// (tests/test_gpu_frontend.py states the measured rates and the pose bound).
 //
 // What bounds it.  The arithmetic is nothing (~150 M lane-instructions for a 120 k-point scan: microseconds of the
 // chip); a node needs sums -> eigen-solve (~1300 dependent fp64 instructions, ~5 us on one wave) -> extents -> partition in
@@ -42,6 +45,7 @@
 #include <stdint.h>
 
 #include "../common/eig3.h"
+#include "../common/split_order.h"
 #include "madicp_hip.h"
 
 #pragma clang fp contract(off)
@@ -53,6 +57,7 @@ namespace tb {
 #define MADICP_TB_SMALL 32
 #endif
 constexpr int kSmallMax = MADICP_TB_SMALL;  // quad regime: a node with at most this many points is handled by four lanes
+static_assert(kSmallMax <= 32, "the quad regime keeps a node's side flags in one 32-bit word");
 #ifndef MADICP_TB_CHIP_MIN
 #define MADICP_TB_CHIP_MIN 512
 #endif
@@ -125,6 +130,10 @@ struct Params {
                         // a small child of a chip node reads its block when its step comes, levels later.
   long part_stride;
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
+  int32_t* tab;         // (n_points) rank tables of the split's permutation (common/split_order.h), one slice per node — its
+                        // own point range [b, e): the positions (relative to b) of the points that go left, in order, from
+                        // the front of the slice, of those that go right from its back.  Wave regime: written and read by the
+                        // node's wavefront; chip regime: written per chunk by tb_chip_stats, read by tb_chip_scatter.
   int32_t n_points;
   double b_max, b_min;
   int32_t first_step;   // wave / quad nodes created above this level wait in its queues: while the chip regime runs (levels
@@ -460,16 +469,17 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
 #pragma unroll
     for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(touch[u]));  // (the touches are consumed here, not before)
     if (lane == 0) TB_STAMP_MAX(level, 5);
-    // ONE sweep for the rest: extents in the eigen frame, the side of every point, and — speculatively, before the leaf
-    // test can be made — the scatter (lefts ascending from b, rights DESCENDING from e - 1: no count needed in advance;
-    // a node that turns out to be a leaf simply leaves its half of the other buffer unused) and the children's sums
+    // Sweep A: extents in the eigen frame, the side of every point, the children's sums, and the two rank tables of the
+    // split's permutation (common/split_order.h) — the positions of the points that go left, in order, from the front of
+    // the node's slice of P.tab, of those that go right from its back.  A point's rank is the running count of the ballots
+    // before it; nothing of this needs the totals, so it runs before the leaf test can be made.
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double* __restrict__ out = level_out(P, level);
-    int lpos = b, rpos = e - 1;
+    int32_t* tab = P.tab;
+    int lcount = 0;  // lefts in front of the current 64 points (wave-uniform)
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
-        const int i0 = base + lane;
+      const int i0 = base + lane;
       double x[kWU], y[kWU], z[kWU];
       bool ok[kWU];
       TB_LOAD4(in, i0, e, b, x, y, z, ok)
@@ -481,15 +491,14 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
           minmax_update(lo, hi, v);
         }
         const bool left = ok[u] && v[2] < 0.0;  // the split test of mad_tree.cpp:96 (v[2] holds its very products)
-        const unsigned long long lm = __ballot(left), vm = __ballot(ok[u]);
-        const unsigned long long rm = vm & ~lm;
+        const unsigned long long lm = __ballot(left);
         if (ok[u]) {
-          const long d = left ? lpos + __popcll(lm & lt) : rpos - __popcll(rm & lt);
-          out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+          const int p = i0 + 64 * u - b;
+          const int lbp = lcount + __popcll(lm & lt);
+          tab[left ? (long)b + lbp : (long)e - 1 - (p - lbp)] = p;
           if (left) add_point(sL, x[u], y[u], z[u]); else add_point(sR, x[u], y[u], z[u]);
         }
-        lpos += __popcll(lm);
-        rpos -= __popcll(rm);
+        lcount += __popcll(lm);
       }
     }
     if (lane == 0) TB_STAMP_MAX(level, 6);
@@ -499,11 +508,47 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
       hi[a] = wave_max_keep(hi[a]);
       ext[a] = hi[a] - lo[a];
     }
-    const int nl = lpos - b;
+    const int nl = lcount;
     if (lane == 0) nd.bbox0 = ext[0];
     const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
     if (!leaf) {
       const int mid = b + nl;
+      {  // Sweep B: every point to the place the reference's `split` (utils.h:37-52) would have left it in.  The tables were
+         // written by this wavefront: its stores have to be complete before its loads (other lanes') go looking for them.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double* __restrict__ out = level_out(P, level);
+        int lc2 = 0;
+        for (int base = b; base < e; base += 64 * kWU) {
+          const int i0 = base + lane;
+          double x[kWU], y[kWU], z[kWU];
+          bool ok[kWU];
+          TB_LOAD4(in, i0, e, b, x, y, z, ok)
+          int dst[kWU];
+#pragma unroll
+          for (int u = 0; u < kWU; ++u) {  // (the same products as in sweep A: the same sides)
+            double v[3] = {0, 0, 0};
+            if (ok[u]) eigen_coords(V, mean, x[u], y[u], z[u], v);
+            const bool left = ok[u] && v[2] < 0.0;
+            const unsigned long long lm = __ballot(left);
+            dst[u] = 0;
+            if (ok[u]) {
+              const madicp_host::SplitPlan sp2 = madicp_host::split_plan(left, i0 + 64 * u - b, lc2 + __popcll(lm & lt), nl, n);
+              dst[u] = sp2.idx;
+              if (sp2.kind == 1) dst[u] = tab[(long)e - 1 - sp2.idx];
+              if (sp2.kind == 2) dst[u] = tab[(long)b + sp2.idx] - 1;
+            }
+            lc2 += __popcll(lm);
+          }
+#pragma unroll
+          for (int u = 0; u < kWU; ++u)
+            if (ok[u]) {
+              const long d = (long)b + dst[u];
+              out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+            }
+        }
+      }
       {  // the children's 18 sums are only needed by lane 0 (it writes the child records): through LDS — every lane
          // stores its 18 partials (column-major, conflict-free), lanes 0..17 add one column each in lane order, lane 0
          // collects — instead of 18 xor butterflies through the LDS crossbar (216 ds_bpermute: ~3 us of every node)
@@ -613,11 +658,12 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
   double mean[3], cov[9], w[3], V[9];
   mean_cov_from_sums(s, max(n, 1), mean, cov);
   madicp_host::eig3_sym(cov, w, V);
+  // Sweep A: extents, the children's sums, and the side of every point — the quad's four bits of a wave ballot per step,
+  // collected into ONE word per node (bit p = the point at position p goes left): the word is all the split's permutation
+  // needs (common/split_order.h, the rank tables of the larger regimes become bit selects)
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  double* __restrict__ out = level_out(P, level);
-  int lpos = b, rpos = e - 1;
-  const unsigned int below = (1u << ql) - 1u;
+  unsigned int mask = 0;
   double nx, ny, nz;
   load_pt(0, nx, ny, nz);
   for (int st = 0; st < steps; ++st) {  // (wave-uniform trip count; the next point is requested before this one is used)
@@ -630,15 +676,11 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
       minmax_update(lo, hi, v);
     }
     const bool left = valid && v[2] < 0.0;
-    const unsigned int lm = (unsigned int)(__ballot(left) >> qshift) & 0xfu, vm = (unsigned int)(__ballot(valid) >> qshift) & 0xfu;
-    const unsigned int rm = vm & ~lm;
+    const unsigned int lm = (unsigned int)(__ballot(left) >> qshift) & 0xfu;
+    mask |= lm << (4 * st);
     if (valid) {
-      const long d = left ? lpos + __popc(lm & below) : rpos - __popc(rm & below);
-      out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
       if (left) add_point(sL, x, y, z); else add_point(sR, x, y, z);
     }
-    lpos += __popc(lm);
-    rpos -= __popc(rm);
   }
   double ext[3];
 #pragma unroll
@@ -651,8 +693,21 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
     }
     ext[a] = hi[a] - lo[a];
   }
-  const int nl = lpos - b;
+  const int nl = __popc(mask);
   const bool leaf = !have || (ext[2] < P.b_max) || nl == 0 || nl == n;
+  // Sweep B (internal nodes): every point to the place the reference's `split` (utils.h:37-52) would have left it in
+  {
+    double* __restrict__ out = level_out(P, level);
+    for (int st = 0; st < steps; ++st) {
+      const int pp = 4 * st + ql;
+      if (!leaf && pp < n) {
+        const long j = (long)b + pp;
+        const double x = in[3 * j], y = in[3 * j + 1], z = in[3 * j + 2];
+        const long d = (long)b + madicp_host::split_dst_small(mask, n, pp);
+        out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+      }
+    }
+  }
   // (both branches below keep whole quads together: `leaf` is the same in the four lanes of a node)
 #pragma unroll
   for (int k = 0; k < 9; ++k) {  // outside the branch: the shuffles need every lane
@@ -937,7 +992,7 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
   __shared__ double s_part[256][9];
   __shared__ double s_tot[9], s_mean[3], s_V[9];
   __shared__ double s_lo[4][3], s_hi[4][3];
-  __shared__ int s_nl[4];
+  __shared__ int s_cnt[8][4];  // lefts per (row of 256 points, wavefront) of the chunk
   const int cnt = chip_prefix(P, level, s_off);
   const int total = s_off[cnt];
   const double* __restrict__ in = level_in(P, level);
@@ -992,7 +1047,12 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
     for (int k = 0; k < 9; ++k) V[k] = s_V[k];
     const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    int nl = 0;
+    // The sides of the chunk's points and, from them, the chunk's slice of the rank tables of the split's permutation
+    // (common/split_order.h): the positions (relative to the node's first point) of the chunk's lefts, in order, from the
+    // front of tab[cb, ce), of its rights from the back.  Point 256 u + t of the chunk belongs to thread t: its rank is
+    // the lefts of the rows and waves in front of it (LDS) plus those of the lower lanes of its own ballot.
+    unsigned int lbits = 0;
+    int inw[8];
     {
       double x[8], y[8], z[8];
       bool ok[8];
@@ -1003,27 +1063,50 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
         const long j = ok[u] ? i : cb;
         x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
       }
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 8; ++u) {
+        double v[3] = {0, 0, 0};
         if (ok[u]) {
-          double v[3];
           eigen_coords(V, mean, x[u], y[u], z[u], v);
           minmax_update(lo, hi, v);
-          nl += (v[2] < 0.0) ? 1 : 0;
         }
+        const bool left = ok[u] && v[2] < 0.0;
+        const unsigned long long lm = __ballot(left);
+        inw[u] = __popcll(lm & lt);
+        lbits |= (left ? 1u : 0u) << u;
+        if (lane == 0) s_cnt[u][wv] = __popcll(lm);
+      }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       lo[a] = wave_min_keep(lo[a]);
       hi[a] = wave_max_keep(hi[a]);
     }
-    nl = wave_sum_int(nl);
     if (lane == 0) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
-      s_nl[wv] = nl;
     }
     __syncthreads();
+    int run = 0;
+    {
+      int32_t* __restrict__ tab = P.tab;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int pre = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if (w == wv) pre = run;
+          run += s_cnt[u][w];
+        }
+        const int q = 256 * u + (int)threadIdx.x;  // position in the chunk
+        if (cb + q < ce) {
+          const int rank = pre + inw[u];
+          const int pnode = cm.chunk * kChunk + q;
+          tab[((lbits >> u) & 1u) ? (long)cb + rank : (long)ce - 1 - (q - rank)] = pnode;
+        }
+      }
+    }
     if (threadIdx.x == 0) {
       double L[3], H[3];
 #pragma unroll
@@ -1037,18 +1120,23 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
         P.part2[(long)slot * 8 + a] = L[a];
         P.part2[(long)slot * 8 + 3 + a] = H[a];
       }
-      P.part2[(long)slot * 8 + 6] = (double)(s_nl[0] + s_nl[1] + s_nl[2] + s_nl[3]);
+      P.part2[(long)slot * 8 + 6] = (double)run;  // the chunk's lefts
     }
     __syncthreads();
   }
 }
 
-// C3: leaf test, children, stable scatter of the chunk
+// C3: leaf test, children, and the scatter of the chunk — every point to the place the reference's `split`
+// (utils.h:37-52) would have left it in (common/split_order.h).  A point that needs a rank-table entry finds the chunk
+// that holds it by a search over the exclusive prefix of the node's per-chunk left counts (LDS), then reads the entry that
+// chunk's tb_chip_stats wrote.
+constexpr int kPrefMax = 4096;  // prefix entries held in LDS; a node with more chunks is searched coarsely, then walked
 __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level) {
   __shared__ int s_off[kMaxBig + 1];
-  __shared__ double s_p2[256][7];
   __shared__ double s_lo[3], s_hi[3];
-  __shared__ int s_before, s_left_total;
+  __shared__ double s_p2[256][7];
+  __shared__ int s_pref[kPrefMax + 1];
+  __shared__ int s_before, s_carry;
   __shared__ int s_wsum[4];
   __shared__ double s_cs[4][18];
   const int cnt = chip_prefix(P, level, s_off);
@@ -1061,15 +1149,33 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
     const int id = level_big(P, level)[cm.node_slot];
     BNode& nd = P.nodes[id];
     const int b = nd.begin, e = nd.end, n = e - b;
+    int shift = 0;
+    while ((cm.n_chunks >> shift) > kPrefMax) ++shift;
+    const int n_gran = (cm.n_chunks + (1 << shift) - 1) >> shift;
     if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0.0; s_hi[threadIdx.x] = 0.0; }
-    if (threadIdx.x == 3) { s_before = 0; s_left_total = 0; }
-    for (int base = 0; base < cm.n_chunks; base += 256) {
+    if (threadIdx.x == 3) { s_before = 0; s_carry = 0; }
+    __syncthreads();
+    for (int base = 0; base < cm.n_chunks; base += 256) {  // the node's chunks, 256 at a time
       const int c = base + threadIdx.x;
-      if (c < cm.n_chunks) {
+      const bool on = c < cm.n_chunks;
+      if (on) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) s_p2[threadIdx.x][k] = P.part2[(long)(cm.first_slot + c) * 8 + k];
       }
+      const int v = on ? (int)s_p2[threadIdx.x][6] : 0;
+      int incl = v;  // exclusive prefix of the left counts: wave scans + the four wave totals + what came before
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+      }
+      if (lane == 63) s_wsum[wv] = incl;
       __syncthreads();
+      int off = s_carry;
+      for (int k = 0; k < wv; ++k) off += s_wsum[k];
+      const int excl = off + incl - v;
+      if (on && (c & ((1 << shift) - 1)) == 0) s_pref[c >> shift] = excl;
+      if (on && c == cm.chunk) s_before = excl;
       const int m = min(256, cm.n_chunks - base);
       if (threadIdx.x < 3) {
         const int a = threadIdx.x;
@@ -1081,20 +1187,15 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
         }
         s_lo[a] = L;
         s_hi[a] = H;
-      } else if (threadIdx.x == 3) {
-        int before = s_before, tot = s_left_total;
-        for (int c2 = 0; c2 < m; ++c2) {
-          const int v = (int)s_p2[c2][6];
-          if (base + c2 < cm.chunk) before += v;
-          tot += v;
-        }
-        s_before = before;
-        s_left_total = tot;
       }
       __syncthreads();
+      if (threadIdx.x == 0) s_carry = s_carry + s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+      __syncthreads();
     }
+    if (threadIdx.x == 0) s_pref[n_gran] = s_carry;
+    __syncthreads();
     const double ext0 = s_hi[0] - s_lo[0], ext2 = s_hi[2] - s_lo[2];
-    const int nl = s_left_total, before = s_before;
+    const int nl = s_carry, before = s_before;
     const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
     const int mid = b + nl;
     double mean[3], col2[3];
@@ -1131,7 +1232,7 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       nd.mid = mid;
       nd.flags |= kDone;
     }
-    // thread t owns points cb + 8 t .. cb + 8 t + 7 (consecutive: one scan keeps the partition stable)
+    // thread t owns points cb + 8 t .. cb + 8 t + 7 (consecutive: one scan gives every point its count of lefts in front)
     const int cb = b + cm.chunk * kChunk, ce = min(cb + kChunk, e);
     const int i0 = cb + 8 * (int)threadIdx.x;
     double px[8], py[8], pz[8];
@@ -1181,16 +1282,34 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
     __syncthreads();
     int wave_off = 0;
     for (int k = 0; k < wv; ++k) wave_off += s_wsum[k];
-    const int lefts_before = wave_off + incl - mine;                   // in this chunk, before this thread
-    const int valid_before = min(8 * (int)threadIdx.x, ce - cb);       // points of this chunk before this thread
-    const int chunk_points_before = cm.chunk * kChunk;                 // points of the node before this chunk
-    long lpos = (long)b + before + lefts_before;
-    long rpos = (long)mid + (chunk_points_before - before) + (valid_before - lefts_before);
+    int lrun = before + wave_off + incl - mine;  // lefts of the NODE in front of this thread's first point
+    const int32_t* __restrict__ tab = P.tab;
+    const double* __restrict__ p2 = P.part2 + (long)cm.first_slot * 8;
+    auto lefts_of = [p2](int c) { return (int)p2[(long)c * 8 + 6]; };
+    int dst[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      dst[k] = 0;
+      if (k < nvalid) {
+        const bool left = (lmask >> k) & 1u;
+        const madicp_host::SplitPlan pl = madicp_host::split_plan(left, cm.chunk * kChunk + 8 * (int)threadIdx.x + k, lrun, nl, n);
+        dst[k] = pl.idx;
+        if (pl.kind == 1) {
+          int c, local;
+          madicp_host::find_right_chunk(s_pref, n_gran, shift, cm.n_chunks, kChunk, n, pl.idx, lefts_of, c, local);
+          dst[k] = tab[(long)b + min(n, (c + 1) * kChunk) - 1 - local];
+        } else if (pl.kind == 2) {
+          int c, local;
+          madicp_host::find_left_chunk(s_pref, n_gran, shift, cm.n_chunks, pl.idx, lefts_of, c, local);
+          dst[k] = tab[(long)b + (long)c * kChunk + local] - 1;
+        }
+        lrun += left ? 1 : 0;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (k < nvalid) {
-        const bool left = (lmask >> k) & 1u;
-        const long d = left ? lpos++ : rpos++;
+        const long d = (long)b + dst[k];
         out[3 * d] = px[k]; out[3 * d + 1] = py[k]; out[3 * d + 2] = pz[k];
       }
     }
@@ -1392,6 +1511,18 @@ __global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, 
     o.leaf_id = -1;
   }
   out[idx] = o;
+}
+
+// ---- diagnostics: the cloud in the order the construction left it (madicp_debug_tree_build_points) --------------------
+// A leaf's members stay where the split of its parent put them — range [begin, end) of the point buffer its level reads.
+// One wavefront per temporary node; internal nodes have nothing to copy.
+__global__ __launch_bounds__(256) void tb_debug_order(const Params P, int n_nodes, double* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n_nodes) return;
+  const BNode& nd = P.nodes[i];
+  if (!(nd.flags & kLeaf)) return;
+  const double* __restrict__ in = level_in(P, nd.level);
+  for (long j = 3 * (long)nd.begin + lane; j < 3 * (long)nd.end; j += 64) out[j] = in[j];
 }
 
 // ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---

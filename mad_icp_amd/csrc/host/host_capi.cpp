@@ -60,6 +60,11 @@ int64_t madicp_host_debug_partition(double* points, int64_t n, const double mean
   return madicp_host::debug_partition(points, n, mean, normal, impl);
 }
 
+int64_t madicp_host_debug_tree_points(double* points, int64_t n, double b_max, double b_min, int max_parallel_level) {
+  if (!points || n <= 0) return -1;
+  return madicp_host::build_tree(points, n, b_max, b_min, max_parallel_level).num_leaves();
+}
+
 // Pipeline::deskew on its own (csrc/host/deskew.h).  route 0: the parallel azimuth order, the reference's serial sort when
 // two azimuths tie; route 1: the reference's route always.  Returns 1 when the parallel order was used, 0 when the serial
 // route ran, < 0 on bad arguments.

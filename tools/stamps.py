@@ -19,9 +19,18 @@ from mad_icp_amd import _build  # noqa: E402
 so = os.environ.get("MADICP_STAMPS_LIB", os.path.join(ROOT, "tools", "libmadicp_hip_stamps.so"))
 os.makedirs(os.path.dirname(so), exist_ok=True)
 src = os.path.join(_build.CSRC, "hip", "madicp_capi.hip")
-if "--build" in sys.argv or not os.path.exists(so):
+# rebuilt whenever the sources changed (a stale copy lacks the current ABI's symbols and capi.hip_lib() refuses it):
+# the hash of the sources it was built from sits beside it
+want = _build.hip_source_hash()
+stamp = so + ".srchash"
+have = open(stamp).read().strip() if os.path.exists(stamp) and os.path.exists(so) else ""
+if "--build" in sys.argv or "--build-only" in sys.argv or have != want:
     subprocess.check_call([_build.HIPCC] + _build.HIP_FLAGS + ["-DMADICP_STAMPS", "-I" + _build.INC,
                                                             "-I" + os.path.join(_build.CSRC, "hip"), src, "-o", so, "-lrccl"])
+    with open(stamp, "w") as f:
+        f.write(want)
+if "--build-only" in sys.argv:
+    sys.exit(0)
 os.environ["MADICP_HIP_LIB"] = so
 from mad_icp_amd import capi, synth  # noqa: E402
 
