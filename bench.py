@@ -717,7 +717,7 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                     "(host), %d distinct scans cycled, upload/read-back streamed inside the timed region"
                     % (len(pb["query_scans"][0]), K, N_ITERS, N_DISTINCT),
                     {"keyframes": K, "scans_in_flight": 1, "moving_leaves": Ls, "map_nodes_this_rank": n_nodes,
-                     "parallelism": "single GPU"})
+                     "parallelism": "single GPU"}, warmup_run=max(args.warmup, MIN_WARMUP))
     out.update({
         "nn_mqueries_per_s": round(value * float(np.mean(Ls)) * K * N_ITERS / 1e6, 1),
         "nn_mqueries_note": "(leaf, tree, round) pairs resolved per second = value x L x K x 15; pairs whose descent is "

@@ -98,6 +98,8 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * end of each launch; bit-identical, measured slower — profiles/r3_j_xcd_fold_negative.md), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
  * registration's collectives before it aborts the communicator and returns MADICP_ERR_COMM)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
+/* the current value of one of the keys above (a caller that changes an option of a context it shares puts it back) */
+int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value);
 
 /* ---- MAD-tree (fixed side) ---------------------------------------------------------------------- */
 /* Upload a linearised tree.  Replaces keeping `MADtree*` alive in Frame::tree_ (frame.h:47).  The node array is
@@ -283,8 +285,10 @@ int madicp_comm_destroy(madicp_ctx* ctx);
 
 /* The same sharded registration over a HOST-STAGED transport supplied by the caller (MPI, gloo, a socket ...) instead of
  * RCCL: after every round's icp_reduce the library copies this rank's [H(21) b(6) n v w] per scan to pinned host memory,
- * waits for it (bounded: "comm_timeout_ms"), calls `fn` — which must leave the element-wise reduction over all ranks in
- * `buf` on every rank — and copies the totals back in front of the next round; the matched flags go through the same
+ * waits for that copy (only this rank's own kernels are in front of it: no peer can stall it), calls `fn` — which must
+ * leave the element-wise reduction over all ranks in `buf` on every rank, and whose own time-out is the only bound on a
+ * peer that never joins ("comm_timeout_ms" covers RCCL's collectives, not the caller's transport) — and copies the totals
+ * back in front of the next round; the matched flags go through the same
  * call once with MADICP_REDUCE_MAX_U8.  Kernel sequence, summation order inside a rank and the K = 0 rank are exactly
  * those of the RCCL path: it is the way to run (and test) the multi-rank product path where RCCL cannot form a
  * communicator — e.g. two ranks sharing one GPU — and a fallback where there is no xGMI/RDMA path between the ranks.

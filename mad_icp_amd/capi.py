@@ -61,7 +61,9 @@ def hip_lib():
         L.madicp_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.madicp_ctx_destroy.argtypes = [C.c_void_p]
         L.madicp_ctx_synchronize.argtypes = [C.c_void_p]
+        L.madicp_ctx_get_option.argtypes = [C.c_void_p, C.c_char_p, _i64p]
         L.madicp_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.madicp_ctx_get_option.argtypes = [C.c_void_p, C.c_char_p, _i64p]
         L.madicp_tree_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _ip]
         L.madicp_tree_upload_trusted.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, _ip]
         L.madicp_tree_release.argtypes = [C.c_void_p, C.c_int]
@@ -275,6 +277,11 @@ class Context:
 
     def set_option(self, key, value):
         _check(hip_lib().madicp_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        _check(hip_lib().madicp_ctx_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
 
     # ---- trees ----
     def tree_upload(self, nodes, n_leaves):

@@ -333,6 +333,18 @@ inline void wait_pause(const madicp_ctx* ctx) {
     __builtin_ia32_pause();
 }
 
+// A collective that will not complete: the communicator is aborted (which releases the kernels parked on the stream), the
+// graphs that captured its calls are dropped, the context falls back to one rank.  Always MADICP_ERR_COMM.
+int comm_abort(madicp_ctx* ctx, const std::string& why) {
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+  ctx->graphs.clear();
+  if (ctx->comm) ncclCommAbort(ctx->comm);
+  ctx->comm = nullptr;
+  ctx->n_ranks = 1;
+  ctx->rank = 0;
+  return fail(MADICP_ERR_COMM, why + "; communicator aborted");
+}
+
 // Host wait for everything enqueued on `s`.  Without a communicator this is hipStreamSynchronize.  With one, a peer
 // that never joins a collective would park this rank's stream for ever: poll instead, ask RCCL for asynchronous errors,
 // and after "comm_timeout_ms" abort the communicator — the hang becomes MADICP_ERR_COMM.
@@ -350,18 +362,10 @@ int bounded_sync(madicp_ctx* ctx, hipStream_t s) {
       ncclResult_t ar = ncclSuccess;
       const bool bad = ncclCommGetAsyncError(ctx->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress;
       const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-      if (bad || ms > ctx->comm_timeout_ms) {
-        const std::string why = bad ? std::string("RCCL asynchronous error: ") + ncclGetErrorString(ar)
-                                    : "a collective did not complete within " + std::to_string(ctx->comm_timeout_ms) +
-                                          " ms (a rank did not join?)";
-        for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
-        ctx->graphs.clear();
-        ncclCommAbort(ctx->comm);  // releases the kernels parked on the stream
-        ctx->comm = nullptr;
-        ctx->n_ranks = 1;
-        ctx->rank = 0;
-        return fail(MADICP_ERR_COMM, why + "; communicator aborted");
-      }
+      if (bad || ms > ctx->comm_timeout_ms)
+        return comm_abort(ctx, bad ? std::string("RCCL asynchronous error: ") + ncclGetErrorString(ar)
+                                   : "a collective did not complete within " + std::to_string(ctx->comm_timeout_ms) +
+                                         " ms (a rank did not join?)");
     }
     if (spins < 256)
       __builtin_ia32_pause();
@@ -973,6 +977,31 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   return MADICP_OK;
 }
 
+int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) {
+  if (!ctx || !key || !out_value) return fail(MADICP_ERR_INVALID, "null argument");
+  const std::string k(key);
+  int64_t v = 0;
+  if (k == "grid_blocks_per_cu") v = ctx->blocks_per_cu;
+  else if (k == "use_graph") v = ctx->use_graph;
+  else if (k == "comm_graph") v = ctx->comm_graph;
+  else if (k == "cache_correspondences") v = ctx->cache_corr;
+  else if (k == "lds_stage_min_leaves") v = ctx->stage_min_leaves;
+  else if (k == "eager_when_busy") v = ctx->eager_when_busy;
+  else if (k == "seq_completion") v = ctx->seq_completion;
+  else if (k == "host_feed_wait") v = ctx->host_feed_wait;
+  else if (k == "xcd_fold") v = ctx->xcd_fold;
+  else if (k == "match_all_rounds") v = ctx->match_all;
+  else if (k == "persistent") v = ctx->persistent;
+  else if (k == "wait_mode") v = ctx->wait_mode;
+  else if (k == "wait_timeout_ms") v = ctx->wait_timeout_ms;
+  else if (k == "comm_timeout_ms") v = ctx->comm_timeout_ms;
+  else if (k == "nn_lds_top") v = ctx->nn_lds_top;
+  else if (k == "queries_per_lane") v = ctx->qpt_override;
+  else return fail(MADICP_ERR_INVALID, "unknown option: " + k);
+  *out_value = v;
+  return MADICP_OK;
+}
+
 // ---- trees ------------------------------------------------------------------------------------------
 namespace {
 
@@ -1449,8 +1478,12 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
         if (bounded) {
           const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
           if (ctx->comm && ms > ctx->comm_timeout_ms) {
+            // over the limit: unless the results arrived this very moment the communicator is aborted and the ticket is
+            // gone — never MADICP_OK without the results copied out, and no second wait of comm_timeout_ms
+            if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) break;
             sl.pending = false;
-            return bounded_sync(ctx, ctx->stream);  // (already over its limit: aborts the communicator, MADICP_ERR_COMM)
+            return comm_abort(ctx, "a collective did not complete within " + std::to_string(ctx->comm_timeout_ms) +
+                                       " ms (a rank did not join?)");
           }
           if (ctx->wait_timeout_ms > 0 && ms > ctx->wait_timeout_ms)
             return fail(MADICP_ERR_TIMEOUT, "registration still in flight after wait_timeout_ms; collect the ticket again");

@@ -40,16 +40,25 @@ void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool trunc
   // A loop the caller cut short (Pipeline's realtime budget): the reference only resets matched_ in iteration
   // MAX_ICP_ITS - 1, so after an early break the flags are the OR of every round that ran (pipeline.cpp:167-176); and a
   // round count that changes from frame to frame must not instantiate hipGraphs inside a time-critical frame.
+  // The context is shared by everything in the process that goes through Device::ctx(): what this call changes it puts
+  // back to what it FOUND (another user's use_graph = 0 for profiling survives a truncated or eager frame).
   struct Restore {
     madicp_ctx* c;
-    bool match_all, no_graph;
-    ~Restore() {
-      if (match_all) madicp_ctx_set_option(c, "match_all_rounds", 0);
-      if (no_graph) madicp_ctx_set_option(c, "use_graph", 1);
+    int64_t match_all = -1, use_graph = -1;  // -1: untouched
+    void set(const char* key, int64_t value, int64_t& saved) {
+      int64_t was = 0;
+      check(madicp_ctx_get_option(c, key, &was), "madicp_ctx_get_option");
+      if (was == value) return;
+      check(madicp_ctx_set_option(c, key, value), "madicp_ctx_set_option");
+      saved = was;
     }
-  } restore{ctx, truncated, truncated || eager};
-  if (truncated) check(madicp_ctx_set_option(ctx, "match_all_rounds", 1), "madicp_ctx_set_option");
-  if (truncated || eager) check(madicp_ctx_set_option(ctx, "use_graph", 0), "madicp_ctx_set_option");
+    ~Restore() {
+      if (match_all >= 0) madicp_ctx_set_option(c, "match_all_rounds", match_all);
+      if (use_graph >= 0) madicp_ctx_set_option(c, "use_graph", use_graph);
+    }
+  } restore{ctx};
+  if (truncated) restore.set("match_all_rounds", 1, restore.match_all);
+  if (truncated || eager) restore.set("use_graph", 0, restore.use_graph);
   std::vector<int> ids;
   ids.reserve(fixed.size());
   for (MADtree* t : fixed) ids.push_back(t->deviceId());

@@ -60,8 +60,35 @@ void Pipeline::waitPrefetched() {
     if (a.order.valid()) a.order.wait();
 }
 
+// A look-ahead result belongs to the scan it was computed from: size, end points and a digest of a strided sample of the
+// points (up to 1024 of them, every coordinate's bit pattern) — a re-filtered, jittered or padded copy with the same size
+// and end points does not get another scan's tree.
+static uint64_t cloud_digest(const ContainerType& c) {
+  const size_t n = c.size(), step = std::max<size_t>(1, n / 1024);
+  uint64_t h = 0x9e3779b97f4a7c15ull ^ n;
+  for (size_t i = 0; i < n; i += step) {
+    uint64_t w[3];
+    std::memcpy(w, c[i].data(), 24);
+    for (int k = 0; k < 3; ++k) {
+      h ^= w[k] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+      h = (h << 13) | (h >> 51);
+    }
+  }
+  return h;
+}
+Pipeline::DevKey Pipeline::DevKey::of(const ContainerType& c) {
+  DevKey k;
+  k.n = c.size();
+  if (!c.empty()) {
+    k.first = c.front();
+    k.last = c.back();
+    k.digest = cloud_digest(c);
+  }
+  return k;
+}
 bool Pipeline::DevKey::matches(const ContainerType& c) const {
-  return n == c.size() && std::memcmp(first.data(), c.front().data(), 24) == 0 && std::memcmp(last.data(), c.back().data(), 24) == 0;
+  return n == c.size() && n > 0 && std::memcmp(first.data(), c.front().data(), 24) == 0 &&
+         std::memcmp(last.data(), c.back().data(), 24) == 0 && digest == cloud_digest(c);
 }
 
 void Pipeline::collectDeviceLookAhead() {
@@ -80,9 +107,7 @@ void Pipeline::beginStagedLookAhead() {
   collectDeviceLookAhead();  // (the one slot: whatever was in flight is collected first)
   dev_pending_ = MADtree::beginDeviceBuild(cloud, b_max_, b_min_);
   if (!dev_pending_) return;
-  dev_pending_key_.n = cloud.size();
-  dev_pending_key_.first = cloud.front();
-  dev_pending_key_.last = cloud.back();
+  dev_pending_key_ = DevKey::of(cloud);
 }
 
 void Pipeline::dropDeviceLookAhead(bool staged_too) {
@@ -153,9 +178,7 @@ void Pipeline::prefetch(ContainerType next_cloud) {
       deskew_ahead_.pop_front();
     }
     DeskewAhead a;
-    a.key.n = next_cloud.size();
-    a.key.first = next_cloud.front();
-    a.key.last = next_cloud.back();
+    a.key = DevKey::of(next_cloud);
     a.order = std::async(std::launch::async, [cloud = std::move(next_cloud)]() { return deskew_order(cloud); });
     deskew_ahead_.push_back(std::move(a));
     return;
@@ -165,9 +188,7 @@ void Pipeline::prefetch(ContainerType next_cloud) {
     prefetched_.pop_front();
   }
   Prefetched p;
-  p.n = next_cloud.size();
-  p.first = next_cloud.front();
-  p.last = next_cloud.back();
+  p.key = DevKey::of(next_cloud);
   const double b_max = b_max_, b_min = b_min_;
   const int levels = max_parallel_levels_;
   p.tree = std::async(std::launch::async, [cloud = std::move(next_cloud), b_max, b_min, levels]() mutable {
@@ -250,8 +271,7 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
     // the look-ahead built for exactly this scan, if there is one; older look-aheads are for scans that never came
     for (size_t q = 0; q < prefetched_.size(); ++q) {
       const Prefetched& p = prefetched_[q];
-      if (p.n == curr_cloud.size() && std::memcmp(p.first.data(), curr_cloud.front().data(), 24) == 0 &&
-          std::memcmp(p.last.data(), curr_cloud.back().data(), 24) == 0) {
+      if (p.key.matches(curr_cloud)) {
         for (size_t d = 0; d < q; ++d) {
           if (prefetched_.front().tree.valid()) prefetched_.front().tree.wait();
           prefetched_.pop_front();
@@ -325,7 +345,8 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
   icp_.setMoving(*current_tree);
   icp_.init(prediction);
 
-  const float preprocessing_time = float(now_ms() - t_pre);
+  const float preprocessing_time = virtual_pre_ms_ >= 0 ? float(virtual_pre_ms_) : float(now_ms() - t_pre);
+  if (virtual_pre_ms_ >= 0) round_ms_estimate_ = virtual_round_ms_;
   const double t_icp = now_ms();
   // The reference re-checks its wall-clock budget before every round: round k runs iff preprocessing + the k rounds run
   // so far + ONE MORE round's time (its `icp_time` term: the duration of the round before, counted a second time) still
@@ -353,6 +374,7 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
     matched_leaves = icp_.numMatched();
   }
   last_icp_ms_ = now_ms() - t_icp;
+  last_rounds_ = rounds;
   if (rounds > 0) round_ms_estimate_ = last_icp_ms_ / rounds;
 
   frame_to_map_ = icp_.X_;
@@ -411,7 +433,11 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
 
 // the reference's current_leaves_ are pointers into the current tree, so after compute() they read map-frame means
 // (pipeline.cpp:290-297); here they are materialised when asked for (the visualiser), not every frame
-const ContainerType Pipeline::currentLeaves() { return current_tree_view_ ? current_tree_view_->leafMeans() : ContainerType{}; }
+// pipeline.cpp:290-297: `current_leaves_` is filled by the first REGISTERED frame (pipeline.cpp:143-144); initialize() (:267-283)
+// leaves it empty, so the reference returns nothing after the first scan — mirrored
+const ContainerType Pipeline::currentLeaves() {
+  return (current_tree_view_ && trajectory_.size() > 1) ? current_tree_view_->leafMeans() : ContainerType{};
+}
 
 const ContainerType Pipeline::modelLeaves() {  // pipeline.cpp:299-308
   ContainerType leaves;

@@ -95,6 +95,11 @@ class Pipeline {
 
   // instrumentation (not in the reference)
   double lastInliersRatio() const { return last_inliers_ratio_; }
+  int lastRounds() const { return last_rounds_; }  // GN rounds the last frame ran (realtime = true can cut them short)
+  // Test seam for realtime = true: with pre_ms >= 0 the wall clock of the budget rule (pipeline.cpp:160-169) is replaced by
+  // a model — this frame's preprocessing took pre_ms, a GN round takes round_ms — so the round count is a deterministic
+  // function that can be held to the reference's per-round check (tests/test_boundary.py); pre_ms < 0: the wall clock again.
+  void setTimingForTest(double pre_ms, double round_ms) { virtual_pre_ms_ = pre_ms; virtual_round_ms_ = round_ms; }
   double lastIcpMs() const { return last_icp_ms_; }
   double lastBuildMs() const { return last_build_ms_; }
   size_t numKeyframes() const { return keyframes_.size(); }
@@ -119,11 +124,18 @@ class Pipeline {
   std::vector<Pose> trajectory_;
   MADtree* current_tree_view_ = nullptr;  // the last scan's tree (owned by a Frame in frames_ / keyframes_)
   size_t current_num_leaves_ = 0;
-  // look-ahead builds: up to two scans ahead, each identified by its size and end points (a prefetch(i + 1) issued BEFORE
-  // compute(i) must not cost scan i its tree)
-  struct Prefetched {
+  // what a look-ahead result is matched to its scan by: size, end points and a digest of a strided sample of the points
+  struct DevKey {
     size_t n = 0;
     Vector3d first{}, last{};
+    uint64_t digest = 0;
+    static DevKey of(const ContainerType& c);
+    bool matches(const ContainerType& c) const;
+  };
+  // look-ahead builds: up to three scans ahead of the one being consumed (kMaxLookAhead), each matched to its scan by its
+  // key (a prefetch(i + 1) issued BEFORE compute(i) must not cost scan i its tree)
+  struct Prefetched {
+    DevKey key;
     std::future<LinearTree> tree;
   };
   static constexpr size_t kMaxLookAhead = 4;  // scan i being consumed, up to three more building
@@ -132,11 +144,6 @@ class Pipeline {
   // device front-end: ONE construction in flight on the library's build stream (`dev_pending_`), and the tree of the scan
   // before it, collected when the next look-ahead was begun (`dev_ready_`) — with the call order prefetch(i + 1),
   // compute(i) the tree of scan i is collected at prefetch(i + 1) and scan i + 1 is built while scan i registers
-  struct DevKey {
-    size_t n = 0;
-    Vector3d first{}, last{};
-    bool matches(const ContainerType& c) const;
-  };
   // deskewed datasets: the tree needs the two previous poses, but the azimuth order of the scan does not — that half of
   // Pipeline::deskew (atan2 per point, the sort: most of a deskewed frame on the host) is what prefetch() computes ahead
   struct DeskewAhead {
@@ -153,6 +160,8 @@ class Pipeline {
   std::unique_ptr<MADtree> dev_ready_;
   void collectDeviceLookAhead();  // dev_pending_ -> dev_ready_
   void dropDeviceLookAhead(bool staged_too = true);  // forget both (and the scan staged for the next frame)
+  double virtual_pre_ms_ = -1.0, virtual_round_ms_ = 0.0;
+  int last_rounds_ = 0;
   double round_ms_estimate_ = 0.05;  // device time of one GN round, from the previous frame (realtime budget)
   bool device_frontend_ = false;
   bool deskew_, realtime_;

@@ -192,9 +192,15 @@ class TaskPool {
 
   TaskPool() {
     const int hw = static_cast<int>(std::max(1u, std::thread::hardware_concurrency()));
-    const int n = std::max(0, std::min(hw, 32) - 1);
+    // never more workers than CPUs this process may run on (a container's mask, taskset): workers poll while idle
+    cpu_set_t allowed;
+    const int usable = sched_getaffinity(0, sizeof(allowed), &allowed) == 0 ? std::max(1, CPU_COUNT(&allowed)) : hw;
+    const int n = std::max(0, std::min(std::min(hw, usable), 32) - 1);
     cpu_set_t where;
-    const bool pin = neighbourhood(&where);
+    // pinned to the creating thread's NUMA node / L3 neighbourhood only when that neighbourhood has room for the pool and its
+    // caller: on NPS4 parts or small masks the workers would otherwise queue on a handful of CPUs (MADICP_HOST_AFFINITY=none
+    // switches pinning off altogether)
+    const bool pin = neighbourhood(&where) && CPU_COUNT(&where) >= n + 1;
     threads_.reserve(static_cast<size_t>(n));
     for (int i = 0; i < n; ++i) {
       threads_.emplace_back([this, i] { worker(i); });

@@ -47,6 +47,8 @@ PYBIND11_MODULE(pypeline, m) {
          py::arg("stamp"), py::arg("records"), py::arg("min_range"), py::arg("max_range"), py::arg("kitti_correction") = false)
     // instrumentation, not in the reference
     .def("lastInliersRatio", &Pipeline::lastInliersRatio)
+    .def("lastRounds", &Pipeline::lastRounds)
+    .def("setTimingForTest", &Pipeline::setTimingForTest, py::arg("pre_ms"), py::arg("round_ms"))
     .def("lastIcpMs", &Pipeline::lastIcpMs)
     .def("lastBuildMs", &Pipeline::lastBuildMs)
     .def("numKeyframes", &Pipeline::numKeyframes);

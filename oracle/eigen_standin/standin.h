@@ -22,7 +22,10 @@
 // cannot see, so this header requires -DMADICP_REDUX_SCALAR_ONLY and the test compares against the oracle built the same
 // way; control flow does not depend on that switch.
 #pragma once
-#ifndef MADICP_REDUX_SCALAR_ONLY
+// (-DMADICP_STANDIN_TYPES_ONLY: a build that needs the TYPES only — the product's host layer compiled in its
+// `__has_include(<Eigen/Core>)` mode under the reference's bin_runner.cpp, oracle/build_bin_runner.sh; nothing on that path
+// evaluates a stand-in reduction whose order matters)
+#if !defined(MADICP_REDUX_SCALAR_ONLY) && !defined(MADICP_STANDIN_TYPES_ONLY)
 #error "the Eigen stand-in implements the scalar reduction order only: compile with -DMADICP_REDUX_SCALAR_ONLY"
 #endif
 // the standard headers Eigen/Core itself pulls in (unqualified abs / sqrt / sin in the reference resolve as they would)
@@ -54,8 +57,9 @@
 namespace Eigen {
 
 enum TransformTraits { Isometry = 1, Affine = 2 };
+enum StorageOptions { ColMajor = 0, RowMajor = 1 };
 
-template <typename S, int R, int C>
+template <typename S, int R, int C, int Opt = ColMajor>
 class Matrix;
 
 namespace standin {
@@ -80,9 +84,9 @@ class Segment3;
 
 }  // namespace standin
 
-template <typename S, int R, int C>
+template <typename S, int R, int C, int Opt>
 class Matrix {
-  static_assert(sizeof(S) == sizeof(double), "stand-in: double only");
+  static_assert(sizeof(S) == sizeof(double) && Opt == ColMajor, "stand-in: double, column-major only (Vector3f: below)");
 
  public:
   enum { Rows = R, Cols = C, Size = R * C };
@@ -103,6 +107,8 @@ class Matrix {
   const double& x() const { return d[0]; }
   const double& y() const { return d[1]; }
   const double& z() const { return d[2]; }
+  double* data() { return d; }
+  const double* data() const { return d; }
 
   Matrix& setZero() {
     for (double& v : d) v = 0.0;
@@ -165,6 +171,18 @@ class Matrix {
     }
   }
   double norm() const { return std::sqrt(squaredNorm()); }
+  // (bin_runner.cpp:155-157, the KITTI correction: orders as restated in tests/oracle_lib.py ingest_f32)
+  Matrix cross(const Matrix& o) const {
+    static_assert(Size == 3, "stand-in: cross of 3-vectors");
+    return Matrix(d[1] * o.d[2] - d[2] * o.d[1], d[2] * o.d[0] - d[0] * o.d[2], d[0] * o.d[1] - d[1] * o.d[0]);
+  }
+  Matrix normalized() const {
+    static_assert(Size == 3, "stand-in: normalized 3-vector");
+    const double sq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2];
+    if (!(sq > 0.0)) return *this;
+    const double n = std::sqrt(sq);
+    return Matrix(d[0] / n, d[1] / n, d[2] / n);
+  }
   double trace() const {
     static_assert(R == 3 && C == 3, "stand-in: trace of 3x3");
     return oracle::trace3(d[0], d[4], d[8]);
@@ -232,13 +250,39 @@ class Matrix {
     return Ldlt{*this};
   }
   Matrix inverse() const {
-    static_assert(R == 6 && C == 6, "stand-in: inverse of 6x6 (Isometry3d has its own)");
+    static_assert((R == 6 && C == 6) || (R == 4 && C == 4), "stand-in: inverse of 6x6 and 4x4 (Isometry3d has its own)");
+    if constexpr (R == 4) {  // bin_runner.cpp:255 (output formatting only): plain Gauss-Jordan with partial pivoting
+      double a[4][8];
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+          a[r][c] = (*this)(r, c);
+          a[r][4 + c] = r == c ? 1.0 : 0.0;
+        }
+      for (int k = 0; k < 4; ++k) {
+        int piv = k;
+        for (int r = k + 1; r < 4; ++r)
+          if (std::fabs(a[r][k]) > std::fabs(a[piv][k])) piv = r;
+        for (int c = 0; c < 8; ++c) std::swap(a[k][c], a[piv][c]);
+        const double p = a[k][k];
+        for (int c = 0; c < 8; ++c) a[k][c] /= p;
+        for (int r = 0; r < 4; ++r) {
+          if (r == k) continue;
+          const double f = a[r][k];
+          for (int c = 0; c < 8; ++c) a[r][c] -= f * a[k][c];
+        }
+      }
+      Matrix out;
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) out(r, c) = a[r][4 + c];
+      return out;
+    } else {
     oracle::Mat6 a;
     std::memcpy(a.m, d, sizeof(a.m));
     const oracle::Mat6 inv = oracle::inverse6(a);
     Matrix out;
     std::memcpy(out.d, inv.m, sizeof(inv.m));
     return out;
+    }
   }
   double determinant() const {
     static_assert(R == 6 && C == 6, "stand-in: determinant of 6x6");
@@ -431,5 +475,80 @@ class Transform {
   }
 };
 using Isometry3d = Transform<double, 3, Isometry>;
+
+// ---- what apps/cpp_runners/bin_runner.cpp needs beyond the hot path (oracle/build_bin_runner.sh) ----------------------
+// Vector3f (bin_runner.cpp:139-147): the float point read from the .bin record; norm() in float with the unrolled scalar
+// reduction x0 + (x1 + x2) — the restatement tests/oracle_lib.py ingest_f32 and the device ingest kernel share
+template <>
+class Matrix<float, 3, 1, ColMajor> {
+  float d[3];
+
+ public:
+  Matrix() {}
+  Matrix(float x, float y, float z) { d[0] = x, d[1] = y, d[2] = z; }
+  float x() const { return d[0]; }
+  float y() const { return d[1]; }
+  float z() const { return d[2]; }
+  float norm() const { return std::sqrt(d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])); }
+  template <typename T>
+  Matrix<T, 3, 1> cast() const {
+    return Matrix<T, 3, 1>(T(d[0]), T(d[1]), T(d[2]));
+  }
+};
+using Vector3f = Matrix<float, 3, 1>;
+
+// AngleAxisd(angle, unit axis) * vector (bin_runner.cpp:157): toRotationMatrix() in Eigen's operation order, then row . vector
+template <typename S>
+class AngleAxis {
+  double angle_;
+  Vector3d axis_;
+
+ public:
+  AngleAxis(double angle, const Vector3d& axis) : angle_(angle), axis_(axis) {}
+  Matrix3d toRotationMatrix() const {
+    const double s = std::sin(angle_), c = std::cos(angle_);
+    const Vector3d sin_axis(s * axis_[0], s * axis_[1], s * axis_[2]);
+    const Vector3d cos1_axis((1.0 - c) * axis_[0], (1.0 - c) * axis_[1], (1.0 - c) * axis_[2]);
+    Matrix3d res;
+    double tmp;
+    tmp = cos1_axis[0] * axis_[1];
+    res(0, 1) = tmp - sin_axis[2];
+    res(1, 0) = tmp + sin_axis[2];
+    tmp = cos1_axis[0] * axis_[2];
+    res(0, 2) = tmp + sin_axis[1];
+    res(2, 0) = tmp - sin_axis[1];
+    tmp = cos1_axis[1] * axis_[2];
+    res(1, 2) = tmp - sin_axis[0];
+    res(2, 1) = tmp + sin_axis[0];
+    res(0, 0) = cos1_axis[0] * axis_[0] + c;
+    res(1, 1) = cos1_axis[1] * axis_[1] + c;
+    res(2, 2) = cos1_axis[2] * axis_[2] + c;
+    return res;
+  }
+  Vector3d operator*(const Vector3d& p) const {
+    const Matrix3d Rm = toRotationMatrix();
+    Vector3d out;
+    for (int i = 0; i < 3; ++i) out[i] = Rm(i, 0) * p[0] + (Rm(i, 1) * p[1] + Rm(i, 2) * p[2]);
+    return out;
+  }
+};
+using AngleAxisd = AngleAxis<double>;
+
+// Map<Matrix<double, 4, 4, RowMajor>>(ptr) -> Matrix4d (bin_runner.cpp:240): sixteen row-major doubles read as a matrix
+template <typename M>
+class Map;
+template <>
+class Map<Matrix<double, 4, 4, RowMajor>> {
+  const double* p_;
+
+ public:
+  explicit Map(const double* p) : p_(p) {}
+  operator Matrix4d() const {
+    Matrix4d m;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) m(r, c) = p_[4 * r + c];
+    return m;
+  }
+};
 
 }  // namespace Eigen

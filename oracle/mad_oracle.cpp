@@ -470,8 +470,9 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud_mem) {
 
   float icp_time = 0;
   float total_icp_time = 0;
-  const float preprocessing_time = float(now_ms() - preprocessing_start);
+  const float preprocessing_time = virtual_pre_ms_ >= 0 ? float(virtual_pre_ms_) : float(now_ms() - preprocessing_start);
   const double loop_start = now_ms();
+  last_rounds_ = 0;
 
   for (size_t icp_iteration = 0; icp_iteration < size_t(MAX_ICP_ITS); ++icp_iteration) {
     const float remaining_time = loop_time - 5.0 - (preprocessing_time + total_icp_time + icp_time);
@@ -490,8 +491,9 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud_mem) {
     }
     icp_.updateState();
 
-    icp_time = float(now_ms() - icp_start);
+    icp_time = virtual_pre_ms_ >= 0 ? float(virtual_round_ms_) : float(now_ms() - icp_start);
     total_icp_time += icp_time;
+    ++last_rounds_;
   }
   last_icp_ms_ = now_ms() - loop_start;
 

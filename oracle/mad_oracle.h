@@ -138,6 +138,11 @@ class Pipeline {  // pipeline.h:45-103
   void compute(const double& curr_stamp, ContainerType curr_cloud_mem);
 
   // instrumentation (not in the reference)
+  // test seam for realtime = true (tests/test_boundary.py): when virtual_pre_ms_ >= 0 the wall clock of pipeline.cpp:160-169,
+  // 186-191 is replaced by a model — preprocessing took virtual_pre_ms_, every round virtual_round_ms_ — so that the
+  // reference's per-round budget check becomes a deterministic function the product's round-count rule can be held to
+  double virtual_pre_ms_ = -1.0, virtual_round_ms_ = 0.0;
+  int last_rounds_ = 0;              // GN rounds the last frame ran
   double last_icp_ms_ = 0.0;         // wall time of the GN loop, the region the reference itself times
   double last_inliers_ratio_ = 0.0;  // pipeline.cpp:204
   size_t numKeyframes() const { return keyframes_.size(); }

@@ -248,6 +248,11 @@ int64_t orc_pipeline_current_id(void* p) { return int64_t(static_cast<Pipeline*>
 int64_t orc_pipeline_keyframe_id(void* p) { return int64_t(static_cast<Pipeline*>(p)->keyframeID()); }
 int orc_pipeline_is_map_updated(void* p) { return static_cast<Pipeline*>(p)->isMapUpdated() ? 1 : 0; }
 int64_t orc_pipeline_num_keyframes(void* p) { return int64_t(static_cast<Pipeline*>(p)->numKeyframes()); }
+void orc_pipeline_set_virtual_times(void* p, double pre_ms, double round_ms) {
+  static_cast<Pipeline*>(p)->virtual_pre_ms_ = pre_ms;
+  static_cast<Pipeline*>(p)->virtual_round_ms_ = round_ms;
+}
+int orc_pipeline_last_rounds(void* p) { return static_cast<Pipeline*>(p)->last_rounds_; }
 double orc_pipeline_last_icp_ms(void* p) { return static_cast<Pipeline*>(p)->last_icp_ms_; }
 double orc_pipeline_last_inliers_ratio(void* p) { return static_cast<Pipeline*>(p)->last_inliers_ratio_; }
 int64_t orc_pipeline_current_leaves(void* p, double* out, int64_t cap) {

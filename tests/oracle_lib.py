@@ -68,6 +68,9 @@ def lib():
             getattr(L, name).restype = C.c_int64
             getattr(L, name).argtypes = [C.c_void_p]
         L.orc_pipeline_is_map_updated.argtypes = [C.c_void_p]
+        if hasattr(L, "orc_pipeline_set_virtual_times"):  # (the oracle's own test seam: the reference stand-in has none)
+            L.orc_pipeline_set_virtual_times.argtypes = [C.c_void_p, C.c_double, C.c_double]
+            L.orc_pipeline_last_rounds.argtypes = [C.c_void_p]
         L.orc_pipeline_last_icp_ms.restype = C.c_double
         L.orc_pipeline_last_icp_ms.argtypes = [C.c_void_p]
         L.orc_pipeline_last_inliers_ratio.restype = C.c_double
@@ -295,6 +298,13 @@ class Pipeline:
 
     def lastInliersRatio(self):
         return lib().orc_pipeline_last_inliers_ratio(self._h)
+
+    def setVirtualTimes(self, pre_ms, round_ms):
+        """test seam (realtime=True): the frame's preprocessing took pre_ms, every GN round round_ms (pre_ms < 0: wall clock)"""
+        lib().orc_pipeline_set_virtual_times(self._h, float(pre_ms), float(round_ms))
+
+    def lastRounds(self):
+        return lib().orc_pipeline_last_rounds(self._h)
 
     def currentLeaves(self):
         n = lib().orc_pipeline_current_leaves(self._h, None, 0)

@@ -1,0 +1,95 @@
+"""The reference's OWN C++ caller, apps/cpp_runners/bin_runner.cpp, compiled UNCHANGED against the product
+(oracle/build_bin_runner.sh: its <odometry/pipeline.h> is mad_icp_amd/csrc/host/pipeline.h in its Eigen-typed mode — the
+`__has_include(<Eigen/Core>)` branch of csrc/host/types.h —, Eigen and yaml-cpp are stand-ins, the GPU half is the shipped
+libmadicp_hip.so) and run on a KITTI-format directory: .bin records in, estimate.txt out (bin_runner.cpp:117-186,253-269),
+compared with the CPU oracle pipeline's poses on the same clouds.
+
+The binary is built where the reference is (this container, __graft_entry__.build()) into oracle/_ref/ and travels to the
+GPU box with the snapshot; without it the test skips."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from mad_icp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNNER = os.path.join(ROOT, "oracle", "_ref", "bin_runner")
+
+# mad_icp/configurations/default.cfg and datasets/kitti.cfg, value for value (configuration data, written out here because
+# /root/reference does not exist on the GPU box)
+MAD_ICP_CFG = """# mad-icp default params
+b_max : 0.2 # [m] max size of kd leaves
+b_min : 0.1 # [m] when a node is flatten than this param, propagate normal
+b_ratio : 0.02 # the increase factor of search radius needed in data association
+p_th : 0.8 # [%] ensuring an update when the curr point cloud is registered less than this param
+rho_ker : 0.1 # huber threshold in mad-icp
+n : 10 # the number of last poses to smooth velocity
+"""
+LIDAR_TO_BASE = np.array([[4.276802385584e-04, -9.999672484946e-01, -8.084491683471e-03, -1.198459927713e-02],
+                          [-7.210626507497e-03, 8.081198471645e-03, -9.999413164504e-01, -5.403984729748e-02],
+                          [9.999738645903e-01, 4.859485810390e-04, -7.206933692422e-03, -2.921968648686e-01],
+                          [0, 0, 0, 1]])
+DATASET_CFG = """# KITTI velodyne-64 params
+min_range : 0.7
+max_range : 120
+sensor_hz : 10
+deskew : False
+apply_correction: True
+lidar_to_base:
+""" + "".join("  - [%s]\n" % ", ".join("%.12e" % v for v in row) for row in LIDAR_TO_BASE)
+
+
+@pytest.mark.parametrize("kitti", [False, True])
+def test_reference_bin_runner_against_the_product(natives, tmp_path, kitti):
+    if not os.path.exists(RUNNER):
+        pytest.skip("oracle/_ref/bin_runner not built (oracle/build_bin_runner.sh needs /root/reference)")
+    scene = synth.Scene(4)
+    n_frames = 8
+    data = tmp_path / "velodyne"
+    data.mkdir()
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    records = []
+    for i in range(n_frames):
+        s = synth.render_scan(scene, synth.path_pose(0.8 * i), 300 + i, n_beams=32, n_azimuth=600)
+        rec = np.zeros((s.shape[0] + 3, 4), np.float32)
+        rec[:-3, :3] = s.astype(np.float32)
+        rec[:-3, 3] = 0.3
+        rec[-3] = [0.1, 0.1, 0.1, 0]      # below min_range: dropped (bin_runner.cpp:147-149)
+        rec[-2] = [np.nan, 1, 1, 0]       # dropped
+        rec[-1] = [300, 0, 0, 0]          # beyond max_range: dropped
+        rec.tofile(str(data / ("%06d.bin" % i)))
+        records.append(rec)
+    (tmp_path / "kitti.cfg").write_text(DATASET_CFG)
+    (tmp_path / "default.cfg").write_text(MAD_ICP_CFG)
+    cmd = [RUNNER, "-data_path", str(data), "-estimate_path", str(out_dir), "-dataset_config", str(tmp_path / "kitti.cfg"),
+           "-mad_icp_config", str(tmp_path / "default.cfg"), "-num_cores", "4", "-num_keyframes", "4"]
+    if kitti:
+        cmd.append("-kitti")
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "Loading frame # 0" in run.stdout and ("Loading frame # %d" % (n_frames - 1)) in run.stdout
+    est = np.loadtxt(str(out_dir / "estimate.txt")).reshape(-1, 3, 4)
+    assert est.shape[0] == n_frames
+    # the oracle pipeline on the same clouds: bin_runner.cpp:126-166 restated (float norm filter, optional KITTI correction),
+    # Pipeline(sensor_hz, deskew, b_max, rho_ker, p_th, b_min, b_ratio, num_keyframes, num_cores, realtime) as at :106-107,
+    # and the base-frame pose of writeTransformedPose (:253-269)
+    op = O.Pipeline(10.0, False, 0.2, 0.1, 0.8, 0.1, 0.02, 4, 4, False)
+    Linv = np.linalg.inv(LIDAR_TO_BASE)
+    worst = 0.0
+    for i, rec in enumerate(records):
+        op.compute(0.1 * i, O.ingest_f32(rec, 0.7, 120.0, int(kitti)))
+        want = (LIDAR_TO_BASE @ op.currentPose() @ Linv)[:3]
+        d = np.abs(est[i] - want).max()
+        worst = max(worst, d)
+        assert d <= 1e-5, (i, d)
+    gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(0.8 * (n_frames - 1))
+    if not kitti:  # (the correction tilts the synthetic scans, which need none: only the agreement is checked then)
+        got = Linv @ np.vstack([est[-1], [0, 0, 0, 1]]) @ LIDAR_TO_BASE
+        assert np.linalg.norm(got[:3, 3] - gt[:3, 3]) < 0.1
+    print("bin_runner vs oracle pipeline: worst coefficient difference %.2e" % worst)

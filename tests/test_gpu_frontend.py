@@ -9,12 +9,16 @@ What "parity" means here, stated per piece:
                     stable and the synthetic scans hold 64 points per azimuth column); with distinct azimuths the output
                     is the oracle's row for row.
   * tree build    — not bitwise, by construction (mad_icp_amd/csrc/hip/tree_build.hip.h: parallel sums, device
-                    trigonometry).  Measured on these inputs and asserted with margin: identical leaf count, identical
-                    topology wherever the leaf count is identical, every leaf mean is an input point, >= 90 % of the leaf
-                    means are the host builder's (measured 95-99 %; the rest are leaves whose members tie in distance to
-                    the centroid — every two-point leaf does — where "first member wins" depends on the member order,
-                    and the device's partition keeps lefts in order and writes rights in reverse), registrations
-                    against device-built maps land within 1 mm of registrations against host-built maps.
+                    trigonometry) — but the same decisions and the same MEMBER ORDER as the reference's in-place split
+                    (utils.h:37-52, common/split_order.h), so that "first member wins" (mad_tree.cpp:76-86) picks the host
+                    builder's representative.  Measured on these inputs and asserted: identical leaf count and topology,
+                    every leaf mean is an input point, on the scans and the Gaussian clouds EVERY leaf mean is the host
+                    builder's at the same leaf ordinal (asserted >= 99.9 %), the construction leaves the points in the
+                    host builder's order row for row (madicp_debug_tree_build_points), registrations against
+                    device-built maps land within 1e-4 m of registrations against host-built maps.  What differs: the
+                    last bits of centroids, split normals, leaf normals and extents (serial vs parallel sums, libm vs
+                    device atan2 / cos / sin), and with them decisions that sit within rounding of their threshold
+                    (equally spaced collinear points: three-point leaves whose outer members tie EXACTLY).
                     Exact properties that must hold regardless: valid DFS preorder (the validating upload accepts it),
                     leaf ordinals in getLeafs() order, a leaf mean queried against its own tree returns itself at
                     distance exactly 0 (the reference's nn_search.py property), bit-reproducible run to run, and the
@@ -79,17 +83,28 @@ def test_device_tree_build_vs_host_builder(ctx, name):
     ht, cid, tid, nodes = build_both(ctx, pts)
     check_exact_properties(ctx, pts, tid, nodes)
     nl = (nodes.shape[0] + 1) // 2
-    # statistical agreement with the host builder
-    assert abs(nl - ht.num_leaves) <= max(1, ht.num_leaves // 200), (nl, ht.num_leaves)
+    # the host builder's tree: same leaves, same topology, same leaf representatives at the same ordinals
+    assert nl == ht.num_leaves, (nl, ht.num_leaves)
     hn = ht.nodes
-    if nl == ht.num_leaves:
-        same_topology = np.mean(nodes["right"] == hn["right"])
-        assert same_topology >= 0.99, same_topology
-    shared = len(keyset(nodes["mean"][nodes["right"] == 0]) & keyset(hn["mean"][hn["right"] == 0])) / ht.num_leaves
+    assert np.array_equal(nodes["right"], hn["right"])
+    leaf = nodes["right"] == 0
+    same_mean = np.all(nodes["mean"][leaf].view(np.uint64) == hn["mean"][leaf].view(np.uint64), axis=1)
     if name == "expline36":
         assert ctx.tree_build_stats()["max_level"] > 20
-    if name not in ("line100",):  # (equally spaced collinear points: nearly every leaf is a two-point tie)
-        assert shared >= 0.90, shared
+    if name == "line100":  # (equally spaced collinear points: three-point leaves whose outer members tie exactly; measured 0.89)
+        assert same_mean.mean() >= 0.8, same_mean.mean()
+    else:
+        assert same_mean.mean() >= 0.999, (same_mean.mean(), int((~same_mean).sum()))
+    # ... and the same member order: the construction left the points where the host builder's in-place splits leave them
+    # (utils.h:37-52), row for row — except that the host, like the reference, also writes a leaf's representative over the
+    # leaf's first member (mad_tree.cpp:76-84)
+    d_order = ctx.tree_build_points(pts.shape[0])
+    h_order, _ = capi.host_tree_points(pts, B_MAX, B_MIN, 2)
+    same_row = np.all(d_order.view(np.uint64) == h_order.view(np.uint64), axis=1)
+    if name != "line100":
+        reps = keyset(hn["mean"][leaf])
+        assert all(bytes(h_order[i].view(np.uint8)) in reps for i in np.flatnonzero(~same_row))
+        assert keyset(d_order) == keyset(pts) and d_order.shape == pts.shape
     # bit-reproducible: a second build of the same cloud gives the same bytes
     t2, _ = ctx.tree_build(cid, B_MAX, B_MIN)
     assert ctx.tree_download(t2, nodes.shape[0]).tobytes() == nodes.tobytes()
@@ -162,8 +177,8 @@ def test_registration_against_device_built_map(ctx):
     rd = ctx.stream_collect(ctx.stream_submit_tree(qt, dev_t, T0, PARAMS, 15), nl)
     rh = ctx.stream_collect(ctx.stream_submit(qh.leaf_means(), host_t, T0, PARAMS, 15), qh.num_leaves)
     d = np.linalg.inv(rh["T"]) @ rd["T"]
-    assert np.linalg.norm(d[:3, 3]) <= 1e-3
-    assert np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)) <= 1e-4
+    assert np.linalg.norm(d[:3, 3]) <= 1e-4   # (measured 1e-6: identical representatives, last-bit normals)
+    assert np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)) <= 1e-5
     for r in (rd, rh):
         assert np.linalg.norm((np.linalg.inv(gt) @ r["T"])[:3, 3]) <= 0.02
     assert abs(rd["n_matched"] / nl - rh["n_matched"] / qh.num_leaves) <= 0.01
@@ -289,14 +304,25 @@ def _pose_err(Ta, Tb):
     return np.linalg.norm(d[:3, 3]), np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1))
 
 
-@pytest.mark.parametrize("deskew", [False, True])
-def test_pipeline_with_device_front_end(natives, drive, deskew, capsys):
+def _jittered(scans, seed=0):
+    """the same scans with 1e-7 m of noise: no two points share an azimuth any more, so std::sort's unspecified order among
+    ties (which the synthetic scans' 64-point azimuth columns are full of) stops separating host and device deskew"""
+    rng = np.random.default_rng(seed)
+    return [sc + rng.normal(scale=1e-7, size=sc.shape) for sc in scans]
+
+
+@pytest.mark.parametrize("deskew,jitter", [(False, False), (True, False), (True, True)])
+def test_pipeline_with_device_front_end(natives, drive, deskew, jitter, capsys):
     """Pipeline.compute with tree construction (and deskew) on the device against the same Pipeline on the host path.
-    The host path is the one held to 1e-5 against the oracle (tests/test_gpu_pipeline_fullsize.py); the device-built
-    trees differ from the host-built ones in a few per cent of their leaf representatives, so the bar here is
-    statistical: every pose within 5 mm (1 cm with deskew, where the two paths also order azimuth ties differently) /
-    1e-3 rad of the host path's (measured: 0.6 mm, 4 mm with deskew), same keyframe decisions on this drive, inlier
-    ratios within 1 %."""
+    The host path is the one held to 1e-5 against the oracle (tests/test_gpu_pipeline_fullsize.py).  Device-built trees
+    have the host builder's leaf representatives and differ in the last bits of normals and centroids, so the two
+    trajectories stay within 2e-4 m / 1e-4 rad — the reference's own sensitivity to Eigen's evaluation order (DESIGN.md 5;
+    measured 4.5e-6 m over this drive) — with the same keyframe decisions and inlier ratios within 1 %.  With deskew on the
+    bar is 1 cm, with or without azimuth ties (the jittered variant has none): the compensated cloud is a function of the
+    two previous POSES, which differ in their last bits between the two paths, and MAD-tree construction is chaotic in the
+    last bit of its input — a leaf of two points, whose members tie in distance to their midpoint up to rounding, flips its
+    representative; the oracle's own pose moves by millimetres under a 1-ulp change of the cloud — measured
+    4-5 mm here."""
     import time
 
     from mad_icp.src.pybind import pypeline as m
@@ -307,7 +333,9 @@ def test_pipeline_with_device_front_end(natives, drive, deskew, capsys):
     assert dev.deviceFrontEnd() and not host.deviceFrontEnd()
     worst = (0.0, 0.0)
     t_dev, t_host = [], []
-    for i, s in enumerate(drive):
+    scans = _jittered(drive) if jitter else drive
+    bar_t, bar_a = (2e-4, 1e-4) if not deskew else (1e-2, 1e-3)
+    for i, s in enumerate(scans):
         t = time.perf_counter()
         host.compute(0.1 * i, s)
         t_host.append(time.perf_counter() - t)
@@ -316,7 +344,7 @@ def test_pipeline_with_device_front_end(natives, drive, deskew, capsys):
         t_dev.append(time.perf_counter() - t)
         dt, da = _pose_err(np.asarray(host.currentPose()), np.asarray(dev.currentPose()))
         worst = (max(worst[0], dt), max(worst[1], da))
-        assert dt <= (1e-2 if deskew else 5e-3) and da <= 1e-3, (i, dt, da)
+        assert dt <= bar_t and da <= bar_a, (i, dt, da)
         assert host.currentID() == dev.currentID() and host.keyframeID() == dev.keyframeID()
         if i > 0:
             assert abs(host.lastInliersRatio() - dev.lastInliersRatio()) <= 0.01
@@ -329,23 +357,23 @@ def test_pipeline_with_device_front_end(natives, drive, deskew, capsys):
     if not deskew:  # (the synthetic scans are instantaneous: compensating them for motion moves them)
         assert np.linalg.norm(np.asarray(dev.currentPose())[:3, 3] - gt[:3, 3]) < 0.1
     with capsys.disabled():
-        print("\n[pipeline, device front-end, deskew=%s] worst deviation from the host path %.2e m / %.2e rad; per frame: device "
+        print("\n[pipeline, device front-end, deskew=%s%s] worst deviation from the host path %.2e m / %.2e rad; per frame: device "
               "front-end %.2f ms (tree+deskew %.2f ms), host path %.2f ms (build %.2f ms)"
-              % (deskew, worst[0], worst[1], 1e3 * np.median(t_dev[2:]), dev.lastBuildMs(), 1e3 * np.median(t_host[2:]),
+              % (deskew, " (jittered: no azimuth ties)" if jitter else "", worst[0], worst[1], 1e3 * np.median(t_dev[2:]), dev.lastBuildMs(), 1e3 * np.median(t_host[2:]),
                  host.lastBuildMs()))
 
 
-@pytest.mark.parametrize("deskew,n_frames", [(False, 200), (True, 100)])
-def test_device_front_end_is_accuracy_neutral_over_a_long_drive(natives, deskew, n_frames, capsys):
-    """The acceptance bar of the device front-end.  Device-built trees cannot be the
-    host builder's bit for bit (tree_build.hip.h), so the contract is stated against GROUND TRUTH over a long full-size
-    drive (1 m per frame, 120 k-point scans), device front-end next to the host path — the one held to 1e-5 against the
-    oracle:
-      * final and RMS translation error against ground truth: not worse than the host path's by more than 2 % + 1 mm
-        (measured over 200 frames: 0.0995 vs 0.0996 m final, 0.0644 vs 0.0646 m RMS);
-      * the two trajectories within 5 mm of each other at every frame (1.5 cm with deskew; measured 1.9 mm / 9.8 mm);
-      * the same number of keyframes promoted, and the same keyframe id on at least 99 % of the frames (a promotion can
-        move by one frame when the inlier ratio sits on p_th; measured: 1 frame of 200 differs, 0 of 100 with deskew)."""
+@pytest.mark.parametrize("deskew,jitter,n_frames", [(False, False, 200), (True, False, 100), (True, True, 100)])
+def test_device_front_end_over_a_long_drive(natives, deskew, jitter, n_frames, capsys):
+    """The acceptance bar of the device front-end over a long full-size drive (1 m
+    per frame, 120 k-point scans), device front-end next to the host path — the one held to 1e-5 against the oracle:
+      * the two trajectories within 2e-4 m of each other at EVERY frame (the reference's own sensitivity to Eigen's
+        evaluation order over 14 frames; measured here over 200 frames: see the printed line) — device-built
+        trees have the host builder's member order and leaf representatives, what differs is last bits;
+      * final and RMS translation error against ground truth equal to the host path's to 1 mm;
+      * the same keyframes promoted at the same frames.
+    With deskew on the bar is 1.5 cm, with or without azimuth ties: the compensated cloud depends on the previous poses'
+    last bits and tree construction is chaotic in the last bit of its input (see test_pipeline_with_device_front_end)."""
     from mad_icp.src.pybind import pypeline as m
 
     scene = synth.Scene(0)
@@ -354,8 +382,11 @@ def test_device_front_end_is_accuracy_neutral_over_a_long_drive(natives, deskew,
     dev.setDeviceFrontEnd(True)
     T0inv = np.linalg.inv(synth.path_pose(0.0))
     eh, ed, between, kf_h, kf_d = [], [], [], [], []
+    rng = np.random.default_rng(3)
     for i in range(n_frames):
         sc = synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i)
+        if jitter:
+            sc = sc + rng.normal(scale=1e-7, size=sc.shape)
         host.compute(0.1 * i, sc)
         dev.compute(0.1 * i, sc)
         gt = T0inv @ synth.path_pose(1.0 * i)
@@ -368,14 +399,19 @@ def test_device_front_end_is_accuracy_neutral_over_a_long_drive(natives, deskew,
     eh, ed, between = np.array(eh), np.array(ed), np.array(between)
     rms_h, rms_d = np.sqrt((eh ** 2).mean()), np.sqrt((ed ** 2).mean())
     with capsys.disabled():
-        print("\n[front-end acceptance, %d frames, deskew=%s] error vs ground truth: host final %.4f rms %.4f m | device final %.4f "
-              "rms %.4f m | device vs host max %.4f m | keyframe id differs on %d frames (%d / %d promoted)"
-              % (n_frames, deskew, eh[-1], rms_h, ed[-1], rms_d, between.max(), int(np.sum(np.array(kf_h) != np.array(kf_d))),
-                 len(set(kf_h)), len(set(kf_d))))
-    assert ed[-1] <= 1.02 * eh[-1] + 1e-3 and rms_d <= 1.02 * rms_h + 1e-3
-    assert between.max() <= (1.5e-2 if deskew else 5e-3)
-    assert len(set(kf_h)) == len(set(kf_d))
-    assert np.sum(np.array(kf_h) != np.array(kf_d)) <= max(1, n_frames // 100)
+        print("\n[front-end acceptance, %d frames, deskew=%s%s] error vs ground truth: host final %.4f rms %.4f m | device final %.4f "
+              "rms %.4f m | device vs host max %.3e m (median %.3e) | keyframe id differs on %d frames (%d / %d promoted)"
+              % (n_frames, deskew, " jittered" if jitter else "", eh[-1], rms_h, ed[-1], rms_d, between.max(), np.median(between),
+                 int(np.sum(np.array(kf_h) != np.array(kf_d))), len(set(kf_h)), len(set(kf_d))))
+    if not deskew:
+        assert between.max() <= 2e-4
+        assert abs(ed[-1] - eh[-1]) <= 1e-3 and abs(rms_d - rms_h) <= 1e-3
+        assert kf_h == kf_d
+    else:
+        assert ed[-1] <= 1.02 * eh[-1] + 1e-3 and rms_d <= 1.02 * rms_h + 1e-3
+        assert between.max() <= 1.5e-2
+        assert len(set(kf_h)) == len(set(kf_d))
+        assert np.sum(np.array(kf_h) != np.array(kf_d)) <= max(1, n_frames // 100)
 
 
 def test_pipeline_compute_records(natives, drive):
