@@ -94,7 +94,11 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * the OR over ALL its rounds instead of the last round's — what the reference's Pipeline leaves behind when its realtime
  * check ends the loop before iteration MAX_ICP_ITS - 1, the only one that resets them: pipeline.cpp:167-176),
  * "persistent" (0/1, default 0: all rounds of a single-GPU registration as ONE launch; bit-identical, measured slower —
- * profiles/r3_b_persist_negative.md), "xcd_fold" (0/1, default 0: per-round launches with the XCD-hierarchical join at the
+ * profiles/r3_b_persist_negative.md), "shard_split" (0/1/2, default 1: with a communicator, a batch of >= 4 scans (2: of >= 2
+ * scans) runs as two halves on two streams, so that one half's per-round all-reduce is in flight under the other half's round
+ * kernel; collectives are enqueued in one order on every rank), "shard_tail" (0/1, default 0: the sharded round kernel leaves
+ * the rank's adders itself instead of a separate icp_reduce launch; bit-identical, measured slower —
+ * profiles/r4_c_shard_probe.md), "xcd_fold" (0/1, default 0: per-round launches with the XCD-hierarchical join at the
  * end of each launch; bit-identical, measured slower — profiles/r3_j_xcd_fold_negative.md), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
  * registration's collectives before it aborts the communicator and returns MADICP_ERR_COMM)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);

@@ -1292,10 +1292,17 @@ constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100
 // WITHOUT the persistent launch.  Every workgroup publishes its row as granules; the leader of each group x = blockIdx.x & 7
 // waits for the group's rows at the END of the launch, folds them in the canonical order and publishes F[x]; the next
 // launch's wave 0 reads eight rows (3.8 KB) instead of every workgroup joining 256 (61 KB).
-template <int QPT, bool TRACE, bool FOLD = false>
+// TAIL (multi-GPU, keyframe sharding): the launch itself leaves this rank's share of the round's adders in
+// `totals_out` — what a separate icp_reduce launch did — so that the all-reduce can be enqueued directly behind the round.
+// Every workgroup publishes its row as tagged granules (like FOLD: the tag, not an ordering of stores, says when a row is
+// there) and takes a ticket; the workgroup that draws the last one folds the scan's rows in the canonical order (stage 1 by
+// all its threads, stage 2 by wave 0: the bits of icp_reduce) and resets the ticket.  `totals` (the reduced sums of the
+// PREVIOUS round, read in the prologue) and `totals_out` are the two parity halves of one buffer, never the same memory.
+template <int QPT, bool TRACE, bool FOLD = false, bool TAIL = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
     const Job* __restrict__ jobs, Job* __restrict__ jobs_out, double* __restrict__ partials,
-    const double* __restrict__ totals, int round, int n_iters, int K, int RPT, unsigned long long* __restrict__ xch) {
+    const double* __restrict__ totals, int round, int n_iters, int K, int RPT, unsigned long long* __restrict__ xch,
+    double* __restrict__ totals_out = nullptr, unsigned int* __restrict__ tickets = nullptr) {
   // (n_iters, K and ranges_per_tree are the same for every scan of the launch: as kernel arguments they are known
   // one memory round trip before anything read through `job`)
   // `jobs` and `jobs_out` are the SAME array: everything this kernel reads goes through the const restrict view, the
@@ -1546,12 +1553,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int wave = threadIdx.x >> 6;
   wave_reduce_scatter(acc, lane, red[wave]);
   const int n_walked = __syncthreads_count(walked ? 1 : 0);
-  const unsigned tag_now = FOLD ? (job->epoch << 8) + (unsigned)round + 1u : 0u;
+  const unsigned tag_now = (FOLD || TAIL) ? (job->epoch << 8) + (unsigned)round + 1u : 0u;
   if (threadIdx.x < kAcc) {
     double s = red[0][threadIdx.x];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) s += red[w][threadIdx.x];
-    if (FOLD)
+    if (FOLD || TAIL)
       granule_store((gptr_g64)(uintptr_t)xch + ((size_t)((round & 1) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * kRowGranules +
                         2 * threadIdx.x, tag_now, s);
     else
@@ -1559,6 +1566,65 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   }
   if (threadIdx.x == 0) hints[(round & 1) * hint_stride + hint_slot] = static_cast<double>(n_walked);
   MADICP_STAMP(6);
+  if (TAIL) {
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {  // (this wave issued the row's granules before the ticket; their tags tell the folder when they are there)
+      const unsigned t = __hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t + 1u == gridDim.x) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last) {  // (workgroup-uniform) every other workgroup of this scan has published its row
+      gptr_g64 src = (gptr_g64)(uintptr_t)xch + ((size_t)((round & 1) * gridDim.y + blockIdx.y) * gridDim.x) * kRowGranules;
+      bool expired = false;
+      const unsigned long long t_start = wall_clock64();
+      // stage 1 of the canonical order: seg[G] = 0 + row[G] + row[G + 48] + ... (rows no workgroup wrote are the zero rows
+      // of the padded layout: adding +0.0 is exact, skipping them gives the same bits)
+      for (int idx = threadIdx.x; idx < kJoinGroups * kAcc; idx += kBlock) {
+        const int G = idx / kAcc, c = idx - G * kAcc;
+        // the group's first kJoinRows rows (all of them up to 288 workgroups) are requested TOGETHER — one round trip to
+        // the other XCDs' rows, not one per row — and polled again only where a tag was not there yet
+        double v[kJoinRows];
+        bool ok[kJoinRows];
+#pragma unroll
+        for (int i = 0; i < kJoinRows; ++i) {
+          v[i] = 0.0;
+          ok[i] = G + kJoinGroups * i >= (int)gridDim.x;  // (a row nobody wrote: +0.0)
+        }
+        for (unsigned spins = 1;; ++spins) {
+          bool all = true;
+#pragma unroll
+          for (int i = 0; i < kJoinRows; ++i)
+            if (!ok[i]) {
+              ok[i] = granule_try(src + (size_t)(G + kJoinGroups * i) * kRowGranules + 2 * c, tag_now, v[i]);
+              all = all && ok[i];
+            }
+          if (all) break;
+          if ((spins & 63u) == 0u && wall_clock64() - t_start > kSpinLimitTicks) { expired = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < kJoinRows; ++i) a += v[i];
+        for (int row = G + kJoinGroups * kJoinRows; row < (int)gridDim.x; row += kJoinGroups) {  // (more than 288 workgroups only)
+          gptr_g64 g = src + (size_t)row * kRowGranules + 2 * c;
+          double w = 0.0;
+          for (unsigned spins = 1; !granule_try(g, tag_now, w); ++spins) {
+            if ((spins & 63u) == 0u && wall_clock64() - t_start > kSpinLimitTicks) { expired = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          a += w;
+        }
+        s_seg[G][c] = a;
+      }
+      if (__syncthreads_or(expired ? 1 : 0)) {
+        if (threadIdx.x == 0) jout->error = 1;
+      } else if (threadIdx.x < 64) {
+        join_stage2_wave0(s_seg, s_total);
+        if (threadIdx.x < kAcc) totals_out[blockIdx.y * kAcc + threadIdx.x] = s_total[threadIdx.x];
+      }
+      if (threadIdx.x == 0) tickets[blockIdx.y] = 0u;  // for the next launch (every workgroup of this one has drawn)
+    }
+  }
   if (FOLD && slot == 0) {  // (workgroup-uniform) the leader of group `xcd`: wait for the group's rows, fold, publish F[x]
     gptr_g64 src = (gptr_g64)(uintptr_t)xch + ((size_t)((round & 1) * gridDim.y + blockIdx.y) * gridDim.x + xcd) * kRowGranules;
     bool expired = false;
@@ -1999,6 +2065,13 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     job->host_out->n_matched = job->n_matched;
     __hip_atomic_store(&job->host_out->seq, job->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// development (option "debug_collective_us"): stands where a collective would — one wavefront that waits for `ticks` of the
+// 100 MHz wall clock — so that the launch structure around an all-reduce can be timed on a box with one GPU
+__global__ void debug_delay(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 // multi-GPU: this rank's partials of the round just linearised -> totals[scan][kAcc], then ncclAllReduce(sum)

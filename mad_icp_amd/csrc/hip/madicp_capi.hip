@@ -171,8 +171,11 @@ struct madicp_ctx {
   Job* h_fetch = nullptr;      // pinned read-back block
   double* d_partials = nullptr;
   size_t partials_cap = 0;     // doubles
-  int partials_grid = -1, partials_batch = -1;  // geometry the zero padding rows of d_partials are valid for
-  double* d_totals = nullptr;  // [MADICP_MAX_BATCH][kAcc]
+  long long partials_key = -1;  // the launch shape(s) the zero padding rows of d_partials are valid for
+  double* d_totals = nullptr;  // [2 round parities][MADICP_MAX_BATCH][kAcc]: this rank's adders of a sharded round, reduced in place
+  unsigned int* d_tickets = nullptr;  // [MADICP_MAX_BATCH]: arrival counters of icp_round's TAIL variant (zero between launches)
+  hipStream_t stream2 = nullptr;      // second half of a sharded batch (option "shard_split"); created on first use
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned long long* d_xch = nullptr;  // icp_persist's exchange granules (kernels.hip.h), sized for every admissible geometry
   uint32_t epoch = 0;          // one per enqueued registration: Job::epoch
   int last_batch = 0;
@@ -205,6 +208,14 @@ struct madicp_ctx {
   int match_all = 0;       // option "match_all_rounds": the matched flags a registration returns are the OR over all its rounds
   int persistent = 0;      // all rounds of a registration as ONE launch (icp_persist) where the geometry admits it
   int xcd_fold = 0;        // per-round launches whose group leaders fold their XCD's rows at the end of the launch (experiment)
+  int debug_collective_us = 0;  // development: a delay kernel of this length behind every collective (tools/shard_probe.py)
+  int shard_tail = 0;      // sharded rounds leave the rank's adders themselves (icp_round's TAIL variant) instead of an icp_reduce
+                           // launch.  Off: built, bit-identical, measured SLOWER (profiles/r4_c_shard_probe.md: the 256 tickets
+                           // on one address and the cross-XCD read of the rows cost ~8 us at the end of every round; the
+                           // separate icp_reduce launch costs 4.5 us and no gap)
+  int shard_split = 1;     // a sharded batch of >= 4 scans runs as two halves on two streams: one half's all-reduce under the
+                           // other half's round (profiles/r4_c_shard_probe.md: -14 % per registration at 8 scans with a 15 us
+                           // collective; a loss without one, and with halves of one scan)
   int stage_min_leaves = 1024;  // LDS staging threshold (leaves per unit); 0 = always, huge = never (measured break-even ~1000)
 
   std::map<GraphKey, hipGraphExec_t> graphs;
@@ -316,7 +327,7 @@ int ensure_partials(madicp_ctx* ctx, size_t doubles) {
   doubles = std::max(doubles, (size_t)2 * 288 * kAcc * 8);  // room for the common geometries: grows once
   HIP_TRY(hipMalloc(&ctx->d_partials, doubles * sizeof(double)));
   ctx->partials_cap = doubles;
-  ctx->partials_grid = ctx->partials_batch = -1;
+  ctx->partials_key = -1;
   // cached graphs hold the old pointer
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
   ctx->graphs.clear();
@@ -376,12 +387,14 @@ int bounded_sync(madicp_ctx* ctx, hipStream_t s) {
 
 // element-wise reduction of a DEVICE buffer over the ranks, stream-ordered on the compute stream: RCCL, or the caller's
 // host transport (copy out, wait, callback, copy back)
-int all_reduce(madicp_ctx* ctx, void* d_buf, size_t count, int kind) {
+int all_reduce(madicp_ctx* ctx, void* d_buf, size_t count, int kind, hipStream_t s) {
   if (ctx->comm) {
     if (kind == MADICP_REDUCE_SUM_F64)
-      NCCL_TRY(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, ctx->stream));
+      NCCL_TRY(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, ctx->comm, s));
     else
-      NCCL_TRY(ncclAllReduce(d_buf, d_buf, count, ncclUint8, ncclMax, ctx->comm, ctx->stream));
+      NCCL_TRY(ncclAllReduce(d_buf, d_buf, count, ncclUint8, ncclMax, ctx->comm, s));
+    if (ctx->debug_collective_us > 0)  // (development: a one-rank all-reduce launches nothing — stand in for its latency)
+      hipLaunchKernelGGL(debug_delay, dim3(1), dim3(64), 0, s, (unsigned long long)ctx->debug_collective_us * 100ull);
     return MADICP_OK;
   }
   const size_t bytes = count * (kind == MADICP_REDUCE_SUM_F64 ? sizeof(double) : 1);
@@ -393,11 +406,12 @@ int all_reduce(madicp_ctx* ctx, void* d_buf, size_t count, int kind) {
     HIP_TRY(hipHostMalloc(&ctx->h_comm, cap, hipHostMallocDefault));
     ctx->h_comm_cap = cap;
   }
-  HIP_TRY(hipMemcpyAsync(ctx->h_comm, d_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemcpyAsync(ctx->h_comm, d_buf, bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   const int rc = ctx->host_ar(ctx->host_ar_user, ctx->h_comm, (int64_t)count, kind);
   if (rc != 0) return fail(MADICP_ERR_COMM, "host all-reduce callback failed with code " + std::to_string(rc));
-  HIP_TRY(hipMemcpyAsync(d_buf, ctx->h_comm, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(d_buf, ctx->h_comm, bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // (the staging block is reused by the next call, possibly for another stream's part)
   return MADICP_OK;
 }
 
@@ -435,13 +449,47 @@ bool use_persist(const madicp_ctx* ctx, const Launch& l) {
 
 bool use_fold(const madicp_ctx* ctx, const Launch& l);
 
-void launch_round(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int round, const double* totals) {
+// Where a launch sequence runs and which scratch it owns.  A registration is one part on the compute stream with the
+// context's buffers; a sharded batch split in two halves (option "shard_split") is two parts with disjoint regions of the
+// same buffers, the second one on the context's second stream.
+struct Part {
+  hipStream_t s = nullptr;
+  Job* jobs = nullptr;
+  double* partials = nullptr;
+  unsigned long long* xch = nullptr;
+  double* totals[2] = {nullptr, nullptr};  // round parity: written by round r (or icp_reduce), all-reduced, read by round r + 1
+  unsigned int* tickets = nullptr;
+};
+Part whole_part(madicp_ctx* ctx, Job* d_jobs) {
+  Part p;
+  p.s = ctx->stream;
+  p.jobs = d_jobs;
+  p.partials = ctx->d_partials;
+  p.xch = ctx->d_xch;
+  p.totals[0] = ctx->d_totals;
+  p.totals[1] = ctx->d_totals + (size_t)MADICP_MAX_BATCH * kAcc;
+  p.tickets = ctx->d_tickets;
+  return p;
+}
+
+// sharded rounds that leave the rank's adders themselves: the TAIL variant of icp_round publishes rows as exchange granules
+bool use_tail(const madicp_ctx* ctx, const Launch& l) {
+  return ctx->sharded() && ctx->shard_tail && !l.trace && l.qpt == 1 && l.iters <= 250 &&
+         madicp::xch_level1(l.batch, l.grid) <= kXchRowsMax * 2 * madicp::kRowGranules;
+}
+
+void launch_round(madicp_ctx* ctx, const Launch& l, const Part& p, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
-  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int, unsigned long long*) =
+  if (use_tail(ctx, l)) {
+    hipLaunchKernelGGL((icp_round<1, false, false, true>), g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials, totals, round,
+                       l.iters, l.K, l.rpt, p.xch, p.totals[round & 1], p.tickets);
+    return;
+  }
+  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int, unsigned long long*, double*, unsigned int*) =
       l.trace ? (l.qpt == 2 ? icp_round<2, true> : icp_round<1, true>) : (l.qpt == 2 ? icp_round<2, false> : icp_round<1, false>);
   if (use_fold(ctx, l)) kern = icp_round<1, false, true>;
-  hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)d_jobs, d_jobs, ctx->d_partials, totals, round, l.iters, l.K,
-                     l.rpt, ctx->d_xch);
+  hipLaunchKernelGGL(kern, g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials, totals, round, l.iters, l.K, l.rpt, p.xch,
+                     (double*)nullptr, (unsigned int*)nullptr);
 }
 
 // (experiment, option "xcd_fold") per-round launches with the XCD-hierarchical join: same admission rules as icp_persist
@@ -450,6 +498,34 @@ bool use_fold(const madicp_ctx* ctx, const Launch& l) {
   return ctx->xcd_fold && !ctx->persistent && !ctx->sharded() && !l.trace && l.qpt == 1 && l.iters >= 2 && l.iters <= 250 &&
          (l.grid >> 3) <= kJoinGroups && l.K >= 1 &&
          madicp::xch_granules(l.batch, l.grid) <= kXchRowsMax * 2 * madicp::kRowGranules;
+}
+
+// one round of a part, and what a sharded round needs behind it: this rank's share of the adders (a rank that owns no tree
+// contributes zeros) -> one all-reduce of [H(21) b(6) n v w] per scan over xGMI: the serial sum of mad_icp.cpp:106-109
+int enqueue_round(madicp_ctx* ctx, const Launch& l, const Part& p, int it) {
+  launch_round(ctx, l, p, it, (ctx->sharded() && it > 0) ? p.totals[(it - 1) & 1] : nullptr);
+  if (ctx->sharded()) {
+    if (!use_tail(ctx, l))
+      hipLaunchKernelGGL(icp_reduce, dim3(l.batch), dim3(kBlock), 0, p.s, p.partials, l.grid, l.batch, it, p.totals[it & 1]);
+    RC_TRY(all_reduce(ctx, p.totals[it & 1], (size_t)l.batch * kAcc, MADICP_REDUCE_SUM_F64, p.s));
+  }
+  return MADICP_OK;
+}
+// what closes a part: the matched flags OR-ed over the ranks, then icp_final
+int enqueue_close(madicp_ctx* ctx, const Launch& l, const Part& p, const int* moving_ids) {
+  if (ctx->sharded()) {
+    // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204)
+    for (int s = 0; s < l.batch; ++s) {
+      const DevMoving& mv = ctx->movings.at(moving_ids[s]);
+      RC_TRY(all_reduce(ctx, mv.matched, (size_t)mv.L, MADICP_REDUCE_MAX_U8, p.s));
+    }
+  }
+  // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
+  hipLaunchKernelGGL(icp_final, dim3(l.batch), dim3(kBlock), 0, p.s, p.jobs, p.partials,
+                     ctx->sharded() ? (const double*)p.totals[(l.iters - 1) & 1] : (const double*)nullptr, l.grid, l.batch,
+                     use_fold(ctx, l) ? (const unsigned long long*)p.xch : (const unsigned long long*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return MADICP_OK;
 }
 
 // the launch sequence of one (batched) registration; valid both eagerly and under stream capture
@@ -464,29 +540,28 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vec
     HIP_TRY(hipGetLastError());
     return MADICP_OK;
   }
-  for (int it = 0; it < iters; ++it) {
-    launch_round(ctx, l, d_jobs, it, (ctx->sharded() && it > 0) ? ctx->d_totals : nullptr);
-    if (ctx->sharded()) {
-      // this rank's share of the adders (a rank that owns no tree contributes zeros) -> one all-reduce of
-      // [H(21) b(6) n v] per scan over xGMI: the serial sum of mad_icp.cpp:106-109
-      hipLaunchKernelGGL(icp_reduce, dim3(batch), dim3(kBlock), 0, ctx->stream, ctx->d_partials, grid, batch, it,
-                         ctx->d_totals);
-      RC_TRY(all_reduce(ctx, ctx->d_totals, (size_t)batch * kAcc, MADICP_REDUCE_SUM_F64));
-    }
-  }
-  if (ctx->sharded()) {
-    // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204)
-    for (int s = 0; s < batch; ++s) {
-      const DevMoving& mv = ctx->movings.at(moving_ids[s]);
-      RC_TRY(all_reduce(ctx, mv.matched, (size_t)mv.L, MADICP_REDUCE_MAX_U8));
-    }
-  }
-  // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
-  hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials,
-                     ctx->sharded() ? ctx->d_totals : nullptr, grid, batch,
-                     use_fold(ctx, l) ? (const unsigned long long*)ctx->d_xch : (const unsigned long long*)nullptr);
-  HIP_TRY(hipGetLastError());
-  return MADICP_OK;
+  const Part p = whole_part(ctx, d_jobs);
+  for (int it = 0; it < iters; ++it) RC_TRY(enqueue_round(ctx, l, p, it));
+  return enqueue_close(ctx, l, p, moving_ids.data());
+}
+
+// A sharded batch as TWO halves on two streams (option "shard_split"): round r of half B runs while half A's all-reduce
+// of round r is in flight, and the other way round — the collective (10-25 us across xGMI for 240 bytes per scan) hides
+// under the other half's round kernel instead of standing between two rounds of the same scans.  The collectives are
+// enqueued in ONE order on every rank — A(0), B(0), A(1), B(1), ... — so RCCL's per-communicator ordering never
+// deadlocks; each half has its own jobs, exchange rows, totals and tickets.  `l` / `p`: the two halves.
+int enqueue_rounds_split(madicp_ctx* ctx, const Launch l[2], const Part p[2], const int* moving_ids) {
+  HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));  // (jobs, moving sets, trees: everything the halves read is behind this)
+  HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  int rc = MADICP_OK;
+  const int iters = l[0].iters;
+  for (int it = 0; it < iters && rc == MADICP_OK; ++it)
+    for (int h = 0; h < 2 && rc == MADICP_OK; ++h) rc = enqueue_round(ctx, l[h], p[h], it);
+  for (int h = 0; h < 2 && rc == MADICP_OK; ++h) rc = enqueue_close(ctx, l[h], p[h], moving_ids + (h ? l[0].batch : 0));
+  // the compute stream carries on behind the second half whatever happened (the caller's fetch / next submission)
+  hipEventRecord(ctx->ev_join, ctx->stream2);
+  hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+  return rc;
 }
 
 // slot: which device Job array the sequence works on (-1: ctx->d_jobs; >= 0: that stream slot's) — part of the graph key
@@ -725,15 +800,24 @@ int check_reg_args(madicp_ctx* ctx, const void* a, const void* b, const void* c,
 // partials for this launch shape: two round parities of join_rows(grid) rows per scan — the rows beyond `grid` are
 // zero and stay zero — then two parities of per-workgroup walk hints, + one padding row (the join's 16-byte loads
 // read one double past)
-int prepare_partials(madicp_ctx* ctx, int grid, int n_scans) {
+size_t partial_doubles_of(int grid, int n_scans) {
   const size_t prows = (size_t)madicp::join_rows(grid);
-  const size_t partial_doubles = (size_t)2 * n_scans * prows * kAcc + (size_t)2 * n_scans * grid + kAcc;
-  RC_TRY(ensure_partials(ctx, partial_doubles));
-  if (ctx->partials_grid != grid || ctx->partials_batch != n_scans) {
+  return align_up(((size_t)2 * n_scans * prows * kAcc + (size_t)2 * n_scans * grid + kAcc) * sizeof(double)) / sizeof(double);
+}
+// (`parts` launch shapes side by side: the halves of a split sharded batch each own a region; out_doubles[h] = its size)
+int prepare_partials(madicp_ctx* ctx, const Launch* shapes, int parts, size_t* out_doubles) {
+  size_t total = 0;
+  long long key = parts;
+  for (int h = 0; h < parts; ++h) {
+    out_doubles[h] = partial_doubles_of(shapes[h].grid, shapes[h].batch);
+    total += out_doubles[h];
+    key = key * 1000003ll + shapes[h].grid * 64ll + shapes[h].batch;
+  }
+  RC_TRY(ensure_partials(ctx, total));
+  if (ctx->partials_key != key) {
     // a row that is padding in this geometry may have been a real row in the previous one
-    HIP_TRY(hipMemsetAsync(ctx->d_partials, 0, partial_doubles * sizeof(double), ctx->stream));
-    ctx->partials_grid = grid;
-    ctx->partials_batch = n_scans;
+    HIP_TRY(hipMemsetAsync(ctx->d_partials, 0, total * sizeof(double), ctx->stream));
+    ctx->partials_key = key;
   }
   return MADICP_OK;
 }
@@ -766,15 +850,27 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     // flags are cleared on the device before the last round; with a single round that is "now"
     if (a.n_iters == 1 || ctx->match_all) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)mv.L, ctx->stream));
   }
-  const Geometry geo = pick_geometry(ctx, max_L, a.K, a.n_scans);
-  const int grid = geo.grid;
-  const Launch launch{grid, a.n_scans, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree, a.d_corr ? 1 : 0};
-  for (int s = 0; s < a.n_scans; ++s) {
-    h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
-    h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
-    h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
+  // a sharded batch of two or more scans goes as two halves on two streams (enqueue_rounds_split): each half is a launch
+  // shape of its own — its scans share the chip among themselves, not with the other half's
+  const bool split = ctx->sharded() && a.n_scans >= (ctx->shard_split >= 2 ? 2 : 4) && ctx->shard_split && !a.time_launches &&
+                     !a.d_corr && !a.d_x_iters;  // (option value 2: split from two scans on — tests, probes)
+  const int n_first = split ? a.n_scans / 2 : a.n_scans;
+  Launch halves[2];
+  Geometry geo = pick_geometry(ctx, max_L, a.K, n_first);
+  for (int h = 0; h < (split ? 2 : 1); ++h) {
+    const int first = h ? n_first : 0, count = h ? a.n_scans - n_first : n_first;
+    if (h) geo = pick_geometry(ctx, max_L, a.K, count);
+    halves[h] = Launch{geo.grid, count, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree, a.d_corr ? 1 : 0};
+    for (int s = first; s < first + count; ++s) {
+      h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
+      h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
+      h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
+    }
   }
-  RC_TRY(prepare_partials(ctx, grid, a.n_scans));
+  const Launch launch = halves[0];
+  const int grid = launch.grid;
+  size_t part_doubles[2] = {0, 0};
+  RC_TRY(prepare_partials(ctx, halves, split ? 2 : 1, part_doubles));
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -790,7 +886,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, launch, ctx->d_jobs, 0, nullptr);
+    for (int i = 0; i < a.time_launches; ++i) launch_round(ctx, launch, whole_part(ctx, ctx->d_jobs), 0, nullptr);
     HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
     HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(exec, ctx->stream));  // warm-up replay
@@ -807,6 +903,27 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     hipGraphDestroy(graph);
     if (a.out_avg_us) *a.out_avg_us = 1e3 * ms / a.time_launches;
     return MADICP_OK;
+  }
+  if (split) {
+    if (!ctx->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    Part parts[2] = {whole_part(ctx, ctx->d_jobs), whole_part(ctx, ctx->d_jobs)};
+    Part& q = parts[1];
+    q.s = ctx->stream2;
+    q.jobs = ctx->d_jobs + n_first;
+    q.partials = ctx->d_partials + part_doubles[0];
+    q.xch = ctx->d_xch + madicp::xch_granules(halves[0].batch, halves[0].grid);
+    q.totals[0] += (size_t)n_first * kAcc;
+    q.totals[1] += (size_t)n_first * kAcc;
+    q.tickets += n_first;
+    if (madicp::xch_granules(halves[0].batch, halves[0].grid) + madicp::xch_granules(halves[1].batch, halves[1].grid) >
+        kXchRowsMax * 2 * madicp::kRowGranules)
+      q.xch = nullptr;  // (no room for two sets of exchange rows: see use_tail — never with MADICP_MAX_BATCH scans at this chip's grids)
+    if (!q.xch) return fail(MADICP_ERR_CAPACITY, "sharded batch too large for the exchange rows of its two halves");
+    return enqueue_rounds_split(ctx, halves, parts, ctx->last_moving.data());
   }
   // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
   const int saved = ctx->use_graph;
@@ -854,7 +971,9 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->h_tree_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc(&ctx->h_fetch, sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
-  if (e == hipSuccess) e = hipMalloc(&ctx->d_totals, sizeof(double) * kAcc * MADICP_MAX_BATCH);
+  if (e == hipSuccess) e = hipMalloc(&ctx->d_totals, sizeof(double) * kAcc * MADICP_MAX_BATCH * 2);
+  if (e == hipSuccess) e = hipMalloc(&ctx->d_tickets, sizeof(unsigned int) * MADICP_MAX_BATCH);
+  if (e == hipSuccess) e = hipMemset(ctx->d_tickets, 0, sizeof(unsigned int) * MADICP_MAX_BATCH);
   if (e == hipSuccess) e = hipMalloc(&ctx->d_xch, kXchRowsMax * 2 * madicp::kRowGranules * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(ctx->d_xch, 0, kXchRowsMax * 2 * madicp::kRowGranules * sizeof(unsigned long long));
   for (int i = 0; i < madicp_ctx::kStreamSlots && e == hipSuccess; ++i) {
@@ -915,6 +1034,13 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->h_fetch) hipHostFree(ctx->h_fetch);
   if (ctx->d_partials) hipFree(ctx->d_partials);
   if (ctx->d_totals) hipFree(ctx->d_totals);
+  if (ctx->d_tickets) hipFree(ctx->d_tickets);
+  if (ctx->stream2) {
+    hipStreamSynchronize(ctx->stream2);
+    hipStreamDestroy(ctx->stream2);
+  }
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->d_xch) hipFree(ctx->d_xch);
   if (ctx->copy) hipStreamDestroy(ctx->copy);
   if (ctx->build) hipStreamDestroy(ctx->build);
@@ -953,6 +1079,12 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->host_feed_wait = value ? 1 : 0;
   } else if (k == "xcd_fold") {
     ctx->xcd_fold = value ? 1 : 0;
+  } else if (k == "debug_collective_us") {
+    ctx->debug_collective_us = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1000));
+  } else if (k == "shard_tail") {
+    ctx->shard_tail = value ? 1 : 0;
+  } else if (k == "shard_split") {
+    ctx->shard_split = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
   } else if (k == "match_all_rounds") {
     ctx->match_all = value ? 1 : 0;
   } else if (k == "persistent") {
@@ -990,6 +1122,9 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "seq_completion") v = ctx->seq_completion;
   else if (k == "host_feed_wait") v = ctx->host_feed_wait;
   else if (k == "xcd_fold") v = ctx->xcd_fold;
+  else if (k == "debug_collective_us") v = ctx->debug_collective_us;
+  else if (k == "shard_tail") v = ctx->shard_tail;
+  else if (k == "shard_split") v = ctx->shard_split;
   else if (k == "match_all_rounds") v = ctx->match_all;
   else if (k == "persistent") v = ctx->persistent;
   else if (k == "wait_mode") v = ctx->wait_mode;
@@ -1423,8 +1558,11 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   else
     HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.ev_up, 0));
   if (n_iters == 1 || ctx->match_all) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)L, ctx->stream));
-  RC_TRY(prepare_partials(ctx, geo.grid, 1));
   const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
+  {
+    size_t doubles = 0;
+    RC_TRY(prepare_partials(ctx, &launch, 1, &doubles));
+  }
   const std::vector<int> ids{sl.moving_id};
   RC_TRY(run_rounds(ctx, launch, sl.d_job, ticket % madicp_ctx::kStreamSlots, ids, busy));
   if (!ctx->seq_completion) HIP_TRY(hipEventRecord(sl.ev_done, ctx->stream));

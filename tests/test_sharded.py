@@ -127,12 +127,45 @@ def test_native_rccl_path_single_rank(ctx):
             ht.transform(T[:3, :3], T[:3, 3])
             t2.append(c2.upload(ht))
         m2 = c2.moving_upload(qh.leaf_means())
+        # three scans in flight (the same leaves from three guesses), fused: as one batch, as a pair, one alone
+        g3 = []
+        for i in range(3):
+            T = pb["query_guess"][0].copy()
+            T[:3, 3] += [0.02 * i, -0.01 * i, 0.0]
+            g3.append(capi.pose12(T))
+        g3 = np.stack(g3)
+        m3 = [c2.moving_upload(qh.leaf_means()) for _ in range(3)]
+        f3 = c2.icp_register_batch(m3, t2, g3, PARAMS, 15)
+        f_pair = c2.icp_register_batch(m3[1:], t2, g3[1:], PARAMS, 15)
+        f_one = c2.icp_register_batch(m3[:1], t2, g3[:1], PARAMS, 15)
         c2.comm_init(capi.Context.comm_unique_id(), 1, 0)
         b = c2.icp_register(m2, t2, pb["query_guess"][0], PARAMS, 15, L)
+        # ... and with the older sequence (a separate icp_reduce launch in front of every all-reduce)
+        # ... and with the variant whose round kernel leaves the rank's adders itself (option "shard_tail": the workgroup that
+        # draws the last ticket folds the rows; measured slower, kept bit-identical)
+        c2.set_option("shard_tail", 1)
+        b_red = c2.icp_register(m2, t2, pb["query_guess"][0], PARAMS, 15, L)
+        c2.set_option("shard_tail", 0)
+        # a sharded batch: unsplit it is the fused batch bit for bit; split in two halves on two streams every
+        # half is a launch shape of its own — scan 0 alone in its half, scans 1-2 the pair
+        c2.set_option("shard_split", 0)
+        s3 = c2.icp_register_batch(m3, t2, g3, PARAMS, 15)
+        c2.set_option("shard_split", 2)  # (2: split from two scans on; the default, 1, starts at four)
+        h3 = c2.icp_register_batch(m3, t2, g3, PARAMS, 15)
+        h3_matched = [c2.icp_fetch_matched(i, L) for i in range(3)]
         c2.comm_destroy()
+        f_pair_again = c2.icp_register_batch(m3[1:], t2, g3[1:], PARAMS, 15)
+        pair_matched = [c2.icp_fetch_matched(i, L) for i in range(2)]
     finally:
         c2.close()
     assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["H"], b["H"]) and np.array_equal(a["matched"], b["matched"])
+    assert np.array_equal(a["X"], b_red["X"]) and np.array_equal(a["H"], b_red["H"]) and np.array_equal(a["matched"], b_red["matched"])
+    for k in ("X", "H", "b", "n_matched"):
+        assert np.array_equal(s3[k], f3[k]), k
+        assert np.array_equal(h3[k][0], f_one[k][0]), k
+        assert np.array_equal(h3[k][1:], f_pair[k]), k
+        assert np.array_equal(f_pair_again[k], f_pair[k]), k
+    assert np.array_equal(h3_matched[1], pair_matched[0]) and np.array_equal(h3_matched[2], pair_matched[1])
     for t in tids:
         ctx.tree_release(t)
     ctx.moving_release(mid)
@@ -274,7 +307,13 @@ def _product_worker(rank, world, port, K, out):
         sm = ctx.stream_collect(tk, L)
         mid2 = ctx.moving_upload(lm[: L // 2])
         X0 = np.stack([capi.pose12(guess), capi.pose12(guess)])
+        # (a batch of two as two halves on two streams — option "shard_split" = 2 — so that the split launch sequence, its second
+        # stream and the one order of collectives on every rank are executed with two ranks)
+        ctx.set_option("shard_split", 2)
         bt = ctx.icp_register_batch([mid, mid2], tids, X0, PARAMS, 15)
+        ctx.set_option("shard_split", 0)
+        bt_whole = ctx.icp_register_batch([mid, mid2], tids, X0, PARAMS, 15)
+        assert np.abs(bt_whole["X"] - bt["X"]).max() <= 1e-9
         ctx.comm_destroy()
         np.savez(out % rank, st_X=st["X"], st_H=st["H"], st_matched=st["matched"], nat_X=nat["X"], nat_H=nat["H"],
                  nat_matched=nat["matched"], nat_Xi=nat["X_iters"], sm_X=sm["X"], sm_H=sm["H"], sm_matched=sm["matched"],
