@@ -268,7 +268,7 @@ int madicp_tree_build_end(madicp_ctx* ctx, int* out_tree_id, int32_t* out_n_leav
 /* drops a look-ahead whose scan never came (waits for the device work, frees the copy of the scan); no-op without one */
 int madicp_tree_build_cancel(madicp_ctx* ctx);
 int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t* out_n_leaves);
-/* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] sub-trees finished by one workgroup each, out[2..65] nodes handled one-workgroup-per-node per level, out[66..129] nodes handled chip-wide per level */
+/* diagnostics of the last madicp_tree_build on this context: out[0] deepest level, out[1] nodes handled one-per-lane, out[2..65] nodes handled one-per-wavefront per level, out[66..129] nodes handled chip-wide per level */
 int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
 /* diagnostics (tests): the (n,3) points of the last madicp_tree_build on this context in the order the construction left
  * them — every leaf's members as the splits above it ordered them, i.e. the caller's container after the reference's

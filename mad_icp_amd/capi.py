@@ -403,7 +403,7 @@ class Context:
     def tree_build_stats(self):
         out = np.zeros(130, np.int32)
         _check(hip_lib().madicp_tree_build_stats(self._h, out.ctypes.data_as(_i32p)))
-        return dict(max_level=int(out[0]), sub_trees=int(out[1]), block_nodes=out[2:66].copy(), chip_nodes=out[66:130].copy())
+        return dict(max_level=int(out[0]), lane_subtrees=int(out[1]), wave_nodes=out[2:66].copy(), chip_nodes=out[66:130].copy())
 
     def tree_build_points(self, n):
         """the points of the last synchronous device build in the order the construction left them (diagnostics)"""

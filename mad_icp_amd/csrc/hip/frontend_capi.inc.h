@@ -46,8 +46,7 @@ struct FrontScratch {
     tb::Params P{};
     int64_t n = 0;
     bool chip = false;
-    int chip_grid = 0, sub_grid = 0, n_tiles = 0, levels_done = 0;
-    int sub_done = 0;      // sub-tree roots covered by tb_subtree launches so far
+    int chip_grid = 0, level_grid = 0, n_tiles = 0, levels_done = 0;
     int seq = 0;           // what tb_finish_b will publish (direct scan path)
     DevCloud cloud;        // look-ahead only
   } fly;
@@ -111,12 +110,12 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_buf0 = take(sizeof(double) * 3 * (size_t)nc);
   const size_t o_buf1 = take(sizeof(double) * 3 * (size_t)nc);
   const size_t o_nodes = take(sizeof(tb::BNode) * 2 * (size_t)nc);
-  const size_t o_q0 = take(sizeof(int4) * ((size_t)nc / 1024 + 1024));  // block-regime nodes hold > kSubMax points
-  const size_t o_q1 = take(sizeof(int4) * ((size_t)nc / 1024 + 1024));
+  const size_t o_q0 = take(sizeof(int4) * ((size_t)nc / tb::kSmallMax + 64));  // wave-regime nodes hold > kSmallMax points
+  const size_t o_q1 = take(sizeof(int4) * ((size_t)nc / tb::kSmallMax + 64));
   const size_t o_big0 = take(sizeof(int32_t) * tb::kMaxBig);
   const size_t o_big1 = take(sizeof(int32_t) * tb::kMaxBig);
-  const size_t o_sub = take(sizeof(int4) * ((size_t)nc / 256 + 1024));  // sub-tree roots: children of nodes of > kSubMax points
-  const size_t o_order = take(sizeof(double) * 3 * (size_t)nc);
+  const size_t o_small0 = take(sizeof(int4) * (size_t)nc);
+  const size_t o_small1 = take(sizeof(int4) * (size_t)nc);
   const size_t o_leaf = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_S = take(sizeof(uint32_t) * ((size_t)nc + 8));
   const size_t o_tiles = take(sizeof(uint32_t) * ((size_t)nc / tb::kScanTile + 8));
@@ -146,8 +145,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.q[1] = reinterpret_cast<int4*>(b + o_q1);
   fs.P.big[0] = reinterpret_cast<int32_t*>(b + o_big0);
   fs.P.big[1] = reinterpret_cast<int32_t*>(b + o_big1);
-  fs.P.sub = reinterpret_cast<int4*>(b + o_sub);
-  fs.P.order = reinterpret_cast<double*>(b + o_order);
+  fs.P.small[0] = reinterpret_cast<int4*>(b + o_small0);
+  fs.P.small[1] = reinterpret_cast<int4*>(b + o_small1);
   fs.P.leaf_start = reinterpret_cast<uint32_t*>(b + o_leaf);
   fs.P.partLR = reinterpret_cast<double*>(b + o_p1);
   fs.P.part_stride = (long)(18 * slots);
@@ -435,7 +434,7 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
   // the compensated cloud replaces the input: written to a fresh buffer, the old one goes back to the pool
   void* fresh = nullptr;
   RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)n, ctx->copy, &fresh));
-  int32_t* d_chunks = out_chunks ? fs->P.tab : nullptr;  // (n ints of the builder's scratch: free during a deskew)
+  int32_t* d_chunks = out_chunks ? reinterpret_cast<int32_t*>(fs->P.small[0]) : nullptr;
   hipLaunchKernelGGL(fe::deskew_apply, dim3(tiles), dim3(256), 0, ctx->copy, (const double*)c->xyz, (const uint32_t*)fs->idx[1], (long)n,
                      (const int32_t*)fs->g, (const int32_t*)fs->tile_min, (const double*)(fs->table + kDeskewTableMax), n_poses,
                      static_cast<double*>(fresh), d_chunks);
@@ -464,33 +463,23 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
 // ---- MAD-tree construction on the device ------------------------------------------------------------------------------
 namespace {
 
-// chip levels [0, kChipLevels) — only clouds of more than kSubMax points have any — and block levels [from, to) of the
-// construction in flight, on its stream
+// the level kernels of steps [from, to) of the construction in flight, on its stream
 void tb_run_levels(FrontScratch::InFlight& f, int from, int to) {
   const tb::Params& P = f.P;
   hipStream_t s = f.s;
   for (int level = from; level < to; ++level) {
-    if (level < tb::kChipLevels) {
-      if (!f.chip) continue;
+    if (f.chip && level < tb::kChipLevels) {
       if (level == 0) hipLaunchKernelGGL(tb::tb_chip_sums, dim3(f.chip_grid), dim3(256), 0, s, P, level);
       hipLaunchKernelGGL(tb::tb_chip_stats, dim3(f.chip_grid), dim3(256), 0, s, P, level);
       hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(f.chip_grid), dim3(256), 0, s, P, level);
-      continue;
     }
-    // one workgroup per node of more than kSubMax points: at most n / kSubMax of them on a level
-    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.n / tb::kSubMax + 1, 1024)));
-    hipLaunchKernelGGL(tb::tb_block_level, dim3(grid), dim3(tb::kSubThreads), 0, s, P, level);
+    if (level < P.first_step) continue;  // (wave / quad nodes born up here wait for step first_step: tree_build.hip.h)
+    // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
+    // workgroups that only look at an empty queue still cost their dispatch)
+    const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, f.n) : f.n;
+    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1)));
+    hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
   }
-}
-// the sub-trees of roots [first, first + count) of the queue: one workgroup each, the whole sub-tree in one launch
-void tb_run_subtrees(FrontScratch::InFlight& f, int first, int count) {
-  if (count < 1) return;
-  static bool lds_set = false;
-  if (!lds_set) {  // (more dynamic LDS than the default limit of a launch)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(tb::tb_subtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tb::kSubLdsBytes);
-    lds_set = true;
-  }
-  hipLaunchKernelGGL(tb::tb_subtree, dim3(count), dim3(tb::kSubThreads), tb::kSubLdsBytes, f.s, f.P, first);
 }
 
 // What the host needs before it can size the tree — leaf count (scan of the leaf starts), root mean, rho, size of the
@@ -499,7 +488,7 @@ void tb_run_subtrees(FrontScratch::InFlight& f, int first, int count) {
 int tb_summary_enqueue(FrontScratch& fs, int next_step, bool again) {
   FrontScratch::InFlight& f = fs.fly;
   if (again)  // (a fresh State is all zero; a second summary must not add to the first)
-    HIP_TRY(hipMemsetAsync(&f.P.st->n_leaves, 0, offsetof(tb::State, sub_count) - offsetof(tb::State, n_leaves), f.s));  // the results line
+    HIP_TRY(hipMemsetAsync(&f.P.st->n_leaves, 0, offsetof(tb::State, q_count) - offsetof(tb::State, n_leaves), f.s));  // the results line
   if (f.n_tiles > tb::kScanDirectMax) return MADICP_OK;
   f.seq = ++fs.build_seq;
   hipLaunchKernelGGL(tb::tb_finish_a, dim3(f.n_tiles + 64), dim3(256), 0, f.s, f.P, kTopLevels, f.n_tiles);
@@ -536,7 +525,7 @@ int tb_summary_wait(madicp_ctx* ctx, FrontScratch& fs, int next_step) {
   const tb::State& h = *fs.h_state;
   hl.n_nodes = h.n_nodes.v; hl.error = h.n_nodes.error; hl.n_leaves = h.n_leaves; hl.n_top = h.n_top;
   hl.max_level = h.max_level; hl.n_valid = h.n_valid; hl.rho_bits = h.rho_bits;
-  hl.pending_wave = h.q_count[next_step].v; hl.pending_quad = h.sub_count.v;
+  hl.pending_wave = h.q_count[next_step].v; hl.pending_quad = h.small_count[next_step].v;
   for (int i = 0; i < 3; ++i) hl.origin[i] = h.origin[i];
   return MADICP_OK;
 }
@@ -551,22 +540,18 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   f.P.n_points = static_cast<int32_t>(n);
   f.P.b_max = b_max;
   f.P.b_min = b_min;
-  f.chip = n > tb::kSubMax;
+  f.chip = n > tb::kChipMin;
+  f.P.first_step = f.chip ? tb::kChipLevels : 0;
   // (State and leaf-start marks are cleared by tb_init itself)
   hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, f.P);
   f.chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
+  // one wave per wave-regime node (at most n / 33 of them on a level) and four lanes per small node (most levels hold far
+  // fewer than the n of them this bound allows for: the queues are walked with a stride)
+  f.level_grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cus * 8, n / (4 * (tb::kSmallMax + 1)) + n / 256 + 1)));
   f.n_tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
-  // Block levels: a balanced tree is down to kSubMax points per node ceil(log2(n / kSubMax)) levels below the root; one
-  // level of slack for the imbalance of a real scan (a 120 k-point scan's largest level-6 node holds 4 500 - 6 800 points,
-  // its level-7 nodes at most 3 500).  More imbalance than that is finished in the second half (pending nodes).
-  int need = 0;
-  while (((int64_t)tb::kSubMax << need) < n) ++need;
-  f.levels_done = f.chip ? std::max(tb::kChipLevels, need + 2) : 0;
+  // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop in the second half
+  f.levels_done = 20;
   tb_run_levels(f, 0, f.levels_done);
-  // every sub-tree root is the child of a node of more than kSubMax points: fewer than 4 n / kSubMax + 8 of them
-  f.sub_grid = f.chip ? static_cast<int>(std::min<int64_t>(4 * n / tb::kSubMax + 8, 65535)) : 1;
-  f.sub_done = 0;
-  tb_run_subtrees(f, 0, f.sub_grid);
   HIP_TRY(hipGetLastError());
   RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
   f.active = true;
@@ -581,30 +566,19 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   tb::HostLine& hl = *fs.h_line;
   f.active = false;  // (whatever happens below, the scratch is free again: every error path leaves the stream drained or dead)
   RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
-  // hl.pending_wave: block-regime nodes waiting at the first level that was not launched; hl.pending_quad: sub-tree roots
-  // queued so far.  Unusually unbalanced or very large clouds need more block levels, and then the sub-trees of their roots.
-  f.sub_done = std::min(f.sub_grid, hl.pending_quad);
-  auto pending = [&]() { return hl.pending_wave > 0 || hl.pending_quad > f.sub_done; };
-  while (hl.error == 0 && pending()) {
-    if (hl.pending_wave > 0) {
-      if (f.levels_done >= tb::kMaxLevels) break;
-      const int to = std::min(f.levels_done + 4, tb::kMaxLevels);
-      tb_run_levels(f, f.levels_done, to);
-      f.levels_done = to;
-    } else {
-      tb_run_subtrees(f, f.sub_done, hl.pending_quad - f.sub_done);
-      f.sub_done = hl.pending_quad;
-    }
+  auto pending = [&]() { return hl.pending_wave > 0 || hl.pending_quad > 0; };
+  while (hl.error == 0 && f.levels_done < tb::kMaxLevels && pending()) {
+    const int to = std::min(f.levels_done + 8, tb::kMaxLevels);
+    tb_run_levels(f, f.levels_done, to);
+    f.levels_done = to;
     RC_TRY(tb_summary_enqueue(fs, f.levels_done, true));
     RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
   }
   fs.state_stale = true;
   if (hl.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
   if (hl.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
-  // (hl.n_nodes: temporary node ids handed out — sub-trees reserve ranges and leave the ids they did not use invalid;
-  // hl.n_valid: temporary nodes that were finished)
   const int32_t n_leaves = hl.n_leaves, n_nodes = 2 * hl.n_leaves - 1;
-  if (n_leaves < 1 || hl.n_nodes < n_nodes || hl.n_valid != n_nodes)
+  if (n_leaves < 1 || hl.n_nodes != n_nodes || hl.n_valid != n_nodes)
     return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(hl.n_nodes) + " nodes, " +
                                        std::to_string(hl.n_valid) + " finished, " + std::to_string(n_leaves) + " leaves)");
   struct { int32_t n_top; unsigned long long rho_bits; double origin[3]; } st{hl.n_top, hl.rho_bits, {hl.origin[0], hl.origin[1], hl.origin[2]}};
@@ -636,8 +610,8 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   t.leaves = reinterpret_cast<LeafRec*>(t.block + off_leaves);
   t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
   set_desc(t, st.origin);
-  hipLaunchKernelGGL(tb::tb_emit, dim3((hl.n_nodes + 255) / 256), dim3(256), 0, s, (const tb::BNode*)P.nodes, hl.n_nodes,
-                     (const uint32_t*)fs.S, t.nodes, n_nodes);
+  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256), dim3(256), 0, s, (const tb::BNode*)P.nodes, n_nodes, (const uint32_t*)fs.S,
+                     t.nodes, n_nodes);
   if (nt)
     hipLaunchKernelGGL(tb::tb_layout_top, dim3(1), dim3(1024), 0, s, (const madicp_node*)t.nodes, kTopLevels, kTopMax, t.top_dfs,
                        t.top_link, t.top_exit, &P.st->n_top);
@@ -782,8 +756,16 @@ int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n) 
   const tb::Params& P = fs.fly.P;
   if (n != P.n_points) return fail(MADICP_ERR_INVALID, "n is not the size of the last build's cloud");
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMemcpyAsync(out_xyz, P.order, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->copy));
-  HIP_TRY(hipStreamSynchronize(ctx->copy));
+  void* d_out = nullptr;
+  RC_TRY(pool_alloc(ctx, sizeof(double) * 3 * (size_t)n, ctx->copy, &d_out));
+  const int n_nodes = fs.h_line->n_nodes;
+  hipLaunchKernelGGL(tb::tb_debug_order, dim3((n_nodes + 3) / 4), dim3(256), 0, ctx->copy, P, n_nodes, static_cast<double*>(d_out));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out_xyz, d_out, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, ctx->copy);
+  const hipError_t e2 = hipStreamSynchronize(ctx->copy);
+  pool_free(ctx, d_out, nullptr);
+  if (e != hipSuccess || e2 != hipSuccess)
+    return fail(MADICP_ERR_DEVICE, std::string("tree build points: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return MADICP_OK;
 }
 
@@ -802,7 +784,9 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]) {
   }
   const tb::State& st = *fs.h_state;
   out[0] = st.max_level;
-  out[1] = st.sub_count.v;
+  int lanes = 0;
+  for (int i = 0; i <= tb::kMaxLevels; ++i) lanes += st.small_count[i].v;
+  out[1] = lanes;
   for (int i = 0; i < 64; ++i) {
     out[2 + i] = st.q_count[i].v;
     out[66 + i] = st.big_count[i].v;

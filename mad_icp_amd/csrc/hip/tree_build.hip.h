@@ -24,14 +24,15 @@
 // levels deep.  So the design is level-synchronous — every node of a level at once, one launch sequence per level, the
 // points ping-ponging between two buffers so that a stable partition is an out-of-place scatter inside the node's own
 // range — and the only question per node is how many lanes share its chain:
-//   chip     (n > kSubMax = 4096, levels 0 .. kChipLevels - 1): the node's points are cut into 2048-point chunks, one workgroup
-//            per chunk; two kernels per level (statistics + extents + left counts + rank tables | scatter), three for the
-//            root (its sums first); every workgroup recombines the per-chunk partials of its node in chunk order (loaded in
-//            parallel, added in order), so nothing waits for a single combiner and the result does not depend on scheduling;
-//   block    (n > kSubMax below the chip levels): one workgroup per node and level, one kernel per level (tree_build_sub.inc.h);
-//   sub-tree (n <= kSubMax, wherever such a node appears): one workgroup finishes the whole sub-tree in LDS, in ONE launch
-//            behind the levels above — teams of wavefronts, single wavefronts or four lanes per node by node size
-//            (tree_build_sub.inc.h).
+//   chip  (n > kChipMin = 512, first levels): the node's points are cut into 2048-point chunks, one workgroup per chunk; three
+//          kernels per level (sums | statistics + extents + left counts | scatter); every workgroup recombines the
+//          per-chunk partials of its node in chunk order (loaded in parallel, added in order), so nothing waits for a
+//          single combiner and the result does not depend on scheduling;
+//   wave  (32 < n <= 512, or larger past the chip levels): one wavefront per node, no barrier — 4-deep unrolled
+//          strided sums, xor butterfly, wave-uniform eigen-solve, ballot-based stable scatter;
+//   quad  (n <= 32): FOUR lanes per node, 16 nodes per wavefront (most nodes of a MAD-tree hold a handful of points; a
+//          wave-uniform eigen-solve per such node would spend 64 lanes on one, a single lane per node makes the sweep a
+//          long serial loop): the wave regime in miniature — quad ballots, two-step xor reductions.
 // Nodes are created in scheduling order into a temporary array; ids and queue slots are handed out by ONE atomic per
 // workgroup (wave regime) or per wavefront (quad regime) on counters that each own a 128-byte line — with one atomic
 // per node on shared lines the allocation alone cost 60 us per level (1 600 nodes x 3 atomics x ~12 ns).  The final
@@ -57,11 +58,14 @@ namespace tb {
 #endif
 constexpr int kSmallMax = MADICP_TB_SMALL;  // quad regime: a node with at most this many points is handled by four lanes
 static_assert(kSmallMax <= 32, "the quad regime keeps a node's side flags in one 32-bit word");
-#ifndef MADICP_TB_CHIP_LEVELS
-#define MADICP_TB_CHIP_LEVELS 3
+#ifndef MADICP_TB_CHIP_MIN
+#define MADICP_TB_CHIP_MIN 512
 #endif
-constexpr int kSubMax = 4096;                       // a node of at most this many points is a sub-tree one workgroup finishes in LDS
-constexpr int kChipLevels = MADICP_TB_CHIP_LEVELS;  // larger nodes: chip regime during the first levels, block regime after
+#ifndef MADICP_TB_CHIP_LEVELS
+#define MADICP_TB_CHIP_LEVELS 6
+#endif
+constexpr int kChipMin = MADICP_TB_CHIP_MIN;        // chip regime above this many points ...
+constexpr int kChipLevels = MADICP_TB_CHIP_LEVELS;  // ... during the first levels only (afterwards the wave regime takes any size)
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
@@ -102,8 +106,8 @@ struct State {  // counters and results of one build, device resident
   unsigned long long rho_bits;  // max |mean - origin|_2 over the internal nodes, as the bits of a non-negative double
   double origin[3];             // the root's mean
   int32_t pad_[20];
-  Counter sub_count;                    // sub-tree roots queued (all levels)
-  Counter q_count[kMaxLevels + 2];      // block-regime nodes queued per level
+  Counter q_count[kMaxLevels + 2];      // wave-regime nodes queued per level
+  Counter small_count[kMaxLevels + 2];  // quad-regime nodes queued per level
   Counter big_count[kMaxLevels + 2];    // chip-regime nodes queued per level
 };
 
@@ -113,10 +117,10 @@ struct Params {
   BNode* nodes;
   int32_t node_cap;
   State* st;
-  int4* q[2];           // block-regime queues, by level parity; an entry is {node id, begin, end, level}
+  int4* q[2];           // wave-regime queues, by level parity; an entry is {node id, begin, end, level}: one hop
+                        // from the queue to everything the sweep needs
   int32_t* big[2];      // chip-regime lists, by level parity
-  int4* sub;            // sub-tree roots, same entries (one queue for all levels)
-  double* order;        // (n_points x 3) the points in the order the construction leaves them (diagnostics)
+  int4* small[2];       // quad-regime queues, by level parity (same entries)
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
   uint32_t* S;          // (n_points + 1): its exclusive scan — leaves in front of a point (made when the levels are done)
   uint32_t* tile_sums;  // scan scratch: marks per 1024-point tile
@@ -132,6 +136,10 @@ struct Params {
                         // node's wavefront; chip regime: written per chunk by tb_chip_stats, read by tb_chip_scatter.
   int32_t n_points;
   double b_max, b_min;
+  int32_t first_step;   // wave / quad nodes created above this level wait in its queues: while the chip regime runs (levels
+                        // 0 .. kChipLevels - 1 of a big cloud) such nodes are rare, and a launch per level that looks at
+                        // two empty queues cost 3 us each.  A queue index is therefore a STEP (>= the node's level); the
+                        // level proper travels in the entry (it selects the point buffer) and in the node.
 };
 
 // (selects, not P.buf[level & 1]: a dynamically indexed member sends the whole by-value Params to scratch memory)
@@ -141,6 +149,7 @@ __device__ __forceinline__ const double* level_in(const Params& P, int level) {
 __device__ __forceinline__ double* level_out(const Params& P, int level) { return (level & 1) ? P.buf[0] : P.buf[1]; }
 __device__ __forceinline__ int4* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
 __device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
+__device__ __forceinline__ int4* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
 __device__ __forceinline__ double* level_part(const Params& P, int level) { return P.partLR + (long)min(level, kChipLevels) * P.part_stride; }
 
 // ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
@@ -251,10 +260,13 @@ __device__ __forceinline__ void chunk_sums(const Params& P, const Inherit& h, do
   }
 }
 
-// Where a new node goes: a node of at most kSubMax points is the root of a sub-tree that ONE workgroup finishes in LDS
-// (tb_subtree, launched once behind the chip and block levels: one queue for all levels); a larger one is handled chip-wide
-// during the first kChipLevels levels (a workgroup per 2048-point chunk) and by one workgroup per node and level after
-// that (tb_block_level; its queue index is the node's level).
+// which queue a node of n points at `level` belongs to: 0 lane, 1 wave, 2 chip
+__device__ __forceinline__ int regime_of(int n, int level) {
+  if (n <= kSmallMax) return 0;
+  if (n > kChipMin && level < kChipLevels) return 2;
+  return 1;
+}
+// queue a node with one atomic of its own (root, children of chip-regime nodes: a handful per level)
 __device__ __forceinline__ void enqueue_single(const Params& P, int id, int begin, int end, int level) {
   const int n = end - begin;
   State* st = P.st;
@@ -262,19 +274,20 @@ __device__ __forceinline__ void enqueue_single(const Params& P, int id, int begi
     st->n_nodes.error = 2;
     return;
   }
-  if (n <= kSubMax) {
-    P.sub[atomicAdd(&st->sub_count.v, 1)] = make_int4(id, begin, end, level);
-    return;
-  }
-  if (level < kChipLevels) {
+  int kind = regime_of(n, level);
+  if (kind == 2) {
     const int pos = atomicAdd(&st->big_count[level].v, 1);
     if (pos < kMaxBig) {
       level_big(P, level)[pos] = id;
       return;
     }
+    kind = 1;
   }
-  const int step = max(level, kChipLevels);  // (the block levels start behind the chip levels)
-  level_q(P, step)[atomicAdd(&st->q_count[step].v, 1)] = make_int4(id, begin, end, level);
+  const int step = max(level, P.first_step);
+  if (kind == 0)
+    level_small(P, step)[atomicAdd(&st->small_count[step].v, 1)] = make_int4(id, begin, end, level);
+  else
+    level_q(P, step)[atomicAdd(&st->q_count[step].v, 1)] = make_int4(id, begin, end, level);
 }
 
 // the surface normal of a leaf (mad_tree.cpp:64-74)
@@ -354,6 +367,33 @@ __global__ __launch_bounds__(256) void tb_init(const Params P) {
 }
 static_assert(sizeof(State) % sizeof(uint4) == 0, "State is cleared 16 bytes at a time");
 
+// development instrumentation (-DMADICP_TB_STAMPS, tools/tb_stamps.py): per level, the 100 MHz wall clock at a few points
+#ifdef MADICP_TB_STAMPS
+// [level][workgroup < 512][wave 4][slot 16]: plain stores by lane 0 of each wave (no atomics: they perturb what they measure)
+__device__ unsigned long long g_tb_stamps[24][512][4][16];
+__device__ __forceinline__ void tb_stamp(int level, int k) {
+  if (level < 24 && blockIdx.x < 512 && k < 16) g_tb_stamps[level][blockIdx.x][(threadIdx.x >> 6) & 3][k] = wall_clock64();
+}
+#define TB_STAMP_MIN(level, k) tb_stamp(level, k)
+#define TB_STAMP_MAX(level, k) tb_stamp(level, k)
+#else
+#define TB_STAMP_MIN(level, k)
+#define TB_STAMP_MAX(level, k)
+#endif
+
+typedef double vd2a __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte load of two doubles at 8-byte alignment
+
+// ---- wave regime: one wavefront per node ------------------------------------------------------------------------
+// What a node hands to the allocation step that follows it (ids and queue slots come from one atomic per workgroup)
+struct Split {
+  bool split;
+  int b, mid, e;
+  double col0[3];
+  double ext0;
+  double sL[9], sR[9];  // sums of the points that went left / right (the children start from them)
+  Inherit inh;          // what the node read of itself when it started
+};
+
 // clamped 8-deep strided access: lane's points i0, i0 + 64, ..., i0 + 448 of [b, e); all twenty-four loads are issued
 // before the first use (a dependent-latency loop of one load per iteration costs ~700 cycles per 64 points)
 #ifndef MADICP_TB_WU
@@ -367,10 +407,493 @@ constexpr int kWU = MADICP_TB_WU;
     const long j_ = ok[u_] ? i_ : (b);                              \
     x[u_] = in[3 * j_]; y[u_] = in[3 * j_ + 1]; z[u_] = in[3 * j_ + 2]; \
   }
+
+// Everything of a node except handing out the children's ids: statistics, leaf test, a leaf's representative, or the
+// stable scatter of an internal node.  Whole wave, every lane the same control flow.
+constexpr int kRedStride = 65;  // doubles per row of a wave's reduction scratch (64 lanes + 1: lanes reading different rows
+                                // hit different banks)
+__device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, double* red /* LDS, 18 x kRedStride of this wave */) {
+  const int lane = threadIdx.x & 63;
+  const int id = ent.x, b = ent.y, e = ent.z, n = e - b, level = ent.w;
+  BNode& nd = P.nodes[id];
+  const double* __restrict__ in = level_in(P, level);
+  Split sp;
+  sp.split = false;
+  sp.b = b; sp.e = e; sp.mid = b;
+  sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
+  sp.ext0 = 0.0;
+  // Everything the node needs of itself in ONE batch of independent loads, and its points touched (one load per
+  // 64-byte line, first 1365 points) so that they are on their way while the eigen-solve runs: a level is a chain of
+  // dependent first touches of memory another kernel has just written — count -> queue entry -> node -> points ->
+  // atomics — at ~2 us each, and that chain, not arithmetic or bandwidth, was most of a level's time.
+  sp.inh = load_inherit(nd, level);
+  double s9[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s9[k] = nd.sums[k];
+  double touch[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long j = min(8 * ((long)lane + 64 * u), 3 * (long)n - 1);  // doubles: one per 64-byte line
+    touch[u] = in[3 * (long)b + j];
+  }
+  double mean[3], V[9], w[3], ext[3];
+  if (lane == 0) TB_STAMP_MAX(level, 3);
+  if (sp.inh.flags & kLeafPending) {  // a chip-regime node that turned out to be a leaf: statistics are already there
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mean[i] = nd.mean[i];
+    V[0] = nd.col0[0]; V[3] = nd.col0[1]; V[6] = nd.col0[2];
+  } else {
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (sp.inh.flags & kHasSums) {  // the parent's scatter sweep already added this node's points up
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] = s9[k];
+    } else if (sp.inh.flags & kChunkSums) {
+      chunk_sums(P, sp.inh, s);
+    } else {
+      for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
+        const int i0 = base + lane;
+        double x[kWU], y[kWU], z[kWU];
+        bool ok[kWU];
+        TB_LOAD4(in, i0, e, b, x, y, z, ok)
+#pragma unroll
+        for (int u = 0; u < kWU; ++u)
+          if (ok[u]) add_point(s, x[u], y[u], z[u]);
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    }
+    double cov[9];
+    if (lane == 0) TB_STAMP_MAX(level, 4);
+    mean_cov_from_sums(s, n, mean, cov);
+    madicp_host::eig3_sym(cov, w, V);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(touch[u]));  // (the touches are consumed here, not before)
+    if (lane == 0) TB_STAMP_MAX(level, 5);
+    // Sweep A: extents in the eigen frame, the side of every point, the children's sums, and the two rank tables of the
+    // split's permutation (common/split_order.h) — the positions of the points that go left, in order, from the front of
+    // the node's slice of P.tab, of those that go right from its back.  A point's rank is the running count of the ballots
+    // before it; nothing of this needs the totals, so it runs before the leaf test can be made.
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t* tab = P.tab;
+    int lcount = 0;  // lefts in front of the current 64 points (wave-uniform)
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
+      const int i0 = base + lane;
+      double x[kWU], y[kWU], z[kWU];
+      bool ok[kWU];
+      TB_LOAD4(in, i0, e, b, x, y, z, ok)
+#pragma unroll
+      for (int u = 0; u < kWU; ++u) {  // (wave-uniform: the ballots below need every lane)
+        double v[3] = {0, 0, 0};
+        if (ok[u]) {
+          eigen_coords(V, mean, x[u], y[u], z[u], v);
+          minmax_update(lo, hi, v);
+        }
+        const bool left = ok[u] && v[2] < 0.0;  // the split test of mad_tree.cpp:96 (v[2] holds its very products)
+        const unsigned long long lm = __ballot(left);
+        if (ok[u]) {
+          const int p = i0 + 64 * u - b;
+          const int lbp = lcount + __popcll(lm & lt);
+          tab[left ? (long)b + lbp : (long)e - 1 - (p - lbp)] = p;
+          if (left) add_point(sL, x[u], y[u], z[u]); else add_point(sR, x[u], y[u], z[u]);
+        }
+        lcount += __popcll(lm);
+      }
+    }
+    if (lane == 0) TB_STAMP_MAX(level, 6);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = wave_min_keep(lo[a]);
+      hi[a] = wave_max_keep(hi[a]);
+      ext[a] = hi[a] - lo[a];
+    }
+    const int nl = lcount;
+    if (lane == 0) nd.bbox0 = ext[0];
+    const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
+    if (!leaf) {
+      const int mid = b + nl;
+      {  // Sweep B: every point to the place the reference's `split` (utils.h:37-52) would have left it in.  The tables were
+         // written by this wavefront: its stores have to be complete before its loads (other lanes') go looking for them.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double* __restrict__ out = level_out(P, level);
+        int lc2 = 0;
+        for (int base = b; base < e; base += 64 * kWU) {
+          const int i0 = base + lane;
+          double x[kWU], y[kWU], z[kWU];
+          bool ok[kWU];
+          TB_LOAD4(in, i0, e, b, x, y, z, ok)
+          int dst[kWU];
+#pragma unroll
+          for (int u = 0; u < kWU; ++u) {  // (the same products as in sweep A: the same sides)
+            double v[3] = {0, 0, 0};
+            if (ok[u]) eigen_coords(V, mean, x[u], y[u], z[u], v);
+            const bool left = ok[u] && v[2] < 0.0;
+            const unsigned long long lm = __ballot(left);
+            dst[u] = 0;
+            if (ok[u]) {
+              const madicp_host::SplitPlan sp2 = madicp_host::split_plan(left, i0 + 64 * u - b, lc2 + __popcll(lm & lt), nl, n);
+              dst[u] = sp2.idx;
+              if (sp2.kind == 1) dst[u] = tab[(long)e - 1 - sp2.idx];
+              if (sp2.kind == 2) dst[u] = tab[(long)b + sp2.idx] - 1;
+            }
+            lc2 += __popcll(lm);
+          }
+#pragma unroll
+          for (int u = 0; u < kWU; ++u)
+            if (ok[u]) {
+              const long d = (long)b + dst[u];
+              out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+            }
+        }
+      }
+      {  // the children's 18 sums are only needed by lane 0 (it writes the child records): through LDS — every lane
+         // stores its 18 partials (column-major, conflict-free), lanes 0..17 add one column each in lane order, lane 0
+         // collects — instead of 18 xor butterflies through the LDS crossbar (216 ds_bpermute: ~3 us of every node)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          red[k * kRedStride + lane] = sL[k];
+          red[(9 + k) * kRedStride + lane] = sR[k];
+        }
+        wave_lds_order();
+        double col = 0.0;
+        if (lane < 18) {
+          for (int j = 0; j < 64; ++j) col += red[lane * kRedStride + j];
+        }
+        wave_lds_order();
+        if (lane < 18) red[lane] = col;  // (row 0, lanes 0..17: every row has been read by now)
+        wave_lds_order();
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { sp.sL[k] = red[k]; sp.sR[k] = red[9 + k]; }
+        }
+        wave_lds_order();  // (the next node's stores must not overtake these reads)
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = V[3 * i + 2]; nd.col0[i] = V[3 * i]; }
+        nd.mid = mid;
+      }
+      sp.split = true;
+      sp.mid = mid;
+      sp.col0[0] = V[0]; sp.col0[1] = V[3]; sp.col0[2] = V[6];
+      sp.ext0 = ext[0];
+      if (lane == 0) TB_STAMP_MAX(level, 7);
+      return sp;
+    }
+  }
+  // leaf: normal, and the member nearest to the centroid (first one on ties, mad_tree.cpp:76-86)
+  double best = 1.7976931348623157e308;
+  int besti = 0x7fffffff;
+  for (int i = b + lane; i < e; i += 64) {
+    const double d[3] = {in[3 * (long)i] - mean[0], in[3 * (long)i + 1] - mean[1], in[3 * (long)i + 2] - mean[2]};
+    const double dist = madicp_host::norm3(d);
+    if (dist < best) { best = dist; besti = i; }
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    const double ob = __shfl_xor(best, m, 64);
+    const int oi = __shfl_xor(besti, m, 64);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (besti == 0x7fffffff) besti = b;  // every distance NaN: the reference keeps *begin
+  if (lane == 0) {
+    double nrm[3];
+    leaf_normal(sp.inh, n, V, nrm);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { nd.mean[i] = in[3 * (long)besti + i]; nd.dir[i] = nrm[i]; }
+    nd.flags = (sp.inh.flags & ~kLeafPending) | kLeaf | kDone;
+    P.leaf_start[b] = 1u;
+  }
+  return sp;
+}
+
+// ---- quad regime: FOUR lanes per node of at most kSmallMax points (16 nodes per wavefront) -------------------------
+// A single lane per node makes the per-node chain long because one lane does everything serially (a 32-point sweep is ~12 us on a
+// wave that has its SIMD to itself).  Four lanes share a node here: point i of the node belongs to lane i % 4, the
+// scatter positions come from the quad's four bits of a wave ballot (like the wave regime, with a quad as the "wave"),
+// sums and extents are reduced over the quad with two xor shuffles.  The eigen-solve runs on all four lanes (identical
+// inputs, identical results): 16 solves per wave instead of 64, still 16 times fewer than the wave regime's one.
+// Control flow is wave-uniform (`steps` = the wave's longest node, lanes past their node's end are masked out), so the
+// ballots and shuffles always see whole quads.
 __device__ __forceinline__ double quad_sum(double v) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   return v;
+}
+__device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool have, int steps) {
+  const int lane = threadIdx.x & 63, ql = lane & 3, qshift = lane & ~3;
+  const int id = have ? ent.x : 0, b = ent.y, e = have ? ent.z : ent.y, n = e - b, level = ent.w;
+  BNode& nd = P.nodes[id];
+  const double* __restrict__ in = level_in(P, level);
+  Split sp;
+  sp.split = false;
+  sp.b = b; sp.e = e; sp.mid = b;
+  sp.col0[0] = sp.col0[1] = sp.col0[2] = 0.0;
+  sp.ext0 = 0.0;
+  sp.inh = load_inherit(nd, level);
+  double s[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = nd.sums[k];
+  const long last = (long)max(e - 1, b);
+  auto load_pt = [&](int step, double& x, double& y, double& z) {
+    const long j = min((long)b + 4 * step + ql, last);
+    x = in[3 * j]; y = in[3 * j + 1]; z = in[3 * j + 2];
+  };
+  if (have && (sp.inh.flags & kChunkSums)) {  // a tiny child of a chip-regime node: its sums are chunk partials
+    chunk_sums(P, sp.inh, s);
+  } else if (!(sp.inh.flags & kHasSums)) {  // (nobody summed it: only the root of a tiny cloud) — wave-uniform loop
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int st = 0; st < steps; ++st) {
+      double x, y, z;
+      load_pt(st, x, y, z);
+      if (have && b + 4 * st + ql < e) add_point(s, x, y, z);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = quad_sum(s[k]);
+  }
+  double mean[3], cov[9], w[3], V[9];
+  mean_cov_from_sums(s, max(n, 1), mean, cov);
+  madicp_host::eig3_sym(cov, w, V);
+  // Sweep A: extents, the children's sums, and the side of every point — the quad's four bits of a wave ballot per step,
+  // collected into ONE word per node (bit p = the point at position p goes left): the word is all the split's permutation
+  // needs (common/split_order.h, the rank tables of the larger regimes become bit selects)
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned int mask = 0;
+  double nx, ny, nz;
+  load_pt(0, nx, ny, nz);
+  for (int st = 0; st < steps; ++st) {  // (wave-uniform trip count; the next point is requested before this one is used)
+    const double x = nx, y = ny, z = nz;
+    if (st + 1 < steps) load_pt(st + 1, nx, ny, nz);
+    const bool valid = have && b + 4 * st + ql < e;
+    double v[3] = {0, 0, 0};
+    if (valid) {
+      eigen_coords(V, mean, x, y, z, v);
+      minmax_update(lo, hi, v);
+    }
+    const bool left = valid && v[2] < 0.0;
+    const unsigned int lm = (unsigned int)(__ballot(left) >> qshift) & 0xfu;
+    mask |= lm << (4 * st);
+    if (valid) {
+      if (left) add_point(sL, x, y, z); else add_point(sR, x, y, z);
+    }
+  }
+  double ext[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+      const double ol = __shfl_xor(lo[a], m, 64), oh = __shfl_xor(hi[a], m, 64);
+      if (ol < lo[a]) lo[a] = ol;
+      if (hi[a] < oh) hi[a] = oh;
+    }
+    ext[a] = hi[a] - lo[a];
+  }
+  const int nl = __popc(mask);
+  const bool leaf = !have || (ext[2] < P.b_max) || nl == 0 || nl == n;
+  // Sweep B (internal nodes): every point to the place the reference's `split` (utils.h:37-52) would have left it in
+  {
+    double* __restrict__ out = level_out(P, level);
+    for (int st = 0; st < steps; ++st) {
+      const int pp = 4 * st + ql;
+      if (!leaf && pp < n) {
+        const long j = (long)b + pp;
+        const double x = in[3 * j], y = in[3 * j + 1], z = in[3 * j + 2];
+        const long d = (long)b + madicp_host::split_dst_small(mask, n, pp);
+        out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+      }
+    }
+  }
+  // (both branches below keep whole quads together: `leaf` is the same in the four lanes of a node)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {  // outside the branch: the shuffles need every lane
+    sp.sL[k] = quad_sum(sL[k]);
+    sp.sR[k] = quad_sum(sR[k]);
+  }
+  // nearest member (leaves): every lane over its own points, then the quad's best, smallest index on ties
+  double best = 1.7976931348623157e308;
+  int besti = 0x7fffffff;
+  for (int st = 0; st < steps; ++st) {
+    const int i = b + 4 * st + ql;
+    if (have && leaf && i < e) {
+      const double d[3] = {in[3 * (long)i] - mean[0], in[3 * (long)i + 1] - mean[1], in[3 * (long)i + 2] - mean[2]};
+      const double dist = madicp_host::norm3(d);
+      if (dist < best) { best = dist; besti = i; }
+    }
+  }
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+    const double ob = __shfl_xor(best, m, 64);
+    const int oi = __shfl_xor(besti, m, 64);
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (!have) return sp;
+  if (ql == 0) nd.bbox0 = ext[0];
+  if (!leaf) {
+    const int mid = b + nl;
+    if (ql == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { nd.mean[k] = mean[k]; nd.dir[k] = V[3 * k + 2]; nd.col0[k] = V[3 * k]; }
+      nd.mid = mid;
+    }
+    sp.split = true;
+    sp.mid = mid;
+    sp.col0[0] = V[0]; sp.col0[1] = V[3]; sp.col0[2] = V[6];
+    sp.ext0 = ext[0];
+    return sp;
+  }
+  if (besti == 0x7fffffff) besti = b;  // every distance NaN: the reference keeps *begin
+  if (ql == 0) {
+    double nrm[3];
+    leaf_normal(sp.inh, n, V, nrm);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { nd.mean[k] = in[3 * (long)besti + k]; nd.dir[k] = nrm[k]; }
+    nd.flags = sp.inh.flags | kLeaf | kDone;
+    P.leaf_start[b] = 1u;
+  }
+  return sp;
+}
+
+// the two children of a split node: records, and their places in the next level's queues
+__device__ __forceinline__ void emit_children(const Params& P, int id, const Split& sp, int c, int slot_small, int slot_wave, int next_step) {
+  BNode& nd = P.nodes[id];
+  const int level = sp.inh.level;
+  const int n = sp.e - sp.b;
+  make_child(P.nodes[c], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
+  make_child(P.nodes[c + 1], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { P.nodes[c].sums[k] = sp.sL[k]; P.nodes[c + 1].sums[k] = sp.sR[k]; }
+  P.nodes[c].flags |= kHasSums;
+  P.nodes[c + 1].flags |= kHasSums;
+  nd.flags = sp.inh.flags | kDone;
+  const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
+  // (children of a wave/lane node are never chip-regime: n <= 4096, or past the chip levels)
+  const int4 eL = make_int4(c, sp.b, sp.mid, level + 1), eR = make_int4(c + 1, sp.mid, sp.e, level + 1);
+  if (nL <= kSmallMax) level_small(P, next_step)[slot_small++] = eL; else level_q(P, next_step)[slot_wave++] = eL;
+  if (nR <= kSmallMax) level_small(P, next_step)[slot_small] = eR; else level_q(P, next_step)[slot_wave] = eR;
+}
+
+// One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
+// 256 threads = 4 wavefronts.
+// (Round 3, measured at compile time and not kept: the eigen-solve as ONE out-of-line function shared by the wave and quad
+// regimes — arguments and results in registers — does not free the registers it was hoped to: the caller's live state has
+// to survive the call, 230 VGPRs + 168 bytes of scratch at two waves per SIMD, 168 + 392 bytes at three, against 256 + 96
+// inlined.  The kernel's registers are the sweep's, not the solver's.)
+#ifndef MADICP_TB_WPE
+#define MADICP_TB_WPE 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_WPE, MADICP_TB_WPE))) void tb_level(const Params P, int level) {
+  State* st = P.st;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int cntW = st->q_count[level].v, cntS = st->small_count[level].v;
+  if (lane == 0) TB_STAMP_MIN(level, 0);
+  if (level + 1 > kMaxLevels) {
+    if ((cntW > 0 || cntS > 0) && blockIdx.x == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
+    return;
+  }
+  // ---- wave regime: the four waves of a workgroup take four consecutive queue entries; ids and queue slots of the
+  // children come from ONE atomic each per workgroup
+  __shared__ int s_split[4], s_ns[4], s_nw[4];
+  __shared__ int s_base_id, s_base_small, s_base_wave;
+  __shared__ double s_red[4][18 * kRedStride];
+  // The two regimes run side by side: the FIRST ceil(cntS / 64) workgroups take the quad-regime queue (first, because
+  // workgroups are dispatched in order and only two fit a CU: behind the wave-regime workgroups the lanes would start
+  // when those finish — measured: a level then costs the sum of the two sides instead of the longer one), the others
+  // the wave-regime queue.
+  const bool single = gridDim.x == 1;  // (tiny clouds: the one workgroup does both, one after the other)
+  int wgS = min((cntS + 63) / 64, (int)gridDim.x);
+  if (!single && cntW > 0 && wgS >= (int)gridDim.x) wgS = (int)gridDim.x - 1;
+  const int wgW = single ? 1 : (int)gridDim.x - wgS;
+  const int wblock = single ? 0 : (int)blockIdx.x - wgS;  // index among the wave-side workgroups
+  const int4* qw = level_q(P, level);
+  if (wblock >= 0 && wgW > 0)
+  for (int t0 = wblock * 4; t0 < cntW; t0 += wgW * 4) {  // (workgroup-uniform trip count)
+    const int t = t0 + wv;
+    const bool active = t < cntW;
+    int id = -1;
+    Split sp;
+    sp.split = false;
+    if (active) {
+      const int4 ent = qw[t];
+      id = ent.x;
+      sp = wave_node(P, ent, s_red[wv]);
+    }
+    const int nL = sp.split ? sp.mid - sp.b : 0, nR = sp.split ? sp.e - sp.mid : 0;
+    const int my_small = sp.split ? ((nL <= kSmallMax) + (nR <= kSmallMax)) : 0;
+    if (lane == 0) {
+      s_split[wv] = sp.split ? 1 : 0;
+      s_ns[wv] = my_small;
+      s_nw[wv] = sp.split ? 2 - my_small : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = s_split[0] + s_split[1] + s_split[2] + s_split[3];
+      const int ts = s_ns[0] + s_ns[1] + s_ns[2] + s_ns[3], tw = s_nw[0] + s_nw[1] + s_nw[2] + s_nw[3];
+      // unconditional (adding 0 is harmless): three independent returning atomics in flight together, one round trip
+      const int a0 = atomicAdd(&st->n_nodes.v, 2 * tot);
+      const int a1 = atomicAdd(&st->small_count[level + 1].v, ts);
+      const int a2 = atomicAdd(&st->q_count[level + 1].v, tw);
+      s_base_id = a0;
+      s_base_small = a1;
+      s_base_wave = a2;
+    }
+    __syncthreads();
+    if (lane == 0) TB_STAMP_MAX(level, 8);
+    if (sp.split && lane == 0) {
+      int before = 0, bs = 0, bw = 0;
+      for (int k = 0; k < wv; ++k) { before += s_split[k]; bs += s_ns[k]; bw += s_nw[k]; }
+      const int c = s_base_id + 2 * before;
+      if (c + 2 > P.node_cap) {
+        st->n_nodes.error = 1;
+      } else {
+        emit_children(P, id, sp, c, s_base_small + bs, s_base_wave + bw, level + 1);
+      }
+    }
+    __syncthreads();
+    if (lane == 0) TB_STAMP_MAX(level, 9);
+  }
+  // ---- quad regime: a wave takes 16 consecutive queue entries, four lanes each; one atomic each per WAVE
+  const int4* qs = level_small(P, level);
+  if (!single && ((int)blockIdx.x >= wgS || wgS <= 0)) return;
+  const int n_waves = max(wgS, 1) * 4, wave = (int)blockIdx.x * 4 + wv;
+  for (int t0 = wave * 16; t0 < cntS; t0 += n_waves * 16) {  // (wave-uniform trip count)
+    const int t = t0 + (lane >> 2);
+    const bool have = t < cntS;
+    int4 ent = make_int4(0, 0, 0, level);
+    if (have) ent = qs[t];
+    int steps = have ? (ent.z - ent.y + 3) / 4 : 0;
+#pragma unroll
+    for (int m = 32; m >= 4; m >>= 1) steps = max(steps, __shfl_xor(steps, m, 64));  // the wave's longest node
+    Split sp = quad_node(P, ent, have, steps);
+    const bool mine = sp.split && (lane & 3) == 0;
+    const unsigned long long sm = __ballot(mine);
+    const int tot = __popcll(sm);
+    if (tot == 0) continue;
+    int base_id = 0, base_q = 0;
+    if (lane == 0) {  // (two independent atomics, one round trip)
+      const int a0 = atomicAdd(&st->n_nodes.v, 2 * tot);
+      const int a1 = atomicAdd(&st->small_count[level + 1].v, 2 * tot);
+      base_id = a0;
+      base_q = a1;
+    }
+    base_id = __shfl(base_id, 0, 64);
+    base_q = __shfl(base_q, 0, 64);
+    if (mine) {
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int rank = __popcll(sm & lt);
+      const int c = base_id + 2 * rank;
+      if (c + 2 > P.node_cap) {
+        st->n_nodes.error = 1;
+      } else {
+        emit_children(P, ent.x, sp, c, base_q + 2 * rank, 0, level + 1);  // children of a quad node are quad nodes
+      }
+    }
+  }
+  if (lane == 0) TB_STAMP_MAX(level, 1);
 }
 
 // ---- chip regime: one workgroup per 2048-point chunk of a big node; three kernels per level --------------------
@@ -680,10 +1203,10 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
     for (int k = 0; k < 3; ++k) { mean[k] = nd.mean[k]; col2[k] = nd.dir[k]; }
     __syncthreads();  // (everybody has read the node and the shared results before chunk 0 rewrites parts of the node)
     if (leaf) {
-      if (cm.chunk == 0 && threadIdx.x == 0) {  // rare: a leaf of more than kSubMax points
+      if (cm.chunk == 0 && threadIdx.x == 0) {  // rare: finished by the wave regime of the next level (nearest member)
         nd.bbox0 = ext0;
         nd.flags |= kLeafPending;
-        const int step = max(level + 1, kChipLevels);  // finished by the block regime (the nearest member is what is missing)
+        const int step = max(level + 1, P.first_step);
         level_q(P, step)[atomicAdd(&P.st->q_count[step].v, 1)] = make_int4(id, b, e, level);  // (its points stay at `level`)
       }
       continue;
@@ -794,8 +1317,6 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
   }
 }
 
-#include "tree_build_sub.inc.h"
-
 // ---- exclusive scan of the leaf-start marks (1024 elements per workgroup) ----------------------------------------
 constexpr int kScanTile = 1024;
 __device__ __forceinline__ void scan_tiles_body(const uint32_t* __restrict__ marks, int n, uint32_t* __restrict__ tile_sums, int block) {
@@ -887,9 +1408,8 @@ __device__ __forceinline__ void summary_body(const Params& P, int top_levels, in
   int tops = 0, lvl = 0, valid = 0;
   for (int i = block * blockDim.x + threadIdx.x; i < n; i += n_blocks * blockDim.x) {
     const BNode& nd = P.nodes[i];
-    if (!(nd.flags & kDone)) continue;  // (an id of a sub-tree's reservation that no node took)
     lvl = max(lvl, nd.level);
-    valid += 1;
+    valid += (nd.flags & kDone) ? 1 : 0;
     if (nd.flags & kLeaf) continue;
     const double e0 = nd.mean[0] - o0, e1 = nd.mean[1] - o1, e2 = nd.mean[2] - o2;
     const double d = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
@@ -931,7 +1451,7 @@ __global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels
 constexpr int kScanDirectMax = 4096;
 struct HostLine {
   int32_t n_nodes, error, n_leaves, n_top, max_level, n_valid;
-  int32_t pending_wave, pending_quad;  // block-regime nodes waiting at the first level that was not launched | sub-tree roots queued
+  int32_t pending_wave, pending_quad;  // queue counts of the first step that was not launched
   unsigned long long rho_bits;
   double origin[3];
   int32_t seq, pad_;
@@ -962,8 +1482,8 @@ __global__ __launch_bounds__(256) void tb_finish_b(const Params P, int n_tiles, 
     host->n_top = st->n_top;
     host->max_level = st->max_level;
     host->n_valid = st->n_valid;
-    host->pending_wave = st->q_count[next_step].v;  // block-regime nodes of the first level that was not launched
-    host->pending_quad = st->sub_count.v;            // sub-tree roots queued so far
+    host->pending_wave = st->q_count[next_step].v;
+    host->pending_quad = st->small_count[next_step].v;
     host->rho_bits = st->rho_bits;
     host->origin[0] = st->origin[0]; host->origin[1] = st->origin[1]; host->origin[2] = st->origin[2];
     __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -976,7 +1496,6 @@ __global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes) return;
   const BNode& nd = nodes[i];
-  if (!(nd.flags & kDone)) return;  // (an id of a sub-tree's reservation that no node took)
   const int sb = (int)S[nd.begin];
   const int idx = 2 * sb + nd.left_turns;
   if (idx < 0 || idx >= out_cap) return;
@@ -992,6 +1511,18 @@ __global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, 
     o.leaf_id = -1;
   }
   out[idx] = o;
+}
+
+// ---- diagnostics: the cloud in the order the construction left it (madicp_debug_tree_build_points) --------------------
+// A leaf's members stay where the split of its parent put them — range [begin, end) of the point buffer its level reads.
+// One wavefront per temporary node; internal nodes have nothing to copy.
+__global__ __launch_bounds__(256) void tb_debug_order(const Params P, int n_nodes, double* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n_nodes) return;
+  const BNode& nd = P.nodes[i];
+  if (!(nd.flags & kLeaf)) return;
+  const double* __restrict__ in = level_in(P, nd.level);
+  for (long j = 3 * (long)nd.begin + lane; j < 3 * (long)nd.end; j += 64) out[j] = in[j];
 }
 
 // ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---

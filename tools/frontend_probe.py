@@ -45,7 +45,7 @@ def compare_tree(ctx, pts, b_max, b_min, tag):
     st = ctx.tree_build_stats()
     print(f"[{tag}] N={pts.shape[0]} host leaves={ht.num_leaves} dev leaves={nl} nodes={nn} | host build {t_host*1e3:.2f} ms, "
           f"dev first {t_dev*1e3:.2f} ms, dev steady {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})")
-    print(f"   levels={st['max_level']} sub_trees={st['sub_trees']} block/level={st['block_nodes'][:30].tolist()} "
+    print(f"   levels={st['max_level']} lane_subtrees={st['lane_subtrees']} wave/level={st['wave_nodes'][:30].tolist()} "
           f"chip/level={st['chip_nodes'][:10].tolist()}")
     nodes = ctx.tree_download(tid, nn)
     # structure: re-upload through the validating path
