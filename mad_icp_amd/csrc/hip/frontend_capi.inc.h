@@ -112,6 +112,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_nodes = take(sizeof(tb::BNode) * 2 * (size_t)nc);
   const size_t o_q0 = take(sizeof(int4) * ((size_t)nc / tb::kSmallMax + 64));  // wave-regime nodes hold > kSmallMax points
   const size_t o_q1 = take(sizeof(int4) * ((size_t)nc / tb::kSmallMax + 64));
+  const size_t o_team0 = take(sizeof(int4) * ((size_t)nc / tb::kTeamMin + 64));
+  const size_t o_team1 = take(sizeof(int4) * ((size_t)nc / tb::kTeamMin + 64));
   const size_t o_big0 = take(sizeof(int32_t) * tb::kMaxBig);
   const size_t o_big1 = take(sizeof(int32_t) * tb::kMaxBig);
   const size_t o_small0 = take(sizeof(int4) * (size_t)nc);
@@ -143,6 +145,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.node_cap = static_cast<int32_t>(std::min<int64_t>(2 * nc, 0x7ffffff0));
   fs.P.q[0] = reinterpret_cast<int4*>(b + o_q0);
   fs.P.q[1] = reinterpret_cast<int4*>(b + o_q1);
+  fs.P.team[0] = reinterpret_cast<int4*>(b + o_team0);
+  fs.P.team[1] = reinterpret_cast<int4*>(b + o_team1);
   fs.P.big[0] = reinterpret_cast<int32_t*>(b + o_big0);
   fs.P.big[1] = reinterpret_cast<int32_t*>(b + o_big1);
   fs.P.small[0] = reinterpret_cast<int4*>(b + o_small0);
@@ -477,7 +481,9 @@ void tb_run_levels(FrontScratch::InFlight& f, int from, int to) {
     // a level has at most 2^level nodes: the early levels get a handful of workgroups, not the full grid (hundreds of
     // workgroups that only look at an empty queue still cost their dispatch)
     const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, f.n) : f.n;
-    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1)));
+    // (+ one workgroup per team-regime node: at most n / kTeamMin of them, and none on a level that holds fewer nodes)
+    const int64_t team_max = std::min<int64_t>(nodes_max, f.n / tb::kTeamMin);
+    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1) + team_max));
     hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
   }
 }
@@ -525,7 +531,7 @@ int tb_summary_wait(madicp_ctx* ctx, FrontScratch& fs, int next_step) {
   const tb::State& h = *fs.h_state;
   hl.n_nodes = h.n_nodes.v; hl.error = h.n_nodes.error; hl.n_leaves = h.n_leaves; hl.n_top = h.n_top;
   hl.max_level = h.max_level; hl.n_valid = h.n_valid; hl.rho_bits = h.rho_bits;
-  hl.pending_wave = h.q_count[next_step].v; hl.pending_quad = h.small_count[next_step].v;
+  hl.pending_wave = h.q_count[next_step].v + h.team_count[next_step].v; hl.pending_quad = h.small_count[next_step].v;
   for (int i = 0; i < 3; ++i) hl.origin[i] = h.origin[i];
   return MADICP_OK;
 }

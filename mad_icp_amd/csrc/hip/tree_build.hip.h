@@ -66,6 +66,10 @@ static_assert(kSmallMax <= 32, "the quad regime keeps a node's side flags in one
 #endif
 constexpr int kChipMin = MADICP_TB_CHIP_MIN;        // chip regime above this many points ...
 constexpr int kChipLevels = MADICP_TB_CHIP_LEVELS;  // ... during the first levels only (afterwards the wave regime takes any size)
+#ifndef MADICP_TB_TEAM_MIN
+#define MADICP_TB_TEAM_MIN 768
+#endif
+constexpr int kTeamMin = MADICP_TB_TEAM_MIN;  // team regime: past the chip levels a node of more points gets a whole workgroup
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
@@ -107,6 +111,7 @@ struct State {  // counters and results of one build, device resident
   double origin[3];             // the root's mean
   int32_t pad_[20];
   Counter q_count[kMaxLevels + 2];      // wave-regime nodes queued per level
+  Counter team_count[kMaxLevels + 2];   // team-regime nodes queued per level
   Counter small_count[kMaxLevels + 2];  // quad-regime nodes queued per level
   Counter big_count[kMaxLevels + 2];    // chip-regime nodes queued per level
 };
@@ -121,6 +126,7 @@ struct Params {
                         // from the queue to everything the sweep needs
   int32_t* big[2];      // chip-regime lists, by level parity
   int4* small[2];       // quad-regime queues, by level parity (same entries)
+  int4* team[2];        // team-regime queues, by level parity (same entries)
   uint32_t* leaf_start; // (n_points + 1): 1 where a leaf's point range starts
   uint32_t* S;          // (n_points + 1): its exclusive scan — leaves in front of a point (made when the levels are done)
   uint32_t* tile_sums;  // scan scratch: marks per 1024-point tile
@@ -150,6 +156,7 @@ __device__ __forceinline__ double* level_out(const Params& P, int level) { retur
 __device__ __forceinline__ int4* level_q(const Params& P, int level) { return (level & 1) ? P.q[1] : P.q[0]; }
 __device__ __forceinline__ int32_t* level_big(const Params& P, int level) { return (level & 1) ? P.big[1] : P.big[0]; }
 __device__ __forceinline__ int4* level_small(const Params& P, int level) { return (level & 1) ? P.small[1] : P.small[0]; }
+__device__ __forceinline__ int4* level_team(const Params& P, int level) { return (level & 1) ? P.team[1] : P.team[0]; }
 __device__ __forceinline__ double* level_part(const Params& P, int level) { return P.partLR + (long)min(level, kChipLevels) * P.part_stride; }
 
 // ---- per-node arithmetic, shared by the three regimes ------------------------------------------------------
@@ -286,6 +293,8 @@ __device__ __forceinline__ void enqueue_single(const Params& P, int id, int begi
   const int step = max(level, P.first_step);
   if (kind == 0)
     level_small(P, step)[atomicAdd(&st->small_count[step].v, 1)] = make_int4(id, begin, end, level);
+  else if (n > kTeamMin)
+    level_team(P, step)[atomicAdd(&st->team_count[step].v, 1)] = make_int4(id, begin, end, level);
   else
     level_q(P, step)[atomicAdd(&st->q_count[step].v, 1)] = make_int4(id, begin, end, level);
 }
@@ -777,6 +786,217 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   if (nR <= kSmallMax) level_small(P, next_step)[slot_small] = eR; else level_q(P, next_step)[slot_wave] = eR;
 }
 
+// ---- team regime: a node of more than kTeamMin points past the chip levels, ONE workgroup (four wavefronts) per node -----
+// One wavefront per such node made steps 6-8 of a 120 k-point scan 72 + 46 + 33 us (nodes of 1 000 - 6 800 points, two
+// sweeps of 512 points a batch each).  Here every wavefront owns a contiguous quarter of the node — the slices play the
+// part of the chip regime's chunks: slice-local rank tables, a prefix over four counts, the same search
+// (common/split_order.h) — and the workgroup synchronises with barriers where the chunks of a chip node need a kernel
+// boundary.  The children compute their own sums (a sweep of at most kTeamMin points for a wave-regime child).
+constexpr int kTeamWaves = 4;
+__device__ __forceinline__ void nearest_update(double& best, int& besti, const double* mean, double x, double y, double z, int i) {
+  const double d[3] = {x - mean[0], y - mean[1], z - mean[2]};
+  const double dist = madicp_host::norm3(d);
+  if (dist < best || (dist == best && i < besti)) { best = dist; besti = i; }
+}
+__device__ __forceinline__ void team_node(const Params& P, const int4 ent, int step) {
+  __shared__ double s_sum[kTeamWaves][9];
+  __shared__ double s_ext[kTeamWaves][6];
+  __shared__ int s_nl[kTeamWaves];
+  __shared__ int s_pref[kTeamWaves + 1];
+  __shared__ double s_best[kTeamWaves];
+  __shared__ int s_besti[kTeamWaves];
+  State* st = P.st;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int id = ent.x, b = ent.y, e = ent.z, n = e - b, level = ent.w;
+  BNode& nd = P.nodes[id];
+  const Inherit inh = load_inherit(nd, level);
+  double s9[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s9[k] = nd.sums[k];
+  const double* __restrict__ in = level_in(P, level);
+  double* __restrict__ out = level_out(P, level);
+  const int S = (n + kTeamWaves - 1) / kTeamWaves;  // the wavefront's slice of the node
+  const int sb = min(b + wv * S, e), se = min(sb + S, e);
+  // ---- the node's nine sums: handed down by the parent, or a sweep of the slices (added in slice order)
+  double s[9];
+  if (inh.flags & kHasSums) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = s9[k];
+  } else if (inh.flags & kChunkSums) {
+    chunk_sums(P, inh, s);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int base = sb; base < se; base += 64 * kWU) {
+      const int i0 = base + lane;
+      double x[kWU], y[kWU], z[kWU];
+      bool ok[kWU];
+      TB_LOAD4(in, i0, se, sb, x, y, z, ok)
+#pragma unroll
+      for (int u = 0; u < kWU; ++u)
+        if (ok[u]) add_point(s, x[u], y[u], z[u]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s_sum[wv][k] = s[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = ((s_sum[0][k] + s_sum[1][k]) + s_sum[2][k]) + s_sum[3][k];
+  }
+  double mean[3], cov[9], w3[3], V[9];
+  mean_cov_from_sums(s, n, mean, cov);
+  madicp_host::eig3_sym(cov, w3, V);  // (every wavefront the same values: nothing to broadcast)
+  // ---- sweep A over the slice: extents, sides, slice-local rank tables
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  int32_t* tab = P.tab;
+  int lcount = 0;
+  for (int base = sb; base < se; base += 64 * kWU) {  // (wave-uniform trip count)
+    const int i0 = base + lane;
+    double x[kWU], y[kWU], z[kWU];
+    bool ok[kWU];
+    TB_LOAD4(in, i0, se, sb, x, y, z, ok)
+#pragma unroll
+    for (int u = 0; u < kWU; ++u) {
+      double v[3] = {0, 0, 0};
+      if (ok[u]) {
+        eigen_coords(V, mean, x[u], y[u], z[u], v);
+        minmax_update(lo, hi, v);
+      }
+      const bool left = ok[u] && v[2] < 0.0;
+      const unsigned long long lm = __ballot(left);
+      if (ok[u]) {
+        const int q = i0 + 64 * u - sb;  // position in the slice
+        const int lbp = lcount + __popcll(lm & lt);
+        tab[left ? (long)sb + lbp : (long)se - 1 - (q - lbp)] = q + (sb - b);
+      }
+      lcount += __popcll(lm);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_min_keep(lo[a]);
+    hi[a] = wave_max_keep(hi[a]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s_ext[wv][a] = lo[a]; s_ext[wv][3 + a] = hi[a]; }
+    s_nl[wv] = lcount;
+  }
+  __syncthreads();  // (also: every slice's table entries are written)
+  double ext[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double L = s_ext[0][a], H = s_ext[0][3 + a];
+#pragma unroll
+    for (int w = 1; w < kTeamWaves; ++w) {
+      if (s_ext[w][a] < L) L = s_ext[w][a];
+      if (H < s_ext[w][3 + a]) H = s_ext[w][3 + a];
+    }
+    ext[a] = H - L;
+  }
+  const int nl = ((s_nl[0] + s_nl[1]) + s_nl[2]) + s_nl[3];
+  if (threadIdx.x <= kTeamWaves) {  // exclusive prefix of the slices' left counts
+    int r = 0;
+    for (int w = 0; w < (int)threadIdx.x; ++w) r += s_nl[w];
+    s_pref[threadIdx.x] = r;
+  }
+  const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;
+  if (leaf) {  // (rare: more than kTeamMin points within b_max of each other)
+    double best = 1.7976931348623157e308;
+    int besti = 0x7fffffff;
+    for (int i = sb + lane; i < se; i += 64) nearest_update(best, besti, mean, in[3 * (long)i], in[3 * (long)i + 1], in[3 * (long)i + 2], i);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const double ob = __shfl_xor(best, m, 64);
+      const int oi = __shfl_xor(besti, m, 64);
+      if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (lane == 0) { s_best[wv] = best; s_besti[wv] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < kTeamWaves; ++k)
+        if (s_best[k] < best || (s_best[k] == best && s_besti[k] < besti)) { best = s_best[k]; besti = s_besti[k]; }
+      if (besti == 0x7fffffff) besti = b;  // every distance NaN: the reference keeps *begin
+      double nrm[3];
+      leaf_normal(inh, n, V, nrm);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { nd.mean[i] = in[3 * (long)besti + i]; nd.dir[i] = nrm[i]; }
+      nd.bbox0 = ext[0];
+      nd.flags = inh.flags | kLeaf | kDone;
+      P.leaf_start[b] = 1u;
+    }
+    return;
+  }
+  // ---- the node's record and its children (thread 0) while everybody scatters
+  if (threadIdx.x == 0) {
+    const int c = atomicAdd(&st->n_nodes.v, 2);
+    if (c + 2 > P.node_cap) {
+      st->n_nodes.error = 1;
+    } else {
+      const double col0[3] = {V[0], V[3], V[6]};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { nd.mean[i] = mean[i]; nd.dir[i] = V[3 * i + 2]; nd.col0[i] = V[3 * i]; }
+      nd.bbox0 = ext[0];
+      nd.mid = b + nl;
+      nd.flags = inh.flags | kDone;
+      make_child(P.nodes[c], inh, id, col0, ext[0], n, P.b_min, b, b + nl, true);
+      make_child(P.nodes[c + 1], inh, id, col0, ext[0], n, P.b_min, b + nl, e, false);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {  // (a handful of team nodes per level: one atomic per child)
+        const int cb = k ? b + nl : b, ce = k ? e : b + nl, cn = ce - cb;
+        const int4 ce4 = make_int4(c + k, cb, ce, level + 1);
+        if (cn <= kSmallMax) level_small(P, step + 1)[atomicAdd(&st->small_count[step + 1].v, 1)] = ce4;
+        else if (cn > kTeamMin) level_team(P, step + 1)[atomicAdd(&st->team_count[step + 1].v, 1)] = ce4;
+        else level_q(P, step + 1)[atomicAdd(&st->q_count[step + 1].v, 1)] = ce4;
+      }
+    }
+  }
+  __syncthreads();  // (s_pref)
+  // ---- sweep B: every point to the place the reference's split would have left it in; the slices are the "chunks" of the
+  // rank search
+  auto lefts_of = [&](int c) { return s_pref[c + 1] - s_pref[c]; };
+  int lc2 = s_pref[wv];
+  for (int base = sb; base < se; base += 64 * kWU) {
+    const int i0 = base + lane;
+    double x[kWU], y[kWU], z[kWU];
+    bool ok[kWU];
+    TB_LOAD4(in, i0, se, sb, x, y, z, ok)
+    int dst[kWU];
+#pragma unroll
+    for (int u = 0; u < kWU; ++u) {
+      double v[3] = {0, 0, 0};
+      if (ok[u]) eigen_coords(V, mean, x[u], y[u], z[u], v);
+      const bool left = ok[u] && v[2] < 0.0;
+      const unsigned long long lm = __ballot(left);
+      dst[u] = 0;
+      if (ok[u]) {
+        const madicp_host::SplitPlan pl = madicp_host::split_plan(left, i0 + 64 * u - b, lc2 + __popcll(lm & lt), nl, n);
+        dst[u] = pl.idx;
+        if (pl.kind == 1) {
+          int c, local;
+          madicp_host::find_right_chunk(s_pref, kTeamWaves, 0, kTeamWaves, S, n, pl.idx, lefts_of, c, local);
+          dst[u] = tab[(long)b + min(n, (c + 1) * S) - 1 - local];
+        } else if (pl.kind == 2) {
+          int c, local;
+          madicp_host::find_left_chunk(s_pref, kTeamWaves, 0, kTeamWaves, pl.idx, lefts_of, c, local);
+          dst[u] = tab[(long)b + (long)c * S + local] - 1;
+        }
+      }
+      lc2 += __popcll(lm);
+    }
+#pragma unroll
+    for (int u = 0; u < kWU; ++u)
+      if (ok[u]) {
+        const long d = (long)b + dst[u];
+        out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+      }
+  }
+}
+
 // One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
 // 256 threads = 4 wavefronts.
 // (Round 3, measured at compile time and not kept: the eigen-solve as ONE out-of-line function shared by the wave and quad
@@ -789,12 +1009,23 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_WPE, MADICP_TB_WPE))) void tb_level(const Params P, int level) {
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int cntW = st->q_count[level].v, cntS = st->small_count[level].v;
+  const int cntW = st->q_count[level].v, cntS = st->small_count[level].v, cntT = st->team_count[level].v;
   if (lane == 0) TB_STAMP_MIN(level, 0);
   if (level + 1 > kMaxLevels) {
-    if ((cntW > 0 || cntS > 0) && blockIdx.x == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
+    if ((cntW > 0 || cntS > 0 || cntT > 0) && blockIdx.x == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
     return;
   }
+  // ---- team regime: the FIRST workgroups take the nodes of more than kTeamMin points, one node each (dispatched first:
+  // they are the longest); the rest of the grid shares the other two queues as before
+  const int wgT = cntT > 0 ? max(1, min(cntT, (int)gridDim.x - 1)) : 0;  // (always leaves a workgroup for the other queues)
+  if ((int)blockIdx.x < wgT) {
+    for (int t = blockIdx.x; t < cntT; t += wgT) {  // (workgroup-uniform)
+      team_node(P, level_team(P, level)[t], level);
+      __syncthreads();  // (the team scratch is reused)
+    }
+    if (gridDim.x > 1 || (cntW == 0 && cntS == 0)) return;
+  }
+  const int gx = (int)gridDim.x > 1 ? (int)gridDim.x - wgT : 1, bx = (int)gridDim.x > 1 ? (int)blockIdx.x - wgT : 0;
   // ---- wave regime: the four waves of a workgroup take four consecutive queue entries; ids and queue slots of the
   // children come from ONE atomic each per workgroup
   __shared__ int s_split[4], s_ns[4], s_nw[4];
@@ -804,11 +1035,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_W
   // workgroups are dispatched in order and only two fit a CU: behind the wave-regime workgroups the lanes would start
   // when those finish — measured: a level then costs the sum of the two sides instead of the longer one), the others
   // the wave-regime queue.
-  const bool single = gridDim.x == 1;  // (tiny clouds: the one workgroup does both, one after the other)
-  int wgS = min((cntS + 63) / 64, (int)gridDim.x);
-  if (!single && cntW > 0 && wgS >= (int)gridDim.x) wgS = (int)gridDim.x - 1;
-  const int wgW = single ? 1 : (int)gridDim.x - wgS;
-  const int wblock = single ? 0 : (int)blockIdx.x - wgS;  // index among the wave-side workgroups
+  const bool single = gx == 1;  // (tiny clouds: the one workgroup does both, one after the other)
+  int wgS = min((cntS + 63) / 64, gx);
+  if (!single && cntW > 0 && wgS >= gx) wgS = gx - 1;
+  const int wgW = single ? 1 : gx - wgS;
+  const int wblock = single ? 0 : bx - wgS;  // index among the wave-side workgroups
   const int4* qw = level_q(P, level);
   if (wblock >= 0 && wgW > 0)
   for (int t0 = wblock * 4; t0 < cntW; t0 += wgW * 4) {  // (workgroup-uniform trip count)
@@ -858,8 +1089,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_W
   }
   // ---- quad regime: a wave takes 16 consecutive queue entries, four lanes each; one atomic each per WAVE
   const int4* qs = level_small(P, level);
-  if (!single && ((int)blockIdx.x >= wgS || wgS <= 0)) return;
-  const int n_waves = max(wgS, 1) * 4, wave = (int)blockIdx.x * 4 + wv;
+  if (!single && (bx >= wgS || wgS <= 0)) return;
+  const int n_waves = max(wgS, 1) * 4, wave = bx * 4 + wv;
   for (int t0 = wave * 16; t0 < cntS; t0 += n_waves * 16) {  // (wave-uniform trip count)
     const int t = t0 + (lane >> 2);
     const bool have = t < cntS;
@@ -1482,7 +1713,7 @@ __global__ __launch_bounds__(256) void tb_finish_b(const Params P, int n_tiles, 
     host->n_top = st->n_top;
     host->max_level = st->max_level;
     host->n_valid = st->n_valid;
-    host->pending_wave = st->q_count[next_step].v;
+    host->pending_wave = st->q_count[next_step].v + st->team_count[next_step].v;
     host->pending_quad = st->small_count[next_step].v;
     host->rho_bits = st->rho_bits;
     host->origin[0] = st->origin[0]; host->origin[1] = st->origin[1]; host->origin[2] = st->origin[2];
