@@ -24,15 +24,21 @@
 // levels deep.  So the design is level-synchronous — every node of a level at once, one launch sequence per level, the
 // points ping-ponging between two buffers so that a stable partition is an out-of-place scatter inside the node's own
 // range — and the only question per node is how many lanes share its chain:
-//   chip  (n > kChipMin = 512, first levels): the node's points are cut into 2048-point chunks, one workgroup per chunk; three
-//          kernels per level (sums | statistics + extents + left counts | scatter); every workgroup recombines the
-//          per-chunk partials of its node in chunk order (loaded in parallel, added in order), so nothing waits for a
-//          single combiner and the result does not depend on scheduling;
-//   wave  (32 < n <= 512, or larger past the chip levels): one wavefront per node, no barrier — 4-deep unrolled
-//          strided sums, xor butterfly, wave-uniform eigen-solve, ballot-based stable scatter;
+//   chip  (n > kChipMin = 512, first levels): the node's points are cut into 2048-point chunks, one workgroup per chunk; two
+//          kernels per level (statistics + extents + left counts + the chunk's rank tables | scatter), three for the root
+//          (its sums first); every workgroup recombines the per-chunk partials of its node in chunk order (loaded in
+//          parallel, added in order), so nothing waits for a single combiner and the result does not depend on scheduling;
+//   team  (n > kTeamMin = 768 past the chip levels): ONE workgroup of four wavefronts per node — every wavefront a
+//          contiguous quarter of the node, the quarters playing the part of the chip regime's chunks, barriers where those
+//          need a kernel boundary (round 4: one wavefront per such node made steps 6-8 of a scan 72 + 46 + 33 us);
+//   wave  (32 < n <= kTeamMin): one wavefront per node, no barrier — strided sums, xor butterfly, wave-uniform
+//          eigen-solve, sweep A (extents, sides, rank tables), sweep B (the scatter);
 //   quad  (n <= 32): FOUR lanes per node, 16 nodes per wavefront (most nodes of a MAD-tree hold a handful of points; a
 //          wave-uniform eigen-solve per such node would spend 64 lanes on one, a single lane per node makes the sweep a
-//          long serial loop): the wave regime in miniature — quad ballots, two-step xor reductions.
+//          long serial loop): the wave regime in miniature — quad ballots, two-step xor reductions, the side flags of a
+//          node in one 32-bit word and the rank tables as bit selects.
+// (A launch that finishes whole sub-trees in LDS instead of a kernel per level was built and measured slower:
+// profiles/r4_e_subtree_negative.md.)
 // Nodes are created in scheduling order into a temporary array; ids and queue slots are handed out by ONE atomic per
 // workgroup (wave regime) or per wavefront (quad regime) on counters that each own a 128-byte line — with one atomic
 // per node on shared lines the allocation alone cost 60 us per level (1 600 nodes x 3 atomics x ~12 ns).  The final
