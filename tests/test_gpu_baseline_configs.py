@@ -1,6 +1,7 @@
-"""Parity at the sizes the bench numbers are quoted on (BASELINE.json configs[1], [2], [4]) — HIP path through the
+"""Parity at the sizes the bench numbers are quoted on (BASELINE.json configs[0], [1], [2], [4]) — HIP path through the
 C ABI vs the CPU oracle on the SAME full-size inputs:
 
+  configs[0]  two 10 000-point four-walls clouds, one pairwise registration (the reference's tools example)
   configs[1]  119 725-point scan vs 1 keyframe MAD-tree
   configs[2]  119 725-point scan vs 16 keyframes, seed 1: exactly bench.py's problem
   configs[4]  64 keyframes (~1.3 M leaves resident), 8 query scans batched in flight
@@ -134,6 +135,56 @@ def run_config(ctx, K, seed, n_queries, gold_name, rounds=(0, 7, 14)):
     except Exception:
         su.close()
         raise
+
+
+def test_config0_two_10k_clouds_pairwise(ctx, natives):
+    """BASELINE configs[0]: two 10 000-point four-walls clouds (apps/utils/tools/tools_utils.py:3-21 with 2 000 points per
+    plane, np.random.seed(42)), one pairwise MADicp registration from the reference's tool guess (mad_registration.py:51-58:
+    euler xyz 0.1 rad, translation np.random.rand(3) drawn after the cloud), default parameters, 15 rounds — through the C ABI
+    against the oracle (correspondences and gates bit-exact at the guess, pose before every round and final pose 1e-5), and
+    through the drop-in `pymadicp.MADicp` surface (mad_icp_wrapper.h:54-102): the same transform, ~ identity."""
+    from scipy.spatial.transform import Rotation
+
+    from fixtures import four_walls
+
+    np.random.seed(42)
+    ref = four_walls(2000)
+    assert ref.shape == (10000, 3)
+    qry = ref.copy()
+    T_guess = np.eye(4)
+    T_guess[:3, :3] = Rotation.from_euler("xyz", [0.1, 0.1, 0.1]).as_matrix()
+    T_guess[:3, 3] = np.random.rand(3)
+    ht, ot = capi.HostTree(ref, B_MAX, B_MIN, 2), O.Tree(ref, B_MAX, B_MIN, 2)
+    qh, qo = capi.HostTree(qry, B_MAX, B_MIN, 2), O.Tree(qry, B_MAX, B_MIN, 2)
+    tid = ctx.upload(ht)
+    mid = ctx.moving_upload(qh.leaf_means())
+    L = qh.num_leaves
+    try:
+        lin = ctx.icp_linearize(mid, [tid], T_guess, PARAMS, L)
+        _, _, corr, rej, _, depth = O.icp_linearize(qo, ot, T_guess, B_MAX, RHO_KER, B_RATIO)
+        assert np.array_equal(lin["corr"][0] & 0x7FFFFFFF, corr) and np.array_equal((lin["corr"][0] >> 31).astype(np.uint8), rej)
+        assert lin["visits"] == int(depth)
+        g = ctx.icp_register(mid, [tid], T_guess, PARAMS, N_ITERS, L)
+        o = O.icp_register(qo, [ot], T_guess, N_ITERS, B_MAX, RHO_KER, B_RATIO, num_threads=1)
+        dt, da = pose_err(o["T"], g["T"])
+        assert dt <= POSE_TOL_M and da <= POSE_TOL_RAD, (dt, da)
+        for it in range(N_ITERS):
+            dt, da = pose_err(O.pose44(o["X_iters"][it]), capi.pose44(g["X_iters"][it]))
+            assert dt <= POSE_TOL_M and da <= POSE_TOL_RAD, (it, dt, da)
+        assert (g["matched"] != o["matched"]).sum() <= 2
+        assert np.abs(g["T"] - np.eye(4)).max() < 1e-6   # the reference's own check: estimate ~ identity
+        # the drop-in surface gives the same transform
+        from mad_icp.src.pybind import pymadicp, pyvector
+
+        m = pymadicp.MADicp(num_threads=4)
+        m.setReferenceCloud(pyvector.VectorEigen3d(ref))
+        m.setQueryCloud(pyvector.VectorEigen3d(qry))
+        T_est = m.compute(T_guess, icp_iterations=N_ITERS)
+        dt, da = pose_err(g["T"], T_est)
+        assert dt <= 1e-9 and da <= 1e-9
+    finally:
+        ctx.tree_release(tid)
+        ctx.moving_release(mid)
 
 
 def test_config1_one_keyframe(ctx):
