@@ -115,6 +115,43 @@ def test_device_tree_build_vs_host_builder(ctx, name):
     ctx.cloud_release(cid)
 
 
+def test_device_tree_matches_host_builder_on_many_full_size_scans(ctx, capsys):
+    """Twelve full-size scans (two scenes, poses along the drive, one of them the keyframe map's first scan): on every one
+    the device-built tree has the host builder's leaf count and `right` links, and at least 99.9 % of its leaf
+    representatives at the same leaf ordinals (measured: all of them) — the member order of the reference's split
+    (utils.h:37-52) is what "first member wins" (mad_tree.cpp:76-86) depends on."""
+    scans = [synth.render_scan(synth.Scene(sc), synth.path_pose(2.5 * i), 700 + 13 * sc + i) for sc in (0, 3) for i in range(6)]
+    worst, total_leaves, total_diff, bitwise_internal = 1.0, 0, 0, []
+    d_bbox = d_nrm = 0.0
+    n_loose = 0
+    for pts in scans:
+        ht, cid, tid, nodes = build_both(ctx, pts)
+        hn = ht.nodes
+        assert nodes.shape[0] == hn.shape[0] and np.array_equal(nodes["right"], hn["right"])
+        leaf = nodes["right"] == 0
+        same = np.all(nodes["mean"][leaf].view(np.uint64) == hn["mean"][leaf].view(np.uint64), axis=1)
+        worst = min(worst, same.mean())
+        total_leaves += int(leaf.sum())
+        total_diff += int((~same).sum())
+        bitwise_internal.append(np.all(nodes["mean"][~leaf].view(np.uint64) == hn["mean"][~leaf].view(np.uint64), axis=1).mean())
+        assert same.mean() >= 0.999, (same.mean(), int((~same).sum()))
+        # bbox0 (the planarity weight's input, mad_icp.cpp:97) and the normals agree as far as the eigen-decomposition's
+        # conditioning lets last-bit differences of the covariance through (close eigenvalues: a direction moves by
+        # eps x norm / gap)
+        d_bbox = max(d_bbox, float(np.abs(nodes["bbox0"][leaf] - hn["bbox0"][leaf]).max()))
+        dn = np.abs(nodes["dir"][leaf] - hn["dir"][leaf]).max(axis=1)
+        d_nrm = max(d_nrm, float(dn.max()))
+        n_loose += int((dn > 1e-9).sum())
+        ctx.tree_release(tid)
+        ctx.cloud_release(cid)
+    with capsys.disabled():
+        print("\n[device vs host builder, %d scans] leaf representatives that differ: %d of %d (worst scan %.5f equal); internal "
+              "centroids bitwise equal: %.2f; largest difference of a leaf's bbox0 %.1e m, of a normal's component %.1e "
+              "(%d leaves beyond 1e-9: nearly collinear members, whose smallest eigenvector the reference itself leaves to rounding)"
+              % (len(scans), total_diff, total_leaves, worst, float(np.mean(bitwise_internal)), d_bbox, d_nrm, n_loose))
+    assert d_bbox <= 1e-5 and n_loose <= total_leaves // 100
+
+
 def test_device_tree_build_on_random_small_clouds(ctx):
     """Sixty random small clouds (blobs, sheets, lines, duplicates at random scales and thresholds, 1 .. 400 points) through
     the device builder: always a valid tree with the exact properties (preorder, leaf ordinals, every leaf mean a member of the
