@@ -32,7 +32,8 @@
 //          contiguous quarter of the node, the quarters playing the part of the chip regime's chunks, barriers where those
 //          need a kernel boundary (round 4: one wavefront per such node made steps 6-8 of a scan 72 + 46 + 33 us);
 //   wave  (32 < n <= kTeamMin): one wavefront per node, no barrier — strided sums, xor butterfly, wave-uniform
-//          eigen-solve, sweep A (extents, sides, rank tables), sweep B (the scatter);
+//          eigen-solve, ONE batch of eight points per lane that stays in registers from the sweep (extents, sides, rank
+//          tables in the wavefront's LDS scratch) to the scatter;
 //   quad  (n <= 32): FOUR lanes per node, 16 nodes per wavefront (most nodes of a MAD-tree hold a handful of points; a
 //          wave-uniform eigen-solve per such node would spend 64 lanes on one, a single lane per node makes the sweep a
 //          long serial loop): the wave regime in miniature — quad ballots, two-step xor reductions, the side flags of a
@@ -141,9 +142,10 @@ struct Params {
   long part_stride;
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
   int32_t* tab;         // (n_points) rank tables of the split's permutation (common/split_order.h), one slice per node — its
-                        // own point range [b, e): the positions (relative to b) of the points that go left, in order, from
-                        // the front of the slice, of those that go right from its back.  Wave regime: written and read by the
-                        // node's wavefront; chip regime: written per chunk by tb_chip_stats, read by tb_chip_scatter.
+                        // own point range [b, e) — cut like the node: per 2048-point chunk (chip regime: written by
+                        // tb_chip_stats, read by tb_chip_scatter) or per wavefront's quarter (team regime): the positions
+                        // (relative to b) of the slice's points that go left, in order, from the front of the slice, of those
+                        // that go right from its back.  (The wave regime keeps its tables in LDS, the quad regime in a word.)
   int32_t n_points;
   double b_max, b_min;
   int32_t first_step;   // wave / quad nodes created above this level wait in its queues: while the chip regime runs (levels

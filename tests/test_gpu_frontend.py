@@ -152,6 +152,32 @@ def test_device_tree_matches_host_builder_on_many_full_size_scans(ctx, capsys):
     assert d_bbox <= 1e-5 and n_loose <= total_leaves // 100
 
 
+@pytest.mark.parametrize("n", [31, 32, 33, 63, 64, 65, 127, 129, 511, 512, 513, 514, 767, 769, 1023, 1025, 2047, 2048, 2049, 4095,
+                               4097, 6143, 6145, 20001])
+def test_device_tree_build_at_regime_boundaries(ctx, n):
+    """Cloud sizes on both sides of every regime boundary of the device builder — four lanes / one wavefront (32 | 33), one
+    wavefront / a team of four (512 | 513), one chunk / two (2048 | 2049), the lane-strided batches in between — on an
+    anisotropic Gaussian cloud: exact properties, the host builder's topology and leaf representatives, and the
+    construction's member order equal to the host builder's row for row (utils.h:37-52)."""
+    rng = np.random.default_rng(1000 + n)
+    pts = rng.normal(size=(n, 3)) * [6.0, 2.5, 0.4] + [3.0, -2.0, 1.0]
+    ht, cid, tid, nodes = build_both(ctx, pts, 0.2, 0.1)
+    check_exact_properties(ctx, pts, tid, nodes)
+    hn = ht.nodes
+    assert nodes.shape[0] == hn.shape[0] and np.array_equal(nodes["right"], hn["right"])
+    leaf = nodes["right"] == 0
+    same = np.all(nodes["mean"][leaf].view(np.uint64) == hn["mean"][leaf].view(np.uint64), axis=1)
+    assert same.mean() >= 0.995, (same.mean(), int((~same).sum()))
+    d_order = ctx.tree_build_points(n)
+    h_order, _ = capi.host_tree_points(pts, 0.2, 0.1, 2)
+    same_row = np.all(d_order.view(np.uint64) == h_order.view(np.uint64), axis=1)
+    reps = keyset(hn["mean"][leaf])
+    assert all(bytes(h_order[i].view(np.uint8)) in reps for i in np.flatnonzero(~same_row))
+    assert keyset(d_order) == keyset(pts)
+    ctx.tree_release(tid)
+    ctx.cloud_release(cid)
+
+
 def test_device_tree_build_on_random_small_clouds(ctx):
     """Sixty random small clouds (blobs, sheets, lines, duplicates at random scales and thresholds, 1 .. 400 points) through
     the device builder: always a valid tree with the exact properties (preorder, leaf ordinals, every leaf mean a member of the
