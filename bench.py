@@ -803,8 +803,16 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
             out_extra["shard_note"] = (
                 "keyframe sharding was developed on ONE GPU (RCCL with one rank; two ranks through a host-staged transport): this line "
                 "is the first multi-GPU measurement of it.  A round is ~14 us of device work per scan and every sharded round adds "
-                "icp_reduce (~4 us) and one %d-byte RCCL all-reduce, so the shard keys are bound by all-reduce latency, not by "
-                "xGMI bandwidth; `replica` (no collective) is the key that scales with the GPU count" % (240 * (args.scans if args.scans > 0 else world)))
+                "icp_reduce (4.5 us) and one %d-byte RCCL all-reduce, so the shard keys are bound by all-reduce latency, not by "
+                "xGMI bandwidth; with four or more scans in flight the batch runs as two halves on two streams so that one half's "
+                "collective is in flight under the other half's round (measured on one GPU with a 15 us stand-in collective: -14 %% "
+                "per registration at 8 scans); `replica` (no collective) is the key that scales with the GPU count"
+                % (240 * (args.scans if args.scans > 0 else world)))
+            out_extra["shard_mode"] = {
+                "sequence": "icp_round -> icp_reduce -> ncclAllReduce(30 f64 per scan) per round; matched flags OR-ed once",
+                "shard_split": ("two half-batches on two streams (one half's all-reduce under the other half's round)" if B >= 4
+                                else "off (fewer than four scans in flight)"),
+                "shard_tail": "off (the round kernel folding its own rows is measured slower: profiles/r4_c_shard_probe.md)"}
             out_extra["all_reduces_per_registration"] = N_ITERS + 1
             out_extra["all_reduce_payload_bytes_per_round"] = 240 * B
             out_extra["max_translation_error_m"] = round(terr, 5)
