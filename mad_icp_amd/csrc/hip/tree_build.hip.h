@@ -636,6 +636,22 @@ __device__ __forceinline__ double quad_sum(double v) {
   v += __shfl_xor(v, 2, 64);
   return v;
 }
+// Nodes of the quad regime (at most 32 points: most nodes of a tree, nearly all its leaves) add their points up ONE AFTER
+// THE OTHER in member order — the reference's own chain (utils.h:54-73) — so their centroid and covariance are the host
+// builder's bit for bit: lane 0 of the quad carries the three coordinate sums, lane 1 (xx, xy, xz), lane 2 (yy, yz, zz),
+// every point broadcast to the four lanes with a DPP quad permute.  (Larger nodes cannot: a chain of 500 or 100 000 dependent
+// additions is the one thing a wavefront is slow at.)  -DMADICP_TB_SERIAL_SMALL=0 restores the lane-strided sums.
+#ifndef MADICP_TB_SERIAL_SMALL
+#define MADICP_TB_SERIAL_SMALL 1
+#endif
+constexpr bool kSerialSmall = MADICP_TB_SERIAL_SMALL != 0;
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {  // the value of lane K of the caller's quad
+  constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // quad_perm:[K,K,K,K]
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool have, int steps) {
   const int lane = threadIdx.x & 63, ql = lane & 3, qshift = lane & ~3;
   const int id = have ? ent.x : 0, b = ent.y, e = have ? ent.z : ent.y, n = e - b, level = ent.w;
@@ -655,7 +671,28 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
     const long j = min((long)b + 4 * step + ql, last);
     x = in[3 * j]; y = in[3 * j + 1]; z = in[3 * j + 2];
   };
-  if (have && (sp.inh.flags & kChunkSums)) {  // a tiny child of a chip-regime node: its sums are chunk partials
+  if (kSerialSmall) {
+    const bool l0 = ql == 0, l1 = ql == 1, l2 = ql == 2;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    double px, py, pz;
+    load_pt(0, px, py, pz);
+    for (int st = 0; st < steps; ++st) {  // (wave-uniform trip count; the next four points are requested before these are used)
+      const double x4 = px, y4 = py, z4 = pz;
+      if (st + 1 < steps) load_pt(st + 1, px, py, pz);
+#define TB_SERIAL_STEP(K)                                                                        \
+      {                                                                                            \
+        const double x = quad_bcast<K>(x4), y = quad_bcast<K>(y4), z = quad_bcast<K>(z4);          \
+        const double u0 = l2 ? y : x, u1 = l1 ? x : y, u2 = l1 ? x : z;                            \
+        const double w0 = l0 ? 1.0 : (l1 ? x : y), w1 = l0 ? 1.0 : (l1 ? y : z), w2 = l0 ? 1.0 : z; \
+        if (have && 4 * st + K < n) { a0 += u0 * w0; a1 += u1 * w1; a2 += u2 * w2; }               \
+      }
+      TB_SERIAL_STEP(0) TB_SERIAL_STEP(1) TB_SERIAL_STEP(2) TB_SERIAL_STEP(3)
+#undef TB_SERIAL_STEP
+    }
+    s[0] = quad_bcast<0>(a0); s[1] = quad_bcast<0>(a1); s[2] = quad_bcast<0>(a2);
+    s[3] = quad_bcast<1>(a0); s[4] = quad_bcast<1>(a1); s[5] = quad_bcast<1>(a2);
+    s[6] = quad_bcast<2>(a0); s[7] = quad_bcast<2>(a1); s[8] = quad_bcast<2>(a2);
+  } else if (have && (sp.inh.flags & kChunkSums)) {  // a tiny child of a chip-regime node: its sums are chunk partials
     chunk_sums(P, sp.inh, s);
   } else if (!(sp.inh.flags & kHasSums)) {  // (nobody summed it: only the root of a tiny cloud) — wave-uniform loop
 #pragma unroll
@@ -691,7 +728,7 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
     const bool left = valid && v[2] < 0.0;
     const unsigned int lm = (unsigned int)(__ballot(left) >> qshift) & 0xfu;
     mask |= lm << (4 * st);
-    if (valid) {
+    if (!kSerialSmall && valid) {  // (serial mode: the children, quad nodes themselves, add their own points up in order)
       if (left) add_point(sL, x, y, z); else add_point(sR, x, y, z);
     }
   }
@@ -722,10 +759,12 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
     }
   }
   // (both branches below keep whole quads together: `leaf` is the same in the four lanes of a node)
+  if (!kSerialSmall) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {  // outside the branch: the shuffles need every lane
-    sp.sL[k] = quad_sum(sL[k]);
-    sp.sR[k] = quad_sum(sR[k]);
+    for (int k = 0; k < 9; ++k) {  // outside the branch: the shuffles need every lane
+      sp.sL[k] = quad_sum(sL[k]);
+      sp.sR[k] = quad_sum(sR[k]);
+    }
   }
   // nearest member (leaves): every lane over its own points, then the quad's best, smallest index on ties
   double best = 1.7976931348623157e308;
@@ -778,12 +817,20 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   const int n = sp.e - sp.b;
   make_child(P.nodes[c], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
   make_child(P.nodes[c + 1], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { P.nodes[c].sums[k] = sp.sL[k]; P.nodes[c + 1].sums[k] = sp.sR[k]; }
-  P.nodes[c].flags |= kHasSums;
-  P.nodes[c + 1].flags |= kHasSums;
-  nd.flags = sp.inh.flags | kDone;
   const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
+  // the children's sums, accumulated by this node's sweep — except for children of the quad regime in serial mode, which add
+  // their own points up in member order
+  if (!kSerialSmall || nL > kSmallMax) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.nodes[c].sums[k] = sp.sL[k];
+    P.nodes[c].flags |= kHasSums;
+  }
+  if (!kSerialSmall || nR > kSmallMax) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P.nodes[c + 1].sums[k] = sp.sR[k];
+    P.nodes[c + 1].flags |= kHasSums;
+  }
+  nd.flags = sp.inh.flags | kDone;
   // (children of a wave/lane node are never chip-regime: n <= 4096, or past the chip levels)
   const int4 eL = make_int4(c, sp.b, sp.mid, level + 1), eR = make_int4(c + 1, sp.mid, sp.e, level + 1);
   if (nL <= kSmallMax) level_small(P, next_step)[slot_small++] = eL; else level_q(P, next_step)[slot_wave++] = eL;
