@@ -78,10 +78,11 @@ class Pipeline {
   // additive, opt-in: the device front-end.  When on, compute() uploads the scan once and
   // deskew (pipeline.cpp:79-123) and MADtree::build (mad_tree.cpp:47-130) run on the MI355X; the tree never exists on
   // the host unless currentLeaves() / modelLeaves() ask for it.  Default: the MAD_ICP_GPU_BUILD environment variable
-  // ("1" = on), else off.  Device-built trees agree with host-built ones statistically, not bitwise
-  // (mad_icp_amd/csrc/hip/tree_build.hip.h): over the full-size test drives poses differ from the host path's by up to
-  // 1e-3 m / 3e-5 rad (3e-3 m / 1.4e-4 rad with deskew), while the error against GROUND TRUTH is the same for both
-  // (tests/test_gpu_frontend.py states and asserts the bars).
+  // ("1" = on), else off.  Device-built trees have the host builder's topology, member order and leaf representatives
+  // and differ from host-built ones in the last bits of their larger nodes (mad_icp_amd/csrc/hip/tree_build.hip.h): over
+  // the full-size test drives poses differ from the host path's by ~1e-12 m (1e-2 m with deskew, where the compensated
+  // cloud depends on the previous poses' last bits and tree construction is chaotic in its input), while the error against
+  // GROUND TRUTH is the same for both (tests/test_gpu_frontend.py states and asserts the bars).
   void setDeviceFrontEnd(bool on) {
     if (!on) dropDeviceLookAhead();
     device_frontend_ = on;
