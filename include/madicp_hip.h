@@ -251,9 +251,11 @@ int madicp_cloud_ingest_f32(madicp_ctx* ctx, const float* records, int64_t n_rec
 int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6], double sensor_hz, int32_t* out_chunks);
 /* MADtree::build + getLeafs + the upload, all on the device (mad_tree.cpp:47-142,154-163): the tree of the cloud becomes
  * a resident tree exactly like one given to madicp_tree_upload (same node format, madicp_tree_download returns it).
- * Same decisions as the reference node by node, but not the same bits: sums have a parallel shape and the
- * eigen-solver's trigonometry comes from the device library (mad_icp_amd/csrc/hip/tree_build.hip.h); bit-reproducible
- * run to run.  The cloud is left untouched.  Synchronises the copy stream once (the leaf count sizes the tree). */
+ * Same decisions as the reference node by node, the reference's member order (the permutation utils.h:37-52 leaves), and
+ * for the nodes of at most 32 points its summation order: same topology and leaf representatives as the host builder on
+ * every scan tried, centroids and covariances of small nodes bit for bit.  Not the same bits everywhere: larger nodes add in
+ * a parallel shape and the eigen-solver's trigonometry comes from the device library (mad_icp_amd/csrc/hip/tree_build.hip.h);
+ * bit-reproducible run to run.  The cloud is left untouched.  Synchronises the copy stream once (the leaf count sizes the tree). */
 int madicp_tree_build(madicp_ctx* ctx, int cloud_id, double b_max, double b_min, int* out_tree_id, int32_t* out_n_leaves);
 /* The same construction as a look-ahead, for a caller that has the NEXT scan in hand while the current one registers
  * (what Pipeline::prefetch does with the device front-end on).  _begin copies the (n,3) float64 scan to the device and

@@ -2,7 +2,8 @@
 // (csrc/host/tree_builder.cpp, bit-identical to the oracle's) and for the device tree builder (csrc/hip/tree_build.hip.h,
 // SURVEY 8 row f-1), so the two cannot drift apart.  On the host this is compiled by g++ exactly as before; on the device
 // the same expressions run with -ffp-contract=off, but atan2 / cos / sin come from the device math library, whose last
-// bit may differ from libm's: the device-built tree is statistically, not bitwise, the host-built one.
+// bit may differ from libm's (~5 % of the solves on identical covariances): a device-built node can differ from the
+// host-built one in the last bits of its eigenvectors and extents.
 #pragma once
 #include <cmath>
 #include <cstring>
