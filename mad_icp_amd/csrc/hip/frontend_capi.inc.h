@@ -38,6 +38,9 @@ struct FrontScratch {
   bool state_stale = false;      // h_state is older than the device State
   double* h_table = nullptr;     // pinned, same layout as `table`
   hipEvent_t h_table_read = nullptr;
+  // the breadth-first layout of a tree's top runs BESIDE the deeper levels of its construction, on a stream of its own
+  hipStream_t side = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
   // a construction between its two halves (tree_build_begin_on / tree_build_end_on)
   struct InFlight {
     bool active = false;
@@ -47,9 +50,12 @@ struct FrontScratch {
     int64_t n = 0;
     bool chip = false;
     int chip_grid = 0, level_grid = 0, n_tiles = 0, levels_done = 0;
+    int quiet_from = -1;   // levels past this one are expected to be empty (FrontScratch::last_depth + 1)
+    bool side_pending = false;  // the top's layout is in flight on the side stream
     int seq = 0;           // what tb_finish_b will publish (direct scan path)
     DevCloud cloud;        // look-ahead only
   } fly;
+  int last_depth = -1;     // deepest level of the previous build on this scratch (consecutive scans: the same +- 1)
 };
 
 constexpr int kDeskewTableMax = 1040;  // > CHUNKS + a few: thresholds fall below -pi after ~1024 steps
@@ -92,6 +98,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   if (fs.block) {
     HIP_TRY(hipStreamSynchronize(ctx->copy));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (fs.side) HIP_TRY(hipStreamSynchronize(fs.side));
     if (ctx->build) HIP_TRY(hipStreamSynchronize(ctx->build));
     HIP_TRY(hipFree(fs.block));
     fs.block = nullptr;
@@ -124,6 +131,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_p1 = take(sizeof(double) * 18 * slots * (tb::kChipLevels + 1));
   const size_t o_p2 = take(sizeof(double) * 8 * slots);
   const size_t o_tab = take(sizeof(int32_t) * ((size_t)nc + 8));
+  const size_t o_topids = take(sizeof(int32_t) * kTopMax);
+  const size_t o_toplink = take(sizeof(uint32_t) * kTopMax);
   const size_t o_key0 = take(sizeof(double) * (size_t)nc);
   const size_t o_key1 = take(sizeof(double) * (size_t)nc);
   const size_t o_idx0 = take(sizeof(uint32_t) * (size_t)nc);
@@ -156,6 +165,8 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.part_stride = (long)(18 * slots);
   fs.P.part2 = reinterpret_cast<double*>(b + o_p2);
   fs.P.tab = reinterpret_cast<int32_t*>(b + o_tab);
+  fs.P.top_ids = reinterpret_cast<int32_t*>(b + o_topids);
+  fs.P.top_link = reinterpret_cast<uint32_t*>(b + o_toplink);
   fs.S = reinterpret_cast<uint32_t*>(b + o_S);
   fs.tile_sums = reinterpret_cast<uint32_t*>(b + o_tiles);
   fs.P.S = fs.S;
@@ -182,6 +193,9 @@ void front_destroy(madicp_ctx* ctx) {  // called by madicp_ctx_destroy (streams 
   if (fs.h_line) hipHostFree(fs.h_line);
   if (fs.h_table) hipHostFree(fs.h_table);
   if (fs.h_table_read) hipEventDestroy(fs.h_table_read);
+  if (fs.side_fork) hipEventDestroy(fs.side_fork);
+  if (fs.side_join) hipEventDestroy(fs.side_join);
+  if (fs.side) hipStreamDestroy(fs.side);
   delete ctx->front;
   ctx->front = nullptr;
 }
@@ -468,7 +482,8 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
 namespace {
 
 // the level kernels of steps [from, to) of the construction in flight, on its stream
-void tb_run_levels(FrontScratch::InFlight& f, int from, int to) {
+int tb_run_levels(FrontScratch& fs, int from, int to) {
+  FrontScratch::InFlight& f = fs.fly;
   const tb::Params& P = f.P;
   hipStream_t s = f.s;
   for (int level = from; level < to; ++level) {
@@ -483,9 +498,27 @@ void tb_run_levels(FrontScratch::InFlight& f, int from, int to) {
     const int64_t nodes_max = level < 30 ? std::min<int64_t>((int64_t)1 << level, f.n) : f.n;
     // (+ one workgroup per team-regime node: at most n / kTeamMin of them, and none on a level that holds fewer nodes)
     const int64_t team_max = std::min<int64_t>(nodes_max, f.n / tb::kTeamMin);
-    const int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1) + team_max));
+    int grid = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(f.level_grid, (nodes_max + 3) / 4 + (nodes_max + 63) / 64 + 1) + team_max));
+    // levels the previous build did not reach are launched all the same (this tree may be deeper) but with a small grid — the
+    // queues are walked with a stride, so any grid is correct, and 1 600 workgroups that find an empty queue cost 4.6 us
+    if (f.quiet_from >= 0 && level > f.quiet_from) grid = std::min(grid, 96);
+    if (level == kTopLevels + 1) {
+      // every node the tree's LDS-staged top can name is finished: its breadth-first layout (eleven dependent memory hops, ~25 us
+      // on one workgroup) runs beside the remaining levels on the side stream; the emission waits for it (tree_build_end_on)
+      if (!fs.side) {
+        HIP_TRY(hipStreamCreateWithFlags(&fs.side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&fs.side_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&fs.side_join, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(fs.side_fork, s));
+      HIP_TRY(hipStreamWaitEvent(fs.side, fs.side_fork, 0));
+      hipLaunchKernelGGL(tb::tb_top_bfs, dim3(1), dim3(256), 0, fs.side, P, kTopLevels, kTopMax);
+      HIP_TRY(hipEventRecord(fs.side_join, fs.side));
+      f.side_pending = true;
+    }
     hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
   }
+  return MADICP_OK;
 }
 
 // What the host needs before it can size the tree — leaf count (scan of the leaf starts), root mean, rho, size of the
@@ -548,6 +581,9 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   f.P.b_min = b_min;
   f.chip = n > tb::kChipMin;
   f.P.first_step = f.chip ? tb::kChipLevels : 0;
+  // (the previous construction's layout of the top reads the node array this one is about to overwrite: normally long
+  // finished and waited for by its emission — after an error or a cancellation it may not be)
+  if (fs.side_join) HIP_TRY(hipStreamWaitEvent(s, fs.side_join, 0));
   // (State and leaf-start marks are cleared by tb_init itself)
   hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, f.P);
   f.chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
@@ -557,7 +593,9 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   f.n_tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
   // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop in the second half
   f.levels_done = 20;
-  tb_run_levels(f, 0, f.levels_done);
+  f.quiet_from = fs.last_depth >= 0 ? fs.last_depth + 1 : -1;
+  f.side_pending = false;
+  RC_TRY(tb_run_levels(fs, 0, f.levels_done));
   HIP_TRY(hipGetLastError());
   RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
   f.active = true;
@@ -575,12 +613,13 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   auto pending = [&]() { return hl.pending_wave > 0 || hl.pending_quad > 0; };
   while (hl.error == 0 && f.levels_done < tb::kMaxLevels && pending()) {
     const int to = std::min(f.levels_done + 8, tb::kMaxLevels);
-    tb_run_levels(f, f.levels_done, to);
+    RC_TRY(tb_run_levels(fs, f.levels_done, to));
     f.levels_done = to;
     RC_TRY(tb_summary_enqueue(fs, f.levels_done, true));
     RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
   }
   fs.state_stale = true;
+  fs.last_depth = hl.error == 0 ? hl.max_level : -1;
   if (hl.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
   if (hl.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
   const int32_t n_leaves = hl.n_leaves, n_nodes = 2 * hl.n_leaves - 1;
@@ -616,14 +655,15 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   t.leaves = reinterpret_cast<LeafRec*>(t.block + off_leaves);
   t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
   set_desc(t, st.origin);
-  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256), dim3(256), 0, s, (const tb::BNode*)P.nodes, n_nodes, (const uint32_t*)fs.S,
-                     t.nodes, n_nodes);
-  if (nt)
-    hipLaunchKernelGGL(tb::tb_layout_top, dim3(1), dim3(1024), 0, s, (const madicp_node*)t.nodes, kTopLevels, kTopMax, t.top_dfs,
-                       t.top_link, t.top_exit, &P.st->n_top);
+  // ONE launch: the DFS-preorder node array, the screening / dense leaf records and the staged top (tree_build.hip.h)
+  if (f.side_pending) {
+    HIP_TRY(hipStreamWaitEvent(s, fs.side_join, 0));
+    f.side_pending = false;
+  }
+  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256 + (t.n_top + 255) / 256), dim3(256), 0, s, P, n_nodes, t.nodes, t.cnodes, t.leaves,
+                     t.n_top, t.top_dfs, t.top_link, t.top_exit, t.top, st.origin[0], st.origin[1], st.origin[2]);
   hipError_t e = hipGetLastError();
   int rc = MADICP_OK;
-  if (e == hipSuccess) rc = compact_tree(t, s);
   if (e == hipSuccess && rc == MADICP_OK) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
   if (e == hipSuccess && rc == MADICP_OK) e = hipEventRecord(t.ready, s);
   // a tree from the build stream: the copy stream feeds registrations from trees it believes it produced itself
@@ -731,7 +771,8 @@ int madicp_tree_build_cancel(madicp_ctx* ctx) {
   if (!ctx->front || !ctx->front->scratch.fly.active || !ctx->front->scratch.fly.lookahead) return MADICP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   FrontScratch& fs = ctx->front->scratch;
-  const hipError_t e = hipStreamSynchronize(fs.fly.s);
+  hipError_t e = hipStreamSynchronize(fs.fly.s);
+  if (e == hipSuccess && fs.side) e = hipStreamSynchronize(fs.side);
   fs.fly.active = false;
   fs.state_stale = true;
   DevCloud c = fs.fly.cloud;

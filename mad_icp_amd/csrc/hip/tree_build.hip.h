@@ -63,6 +63,10 @@ namespace tb {
 #ifndef MADICP_TB_SMALL
 #define MADICP_TB_SMALL 32
 #endif
+#ifndef MADICP_TB_SERIAL_SMALL
+#define MADICP_TB_SERIAL_SMALL 1
+#endif
+constexpr bool kSerialSmall = MADICP_TB_SERIAL_SMALL != 0;  // quad-regime nodes add their points up in member order (see quad_node)
 constexpr int kSmallMax = MADICP_TB_SMALL;  // quad regime: a node with at most this many points is handled by four lanes
 static_assert(kSmallMax <= 32, "the quad regime keeps a node's side flags in one 32-bit word");
 #ifndef MADICP_TB_CHIP_MIN
@@ -93,8 +97,10 @@ struct BNode {          // a node while the tree is being built
   int32_t flags, level;
   int32_t sum_first, sum_n;  // kChunkSums: the node's sums are the per-chunk partials [sum_first, sum_first + sum_n) that its
                              // chip-regime parent's scatter left behind (left or right half: kSumRight), added in order
+  int32_t child, pad_;       // internal: temporary id of the left child (the right one is child + 1) — what the breadth-first
+                             // layout of the top levels walks (top_bfs_body)
 };
-static_assert(sizeof(BNode) == 232, "BNode layout");
+static_assert(sizeof(BNode) == 240, "BNode layout");
 
 struct Counter {  // one 128-byte line per counter: atomics on different counters do not queue behind each other
   int32_t v;
@@ -146,6 +152,8 @@ struct Params {
                         // tb_chip_stats, read by tb_chip_scatter) or per wavefront's quarter (team regime): the positions
                         // (relative to b) of the slice's points that go left, in order, from the front of the slice, of those
                         // that go right from its back.  (The wave regime keeps its tables in LDS, the quad regime in a word.)
+  int32_t* top_ids;     // (kTopMax) breadth-first layout of the first kTopLevels levels (tb_top_bfs, beside the steps past kTopLevels):
+  uint32_t* top_link;   // temporary ids of the internal nodes in that order, and their link words
   int32_t n_points;
   double b_max, b_min;
   int32_t first_step;   // wave / quad nodes created above this level wait in its queues: while the chip regime runs (levels
@@ -562,7 +570,8 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
           }
         wave_lds_order();  // (the table's memory is the reduction scratch of the next block)
       }
-      {  // the children's 18 sums are only needed by lane 0 (it writes the child records): through LDS — every lane
+      if (!kSerialSmall || nl > kSmallMax || n - nl > kSmallMax) {  // (quad-regime children add their own points up)
+         // the children's 18 sums are only needed by lane 0 (it writes the child records): through LDS — every lane
          // stores its 18 partials (column-major, conflict-free), lanes 0..17 add one column each in lane order, lane 0
          // collects — instead of 18 xor butterflies through the LDS crossbar (216 ds_bpermute: ~3 us of every node)
 #pragma unroll
@@ -641,10 +650,6 @@ __device__ __forceinline__ double quad_sum(double v) {
 // builder's bit for bit: lane 0 of the quad carries the three coordinate sums, lane 1 (xx, xy, xz), lane 2 (yy, yz, zz),
 // every point broadcast to the four lanes with a DPP quad permute.  (Larger nodes cannot: a chain of 500 or 100 000 dependent
 // additions is the one thing a wavefront is slow at.)  -DMADICP_TB_SERIAL_SMALL=0 restores the lane-strided sums.
-#ifndef MADICP_TB_SERIAL_SMALL
-#define MADICP_TB_SERIAL_SMALL 1
-#endif
-constexpr bool kSerialSmall = MADICP_TB_SERIAL_SMALL != 0;
 template <int K>
 __device__ __forceinline__ double quad_bcast(double v) {  // the value of lane K of the caller's quad
   constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);  // quad_perm:[K,K,K,K]
@@ -815,6 +820,7 @@ __device__ __forceinline__ void emit_children(const Params& P, int id, const Spl
   BNode& nd = P.nodes[id];
   const int level = sp.inh.level;
   const int n = sp.e - sp.b;
+  nd.child = c;
   make_child(P.nodes[c], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.b, sp.mid, true);
   make_child(P.nodes[c + 1], sp.inh, id, sp.col0, sp.ext0, n, P.b_min, sp.mid, sp.e, false);
   const int nL = sp.mid - sp.b, nR = sp.e - sp.mid;
@@ -994,6 +1000,7 @@ __device__ __forceinline__ void team_node(const Params& P, const int4 ent, int s
       nd.bbox0 = ext[0];
       nd.mid = b + nl;
       nd.flags = inh.flags | kDone;
+      nd.child = c;
       make_child(P.nodes[c], inh, id, col0, ext[0], n, P.b_min, b, b + nl, true);
       make_child(P.nodes[c + 1], inh, id, col0, ext[0], n, P.b_min, b + nl, e, false);
 #pragma unroll
@@ -1048,6 +1055,89 @@ __device__ __forceinline__ void team_node(const Params& P, const int4 ent, int s
   }
 }
 
+// ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---
+// ONE workgroup of 256 threads, over the TEMPORARY nodes (a node knows its children: BNode::child), so that it needs neither
+// the leaf scan nor the emitted array: it is launched on a side stream when step top_levels + 1 begins (every node the top can name has been
+// finished by then) and runs beside the remaining levels — a level is one dependent memory hop (the children's flags and
+// child ids), eleven levels were 19 us as a kernel of their own behind the emission, 26 us as an extra workgroup of the
+// summary kernel or of a level kernel (whatever came next had to wait for it).  Output: the temporary ids of the internal nodes of levels
+// 0 .. top_levels - 1 in breadth-first order (P.top_ids) and their link words (P.top_link: positions of the children in that
+// order, or "leaf" / "below the top"); everything that needs the leaf scan (DFS index, leaf ordinals) is filled in by the
+// emission kernel, entry by entry.  A level has at most 1024 internal nodes: four consecutive entries per thread.
+__device__ __forceinline__ void top_bfs_body(const Params& P, int top_levels, int top_max) {
+  __shared__ int s_id[2][1024], s_child[2][1024];
+  __shared__ int s_w[4];
+  __shared__ int s_total;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int ncur = 0, base = 0;
+  {
+    const BNode& root = P.nodes[0];
+    if (!(root.flags & kLeaf)) {
+      ncur = 1;
+      if (threadIdx.x == 0) { s_id[0][0] = 0; s_child[0][0] = root.child; }
+    }
+  }
+  __syncthreads();
+  int par = 0;
+  for (int lev = 0; lev < top_levels && ncur > 0; ++lev, par ^= 1) {
+    const bool deeper = lev + 1 < top_levels;
+    int ch[4], lc[4], rc[4];
+    bool on[4], l_leaf[4], r_leaf[4], l_in[4], r_in[4];
+    int c = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = 4 * (int)threadIdx.x + u;
+      on[u] = t < ncur && base + t < top_max - 1;
+      ch[u] = on[u] ? s_child[par][t] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // (the eight loads of a thread are independent: one memory round trip per level)
+      int lf = kLeaf, rf = kLeaf;
+      lc[u] = rc[u] = 0;
+      if (on[u]) {
+        lf = P.nodes[ch[u]].flags; lc[u] = P.nodes[ch[u]].child;
+        rf = P.nodes[ch[u] + 1].flags; rc[u] = P.nodes[ch[u] + 1].child;
+      }
+      l_leaf[u] = (lf & kLeaf) != 0;
+      r_leaf[u] = (rf & kLeaf) != 0;
+      l_in[u] = on[u] && !l_leaf[u] && deeper;
+      r_in[u] = on[u] && !r_leaf[u] && deeper;
+      c += (l_in[u] ? 1 : 0) + (r_in[u] ? 1 : 0);
+    }
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < wv; ++k) off += s_w[k];
+    if (threadIdx.x == blockDim.x - 1) s_total = off + incl;
+    int excl = off + incl - c;
+    const int next_base = base + ncur;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!on[u]) continue;
+      const int t = 4 * (int)threadIdx.x + u;
+      const int first = next_base + excl;
+      if (l_in[u]) { s_id[par ^ 1][excl] = ch[u]; s_child[par ^ 1][excl] = lc[u]; }
+      if (r_in[u]) {
+        const int at = excl + (l_in[u] ? 1 : 0);
+        s_id[par ^ 1][at] = ch[u] + 1; s_child[par ^ 1][at] = rc[u];
+      }
+      P.top_ids[base + t] = s_id[par][t];
+      P.top_link[base + t] = top_link_word(l_in[u] ? first : -1, r_in[u] ? first + (l_in[u] ? 1 : 0) : -1, l_leaf[u], r_leaf[u]);
+      excl += (l_in[u] ? 1 : 0) + (r_in[u] ? 1 : 0);
+    }
+    __syncthreads();
+    base = next_base;
+    ncur = s_total;
+    __syncthreads();
+  }
+}
+
 // One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
 // 256 threads = 4 wavefronts.
 // (Round 3, measured at compile time and not kept: the eigen-solve as ONE out-of-line function shared by the wave and quad
@@ -1058,6 +1148,7 @@ __device__ __forceinline__ void team_node(const Params& P, const int4 ent, int s
 #define MADICP_TB_WPE 2
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_WPE, MADICP_TB_WPE))) void tb_level(const Params P, int level) {
+  const int G = (int)gridDim.x;
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cntW = st->q_count[level].v, cntS = st->small_count[level].v, cntT = st->team_count[level].v;
@@ -1068,15 +1159,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_W
   }
   // ---- team regime: the FIRST workgroups take the nodes of more than kTeamMin points, one node each (dispatched first:
   // they are the longest); the rest of the grid shares the other two queues as before
-  const int wgT = cntT > 0 ? max(1, min(cntT, (int)gridDim.x - 1)) : 0;  // (always leaves a workgroup for the other queues)
+  const int wgT = cntT > 0 ? max(1, min(cntT, G - 1)) : 0;  // (always leaves a workgroup for the other queues)
   if ((int)blockIdx.x < wgT) {
     for (int t = blockIdx.x; t < cntT; t += wgT) {  // (workgroup-uniform)
       team_node(P, level_team(P, level)[t], level);
       __syncthreads();  // (the team scratch is reused)
     }
-    if (gridDim.x > 1 || (cntW == 0 && cntS == 0)) return;
+    if (G > 1 || (cntW == 0 && cntS == 0)) return;
   }
-  const int gx = (int)gridDim.x > 1 ? (int)gridDim.x - wgT : 1, bx = (int)gridDim.x > 1 ? (int)blockIdx.x - wgT : 0;
+  const int gx = G > 1 ? G - wgT : 1, bx = G > 1 ? (int)blockIdx.x - wgT : 0;
   // ---- wave regime: the four waves of a workgroup take four consecutive queue entries; ids and queue slots of the
   // children come from ONE atomic each per workgroup
   __shared__ int s_split[4], s_ns[4], s_nw[4];
@@ -1500,6 +1591,7 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
         P.st->n_nodes.error = 1;
       } else {
         const Inherit inh = load_inherit(nd, level);
+        nd.child = c;
         make_child(P.nodes[c], inh, id, col0, ext0, n, P.b_min, b, mid, true);
         make_child(P.nodes[c + 1], inh, id, col0, ext0, n, P.b_min, mid, e, false);
         // their sums: this node's per-chunk partials, written below by every chunk of it
@@ -1772,17 +1864,15 @@ __global__ __launch_bounds__(256) void tb_finish_b(const Params P, int n_tiles, 
   }
 }
 
-// ---- emission: temporary nodes -> the DFS-preorder madicp_node array ------------------------------------------
-__global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, int n_nodes, const uint32_t* __restrict__ S,
-                                               madicp_node* __restrict__ out, int out_cap) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes) return;
-  const BNode& nd = nodes[i];
-  const int sb = (int)S[nd.begin];
-  const int idx = 2 * sb + nd.left_turns;
-  if (idx < 0 || idx >= out_cap) return;
+// ---- emission: temporary nodes -> the DFS-preorder madicp_node array, and everything derived from it -------------------
+// One launch writes what used to take four (tb_emit, tree_compact, tb_layout_top, tree_compact_top: 41 us of the 80 us a
+// build spent behind its last level): the leaf scan S answers every question the later kernels asked the emitted array —
+// a node's `right` offset is 2 (S[mid] - S[begin]), a child is a leaf iff its range holds one leaf, a leaf's ordinal is
+// S[begin] — so the screening record / dense leaf record of a node is made by the thread that emits it, and the records of
+// the LDS-staged top by the workgroups behind the node range, one thread per entry of the breadth-first order top_bfs_body left.
+__device__ __forceinline__ madicp_node emit_node(const BNode& nd, const uint32_t* __restrict__ S, int sb) {
   madicp_node o;
-  #pragma unroll
+#pragma unroll
   for (int k = 0; k < 3; ++k) { o.mean[k] = nd.mean[k]; o.dir[k] = nd.dir[k]; }
   o.bbox0 = nd.bbox0;
   if (nd.flags & kLeaf) {
@@ -1792,8 +1882,60 @@ __global__ __launch_bounds__(256) void tb_emit(const BNode* __restrict__ nodes, 
     o.right = 2 * ((int)S[nd.mid] - sb);
     o.leaf_id = -1;
   }
-  out[idx] = o;
+  return o;
 }
+__global__ __launch_bounds__(256) void tb_emit(const Params P, int n_nodes, madicp_node* __restrict__ out, CNode* __restrict__ cnodes,
+                                               LeafRec* __restrict__ leaves, int n_top, int* __restrict__ dfs,
+                                               unsigned int* __restrict__ link, int4* __restrict__ exits, CNode* __restrict__ top,
+                                               double o0, double o1, double o2) {
+  const uint32_t* __restrict__ S = P.S;
+  const int node_blocks = (n_nodes + 255) / 256;
+  if ((int)blockIdx.x >= node_blocks) {  // ---- the staged top: entry e of the breadth-first order
+    const int e = ((int)blockIdx.x - node_blocks) * 256 + (int)threadIdx.x;
+    if (e >= n_top) return;
+    const int id = P.top_ids[e];
+    if (id < 0 || id >= n_nodes) return;
+    const BNode& nd = P.nodes[id];
+    const int sb = (int)S[nd.begin];
+    const int i = 2 * sb + nd.left_turns;
+    const madicp_node o = emit_node(nd, S, sb);
+    CNode c;
+    make_record(o, o0, o1, o2, c);
+    c.right = P.top_link[e];
+    top[e] = c;
+    dfs[e] = i;
+    link[e] = P.top_link[e];
+    exits[e] = make_int4(i + 1, o.right >> 1, sb, nd.level);
+    return;
+  }
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_nodes) return;
+  const BNode& nd = P.nodes[t];
+  const int sb = (int)S[nd.begin];
+  const int idx = 2 * sb + nd.left_turns;
+  if (idx < 0 || idx >= n_nodes) return;
+  const madicp_node o = emit_node(nd, S, sb);
+  out[idx] = o;
+  CNode c;
+  c.npack = 0ull;
+  c.c = 0.f;
+  c.right = 0u;  // (leaf records are never read, except the root's in a single-node tree: tree_compact)
+  if (o.right != 0) {
+    make_record(o, o0, o1, o2, c);
+    const int sm = (int)S[nd.mid];
+    c.right = (unsigned int)o.right | ((sm - sb) == 1 ? kLeftLeaf : 0u) | (((int)S[nd.end] - sm) == 1 ? kRightLeaf : 0u);
+  } else {
+    LeafRec lr;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lr.mean[a] = o.mean[a]; lr.normal[a] = o.dir[a]; }
+    lr.bbox0 = o.bbox0;
+    lr.pad_ = 0.0;
+    leaves[sb] = lr;
+  }
+  cnodes[idx] = c;
+}
+
+__global__ __launch_bounds__(256) void tb_top_bfs(const Params P, int top_levels, int top_max) { top_bfs_body(P, top_levels, top_max); }
 
 // ---- diagnostics: the cloud in the order the construction left it (madicp_debug_tree_build_points) --------------------
 // A leaf's members stay where the split of its parent put them — range [begin, end) of the point buffer its level reads.
@@ -1807,80 +1949,6 @@ __global__ __launch_bounds__(256) void tb_debug_order(const Params P, int n_node
   for (long j = 3 * (long)nd.begin + lane; j < 3 * (long)nd.end; j += 64) out[j] = in[j];
 }
 
-// ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---
-// one workgroup of 1024 threads; a level has at most 1024 internal nodes
-__global__ __launch_bounds__(1024) void tb_layout_top(const madicp_node* __restrict__ nodes, int top_levels, int top_max,
-                                                      int* __restrict__ dfs, unsigned int* __restrict__ link, int4* __restrict__ exits,
-                                                      int* __restrict__ out_n_top) {
-  // (node index, its `right` offset) of the current level's entries, in breadth-first order: the offset of an entry was
-  // read by its PARENT's step (to tell whether the child is a leaf), so a level costs one dependent memory hop, not two
-  __shared__ int s_cur[1024], s_next[1024], s_cur_right[1024], s_next_right[1024];
-  __shared__ int s_cur_leaf[1024], s_next_leaf[1024];  // leaf ordinal of the entry's left-most leaf
-  __shared__ int s_w[16];
-  __shared__ int s_total;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int ncur = 0, base = 0;
-  const int root_right = nodes[0].right;
-  if (root_right != 0) {
-    ncur = 1;
-    if (threadIdx.x == 0) { s_cur[0] = 0; s_cur_right[0] = root_right; s_cur_leaf[0] = 0; }
-  }
-  __syncthreads();
-  for (int lev = 0; lev < top_levels && ncur > 0; ++lev) {
-    const bool on = (int)threadIdx.x < ncur && base + (int)threadIdx.x < top_max - 1;
-    int i = 0, l = 0, r = 0, l_right = 0, r_right = 0, first_leaf = 0;
-    bool l_leaf = false, r_leaf = false, l_in = false, r_in = false;
-    if (on) {
-      i = s_cur[threadIdx.x];
-      l = i + 1;
-      r = i + s_cur_right[threadIdx.x];
-      first_leaf = s_cur_leaf[threadIdx.x];
-      l_right = nodes[l].right;
-      r_right = nodes[r].right;
-      l_leaf = l_right == 0;
-      r_leaf = r_right == 0;
-      const bool deeper = lev + 1 < top_levels;
-      l_in = !l_leaf && deeper;
-      r_in = !r_leaf && deeper;
-    }
-    const int c = (l_in ? 1 : 0) + (r_in ? 1 : 0);
-    int incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) s_w[wv] = incl;
-    __syncthreads();
-    int off = 0;
-    for (int k = 0; k < wv; ++k) off += s_w[k];
-    if (threadIdx.x == 1023) s_total = off + incl;
-    const int excl = off + incl - c;
-    const int next_base = base + ncur;
-    if (on) {
-      const int first = next_base + excl;
-      const int left_leaves = (r - l + 1) >> 1;
-      if (l_in) { s_next[excl] = l; s_next_right[excl] = l_right; s_next_leaf[excl] = first_leaf; }
-      if (r_in) {
-        const int at = excl + (l_in ? 1 : 0);
-        s_next[at] = r; s_next_right[at] = r_right; s_next_leaf[at] = first_leaf + left_leaves;
-      }
-      dfs[base + threadIdx.x] = i;
-      link[base + threadIdx.x] = top_link_word(l_in ? first : -1, r_in ? first + (l_in ? 1 : 0) : -1, l_leaf, r_leaf);
-      exits[base + threadIdx.x] = make_int4(l, left_leaves, first_leaf, lev);
-    }
-    __syncthreads();
-    base = next_base;
-    ncur = s_total;
-    if ((int)threadIdx.x < ncur) {
-      s_cur[threadIdx.x] = s_next[threadIdx.x];
-      s_cur_right[threadIdx.x] = s_next_right[threadIdx.x];
-      s_cur_leaf[threadIdx.x] = s_next_leaf[threadIdx.x];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *out_n_top = base;
-}
 
 }  // namespace tb
 }  // namespace madicp

@@ -18,5 +18,14 @@ def rate(nb, n):
     ctx.synchronize(); t = time.perf_counter()
     for _ in range(n): ctx.icp_register_batch_enqueue(mids[:nb], tids, X0[:nb], PARAMS, 15)
     ctx.synchronize(); return nb * n / (time.perf_counter() - t)
-r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
-print("K=64: 1 scan %.0f/s   8 scans %.0f/s   checksum %.12f" % (rate(1, 30), rate(8, 12), float(np.abs(r["X"]).sum())))
+def once(label):
+    r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+    only8 = os.environ.get("K64_ONLY8", "0") == "1"  # (counter passes: every icp_round launch then has the 8-scan geometry)
+    print("K=64 %-28s: 1 scan %.0f/s   8 scans %.0f/s   checksum %.12f" % (label, 0.0 if only8 else rate(1, 30), rate(8, 12), float(np.abs(r["X"]).sum())), flush=True)
+once("defaults")
+# development A/B: MADICP_AB="key=value;key=value,key2=value" — one more line per ';'-separated option set (options stay set)
+for group in filter(None, os.environ.get("MADICP_AB", "").split(";")):
+    for kv in group.split(","):
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    once(group)
