@@ -166,7 +166,7 @@
         const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
         const double src_ball = min_ball + b_ratio * pn[j];
         const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
-        if (TRACE && corr) corr[(long long)k * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
+        if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
         if (mark_matched) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
 

@@ -194,6 +194,9 @@ struct madicp_ctx {
 
   // options
   int blocks_per_cu = 1;  // icp_round workgroups (768 threads) per CU
+  int deal_trees = 1;     // a Job lists the caller's trees dealt round-robin over the eight XCD pieces (fill_job)
+  int units_per_wg = 1;   // when a scan has more trees than workgroups: cut every tree's leaves into enough ranges for at least
+                          // this many (tree, range) units per workgroup (see pick_geometry)
   int use_graph = 1;
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
@@ -428,6 +431,14 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   grid = std::max<long long>(8, std::min(grid, max_useful) / 8 * 8);
   g.grid = static_cast<int>(grid);
   g.ranges_per_tree = static_cast<int>(std::max<long long>(1, grid / std::max(1, K)));
+  if (ctx->units_per_wg > 1 && K > 0) {
+    // More trees than workgroups (a batch shares the chip): with one range per tree a workgroup owns whole trees, and trees
+    // differ in cost (how many of the scan's leaves still have to walk them, how many match) — the launch waits for the
+    // workgroup with the expensive ones.  Finer ranges give every workgroup of an XCD piece a slice of ALL the piece's trees.
+    const long long want = ((long long)ctx->units_per_wg * grid + K - 1) / K;
+    const long long cap = std::max<long long>(1, max_L / 256);  // (a range of fewer than 256 leaves is not worth a descriptor)
+    g.ranges_per_tree = static_cast<int>(std::max<long long>(g.ranges_per_tree, std::min(want, cap)));
+  }
   const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
   g.lds_bytes = (K > 0 && per_range >= ctx->stage_min_leaves) ? kTopLdsBytes : 0;
   return g;
@@ -779,12 +790,20 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
   j.rho = std::sqrt(params->rho_ker);  // MADicp ctor, mad_icp.cpp:32
   j.b_ratio = params->b_ratio;
   if (K == 0) std::memset(&j.trees[0], 0, sizeof(TreeDesc));
-  for (int k = 0; k < K; ++k) {
-    auto tit = ctx->trees.find(tree_ids[k]);
-    if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
-    RC_TRY(wait_tree(ctx, tit->second));
-    j.trees[k] = tit->second.desc;
-  }
+  // The kernel cuts the Job's tree list into eight contiguous pieces, one per XCD (kernels.hip.h).  The caller's list is DEALT
+  // over them — position p holds the caller's tree order[p], trees 0, 8, 16, .. first — so that neighbours in the caller's
+  // list (keyframes along a trajectory: similar cost for a given scan) land on different XCDs.  Everything the kernels index
+  // by tree is internal and follows the Job's positions; the one per-tree OUTPUT (the correspondence trace) goes by `slot`.
+  int p = 0;
+  for (int c = 0; c < (ctx->deal_trees ? 8 : 1); ++c)
+    for (int k = c; k < K; k += (ctx->deal_trees ? 8 : 1)) {
+      auto tit = ctx->trees.find(tree_ids[k]);
+      if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
+      RC_TRY(wait_tree(ctx, tit->second));
+      j.trees[p] = tit->second.desc;
+      j.trees[p].slot = k;
+      ++p;
+    }
   return MADICP_OK;
 }
 
@@ -1062,6 +1081,11 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   if (k == "grid_blocks_per_cu") {
     if (value < 1 || value > 4) return fail(MADICP_ERR_INVALID, "grid_blocks_per_cu must be in 1..4");
     ctx->blocks_per_cu = (int)value;
+  } else if (k == "deal_trees") {
+    ctx->deal_trees = value ? 1 : 0;
+  } else if (k == "units_per_workgroup") {
+    if (value < 1 || value > 64) return fail(MADICP_ERR_INVALID, "units_per_workgroup must be in 1..64");
+    ctx->units_per_wg = (int)value;
   } else if (k == "use_graph") {
     ctx->use_graph = value ? 1 : 0;
   } else if (k == "comm_graph") {
@@ -1114,6 +1138,8 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   const std::string k(key);
   int64_t v = 0;
   if (k == "grid_blocks_per_cu") v = ctx->blocks_per_cu;
+  else if (k == "deal_trees") v = ctx->deal_trees;
+  else if (k == "units_per_workgroup") v = ctx->units_per_wg;
   else if (k == "use_graph") v = ctx->use_graph;
   else if (k == "comm_graph") v = ctx->comm_graph;
   else if (k == "cache_correspondences") v = ctx->cache_corr;
