@@ -78,6 +78,11 @@ int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
+ * "deal_trees" (0/1, default 1: a registration lists the caller's trees dealt round-robin over the eight XCD pieces of the
+ * round kernel — neighbours in the caller's list, e.g. keyframes along a trajectory, cost a given scan about the same, and
+ * with them in one piece one XCD worked while seven waited; results keep the caller's indices),
+ * "units_per_workgroup" (1..64, default 1: with more trees than workgroups per scan, cut the leaves into enough ranges for at
+ * least this many (tree, range) units per workgroup; measured: no gain),
  * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves),
  * "nn_lds_top" (0/1: madicp_nn_search batches of >= 16 k queries stage the tree's top levels in LDS; default 0, measured
  * slower for single launches), "comm_graph" (0/1: with a communicator, capture the per-round RCCL all-reduces into the registration's hipGraph

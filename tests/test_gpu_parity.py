@@ -203,6 +203,38 @@ def test_linearize_correspondences_bit_exact(ctx, K):
     _teardown(ctx, tids, mids)
 
 
+def test_trees_dealt_over_the_xcd_pieces_keep_the_callers_indices(ctx):
+    """A Job lists the caller's trees dealt round-robin over the kernel's eight XCD pieces (fill_job; option deal_trees).
+    Nothing the caller sees may depend on it: the correspondence trace is indexed by the CALLER's tree index — checked
+    against the oracle tree by tree, with a tree count that is not a multiple of eight — the matched flags and the visit
+    count are identical with the option off and on, H and b equal to summation-order rounding, and a registration ends at
+    the same pose to 1e-12."""
+    K = 11
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
+    T = pb["query_guess"][0]
+    L = qh[0].num_leaves
+    assert ctx.get_option("deal_trees") == 1
+    res = {}
+    for deal in (1, 0):
+        ctx.set_option("deal_trees", deal)
+        res[deal] = (ctx.icp_linearize(mids[0], tids, T, PARAMS, L), ctx.icp_register(mids[0], tids, T, PARAMS, 6, L))
+    ctx.set_option("deal_trees", 1)
+    g, _ = res[1]
+    for k in range(K):
+        _, _, corr, rej, _, _ = O.icp_linearize(qo[0], ots[k], T, B_MAX, RHO_KER, B_RATIO)
+        assert np.array_equal(g["corr"][k] & 0x7FFFFFFF, corr), f"tree {k}: the trace is not in the caller's order"
+        assert np.array_equal((g["corr"][k] >> 31).astype(np.uint8), rej)
+    assert np.array_equal(res[1][0]["corr"], res[0][0]["corr"])
+    assert np.array_equal(res[1][0]["matched"], res[0][0]["matched"])
+    assert res[1][0]["visits"] == res[0][0]["visits"]
+    scale = np.abs(res[0][0]["H"]).max()
+    assert np.allclose(res[1][0]["H"], res[0][0]["H"], rtol=0, atol=1e-12 * scale)
+    assert np.allclose(res[1][0]["b"], res[0][0]["b"], rtol=0, atol=1e-12 * max(1.0, np.abs(res[0][0]["b"]).max()))
+    assert np.abs(res[1][1]["X"] - res[0][1]["X"]).max() < 1e-12
+    assert np.array_equal(res[1][1]["matched"], res[0][1]["matched"])
+    _teardown(ctx, tids, mids)
+
+
 @pytest.mark.parametrize("K", [1, 4])
 def test_register_pose_and_per_iteration_correspondences(ctx, K):
     pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
