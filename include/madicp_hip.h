@@ -78,6 +78,10 @@ int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
+ * "publish_side" (0/1, default 1: a streamed registration leaves its results in a device-resident outbox and a one-workgroup
+ * kernel on a side stream carries them, and the matched flags, to the caller's pinned block while the compute stream is already
+ * running the next registration — the two PCIe round trips of that hand-over were 5 us of every registration; off: the
+ * closing kernel writes them itself),
  * "deal_trees" (0/1, default 1: a registration lists the caller's trees dealt round-robin over the eight XCD pieces of the
  * round kernel — neighbours in the caller's list, e.g. keyframes along a trajectory, cost a given scan about the same, and
  * with them in one piece one XCD worked while seven waited; results keep the caller's indices),

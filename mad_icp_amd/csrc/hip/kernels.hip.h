@@ -144,6 +144,18 @@ struct HostResult {
   int32_t error;  // Job::error (icp_persist: an in-launch wait ran out)
 };
 
+// Streamed registrations, results out (option "publish_side", default on).  icp_final writing its results straight into the
+// caller's pinned block costs it two PCIe round trips — the stores' acknowledgement before the sequence number may go out,
+// then the sequence number's own at the end of the kernel: 10 us instead of 4.9, on the stream the NEXT registration is
+// waiting on.  Instead it leaves them in this device-resident outbox as tagged 16-byte granules (value halves + the
+// registration's sequence number: the tag, not an ordering of stores, says that a value is there — no fence), and a
+// one-workgroup kernel on a side stream (icp_publish, enqueued when the registration is submitted) waits for the tags and
+// carries results and matched flags to the host while the compute stream is already running the next registration.
+constexpr int kOutboxGranules = 64;
+struct Outbox {
+  unsigned long long g[2 * kOutboxGranules];  // granule i = words 2i, 2i + 1:  0..35 H, 36..47 X, 48..53 b, 54 n_pairs,
+};                                             // 55 visits, 56 walked, 57 (n_matched | iter << 32), 58 error
+
 // One registration in flight; lives in device memory, written by the host before each launch sequence
 // and advanced by workgroup 0 of every icp_round / by icp_final.  Keeping every per-registration quantity behind this one pointer is what lets
 // a single captured hipGraph serve every scan / keyframe set of the same launch geometry.
@@ -179,6 +191,7 @@ struct Job {
 #endif
   HostResult* host_out;     // optional: pinned host block icp_final also writes the results to
   uint8_t* host_matched;    // optional: pinned host copy of the matched_ flags (L bytes, 16-byte aligned)
+  Outbox* outbox;           // optional (instead of the two above): icp_final leaves the results here, icp_publish carries them out
   TreeDesc trees[MADICP_MAX_TREES];
 };
 constexpr int kFlagNoUpdate = 1;
@@ -1959,7 +1972,7 @@ __device__ __forceinline__ void count_matched(Job* job) {
   __shared__ int cnt[kBlock / 64];
   const int L = job->L;
   const uint4* m16 = reinterpret_cast<const uint4*>(job->matched);
-  uint8_t* hm = job->host_matched;  // pinned host copy of the flags (posted PCIe writes, 16 bytes per lane)
+  uint8_t* hm = job->outbox ? nullptr : job->host_matched;  // pinned host copy of the flags (posted PCIe writes, 16 bytes per lane)
   int c = 0;
   for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) {
     const uint4 v = m16[i];  // flags are 0/1 bytes: popcount counts them
@@ -2025,6 +2038,8 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     for (int i = 0; i < 12; ++i) Xp[i] = job->Xring[(n - 1) & 1][i];
     double moved[2];
     solve_pose(s_total, Xp, !(job->flags & kFlagNoUpdate), Xn, H, b, moved, threadIdx.x & 63);
+    const unsigned long long visits = job->visits + static_cast<unsigned long long>(s_total[28]);
+    const unsigned long long walked_n = job->walked + static_cast<unsigned long long>(s_total[29]);
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int i = 0; i < 36; ++i) job->H[i] = H[i];
@@ -2033,31 +2048,47 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
 #pragma unroll
       for (int i = 0; i < 12; ++i) job->X[i] = Xn[i];
       job->n_pairs = s_total[27];
-      job->visits += static_cast<unsigned long long>(s_total[28]);
-      job->walked += static_cast<unsigned long long>(s_total[29]);
+      job->visits = visits;
+      job->walked = walked_n;
       job->iter = n;
     }
-    // the same results straight to the caller's pinned block: lanes 0..35 write H, 0..11 X, 0..5 b
-    if (HostResult* ho = job->host_out) {
-      const int l = threadIdx.x;
-      double h = H[0], x = Xn[0], bb = b[0];
+    // the same results for the caller: lanes 0..35 carry H, then 12 lanes X, 6 lanes b (every lane holds all of them)
+    const int l = threadIdx.x;
+    double h = H[0], x = Xn[0], bb = b[0];
 #pragma unroll
-      for (int i = 1; i < 36; ++i) h = (l == i) ? H[i] : h;
+    for (int i = 1; i < 36; ++i) h = (l == i) ? H[i] : h;
 #pragma unroll
-      for (int i = 1; i < 12; ++i) x = (l == i) ? Xn[i] : x;
+    for (int i = 1; i < 12; ++i) x = (l - 36 == i) ? Xn[i] : x;
 #pragma unroll
-      for (int i = 1; i < 6; ++i) bb = (l == i) ? b[i] : bb;
+    for (int i = 1; i < 6; ++i) bb = (l - 48 == i) ? b[i] : bb;
+    if (Outbox* ob = job->outbox) {
+      // ... as tagged granules in the device-resident outbox (icp_publish carries them to the host from a side stream)
+      double v = l < 36 ? h : (l < 48 ? x : bb);
+      if (l == 54) v = s_total[27];
+      if (l == 55) v = __longlong_as_double((long long)visits);
+      if (l == 56) v = __longlong_as_double((long long)walked_n);
+      if (l == 58) v = __longlong_as_double((long long)job->error);
+      if (l < 59 && l != 57) granule_store((gptr_g64)(uintptr_t)ob->g + 2 * l, (unsigned)job->seq, v);
+    } else if (HostResult* ho = job->host_out) {
+      // ... straight to the caller's pinned block
       if (l < 36) ho->H[l] = h;
-      if (l < 12) ho->X[l] = x;
-      if (l < 6) ho->b[l] = bb;
+      if (l >= 36 && l < 48) ho->X[l - 36] = x;
+      if (l >= 48 && l < 54) ho->b[l - 48] = bb;
       if (l == 0) {
         ho->n_pairs = s_total[27];
-        ho->visits = job->visits;
-        ho->walked = job->walked;
+        ho->visits = visits;
+        ho->walked = walked_n;
         ho->iter = n;
         ho->error = job->error;
       }
     }
+  }
+  if (job->outbox) {
+    __syncthreads();  // count_matched's n_matched (thread 0) is final
+    if (threadIdx.x == 0)
+      granule_store((gptr_g64)(uintptr_t)job->outbox->g + 2 * 57, (unsigned)job->seq,
+                    __longlong_as_double((long long)(((unsigned long long)(unsigned)n << 32) | (unsigned)job->n_matched)));
+    return;
   }
   // The caller's completion signal is HostResult::seq in its pinned block (no event behind the registration: a
   // barrier packet on the queue costs more than this kernel).  Every thread orders its own host stores (flags, H, X, b)
@@ -2068,6 +2099,57 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     job->host_out->n_matched = job->n_matched;
     __hip_atomic_store(&job->host_out->seq, job->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// Streamed registrations: carries one registration's results from its device-resident outbox to the caller's pinned block
+// (see Outbox).  ONE workgroup, enqueued on the side stream when the registration is submitted: it waits — one wavefront
+// polling with s_sleep, bounded — until icp_final's tags are there, then copies H / X / b / counters and the matched flags
+// (written by the round kernels, i.e. before icp_final started: in memory, but possibly shadowed by stale lines of this
+// XCD's L2 — hence the acquire) and releases the sequence number at system scope.  On a time-out the caller finds
+// HostResult::error = 3 behind the sequence number.
+__global__ __launch_bounds__(256) void icp_publish(const Outbox* __restrict__ ob, const uint8_t* __restrict__ matched, int L, int seq,
+                                                   HostResult* __restrict__ ho, uint8_t* __restrict__ hm) {
+  __shared__ int s_bad;
+  __shared__ double s_v[kOutboxGranules];
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  if (threadIdx.x < 59) {
+    gptr_g64 g = (gptr_g64)(uintptr_t)ob->g + 2 * threadIdx.x;
+    double v = 0.0;
+    const unsigned long long t0 = wall_clock64();
+    bool ok = granule_try(g, (unsigned)seq, v);
+    while (!ok) {
+      __builtin_amdgcn_s_sleep(32);
+      ok = granule_try(g, (unsigned)seq, v);
+      if (!ok && wall_clock64() - t0 > 50ull * kSpinLimitTicks) break;  // 10 s: the registration never finished
+    }
+    if (!ok) s_bad = 1;
+    s_v[threadIdx.x] = v;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const bool bad = s_bad != 0;
+  if (!bad) {
+    const uint4* m16 = reinterpret_cast<const uint4*>(matched);
+    for (int i = threadIdx.x; i < (L >> 4); i += blockDim.x) reinterpret_cast<uint4*>(hm)[i] = m16[i];
+    for (int i = (L & ~15) + threadIdx.x; i < L; i += blockDim.x) hm[i] = matched[i];
+    const int l = threadIdx.x;
+    if (l < 36) ho->H[l] = s_v[l];
+    if (l >= 36 && l < 48) ho->X[l - 36] = s_v[l];
+    if (l >= 48 && l < 54) ho->b[l - 48] = s_v[l];
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long packed = (unsigned long long)__double_as_longlong(s_v[57]);
+    ho->n_pairs = s_v[54];
+    ho->visits = (unsigned long long)__double_as_longlong(s_v[55]);
+    ho->walked = (unsigned long long)__double_as_longlong(s_v[56]);
+    ho->n_matched = (int32_t)(unsigned)(packed & 0xffffffffull);
+    ho->iter = (int32_t)(unsigned)(packed >> 32);
+    ho->error = bad ? 3 : (int32_t)__double_as_longlong(s_v[58]);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&ho->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // development (option "debug_collective_us"): stands where a collective would — one wavefront that waits for `ticks` of the

@@ -131,6 +131,8 @@ struct StreamSlot {
   int moving_id = -1;       // a DevMoving owned by this slot
   Job* d_job = nullptr;     // this slot's Job on the device (its graphs bake the pointer)
   Job* h_job = nullptr;     // pinned staging of it
+  Outbox* d_outbox = nullptr;    // device: icp_final leaves the results here when icp_publish carries them out (option "publish_side")
+  bool side = false;             // this ticket's results come through the outbox / the side stream
   HostResult* h_out = nullptr;   // pinned: icp_final writes the results here
   uint8_t* h_matched = nullptr;  // pinned: and the matched_ flags here
   size_t h_matched_cap = 0;
@@ -175,6 +177,8 @@ struct madicp_ctx {
   double* d_totals = nullptr;  // [2 round parities][MADICP_MAX_BATCH][kAcc]: this rank's adders of a sharded round, reduced in place
   unsigned int* d_tickets = nullptr;  // [MADICP_MAX_BATCH]: arrival counters of icp_round's TAIL variant (zero between launches)
   hipStream_t stream2 = nullptr;      // second half of a sharded batch (option "shard_split"); created on first use
+  hipStream_t pub = nullptr;          // streamed registrations: icp_publish carries results to the host beside the next registration
+  int publish_side = 1;               // option "publish_side"
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned long long* d_xch = nullptr;  // icp_persist's exchange granules (kernels.hip.h), sized for every admissible geometry
   uint32_t epoch = 0;          // one per enqueued registration: Job::epoch
@@ -983,6 +987,7 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
     ctx->own_stream = true;
   }
   e = hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pub, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&ctx->d_jobs, sizeof(Job) * MADICP_MAX_BATCH);
   for (int i = 0; i < madicp_ctx::kStageSlots && e == hipSuccess; ++i) {
     e = hipHostMalloc(&ctx->h_stage[i], sizeof(Job) * MADICP_MAX_BATCH, hipHostMallocDefault);
@@ -1000,6 +1005,8 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
     e = hipMalloc(&sl.d_job, sizeof(Job));
     if (e == hipSuccess) e = hipHostMalloc(&sl.h_job, sizeof(Job), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(&sl.h_out, sizeof(HostResult), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&sl.d_outbox, sizeof(Outbox));
+    if (e == hipSuccess) e = hipMemset(sl.d_outbox, 0, sizeof(Outbox));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming);
   }
@@ -1017,6 +1024,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->copy) hipStreamSynchronize(ctx->copy);
   if (ctx->build) hipStreamSynchronize(ctx->build);
+  if (ctx->pub) hipStreamSynchronize(ctx->pub);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   if (ctx->h_comm) hipHostFree(ctx->h_comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
@@ -1046,6 +1054,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     if (sl.d_job) hipFree(sl.d_job);
     if (sl.h_job) hipHostFree(sl.h_job);
     if (sl.h_out) hipHostFree(sl.h_out);
+    if (sl.d_outbox) hipFree(sl.d_outbox);
     if (sl.h_matched) hipHostFree(sl.h_matched);
     if (sl.ev_up) hipEventDestroy(sl.ev_up);
     if (sl.ev_done) hipEventDestroy(sl.ev_done);
@@ -1058,6 +1067,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     hipStreamSynchronize(ctx->stream2);
     hipStreamDestroy(ctx->stream2);
   }
+  if (ctx->pub) hipStreamDestroy(ctx->pub);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->d_xch) hipFree(ctx->d_xch);
@@ -1072,7 +1082,9 @@ int madicp_ctx_synchronize(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   HIP_TRY(hipStreamSynchronize(ctx->copy));
   if (ctx->build) HIP_TRY(hipStreamSynchronize(ctx->build));
-  return bounded_sync(ctx, ctx->stream);
+  RC_TRY(bounded_sync(ctx, ctx->stream));
+  if (ctx->pub) HIP_TRY(hipStreamSynchronize(ctx->pub));  // (behind the compute stream: its kernels wait for icp_final's tags)
+  return MADICP_OK;
 }
 
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
@@ -1081,6 +1093,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   if (k == "grid_blocks_per_cu") {
     if (value < 1 || value > 4) return fail(MADICP_ERR_INVALID, "grid_blocks_per_cu must be in 1..4");
     ctx->blocks_per_cu = (int)value;
+  } else if (k == "publish_side") {
+    ctx->publish_side = value ? 1 : 0;
   } else if (k == "deal_trees") {
     ctx->deal_trees = value ? 1 : 0;
   } else if (k == "units_per_workgroup") {
@@ -1138,6 +1152,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   const std::string k(key);
   int64_t v = 0;
   if (k == "grid_blocks_per_cu") v = ctx->blocks_per_cu;
+  else if (k == "publish_side") v = ctx->publish_side;
   else if (k == "deal_trees") v = ctx->deal_trees;
   else if (k == "units_per_workgroup") v = ctx->units_per_wg;
   else if (k == "use_graph") v = ctx->use_graph;
@@ -1568,6 +1583,14 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   j.lds_top = geo.lds_bytes ? 1 : 0;
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_out), sl.h_out, 0));
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_matched), sl.h_matched, 0));
+  // results out: through the device-resident outbox and icp_publish on the side stream (kernels.hip.h, Outbox), unless the
+  // completion is an event on the compute stream or the loop is sharded (its matched flags are reduced behind icp_final)
+  // — or the rounds need the whole chip to themselves: icp_persist / the xcd_fold variant wait INSIDE a launch for workgroups
+  // that must all be resident, at 3 x 168 registers per SIMD lane nothing fits beside them, and an icp_publish workgroup that got
+  // its CU first (the compute stream is still waiting for the feed) would keep one of them out until their bounded waits expire
+  const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
+  const bool side = ctx->publish_side && ctx->seq_completion && !ctx->sharded() && !use_persist(ctx, launch) && !use_fold(ctx, launch);
+  j.outbox = side ? sl.d_outbox : nullptr;
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, K);
   j.seq = ticket + 1;
   sl.h_out->seq = 0;
@@ -1584,13 +1607,18 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   else
     HIP_TRY(hipStreamWaitEvent(ctx->stream, sl.ev_up, 0));
   if (n_iters == 1 || ctx->match_all) HIP_TRY(hipMemsetAsync(mv.matched, 0, (size_t)L, ctx->stream));
-  const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
   {
     size_t doubles = 0;
     RC_TRY(prepare_partials(ctx, &launch, 1, &doubles));
   }
   const std::vector<int> ids{sl.moving_id};
   RC_TRY(run_rounds(ctx, launch, sl.d_job, ticket % madicp_ctx::kStreamSlots, ids, busy));
+  if (side) {
+    hipLaunchKernelGGL(icp_publish, dim3(1), dim3(256), 0, ctx->pub, (const Outbox*)sl.d_outbox, (const uint8_t*)mv.matched, L, ticket + 1,
+                       j.host_out, j.host_matched);
+    HIP_TRY(hipGetLastError());
+  }
+  sl.side = side;
   if (!ctx->seq_completion) HIP_TRY(hipEventRecord(sl.ev_done, ctx->stream));
   sl.by_seq = ctx->seq_completion != 0;
   sl.pending = true;
@@ -1629,7 +1657,7 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != want; ++spins) {
       if ((spins & check_mask) == 0) {
-        const hipError_t q = hipStreamQuery(ctx->stream);
+        const hipError_t q = hipStreamQuery(sl.side ? ctx->pub : ctx->stream);  // (the stream the sequence number comes from)
         if (q == hipSuccess) {
           if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) break;
           sl.pending = false;
@@ -1665,7 +1693,8 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
   const HostResult& r = *sl.h_out;
   if (r.error) {
     sl.pending = false;
-    return fail(MADICP_ERR_DEVICE, "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(r.error) + ")");
+    return fail(MADICP_ERR_DEVICE, r.error == 3 ? std::string("registration never left its results in the outbox (icp_publish timed out)")
+                                                : "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(r.error) + ")");
   }
   if (out_X) std::memcpy(out_X, r.X, sizeof(r.X));
   if (out_H) std::memcpy(out_H, r.H, sizeof(r.H));

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 has() { case " $WHAT " in *" $1 "*) return 0;; esac; return 1; }
 if has tests; then
-  timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 > $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log
+  timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 > $OUT/pytest_gpu.log; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2
 fi
 if has build; then
   timeout 300 python tools/order_probe.py 3 > $OUT/order_probe.log 2>&1; grep -E "scan120k|kf0|line100|rand1 |rand9" $OUT/order_probe.log
