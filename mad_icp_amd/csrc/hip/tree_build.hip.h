@@ -327,27 +327,57 @@ __device__ __forceinline__ void leaf_normal(const Inherit& nd, int n, const doub
 }
 
 // ---- wave helpers ---------------------------------------------------------------------------------------------
+// The value of lane (lane ^ M) — the partner of an xor butterfly — WITHOUT the LDS crossbar: __shfl_xor of a double is two
+// ds_bpermute_b32 plus an address, ~100 cycles of latency each, and a node's reductions are 15-24 such butterflies (in-kernel
+// stamps: 3.3 us of tb_chip_scatter for its 18 sums, 2 us of every sweep for its 6 extents).  gfx950 has a VALU route for
+// every distance: v_permlane32_swap / v_permlane16_swap for 32 / 16 (a copy of the value swapped against itself leaves the
+// lower and the upper partner in the two registers), DPP row_ror:8 for 8, row_shl:4 / row_shr:4 under complementary bank masks
+// for 4, quad_perm for 2 and 1.  Same partners, same order, same operands as the __shfl_xor loops they replace: the same bits.
+// (MADICP_TB_BPERMUTE=1 restores those, for the A/B.)
+#ifndef MADICP_TB_BPERMUTE
+#define MADICP_TB_BPERMUTE 0
+#endif
+template <int M>
+__device__ __forceinline__ double xor_fetch(double v) {
+  if (MADICP_TB_BPERMUTE) return __shfl_xor(v, M, 64);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  if (M == 32 || M == 16) {
+    // after swapping a register against a copy of itself: [0] holds the lower partner's value on both sides, [1] the upper's
+    const auto l2 = M == 32 ? __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false)
+                            : __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false);
+    const auto h2 = M == 32 ? __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false)
+                            : __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false);
+    const bool upper = (threadIdx.x & M) != 0;  // (an upper lane's partner is the lower one)
+    return __hiloint2double((int)(upper ? h2[0] : h2[1]), (int)(upper ? l2[0] : l2[1]));
+  }
+  if (M == 8) return dpp_fetch<0x128>(v);  // row_ror:8
+  if (M == 4) {
+    // banks 0 and 2 of a row read four lanes up (row_shl:4), banks 1 and 3 four lanes down (row_shr:4)
+    const int l1 = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xf, 0x5, false);
+    const int h1 = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xf, 0x5, false);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(h1, hi, 0x114, 0xf, 0xA, false),
+                            __builtin_amdgcn_update_dpp(l1, lo, 0x114, 0xf, 0xA, false));
+  }
+  if (M == 2) return dpp_fetch<0x4E>(v);  // quad_perm [2,3,0,1]
+  return dpp_fetch<0xB1>(v);              // quad_perm [1,0,3,2]
+}
 __device__ __forceinline__ double wave_sum(double v) {  // xor butterfly: every lane ends with the same bits
-  #pragma unroll
-  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += xor_fetch<32>(v); v += xor_fetch<16>(v); v += xor_fetch<8>(v);
+  v += xor_fetch<4>(v); v += xor_fetch<2>(v); v += xor_fetch<1>(v);
   return v;
 }
+#define MADICP_TB_KEEP_STEP(M, CMP) { const double o = xor_fetch<M>(v); if (CMP) v = o; }
 __device__ __forceinline__ double wave_min_keep(double v) {  // min with "keep mine unless the other is smaller"
-  #pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    const double o = __shfl_xor(v, m, 64);
-    if (o < v) v = o;
-  }
+  MADICP_TB_KEEP_STEP(32, o < v) MADICP_TB_KEEP_STEP(16, o < v) MADICP_TB_KEEP_STEP(8, o < v)
+  MADICP_TB_KEEP_STEP(4, o < v) MADICP_TB_KEEP_STEP(2, o < v) MADICP_TB_KEEP_STEP(1, o < v)
   return v;
 }
 __device__ __forceinline__ double wave_max_keep(double v) {
-  #pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    const double o = __shfl_xor(v, m, 64);
-    if (v < o) v = o;
-  }
+  MADICP_TB_KEEP_STEP(32, v < o) MADICP_TB_KEEP_STEP(16, v < o) MADICP_TB_KEEP_STEP(8, v < o)
+  MADICP_TB_KEEP_STEP(4, v < o) MADICP_TB_KEEP_STEP(2, v < o) MADICP_TB_KEEP_STEP(1, v < o)
   return v;
 }
+#undef MADICP_TB_KEEP_STEP
 __device__ __forceinline__ int wave_sum_int(int v) {
   #pragma unroll
   for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -1370,10 +1400,12 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
   const int total = s_off[cnt];
   const double* __restrict__ in = level_in(P, level);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { TB_STAMP_MIN(level, 8); }
   for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
     const ChunkMap cm = chip_find(s_off, cnt, slot);
     BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
     const int n = nd.end - nd.begin;
+    if (lane == 0) { TB_STAMP_MAX(level, 9); }
     // the node's nine sums: per-chunk partials of its PARENT's scatter (left or right half), or of tb_chip_sums (root)
     const int nflags = nd.flags;
     const int pfirst = (nflags & kChunkSums) ? nd.sum_first : cm.first_slot;
@@ -1395,12 +1427,26 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
       }
       __syncthreads();
     }
+    // the chunk's points are requested BEFORE the eigen-solve (they do not depend on it): their first touch of memory the
+    // previous kernel has just written (~2 us) passes while wave 0 solves
+    const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
+    double x[8], y[8], z[8];
+    bool ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = cb + (int)threadIdx.x + 256 * u;
+      ok[u] = i < ce;
+      const long j = ok[u] ? i : cb;
+      x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
+    }
     if (threadIdx.x < 64) {  // wave 0, every lane the same values
       double tot[9], mean[3], cov[9], w[3], V[9];
+      if (lane == 0) { TB_STAMP_MAX(level, 10); }
 #pragma unroll
       for (int k = 0; k < 9; ++k) tot[k] = s_tot[k];
       mean_cov_from_sums(tot, n, mean, cov);
       madicp_host::eig3_sym(cov, w, V);
+      if (lane == 0) { TB_STAMP_MAX(level, 11); }
       if (threadIdx.x == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) s_mean[k] = mean[k];
@@ -1418,7 +1464,7 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
     for (int k = 0; k < 3; ++k) mean[k] = s_mean[k];
 #pragma unroll
     for (int k = 0; k < 9; ++k) V[k] = s_V[k];
-    const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
+    if (lane == 0) { TB_STAMP_MAX(level, 12); }
     double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     // The sides of the chunk's points and, from them, the chunk's slice of the rank tables of the split's permutation
     // (common/split_order.h): the positions (relative to the node's first point) of the chunk's lefts, in order, from the
@@ -1427,15 +1473,6 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
     unsigned int lbits = 0;
     int inw[8];
     {
-      double x[8], y[8], z[8];
-      bool ok[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = cb + (int)threadIdx.x + 256 * u;
-        ok[u] = i < ce;
-        const long j = ok[u] ? i : cb;
-        x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
-      }
       const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -1460,6 +1497,7 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
 #pragma unroll
       for (int a = 0; a < 3; ++a) { s_lo[wv][a] = lo[a]; s_hi[wv][a] = hi[a]; }
     }
+    if (lane == 0) { TB_STAMP_MAX(level, 13); }
     __syncthreads();
     int run = 0;
     {
@@ -1495,6 +1533,7 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
       }
       P.part2[(long)slot * 8 + 6] = (double)run;  // the chunk's lefts
     }
+    if (lane == 0) { TB_STAMP_MAX(level, 14); }
     __syncthreads();
   }
 }
@@ -1517,11 +1556,27 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
   const double* __restrict__ in = level_in(P, level);
   double* __restrict__ out = level_out(P, level);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { TB_STAMP_MIN(level, 0); }
   for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
     const ChunkMap cm = chip_find(s_off, cnt, slot);
     const int id = level_big(P, level)[cm.node_slot];
     BNode& nd = P.nodes[id];
     const int b = nd.begin, e = nd.end, n = e - b;
+    if (lane == 0) { TB_STAMP_MAX(level, 2); }
+    // thread t owns points cb + 8 t .. cb + 8 t + 7 (consecutive: one scan gives every point its count of lefts in front).
+    // Requested first: nothing below depends on them until the sides are needed, and their first touch passes meanwhile.
+    const int cb = b + cm.chunk * kChunk, ce = min(cb + kChunk, e);
+    const int i0 = cb + 8 * (int)threadIdx.x;
+    double px[8], py[8], pz[8];
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k;
+      const bool ok = i < ce;
+      const long j = ok ? i : cb;
+      px[k] = in[3 * j]; py[k] = in[3 * j + 1]; pz[k] = in[3 * j + 2];
+      nvalid += ok ? 1 : 0;
+    }
     int shift = 0;
     while ((cm.n_chunks >> shift) > kPrefMax) ++shift;
     const int n_gran = (cm.n_chunks + (1 << shift) - 1) >> shift;
@@ -1569,6 +1624,7 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
     __syncthreads();
     const double ext0 = s_hi[0] - s_lo[0], ext2 = s_hi[2] - s_lo[2];
     const int nl = s_carry, before = s_before;
+    if (lane == 0) { TB_STAMP_MAX(level, 3); }
     const bool leaf = (ext2 < P.b_max) || nl == 0 || nl == n;
     const int mid = b + nl;
     double mean[3], col2[3];
@@ -1584,45 +1640,59 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       }
       continue;
     }
-    if (cm.chunk == 0 && threadIdx.x == 0) {
-      const double col0[3] = {nd.col0[0], nd.col0[1], nd.col0[2]};
-      const int c = atomicAdd(&P.st->n_nodes.v, 2);
-      if (c + 2 > P.node_cap) {
-        P.st->n_nodes.error = 1;
-      } else {
-        const Inherit inh = load_inherit(nd, level);
-        nd.child = c;
-        make_child(P.nodes[c], inh, id, col0, ext0, n, P.b_min, b, mid, true);
-        make_child(P.nodes[c + 1], inh, id, col0, ext0, n, P.b_min, mid, e, false);
-        // their sums: this node's per-chunk partials, written below by every chunk of it
-        P.nodes[c].flags |= kChunkSums;
-        P.nodes[c + 1].flags |= kChunkSums | kSumRight;
-        P.nodes[c].sum_first = P.nodes[c + 1].sum_first = cm.first_slot;
-        P.nodes[c].sum_n = P.nodes[c + 1].sum_n = cm.n_chunks;
-        enqueue_single(P, c, b, mid, level + 1);
-        enqueue_single(P, c + 1, mid, e, level + 1);
-      }
-      nd.bbox0 = ext0;
-      nd.mid = mid;
-      nd.flags |= kDone;
-    }
-    // thread t owns points cb + 8 t .. cb + 8 t + 7 (consecutive: one scan gives every point its count of lefts in front)
-    const int cb = b + cm.chunk * kChunk, ce = min(cb + kChunk, e);
-    const int i0 = cb + 8 * (int)threadIdx.x;
-    double px[8], py[8], pz[8];
     unsigned int lmask = 0;
-    int nvalid = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = i0 + k;
-      const bool ok = i < ce;
-      const long j = ok ? i : cb;
-      px[k] = in[3 * j]; py[k] = in[3 * j + 1]; pz[k] = in[3 * j + 2];
-      nvalid += ok ? 1 : 0;
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       if (k < nvalid && goes_left(mean, col2, px[k], py[k], pz[k])) lmask |= 1u << k;
+    const int mine = __popc(lmask);
+    // exclusive scan of `mine` over the 256 threads: wave scan + wave totals
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int k = 0; k < wv; ++k) wave_off += s_wsum[k];
+    int lrun = before + wave_off + incl - mine;  // lefts of the NODE in front of this thread's first point
+    if (lane == 0) { TB_STAMP_MAX(level, 4); }
+    const int32_t* __restrict__ tab = P.tab;
+    const double* __restrict__ p2 = P.part2 + (long)cm.first_slot * 8;
+    auto lefts_of = [p2](int c) { return (int)p2[(long)c * 8 + 6]; };
+    // The plan: every point's place from the closed form; for the two kinds that need a rank table the table entry is
+    // REQUESTED here (a dependent first touch of memory tb_chip_stats wrote) and used after the children's sums below,
+    // which do not depend on it — the round trip passes under ~2 us of shuffles.
+    int dst[8];
+    long tix[8];
+    int tadd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      dst[k] = 0;
+      tix[k] = -1;
+      tadd[k] = 0;
+      if (k < nvalid) {
+        const bool left = (lmask >> k) & 1u;
+        const madicp_host::SplitPlan pl = madicp_host::split_plan(left, cm.chunk * kChunk + 8 * (int)threadIdx.x + k, lrun, nl, n);
+        dst[k] = pl.idx;
+        if (pl.kind == 1) {
+          int c, local;
+          madicp_host::find_right_chunk(s_pref, n_gran, shift, cm.n_chunks, kChunk, n, pl.idx, lefts_of, c, local);
+          tix[k] = (long)b + min(n, (c + 1) * kChunk) - 1 - local;
+        } else if (pl.kind == 2) {
+          int c, local;
+          madicp_host::find_left_chunk(s_pref, n_gran, shift, cm.n_chunks, pl.idx, lefts_of, c, local);
+          tix[k] = (long)b + (long)c * kChunk + local;
+          tadd[k] = -1;
+        }
+        lrun += left ? 1 : 0;
+      }
+    }
+    int tval[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tval[k] = tab[tix[k] >= 0 ? tix[k] : (long)b];
+    if (lane == 0) { TB_STAMP_MAX(level, 5); }
     {  // the children's sums over this chunk (they will not have to sweep their points for them)
       double sL[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, sR[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1644,49 +1714,40 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
         level_part(P, level + 1)[(long)slot * 18 + threadIdx.x] =
             ((s_cs[0][threadIdx.x] + s_cs[1][threadIdx.x]) + s_cs[2][threadIdx.x]) + s_cs[3][threadIdx.x];
     }
-    const int mine = __popc(lmask);
-    // exclusive scan of `mine` over the 256 threads: wave scan + wave totals
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    int wave_off = 0;
-    for (int k = 0; k < wv; ++k) wave_off += s_wsum[k];
-    int lrun = before + wave_off + incl - mine;  // lefts of the NODE in front of this thread's first point
-    const int32_t* __restrict__ tab = P.tab;
-    const double* __restrict__ p2 = P.part2 + (long)cm.first_slot * 8;
-    auto lefts_of = [p2](int c) { return (int)p2[(long)c * 8 + 6]; };
-    int dst[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      dst[k] = 0;
-      if (k < nvalid) {
-        const bool left = (lmask >> k) & 1u;
-        const madicp_host::SplitPlan pl = madicp_host::split_plan(left, cm.chunk * kChunk + 8 * (int)threadIdx.x + k, lrun, nl, n);
-        dst[k] = pl.idx;
-        if (pl.kind == 1) {
-          int c, local;
-          madicp_host::find_right_chunk(s_pref, n_gran, shift, cm.n_chunks, kChunk, n, pl.idx, lefts_of, c, local);
-          dst[k] = tab[(long)b + min(n, (c + 1) * kChunk) - 1 - local];
-        } else if (pl.kind == 2) {
-          int c, local;
-          madicp_host::find_left_chunk(s_pref, n_gran, shift, cm.n_chunks, pl.idx, lefts_of, c, local);
-          dst[k] = tab[(long)b + (long)c * kChunk + local] - 1;
-        }
-        lrun += left ? 1 : 0;
-      }
-    }
+    if (lane == 0) { TB_STAMP_MAX(level, 6); }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (k < nvalid) {
-        const long d = (long)b + dst[k];
+        const long d = (long)b + (tix[k] >= 0 ? tval[k] + tadd[k] : dst[k]);
         out[3 * d] = px[k]; out[3 * d + 1] = py[k]; out[3 * d + 2] = pz[k];
       }
     }
+    if (lane == 0) { TB_STAMP_MAX(level, 7); }
+    // the node's record and its children (chunk 0, thread 0): last, so that the atomic's round trip and ~100 stores do not hold
+    // up the workgroup's barriers above — only the NEXT kernel reads any of it
+    if (cm.chunk == 0 && threadIdx.x == 0) {
+      const double col0[3] = {nd.col0[0], nd.col0[1], nd.col0[2]};
+      const int c = atomicAdd(&P.st->n_nodes.v, 2);
+      if (c + 2 > P.node_cap) {
+        P.st->n_nodes.error = 1;
+      } else {
+        const Inherit inh = load_inherit(nd, level);
+        nd.child = c;
+        make_child(P.nodes[c], inh, id, col0, ext0, n, P.b_min, b, mid, true);
+        make_child(P.nodes[c + 1], inh, id, col0, ext0, n, P.b_min, mid, e, false);
+        // their sums: this node's per-chunk partials, written above by every chunk of it
+        P.nodes[c].flags |= kChunkSums;
+        P.nodes[c + 1].flags |= kChunkSums | kSumRight;
+        P.nodes[c].sum_first = P.nodes[c + 1].sum_first = cm.first_slot;
+        P.nodes[c].sum_n = P.nodes[c + 1].sum_n = cm.n_chunks;
+        enqueue_single(P, c, b, mid, level + 1);
+        enqueue_single(P, c + 1, mid, e, level + 1);
+      }
+      nd.bbox0 = ext0;
+      nd.mid = mid;
+      nd.flags |= kDone;
+    }
+    if (lane == 0) { TB_STAMP_MAX(level, 1); }
     __syncthreads();
   }
 }

@@ -30,6 +30,22 @@ s = buf.reshape(24, 2048, 16).astype(np.int64)
 st = ctx.tree_build_stats()
 cols = [(0, "start"), (3, "w:node"), (4, "w:sums"), (5, "w:eig"), (6, "w:sweep"), (7, "w:reduce"), (8, "w:alloc"), (9, "w:emit"),
         (10, "l:sums"), (11, "l:eig"), (12, "l:sweep"), (13, "l:leaf"), (14, "l:alloc"), (15, "l:emit"), (1, "end")]
+# chip levels 0-5: tb_chip_stats (slots 8-14) and tb_chip_scatter (slots 0-7, 1 = end), median / max over the wavefronts,
+# microseconds after the kernel's own first wavefront
+names_st = [(8, "start"), (9, "node"), (10, "sums joined"), (11, "eig"), (12, "V seen"), (13, "sides+ext"), (14, "tables out")]
+names_sc = [(0, "start"), (2, "node"), (3, "part2 scan"), (4, "sides+scan"), (5, "plan,tab req"), (6, "child sums"), (7, "stores"), (1, "alloc/end")]
+for lv in range(0, 6):
+    for title, names in (("stats", names_st), ("scatter", names_sc)):
+        a = s[lv]
+        st0 = a[:, names[0][0]][a[:, names[0][0]] > 0]
+        if st0.size == 0:
+            continue
+        t0 = st0.min()
+        row = []
+        for k, nm in names:
+            v = a[:, k][a[:, k] > 0]
+            row.append("%s %5.2f/%5.2f" % (nm, np.median(v - t0) / 100.0, (v.max() - t0) / 100.0) if v.size else nm + " -")
+        print("chip level %d %-7s | %s" % (lv, title, " | ".join(row)))
 print("level waveN | " + " ".join("%13s" % n for _, n in cols) + "   (median/max us)")
 for lv in range(0, min(st["max_level"] + 2, 24)):
     a = s[lv]
