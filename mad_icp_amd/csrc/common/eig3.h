@@ -52,10 +52,17 @@ MADICP_HD inline void kernel_vector(const Sym3& m, double* res, double* repr) {
   double best = std::fabs(m.a00);
   if (std::fabs(m.a11) > best) { best = std::fabs(m.a11); i0 = 1; }
   if (std::fabs(m.a22) > best) { i0 = 2; }
+  // columns i0, i0 + 1, i0 + 2 (mod 3) of the symmetric matrix, picked element by element with selects on NAMED scalars: an
+  // index into the matrix (m.at(r, c) with a run-time column) is turned into a table in scratch memory by the device compiler —
+  // three 16-byte stores and nine dependent loads per call, ~1.5 us of every eigen-solve on the GPU
+  const bool is0 = i0 == 0, is1 = i0 == 1;
+  const double k0[3] = {m.a00, m.a10, m.a20}, k1[3] = {m.a10, m.a11, m.a21}, k2[3] = {m.a20, m.a21, m.a22};
   double c1[3], c2[3], x1[3], x2[3];
-  m.col(i0, repr);
-  m.col((i0 + 1) % 3, c1);
-  m.col((i0 + 2) % 3, c2);
+  for (int i = 0; i < 3; ++i) {
+    repr[i] = is0 ? k0[i] : (is1 ? k1[i] : k2[i]);
+    c1[i] = is0 ? k1[i] : (is1 ? k2[i] : k0[i]);
+    c2[i] = is0 ? k2[i] : (is1 ? k0[i] : k1[i]);
+  }
   cross3(repr, c1, x1);
   cross3(repr, c2, x2);
   const double n1 = dot3c(x1, x1), n2 = dot3c(x2, x2);

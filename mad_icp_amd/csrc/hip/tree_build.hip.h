@@ -484,9 +484,13 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
   double s9[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) s9[k] = nd.sums[k];
-  double touch[8];
+#ifndef MADICP_TB_TOUCH
+#define MADICP_TB_TOUCH 0
+#endif
+  constexpr int kTouch = MADICP_TB_TOUCH;  // line-touches made (round 2-3: eight, worth 1.5 us of a level then; round 4: the sixteen registers they hold across the eigen-solve cost 18 spilled registers, 11 us of a build — none)
+  double touch[kTouch > 0 ? kTouch : 1];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
+  for (int u = 0; u < kTouch; ++u) {
     const long j = min(8 * ((long)lane + 64 * u), 3 * (long)n - 1);  // doubles: one per 64-byte line
     touch[u] = in[3 * (long)b + j];
   }
@@ -525,7 +529,7 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
     mean_cov_from_sums(s, n, mean, cov);
     madicp_host::eig3_sym(cov, w, V);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(touch[u]));  // (the touches are consumed here, not before)
+    for (int u = 0; u < kTouch; ++u) asm volatile("" ::"v"(touch[u]));  // (the touches are consumed here, not before)
     if (lane == 0) TB_STAMP_MAX(level, 5);
     // A wave-regime node holds at most kTeamMin = 512 points: ONE batch of eight points per lane, which stay in registers
     // from the sweep that reads them to the scatter that writes them.
