@@ -38,9 +38,6 @@ struct FrontScratch {
   bool state_stale = false;      // h_state is older than the device State
   double* h_table = nullptr;     // pinned, same layout as `table`
   hipEvent_t h_table_read = nullptr;
-  // the breadth-first layout of a tree's top runs BESIDE the deeper levels of its construction, on a stream of its own
-  hipStream_t side = nullptr;
-  hipEvent_t side_fork = nullptr, side_join = nullptr;
   // a construction between its two halves (tree_build_begin_on / tree_build_end_on)
   struct InFlight {
     bool active = false;
@@ -51,7 +48,6 @@ struct FrontScratch {
     bool chip = false;
     int chip_grid = 0, level_grid = 0, n_tiles = 0, levels_done = 0;
     int quiet_from = -1;   // levels past this one are expected to be empty (FrontScratch::last_depth + 1)
-    bool side_pending = false;  // the top's layout is in flight on the side stream
     int seq = 0;           // what tb_finish_b will publish (direct scan path)
     DevCloud cloud;        // look-ahead only
   } fly;
@@ -98,7 +94,6 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   if (fs.block) {
     HIP_TRY(hipStreamSynchronize(ctx->copy));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (fs.side) HIP_TRY(hipStreamSynchronize(fs.side));
     if (ctx->build) HIP_TRY(hipStreamSynchronize(ctx->build));
     HIP_TRY(hipFree(fs.block));
     fs.block = nullptr;
@@ -133,6 +128,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   const size_t o_tab = take(sizeof(int32_t) * ((size_t)nc + 8));
   const size_t o_topids = take(sizeof(int32_t) * kTopMax);
   const size_t o_toplink = take(sizeof(uint32_t) * kTopMax);
+  const size_t o_topfront = take(sizeof(int32_t) * (2 + 2 * 1024));
   const size_t o_key0 = take(sizeof(double) * (size_t)nc);
   const size_t o_key1 = take(sizeof(double) * (size_t)nc);
   const size_t o_idx0 = take(sizeof(uint32_t) * (size_t)nc);
@@ -167,6 +163,7 @@ int ensure_scratch(madicp_ctx* ctx, int64_t n, FrontScratch** out) {
   fs.P.tab = reinterpret_cast<int32_t*>(b + o_tab);
   fs.P.top_ids = reinterpret_cast<int32_t*>(b + o_topids);
   fs.P.top_link = reinterpret_cast<uint32_t*>(b + o_toplink);
+  fs.P.top_front = reinterpret_cast<int32_t*>(b + o_topfront);
   fs.S = reinterpret_cast<uint32_t*>(b + o_S);
   fs.tile_sums = reinterpret_cast<uint32_t*>(b + o_tiles);
   fs.P.S = fs.S;
@@ -193,9 +190,6 @@ void front_destroy(madicp_ctx* ctx) {  // called by madicp_ctx_destroy (streams 
   if (fs.h_line) hipHostFree(fs.h_line);
   if (fs.h_table) hipHostFree(fs.h_table);
   if (fs.h_table_read) hipEventDestroy(fs.h_table_read);
-  if (fs.side_fork) hipEventDestroy(fs.side_fork);
-  if (fs.side_join) hipEventDestroy(fs.side_join);
-  if (fs.side) hipStreamDestroy(fs.side);
   delete ctx->front;
   ctx->front = nullptr;
 }
@@ -482,6 +476,19 @@ int madicp_cloud_deskew(madicp_ctx* ctx, int cloud_id, const double velocity[6],
 namespace {
 
 // the level kernels of steps [from, to) of the construction in flight, on its stream
+// The breadth-first layout of the tree's LDS-staged top is made in three parts, each as the first workgroup of a level launch.
+// Part [a, b) reads the nodes of levels a .. b, so they must be FINISHED, and a node of level L is finished by step L + 5 at
+// the latest, not L: a small node born during the chip levels waits for step kChipLevels, and its descendants follow one
+// step per level from there (a child of the root's small child, level 2, is step 7).  Hence step b + 6.  (Looking at the
+// nodes themselves does not work: the array is not cleared between builds, an unwritten slot looks like last build's node.)
+struct TopPart { int from, to, step; };
+#ifndef MADICP_TB_TOP_EARLY  // (development: -DMADICP_TB_TOP_EARLY=5 runs the parts at step b + 1 — the schedule that looks right and is
+#define MADICP_TB_TOP_EARLY 0  //  a race: the 200-frame drive of tests/test_gpu_frontend.py ended 1.8e-2 m off the host path with it)
+#endif
+constexpr int kTopLag = tb::kChipLevels - MADICP_TB_TOP_EARLY;
+constexpr TopPart kTopParts[3] = {{0, 6, 6 + kTopLag}, {6, 9, 9 + kTopLag}, {9, kTopLevels, kTopLevels + kTopLag}};
+static_assert(kTopLevels + kTopLag < 20, "the last part needs a step among the twenty that are always launched");
+
 int tb_run_levels(FrontScratch& fs, int from, int to) {
   FrontScratch::InFlight& f = fs.fly;
   const tb::Params& P = f.P;
@@ -502,21 +509,11 @@ int tb_run_levels(FrontScratch& fs, int from, int to) {
     // levels the previous build did not reach are launched all the same (this tree may be deeper) but with a small grid — the
     // queues are walked with a stride, so any grid is correct, and 1 600 workgroups that find an empty queue cost 4.6 us
     if (f.quiet_from >= 0 && level > f.quiet_from) grid = std::min(grid, 96);
-    if (level == kTopLevels + 1) {
-      // every node the tree's LDS-staged top can name is finished: its breadth-first layout (eleven dependent memory hops, ~25 us
-      // on one workgroup) runs beside the remaining levels on the side stream; the emission waits for it (tree_build_end_on)
-      if (!fs.side) {
-        HIP_TRY(hipStreamCreateWithFlags(&fs.side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&fs.side_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&fs.side_join, hipEventDisableTiming));
-      }
-      HIP_TRY(hipEventRecord(fs.side_fork, s));
-      HIP_TRY(hipStreamWaitEvent(fs.side, fs.side_fork, 0));
-      hipLaunchKernelGGL(tb::tb_top_bfs, dim3(1), dim3(256), 0, fs.side, P, kTopLevels, kTopMax);
-      HIP_TRY(hipEventRecord(fs.side_join, fs.side));
-      f.side_pending = true;
-    }
-    hipLaunchKernelGGL(tb::tb_level, dim3(grid), dim3(256), 0, s, P, level);
+    // the breadth-first layout of the tree's LDS-staged top: the FIRST workgroup of two level launches (tree_build.hip.h)
+    int bfs_from = 0, bfs_to = 0;
+    for (const TopPart& tp : kTopParts)
+      if (level == tp.step) { bfs_from = tp.from; bfs_to = tp.to; }
+    hipLaunchKernelGGL(tb::tb_level, dim3(grid + (bfs_to > bfs_from ? 1 : 0)), dim3(256), 0, s, P, level, bfs_from, bfs_to, kTopLevels, kTopMax);
   }
   return MADICP_OK;
 }
@@ -581,9 +578,6 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   f.P.b_min = b_min;
   f.chip = n > tb::kChipMin;
   f.P.first_step = f.chip ? tb::kChipLevels : 0;
-  // (the previous construction's layout of the top reads the node array this one is about to overwrite: normally long
-  // finished and waited for by its emission — after an error or a cancellation it may not be)
-  if (fs.side_join) HIP_TRY(hipStreamWaitEvent(s, fs.side_join, 0));
   // (State and leaf-start marks are cleared by tb_init itself)
   hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, f.P);
   f.chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
@@ -594,7 +588,6 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop in the second half
   f.levels_done = 20;
   f.quiet_from = fs.last_depth >= 0 ? fs.last_depth + 1 : -1;
-  f.side_pending = false;
   RC_TRY(tb_run_levels(fs, 0, f.levels_done));
   HIP_TRY(hipGetLastError());
   RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
@@ -656,10 +649,6 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
   set_desc(t, st.origin);
   // ONE launch: the DFS-preorder node array, the screening / dense leaf records and the staged top (tree_build.hip.h)
-  if (f.side_pending) {
-    HIP_TRY(hipStreamWaitEvent(s, fs.side_join, 0));
-    f.side_pending = false;
-  }
   hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256 + (t.n_top + 255) / 256), dim3(256), 0, s, P, n_nodes, t.nodes, t.cnodes, t.leaves,
                      t.n_top, t.top_dfs, t.top_link, t.top_exit, t.top, st.origin[0], st.origin[1], st.origin[2]);
   hipError_t e = hipGetLastError();
@@ -771,8 +760,7 @@ int madicp_tree_build_cancel(madicp_ctx* ctx) {
   if (!ctx->front || !ctx->front->scratch.fly.active || !ctx->front->scratch.fly.lookahead) return MADICP_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   FrontScratch& fs = ctx->front->scratch;
-  hipError_t e = hipStreamSynchronize(fs.fly.s);
-  if (e == hipSuccess && fs.side) e = hipStreamSynchronize(fs.side);
+  const hipError_t e = hipStreamSynchronize(fs.fly.s);
   fs.fly.active = false;
   fs.state_stale = true;
   DevCloud c = fs.fly.cloud;

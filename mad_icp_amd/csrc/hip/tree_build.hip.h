@@ -152,8 +152,10 @@ struct Params {
                         // tb_chip_stats, read by tb_chip_scatter) or per wavefront's quarter (team regime): the positions
                         // (relative to b) of the slice's points that go left, in order, from the front of the slice, of those
                         // that go right from its back.  (The wave regime keeps its tables in LDS, the quad regime in a word.)
-  int32_t* top_ids;     // (kTopMax) breadth-first layout of the first kTopLevels levels (tb_top_bfs, beside the steps past kTopLevels):
+  int32_t* top_ids;     // (kTopMax) breadth-first layout of the first kTopLevels levels (top_bfs_body, inside three level launches):
   uint32_t* top_link;   // temporary ids of the internal nodes in that order, and their link words
+  int32_t* top_front;   // (2 + 2 * 1024) the layout between two of its parts: entries and first position of the next level, then
+                        // the entries' ids and their left children's ids
   int32_t n_points;
   double b_max, b_min;
   int32_t first_step;   // wave / quad nodes created above this level wait in its queues: while the chip regime runs (levels
@@ -1091,29 +1093,34 @@ __device__ __forceinline__ void team_node(const Params& P, const int4 ent, int s
 
 // ---- breadth-first layout of the first kTopLevels levels (what layout_top does on the host for uploaded trees) ---
 // ONE workgroup of 256 threads, over the TEMPORARY nodes (a node knows its children: BNode::child), so that it needs neither
-// the leaf scan nor the emitted array: it is launched on a side stream when step top_levels + 1 begins (every node the top can name has been
-// finished by then) and runs beside the remaining levels — a level is one dependent memory hop (the children's flags and
-// child ids), eleven levels were 19 us as a kernel of their own behind the emission, 26 us as an extra workgroup of the
-// summary kernel or of a level kernel (whatever came next had to wait for it).  Output: the temporary ids of the internal nodes of levels
+// the leaf scan nor the emitted array: it runs in three parts, each as the FIRST workgroup of a level launch late enough for every node it reads
+// to be finished (frontend_capi.inc.h, kTopParts: a node of level L is finished by step L + 5) — 6-15 us each beside a step's
+// own nodes (a level is one dependent memory hop, the children's flags and child ids; eleven levels were 19 us as a kernel of
+// their own behind the emission, 26-34 us as ONE extra workgroup of the summary kernel or of a level kernel — whatever came
+// next had to wait for it — and on a side stream the fork's event cost the main stream 18 us).  Output: the temporary ids of the internal nodes of levels
 // 0 .. top_levels - 1 in breadth-first order (P.top_ids) and their link words (P.top_link: positions of the children in that
 // order, or "leaf" / "below the top"); everything that needs the leaf scan (DFS index, leaf ordinals) is filled in by the
 // emission kernel, entry by entry.  A level has at most 1024 internal nodes: four consecutive entries per thread.
-__device__ __forceinline__ void top_bfs_body(const Params& P, int top_levels, int top_max) {
+__device__ __forceinline__ void top_bfs_body(const Params& P, int lev_from, int lev_to, int top_levels, int top_max) {
   __shared__ int s_id[2][1024], s_child[2][1024];
   __shared__ int s_w[4];
   __shared__ int s_total;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int ncur = 0, base = 0;
-  {
+  if (lev_from == 0) {
     const BNode& root = P.nodes[0];
     if (!(root.flags & kLeaf)) {
       ncur = 1;
       if (threadIdx.x == 0) { s_id[0][0] = 0; s_child[0][0] = root.child; }
     }
+  } else {  // a later part picks up where the one before it stopped
+    ncur = P.top_front[0];
+    base = P.top_front[1];
+    for (int t = threadIdx.x; t < ncur; t += blockDim.x) { s_id[0][t] = P.top_front[2 + t]; s_child[0][t] = P.top_front[2 + 1024 + t]; }
   }
   __syncthreads();
   int par = 0;
-  for (int lev = 0; lev < top_levels && ncur > 0; ++lev, par ^= 1) {
+  for (int lev = lev_from; lev < lev_to && ncur > 0; ++lev, par ^= 1) {
     const bool deeper = lev + 1 < top_levels;
     int ch[4], lc[4], rc[4];
     bool on[4], l_leaf[4], r_leaf[4], l_in[4], r_in[4];
@@ -1170,6 +1177,10 @@ __device__ __forceinline__ void top_bfs_body(const Params& P, int top_levels, in
     ncur = s_total;
     __syncthreads();
   }
+  if (lev_to < top_levels) {  // hand the next level's entries to the next part
+    if (threadIdx.x == 0) { P.top_front[0] = ncur; P.top_front[1] = base; }
+    for (int t = threadIdx.x; t < ncur; t += blockDim.x) { P.top_front[2 + t] = s_id[par][t]; P.top_front[2 + 1024 + t] = s_child[par][t]; }
+  }
 }
 
 // One step of the wave and quad regimes (`level` is the step: the queue index; a node's own level is in its entry).
@@ -1181,27 +1192,33 @@ __device__ __forceinline__ void top_bfs_body(const Params& P, int top_levels, in
 #ifndef MADICP_TB_WPE
 #define MADICP_TB_WPE 2
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_WPE, MADICP_TB_WPE))) void tb_level(const Params P, int level) {
-  const int G = (int)gridDim.x;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_WPE, MADICP_TB_WPE))) void tb_level(const Params P, int level, int bfs_from, int bfs_to, int top_levels, int top_max) {
+  // bfs_to > bfs_from: the first workgroup of this launch makes levels [bfs_from, bfs_to) of the top's breadth-first layout
+  const int bfs = bfs_to > bfs_from ? 1 : 0;
+  if (bfs && blockIdx.x == 0) {
+    top_bfs_body(P, bfs_from, bfs_to, top_levels, top_max);
+    return;
+  }
+  const int G = (int)gridDim.x - bfs, bid = (int)blockIdx.x - bfs;
   State* st = P.st;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cntW = st->q_count[level].v, cntS = st->small_count[level].v, cntT = st->team_count[level].v;
   if (lane == 0) TB_STAMP_MIN(level, 0);
   if (level + 1 > kMaxLevels) {
-    if ((cntW > 0 || cntS > 0 || cntT > 0) && blockIdx.x == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
+    if ((cntW > 0 || cntS > 0 || cntT > 0) && bid == 0 && threadIdx.x == 0) st->n_nodes.error = 2;
     return;
   }
   // ---- team regime: the FIRST workgroups take the nodes of more than kTeamMin points, one node each (dispatched first:
   // they are the longest); the rest of the grid shares the other two queues as before
   const int wgT = cntT > 0 ? max(1, min(cntT, G - 1)) : 0;  // (always leaves a workgroup for the other queues)
-  if ((int)blockIdx.x < wgT) {
-    for (int t = blockIdx.x; t < cntT; t += wgT) {  // (workgroup-uniform)
+  if (bid < wgT) {
+    for (int t = bid; t < cntT; t += wgT) {  // (workgroup-uniform)
       team_node(P, level_team(P, level)[t], level);
       __syncthreads();  // (the team scratch is reused)
     }
     if (G > 1 || (cntW == 0 && cntS == 0)) return;
   }
-  const int gx = G > 1 ? G - wgT : 1, bx = G > 1 ? (int)blockIdx.x - wgT : 0;
+  const int gx = G > 1 ? G - wgT : 1, bx = G > 1 ? bid - wgT : 0;
   // ---- wave regime: the four waves of a workgroup take four consecutive queue entries; ids and queue slots of the
   // children come from ONE atomic each per workgroup
   __shared__ int s_split[4], s_ns[4], s_nw[4];
@@ -1999,8 +2016,6 @@ __global__ __launch_bounds__(256) void tb_emit(const Params P, int n_nodes, madi
   }
   cnodes[idx] = c;
 }
-
-__global__ __launch_bounds__(256) void tb_top_bfs(const Params P, int top_levels, int top_max) { top_bfs_body(P, top_levels, top_max); }
 
 // ---- diagnostics: the cloud in the order the construction left it (madicp_debug_tree_build_points) --------------------
 // A leaf's members stay where the split of its parent put them — range [begin, end) of the point buffer its level reads.

@@ -258,6 +258,42 @@ def test_registration_against_device_built_map(ctx):
     ctx.cloud_release(c)
 
 
+def test_top_layout_with_a_deep_small_sub_tree_born_during_the_chip_levels(ctx):
+    """The LDS-staged top of a device-built tree is laid out INSIDE level launches of the construction (tb_level's first
+    workgroup, three parts), which is only right if every node a part reads has been finished — and a node of level L is
+    finished by step L + 5, not L: a small node born while the chip regime runs waits for step 6 and its descendants follow
+    one step per level.  Here such a node exists: 400 points on a 60 m line, 300 m from a 60 k-point slab, split off at
+    level 3 and ten levels deep — its level-11 nodes are made at step 14.  Checked: the host builder's topology, and the
+    device-made top layout gives the bits of the host-made one (the same tree through the upload path) in a registration
+    whose leaves walk both parts of the tree.  (A layout made too early is a RACE, not a certain failure: this input passes
+    with the parts one step behind their levels more often than not; what caught that schedule was the 200-frame drive of
+    test_device_front_end_over_a_long_drive, 1.8e-2 m off the host path.)"""
+    rng = np.random.default_rng(11)
+    slab = rng.uniform([-20, -20, -2], [20, 20, 2], size=(60000, 3))
+    line = np.stack([np.linspace(300.0, 360.0, 400), 0.01 * rng.normal(size=400), 0.01 * rng.normal(size=400)], 1)
+    pts = np.concatenate([slab, line])[rng.permutation(60400)]
+    ht = capi.HostTree(pts, B_MAX, B_MIN, 2)
+    cid = ctx.cloud_upload(pts)
+    tid, nl = ctx.tree_build(cid, B_MAX, B_MIN)
+    ctx.cloud_release(cid)
+    assert nl == ht.num_leaves
+    nodes = ctx.tree_download(tid, 2 * nl - 1)
+    assert np.array_equal(nodes["right"], ht.nodes["right"])
+    st = ctx.tree_build_stats()
+    assert st["max_level"] >= 12  # (the line's sub-tree really is deep)
+    re_t = ctx.tree_upload(nodes, nl)
+    # moving set: the tree's own leaves, nudged — every leaf of the line and of the slab walks the staged top
+    leaves = nodes["mean"][nodes["right"] == 0] + 0.01
+    T0 = np.eye(4)
+    T0[:3, 3] = [0.02, -0.01, 0.0]
+    a = ctx.stream_collect(ctx.stream_submit(leaves, [tid], T0, PARAMS, 4), leaves.shape[0])
+    b = ctx.stream_collect(ctx.stream_submit(leaves, [re_t], T0, PARAMS, 4), leaves.shape[0])
+    assert np.array_equal(a["X"], b["X"]) and np.array_equal(a["H"], b["H"]) and np.array_equal(a["matched"], b["matched"])
+    assert a["n_matched"] > 0.5 * leaves.shape[0]
+    ctx.tree_release(tid)
+    ctx.tree_release(re_t)
+
+
 def _pose(tx, ty, yaw, pitch):
     T = np.eye(4)
     cy, sy, cp, sp = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch)
