@@ -677,8 +677,8 @@ __device__ __forceinline__ Split wave_node(const Params& P, const int4 ent, doub
 // Control flow is wave-uniform (`steps` = the wave's longest node, lanes past their node's end are masked out), so the
 // ballots and shuffles always see whole quads.
 __device__ __forceinline__ double quad_sum(double v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
+  v += xor_fetch<1>(v);
+  v += xor_fetch<2>(v);
   return v;
 }
 // Nodes of the quad regime (at most 32 points: most nodes of a tree, nearly all its leaves) add their points up ONE AFTER
@@ -776,9 +776,11 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
   double ext[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {
-      const double ol = __shfl_xor(lo[a], m, 64), oh = __shfl_xor(hi[a], m, 64);
+    {  // (the quad's two xor steps, by DPP quad_perm: same partners and order as the shuffles they replace)
+      double ol = xor_fetch<1>(lo[a]), oh = xor_fetch<1>(hi[a]);
+      if (ol < lo[a]) lo[a] = ol;
+      if (hi[a] < oh) hi[a] = oh;
+      ol = xor_fetch<2>(lo[a]); oh = xor_fetch<2>(hi[a]);
       if (ol < lo[a]) lo[a] = ol;
       if (hi[a] < oh) hi[a] = oh;
     }
@@ -818,10 +820,12 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
       if (dist < best) { best = dist; besti = i; }
     }
   }
-#pragma unroll
-  for (int m = 1; m <= 2; m <<= 1) {
-    const double ob = __shfl_xor(best, m, 64);
-    const int oi = __shfl_xor(besti, m, 64);
+  {
+    double ob = xor_fetch<1>(best);
+    int oi = __builtin_amdgcn_mov_dpp(besti, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+    if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    ob = xor_fetch<2>(best);
+    oi = __builtin_amdgcn_mov_dpp(besti, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
     if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
   }
   if (!have) return sp;
@@ -1290,8 +1294,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_W
     int4 ent = make_int4(0, 0, 0, level);
     if (have) ent = qs[t];
     int steps = have ? (ent.z - ent.y + 3) / 4 : 0;
+    {  // the wave's longest node (steps <= kSmallMax / 4): eight ballots instead of a four-step butterfly through the LDS crossbar
+      int mx = 0;
 #pragma unroll
-    for (int m = 32; m >= 4; m >>= 1) steps = max(steps, __shfl_xor(steps, m, 64));  // the wave's longest node
+      for (int k = 1; k <= kSmallMax / 4; ++k)
+        if (__ballot(steps >= k) != 0ull) mx = k;
+      steps = mx;
+    }
     Split sp = quad_node(P, ent, have, steps);
     const bool mine = sp.split && (lane & 3) == 0;
     const unsigned long long sm = __ballot(mine);
@@ -1304,8 +1313,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_W
       base_id = a0;
       base_q = a1;
     }
-    base_id = __shfl(base_id, 0, 64);
-    base_q = __shfl(base_q, 0, 64);
+    base_id = __builtin_amdgcn_readfirstlane(base_id);
+    base_q = __builtin_amdgcn_readfirstlane(base_q);
     if (mine) {
       const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       const int rank = __popcll(sm & lt);
