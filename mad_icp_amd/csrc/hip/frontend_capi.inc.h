@@ -495,7 +495,6 @@ int tb_run_levels(FrontScratch& fs, int from, int to) {
   hipStream_t s = f.s;
   for (int level = from; level < to; ++level) {
     if (f.chip && level < tb::kChipLevels) {
-      if (level == 0) hipLaunchKernelGGL(tb::tb_chip_sums, dim3(f.chip_grid), dim3(256), 0, s, P, level);
       hipLaunchKernelGGL(tb::tb_chip_stats, dim3(f.chip_grid), dim3(256), 0, s, P, level);
       hipLaunchKernelGGL(tb::tb_chip_scatter, dim3(f.chip_grid), dim3(256), 0, s, P, level);
     }
@@ -579,7 +578,11 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   f.chip = n > tb::kChipMin;
   f.P.first_step = f.chip ? tb::kChipLevels : 0;
   // (State and leaf-start marks are cleared by tb_init itself)
-  hipLaunchKernelGGL(tb::tb_init, dim3(1 + static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512))), dim3(256), 0, s, f.P);
+  {  // one workgroup for the State and the root, some to clear the leaf-start marks, and (chip regime) one per chunk of the root for its sums
+    const int clear_wgs = static_cast<int>(std::min<int64_t>((n + 4096) / 4096, 512));
+    const int sum_wgs = f.chip ? static_cast<int>((n + tb::kChunk - 1) / tb::kChunk) : 0;
+    hipLaunchKernelGGL(tb::tb_init, dim3(1 + clear_wgs + sum_wgs), dim3(256), 0, s, f.P, clear_wgs);
+  }
   f.chip_grid = static_cast<int>(std::min<int64_t>(n / tb::kChunk + tb::kMaxBig, (int64_t)ctx->n_cus * 4));
   // one wave per wave-regime node (at most n / 33 of them on a level) and four lanes per small node (most levels hold far
   // fewer than the n of them this bound allows for: the queues are walked with a stride)

@@ -143,7 +143,7 @@ struct Params {
   uint32_t* tile_sums;  // scan scratch: marks per 1024-point tile
   double* partLR;       // chip regime, one block of part_stride doubles per level 0 .. kChipLevels: per chunk slot 18 doubles —
                         // the nine sums of the chunk's points that go left, then of those that go right (written by the
-                        // PARENT level's scatter; level 0: by tb_chip_sums into the first nine).  Per level, not by parity:
+                        // PARENT level's scatter; level 0: by tb_init into the first nine).  Per level, not by parity:
                         // a small child of a chip node reads its block when its step comes, levels later.
   long part_stride;
   double* part2;        // chip regime: per chunk slot 8 doubles (lo 3, hi 3, left count)
@@ -389,12 +389,47 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 // ---- init ---------------------------------------------------------------------------------------------------
 // Workgroup 0 clears the State and sets the root up; the others clear the leaf-start marks (no fill commands in front of
 // a build: each was a dispatch of its own).  256 threads.
-__global__ __launch_bounds__(256) void tb_init(const Params P) {
+__global__ __launch_bounds__(256) void tb_init(const Params P, int clear_wgs) {
+  if ((int)blockIdx.x > clear_wgs) {
+    // The workgroups behind the clearing ones: the ROOT's nine sums per 2048-point chunk (chip regime: what tb_chip_sums did
+    // as a launch of its own — the first launches of a build are spaced by the host's enqueue time, not by their work, so a
+    // launch less is ~8 us less).  Needs nothing the other workgroups write: the root is points [0, n) of the caller's cloud.
+    __shared__ double s_red[4][9];
+    const int chunk = (int)blockIdx.x - 1 - clear_wgs;
+    const double* __restrict__ in = P.cloud;
+    const int cb = chunk * kChunk, ce = min(cb + kChunk, P.n_points);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {  // 8 points per thread, every load issued before the first add
+      double x[8], y[8], z[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = cb + (int)threadIdx.x + 256 * u;
+        ok[u] = i < ce;
+        const long j = ok[u] ? i : cb;
+        x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ok[u]) add_point(s, x[u], y[u], z[u]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s_red[wv][k] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+      level_part(P, 0)[(long)chunk * 18 + threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
+    return;
+  }
   if (blockIdx.x != 0) {
     const long n = (long)P.n_points + 1;
     uint32_t* __restrict__ m = P.leaf_start;  // (256-byte aligned, padded to a multiple of 4 and more: ensure_scratch)
     const long n4 = (n + 3) / 4;
-    for (long i = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x; i < n4; i += (long)(gridDim.x - 1) * blockDim.x)
+    for (long i = (long)(blockIdx.x - 1) * blockDim.x + threadIdx.x; i < n4; i += (long)clear_wgs * blockDim.x)
       reinterpret_cast<uint4*>(m)[i] = make_uint4(0u, 0u, 0u, 0u);
     return;
   }
@@ -1378,45 +1413,6 @@ __device__ __forceinline__ ChunkMap chip_find(const int* s_off, int cnt, int slo
   return cm;
 }
 
-// C1: per-chunk sums — level 0 only (the root has no parent to hand them down); deeper chip nodes get theirs from the
-// scatter of the level above
-__global__ __launch_bounds__(256) void tb_chip_sums(const Params P, int level) {
-  __shared__ int s_off[kMaxBig + 1];
-  __shared__ double s_red[4][9];
-  const int cnt = chip_prefix(P, level, s_off);
-  const int total = s_off[cnt];
-  const double* __restrict__ in = level_in(P, level);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
-    const ChunkMap cm = chip_find(s_off, cnt, slot);
-    const BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
-    const int cb = nd.begin + cm.chunk * kChunk, ce = min(cb + kChunk, nd.end);
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    {  // 8 points per thread, every load issued before the first add
-      double x[8], y[8], z[8];
-      bool ok[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = cb + (int)threadIdx.x + 256 * u;
-        ok[u] = i < ce;
-        const long j = ok[u] ? i : cb;
-        x[u] = in[3 * j]; y[u] = in[3 * j + 1]; z[u] = in[3 * j + 2];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (ok[u]) add_point(s, x[u], y[u], z[u]);
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = wave_sum(s[k]);
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s_red[wv][k] = s[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 9) level_part(P, level)[(long)slot * 18 + threadIdx.x] = ((s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + s_red[2][threadIdx.x]) + s_red[3][threadIdx.x];
-    __syncthreads();
-  }
-}
 
 // C2: node statistics (recombined by every chunk of the node: partials loaded in parallel, added in chunk order),
 // extents and left count of the chunk
@@ -1436,7 +1432,7 @@ __global__ __launch_bounds__(256) void tb_chip_stats(const Params P, int level) 
     BNode& nd = P.nodes[level_big(P, level)[cm.node_slot]];
     const int n = nd.end - nd.begin;
     if (lane == 0) { TB_STAMP_MAX(level, 9); }
-    // the node's nine sums: per-chunk partials of its PARENT's scatter (left or right half), or of tb_chip_sums (root)
+    // the node's nine sums: per-chunk partials of its PARENT's scatter (left or right half), or of tb_init (root)
     const int nflags = nd.flags;
     const int pfirst = (nflags & kChunkSums) ? nd.sum_first : cm.first_slot;
     const int pcount = (nflags & kChunkSums) ? nd.sum_n : cm.n_chunks;
