@@ -508,7 +508,7 @@ int tb_run_levels(FrontScratch& fs, int from, int to) {
     // levels the previous build did not reach are launched all the same (this tree may be deeper) but with a small grid — the
     // queues are walked with a stride, so any grid is correct, and 1 600 workgroups that find an empty queue cost 4.6 us
     if (f.quiet_from >= 0 && level > f.quiet_from) grid = std::min(grid, 96);
-    // the breadth-first layout of the tree's LDS-staged top: the FIRST workgroup of two level launches (tree_build.hip.h)
+    // the breadth-first layout of the tree's LDS-staged top: the FIRST workgroup of three level launches (kTopParts above)
     int bfs_from = 0, bfs_to = 0;
     for (const TopPart& tp : kTopParts)
       if (level == tp.step) { bfs_from = tp.from; bfs_to = tp.to; }
