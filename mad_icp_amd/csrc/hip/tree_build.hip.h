@@ -823,19 +823,6 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
   }
   const int nl = __popc(mask);
   const bool leaf = !have || (ext[2] < P.b_max) || nl == 0 || nl == n;
-  // Sweep B (internal nodes): every point to the place the reference's `split` (utils.h:37-52) would have left it in
-  {
-    double* __restrict__ out = level_out(P, level);
-    for (int st = 0; st < steps; ++st) {
-      const int pp = 4 * st + ql;
-      if (!leaf && pp < n) {
-        const long j = (long)b + pp;
-        const double x = in[3 * j], y = in[3 * j + 1], z = in[3 * j + 2];
-        const long d = (long)b + madicp_host::split_dst_small(mask, n, pp);
-        out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
-      }
-    }
-  }
   // (both branches below keep whole quads together: `leaf` is the same in the four lanes of a node)
   if (!kSerialSmall) {
 #pragma unroll
@@ -844,15 +831,29 @@ __device__ __forceinline__ Split quad_node(const Params& P, const int4 ent, bool
       sp.sR[k] = quad_sum(sR[k]);
     }
   }
-  // nearest member (leaves): every lane over its own points, then the quad's best, smallest index on ties
+  // Sweep B, ONE more pass over the points (the next four requested before these are used: the passes are chains of L1 round
+  // trips).  Internal nodes: every point to the place the reference's `split` (utils.h:37-52) would have left it in.  Leaves:
+  // the member nearest to the centroid — every lane over its own points, then the quad's best, smallest index on ties.
   double best = 1.7976931348623157e308;
   int besti = 0x7fffffff;
-  for (int st = 0; st < steps; ++st) {
-    const int i = b + 4 * st + ql;
-    if (have && leaf && i < e) {
-      const double d[3] = {in[3 * (long)i] - mean[0], in[3 * (long)i + 1] - mean[1], in[3 * (long)i + 2] - mean[2]};
-      const double dist = madicp_host::norm3(d);
-      if (dist < best) { best = dist; besti = i; }
+  {
+    double* __restrict__ out = level_out(P, level);
+    double qx, qy, qz;
+    load_pt(0, qx, qy, qz);
+    for (int st = 0; st < steps; ++st) {
+      const double x = qx, y = qy, z = qz;
+      if (st + 1 < steps) load_pt(st + 1, qx, qy, qz);
+      const int pp = 4 * st + ql;
+      if (have && pp < n) {
+        if (!leaf) {
+          const long d = (long)b + madicp_host::split_dst_small(mask, n, pp);
+          out[3 * d] = x; out[3 * d + 1] = y; out[3 * d + 2] = z;
+        } else {
+          const double dv[3] = {x - mean[0], y - mean[1], z - mean[2]};
+          const double dist = madicp_host::norm3(dv);
+          if (dist < best) { best = dist; besti = b + pp; }
+        }
+      }
     }
   }
   {
