@@ -1294,6 +1294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MADICP_TB_W
       s_nw[wv] = sp.split ? 2 - my_small : 0;
     }
     __syncthreads();
+    if (lane == 0) TB_STAMP_MAX(level, 10);  // (the workgroup's four nodes are through: what follows is the allocation proper)
     if (threadIdx.x == 0) {
       const int tot = s_split[0] + s_split[1] + s_split[2] + s_split[3];
       const int ts = s_ns[0] + s_ns[1] + s_ns[2] + s_ns[3], tw = s_nw[0] + s_nw[1] + s_nw[2] + s_nw[3];

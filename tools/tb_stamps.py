@@ -28,7 +28,7 @@ buf = np.zeros(24 * 512 * 4 * 16, np.uint64)
 assert lib.madicp_debug_tb_stamps(ctx._h, buf.ctypes.data, 0) == 0
 s = buf.reshape(24, 2048, 16).astype(np.int64)
 st = ctx.tree_build_stats()
-cols = [(0, "start"), (3, "w:node"), (4, "w:sums"), (5, "w:eig"), (6, "w:sweep"), (7, "w:reduce"), (8, "w:alloc"), (9, "w:emit"),
+cols = [(0, "start"), (3, "w:node"), (4, "w:sums"), (5, "w:eig"), (6, "w:sweep"), (7, "w:reduce"), (10, "w:barrier"), (8, "w:alloc"), (9, "w:emit"),
         (10, "l:sums"), (11, "l:eig"), (12, "l:sweep"), (13, "l:leaf"), (14, "l:alloc"), (15, "l:emit"), (1, "end")]
 # chip levels 0-5: tb_chip_stats (slots 8-14) and tb_chip_scatter (slots 0-7, 1 = end), median / max over the wavefronts,
 # microseconds after the kernel's own first wavefront
