@@ -147,4 +147,42 @@ MADICP_SO_HD inline void find_right_chunk(const int* pref, int n_gran, int shift
   local = j - before;
 }
 
+// The same two searches for a caller that asks for CONSECUTIVE ranks (a thread of the chip regime's scatter owns eight
+// consecutive points, and their ranks run up or down by one): the chunk found last is remembered with its first rank and its
+// count, and a rank inside those bounds needs no search.  (With a coarse table, shift > 0, nothing is remembered.)
+struct ChunkCache {
+  int chunk = -1, first = 0, count = 0;
+};
+template <class CountFn>
+MADICP_SO_HD inline void find_left_chunk_cached(ChunkCache& cc, const int* pref, int n_gran, int shift, int n_chunks, int i,
+                                                CountFn lefts_of, int& chunk, int& local) {
+  if (cc.chunk >= 0 && i >= cc.first && i < cc.first + cc.count) {
+    chunk = cc.chunk;
+    local = i - cc.first;
+    return;
+  }
+  find_left_chunk(pref, n_gran, shift, n_chunks, i, lefts_of, chunk, local);
+  if (shift == 0) {
+    cc.chunk = chunk;
+    cc.first = i - local;
+    cc.count = pref[chunk + 1] - pref[chunk];
+  }
+}
+template <class CountFn>
+MADICP_SO_HD inline void find_right_chunk_cached(ChunkCache& cc, const int* pref, int n_gran, int shift, int n_chunks, int chunk_points,
+                                                 int n, int j, CountFn lefts_of, int& chunk, int& local) {
+  if (cc.chunk >= 0 && j >= cc.first && j < cc.first + cc.count) {
+    chunk = cc.chunk;
+    local = j - cc.first;
+    return;
+  }
+  find_right_chunk(pref, n_gran, shift, n_chunks, chunk_points, n, j, lefts_of, chunk, local);
+  if (shift == 0) {
+    const int size = (chunk + 1) * chunk_points <= n ? chunk_points : n - chunk * chunk_points;
+    cc.chunk = chunk;
+    cc.first = j - local;
+    cc.count = size - (pref[chunk + 1] - pref[chunk]);
+  }
+}
+
 }  // namespace madicp_host

@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
     int dst[8];
     long tix[8];
     int tadd[8];
-    int rc = -1, rb = 0, rn = 0, lc = -1, lb = 0, ln = 0;  // the last chunk found for a right / a left rank, its first rank, its count
+    madicp_host::ChunkCache rcache, lcache;  // the last chunk found for a right / a left rank
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       dst[k] = 0;
@@ -1706,35 +1706,14 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
         const madicp_host::SplitPlan pl = madicp_host::split_plan(left, cm.chunk * kChunk + 8 * (int)threadIdx.x + k, lrun, nl, n);
         dst[k] = pl.idx;
         // (a thread's eight points are consecutive, so are the ranks they ask for: the chunk found for one usually holds
-        // the next — remembered with its bounds, a rank inside them needs no search: eight serial binary searches in LDS
-        // were 2.3 us of this kernel)
+        // the next — common/split_order.h remembers it; eight serial binary searches in LDS were 2.3 us of this kernel)
         if (pl.kind == 1) {
           int c, local;
-          if (rc >= 0 && pl.idx >= rb && pl.idx < rb + rn) {
-            c = rc;
-            local = pl.idx - rb;
-          } else {
-            madicp_host::find_right_chunk(s_pref, n_gran, shift, cm.n_chunks, kChunk, n, pl.idx, lefts_of, c, local);
-            if (shift == 0) {
-              rc = c;
-              rb = pl.idx - local;
-              rn = min(kChunk, n - c * kChunk) - (s_pref[c + 1] - s_pref[c]);
-            }
-          }
+          madicp_host::find_right_chunk_cached(rcache, s_pref, n_gran, shift, cm.n_chunks, kChunk, n, pl.idx, lefts_of, c, local);
           tix[k] = (long)b + min(n, (c + 1) * kChunk) - 1 - local;
         } else if (pl.kind == 2) {
           int c, local;
-          if (lc >= 0 && pl.idx >= lb && pl.idx < lb + ln) {
-            c = lc;
-            local = pl.idx - lb;
-          } else {
-            madicp_host::find_left_chunk(s_pref, n_gran, shift, cm.n_chunks, pl.idx, lefts_of, c, local);
-            if (shift == 0) {
-              lc = c;
-              lb = pl.idx - local;
-              ln = s_pref[c + 1] - s_pref[c];
-            }
-          }
+          madicp_host::find_left_chunk_cached(lcache, s_pref, n_gran, shift, cm.n_chunks, pl.idx, lefts_of, c, local);
           tix[k] = (long)b + (long)c * kChunk + local;
           tadd[k] = -1;
         }

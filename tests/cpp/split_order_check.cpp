@@ -79,17 +79,23 @@ static bool check_tables(const std::vector<uint8_t>& left, int chunk_points, int
     }
     auto lefts_of = [&](int c) { return cnt[c]; };
     int lb = 0;
+    ChunkCache rcache, lcache;  // (as the chip regime's scatter uses them: one pair per thread, eight consecutive points each)
     for (int p = 0; p < n; ++p) {
+      if (p % 8 == 0) rcache = lcache = ChunkCache{};
       const SplitPlan s = split_plan(left[p], p, lb, n_left, n);
       int d = s.idx;
       if (s.kind == 1) {
-        int c, local;
+        int c, local, c2, local2;
         find_right_chunk(pref.data(), n_gran, shift, n_chunks, chunk_points, n, s.idx, lefts_of, c, local);
+        find_right_chunk_cached(rcache, pref.data(), n_gran, shift, n_chunks, chunk_points, n, s.idx, lefts_of, c2, local2);
+        if (c2 != c || local2 != local) return false;
         const int ce = std::min(n, (c + 1) * chunk_points);
         d = tab[ce - 1 - local];
       } else if (s.kind == 2) {
-        int c, local;
+        int c, local, c2, local2;
         find_left_chunk(pref.data(), n_gran, shift, n_chunks, s.idx, lefts_of, c, local);
+        find_left_chunk_cached(lcache, pref.data(), n_gran, shift, n_chunks, s.idx, lefts_of, c2, local2);
+        if (c2 != c || local2 != local) return false;
         d = tab[c * chunk_points + local] - 1;
       }
       if (d < 0 || d >= n || got[d] != -1) return false;
