@@ -629,11 +629,12 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         # synthetic scans share 64 points per azimuth column, so the deskew keys run on a copy with 1e-7 m of jitter
         jitter = np.random.default_rng(0)
         drive_j = [sc + jitter.normal(scale=1e-7, size=sc.shape) for sc in drive]
-        for key, dev, ahead, dsk in (("host_path", False, 0, False), ("host_path_lookahead", False, 2, False),
+        for key, dev, ahead, dsk in (("default", None, 0, False), ("host_path", False, 0, False), ("host_path_lookahead", False, 2, False),
                                      ("device_front_end", True, 0, False), ("device_front_end_lookahead", True, 1, False),
                                      ("host_path_deskew", False, 1, True), ("device_front_end_deskew", True, 0, True)):
             pl = pm.Pipeline(10.0, dsk, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)
-            pl.setDeviceFrontEnd(dev)
+            if dev is not None:
+                pl.setDeviceFrontEnd(dev)
             ts = []
             scans_ = drive_j if dsk else drive
             for d in range(ahead):
@@ -653,7 +654,10 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                          "ms_per_frame_median": round(float(np.median(ts[2:])) * 1e3, 3),
                          "tree_ms": round(pl.lastBuildMs(), 3), "registration_ms": round(pl.lastIcpMs(), 3),
                          "end_translation_error_m": round(float(np.linalg.norm(np.asarray(pl.currentPose())[:3, 3] - gt[:3, 3])), 4)}
-        pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: host_path = the default (host tree builder, "
+        pipe["default_is_device_front_end"] = bool(pm.Pipeline(10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False).deviceFrontEnd())
+        pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: default = what an UNMODIFIED caller gets "
+                        "(no setDeviceFrontEnd call, MAD_ICP_GPU_BUILD unset; round 5: the device front-end for deskew = false); "
+                        "host_path = setDeviceFrontEnd(False) / MAD_ICP_GPU_BUILD=0 (host tree builder, "
                         "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(scan i + 2) issued "
                         "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "
                         "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU; "

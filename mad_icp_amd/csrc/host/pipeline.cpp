@@ -50,7 +50,16 @@ Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, 
   loop_time_ = (1. / sensor_hz_) * 1000;
   max_parallel_levels_ = static_cast<int>(std::log2(num_threads));  // pipeline.cpp:64
   TaskPool::instance().set_limit(num_threads);  // omp_set_num_threads(num_threads), pipeline.cpp:65
-  if (const char* e = std::getenv("MAD_ICP_GPU_BUILD")) device_frontend_ = (e[0] == '1');
+  // Round 5: the device front-end is the DEFAULT wherever the scan's tree does not depend on the previous poses
+  // (deskew = false: every dataset configuration of the reference but the deskewed ones) — an unmodified caller then gets
+  // tree construction on the MI355X (tests/test_gpu_frontend_oracle.py holds that path to the oracle pipeline directly).
+  // MAD_ICP_GPU_BUILD=0 keeps the host builder (the reference's trees bit for bit), =1 forces the device front-end for
+  // deskewed datasets too; setDeviceFrontEnd() overrides both.
+  device_frontend_ = !deskew;
+  if (const char* e = std::getenv("MAD_ICP_GPU_BUILD")) {
+    if (e[0] == '1') device_frontend_ = true;
+    if (e[0] == '0') device_frontend_ = false;
+  }
 }
 
 void Pipeline::waitPrefetched() {

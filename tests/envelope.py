@@ -1,0 +1,62 @@
+"""The reference's OWN sensitivity to last-bit changes, measured with the oracle (test infrastructure, like oracle_lib).
+
+MAD-tree construction is chaotic in the last bit of its input: a leaf's representative is the member nearest to the centroid
+(mad_tree.cpp:76-86), and the two members of a two-point leaf are equally far from their midpoint up to rounding, so a
+1-ulp change anywhere upstream flips representatives by up to b_max.  With `deskew = true` the cloud a tree is built from is
+a function of the two previous POSES (pipeline.cpp:79-123, :138-139), and the reference's poses already depend in their last
+bits on `num_threads` (the per-thread adders are summed in thread order, mad_icp.cpp:106-109).  So two correct
+implementations of the deskewed pipeline drift apart by what the reference drifts apart from ITSELF under such changes.
+
+`self_envelope` measures exactly that: the oracle pipeline against itself with other thread counts and with ONE coordinate of
+ONE point of one early cloud moved by one ulp.  A product path (host builder or device front-end) is then held INSIDE that
+envelope — if it were not, the difference would be a bug, not chaos."""
+import numpy as np
+
+import oracle_lib as O
+from fixtures import B_MAX, B_MIN, B_RATIO, RHO_KER
+
+
+def pose_dev(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    return float(np.linalg.norm(d[:3, 3])), float(np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)))
+
+
+def oracle_drive(scans, deskew, threads=4, ulp_at=None, num_keyframes=16, p_th=0.8):
+    """Poses of the oracle pipeline over `scans`.  ulp_at = (frame, point, coordinate): that one double moved by one ulp."""
+    p = O.Pipeline(10.0, bool(deskew), B_MAX, RHO_KER, p_th, B_MIN, B_RATIO, num_keyframes, threads, False)
+    poses, kf = [], []
+    for i, s in enumerate(scans):
+        if ulp_at is not None and ulp_at[0] == i:
+            s = np.ascontiguousarray(s, dtype=np.float64).copy()
+            s.view(np.int64)[ulp_at[1] % s.shape[0], ulp_at[2]] += 1
+        p.compute(0.1 * i, s)
+        poses.append(p.currentPose().copy())
+        kf.append(p.keyframeID())
+    return poses, kf
+
+
+VARIANTS = (("threads=1", dict(threads=1)), ("threads=2", dict(threads=2)), ("threads=3", dict(threads=3)),
+            ("threads=8", dict(threads=8)), ("1 ulp, cloud 0, point 5, x", dict(ulp_at=(0, 5, 0))),
+            ("1 ulp, cloud 1, point 77, y", dict(ulp_at=(1, 77, 1))), ("1 ulp, cloud 2, point 1234, z", dict(ulp_at=(2, 1234, 2))),
+            ("1 ulp, cloud 1, point 9, z; threads=2", dict(ulp_at=(1, 9, 2), threads=2)),
+            ("1 ulp, cloud 0, point 4321, y", dict(ulp_at=(0, 4321, 1))), ("1 ulp, cloud 1, point 2500, x", dict(ulp_at=(1, 2500, 0))),
+            ("1 ulp, cloud 2, point 31, x", dict(ulp_at=(2, 31, 0))), ("1 ulp, cloud 3, point 800, z", dict(ulp_at=(3, 800, 2))))
+
+
+def self_envelope(scans, deskew, base_threads=4, variants=VARIANTS, **kw):
+    """(base poses, base keyframe ids, per-variant per-frame translation deviation [V, F], rotation deviation [V, F])."""
+    base, kf = oracle_drive(scans, deskew, base_threads, **kw)
+    dt = np.zeros((len(variants), len(scans)))
+    da = np.zeros_like(dt)
+    for v, (_, opts) in enumerate(variants):
+        o = dict(threads=base_threads)
+        o.update(opts)
+        poses, _ = oracle_drive(scans, deskew, **o, **kw)
+        for i, (a, b) in enumerate(zip(base, poses)):
+            dt[v, i], da[v, i] = pose_dev(a, b)
+    return base, kf, dt, da
+
+
+def running_bound(dev):
+    """What a path is held to at frame i: the largest deviation any variant has shown up to and including frame i."""
+    return np.maximum.accumulate(dev.max(axis=0))

@@ -27,3 +27,17 @@ def four_walls(points_per_wall, wall_height=2.0, wall_width=4.0):
 def street_problem(n_keyframes, seed=3, n_beams=32, n_azimuth=600, n_queries=1):
     """Reduced-resolution street problem (19k rays per scan) for oracle-speed parity tests."""
     return synth.make_problem(n_keyframes, seed=seed, n_beams=n_beams, n_azimuth=n_azimuth, n_queries=n_queries)
+
+
+@functools.lru_cache(maxsize=8)
+def _scene(seed):
+    return synth.Scene(seed)
+
+
+@functools.lru_cache(maxsize=320)
+def full_scan(scene_seed, s, noise_seed):
+    """One full-size (64 x 1875 rays) scan at arc parameter `s` of scene `scene_seed` — rendering costs 0.16 s and the long
+    drives of several test files walk the same frames.  Callers must not modify the returned array."""
+    a = synth.render_scan(_scene(scene_seed), synth.path_pose(s), noise_seed)
+    a.setflags(write=False)
+    return a

@@ -155,9 +155,12 @@ def test_mad_registration_tool_flow(mods):
 
 
 @pytest.mark.gpu
-def test_pipeline_matches_oracle_pipeline(mods):
+@pytest.mark.parametrize("front_end", ["default", "host"])
+def test_pipeline_matches_oracle_pipeline(mods, front_end):
     """Pipeline.compute over a short synthetic drive: poses within 1e-5 m / 1e-5 rad of the CPU oracle pipeline at
-    every frame, identical keyframe decisions."""
+    every frame, identical keyframe decisions.  `default` is what an unmodified caller gets — round 5: MAD-tree construction
+    on the device for deskew = false —, `host` the host builder (MAD_ICP_GPU_BUILD=0 / setDeviceFrontEnd(False)), whose trees
+    are the oracle's bit for bit."""
     import oracle_lib as O
     from mad_icp_amd import synth
 
@@ -168,6 +171,9 @@ def test_pipeline_matches_oracle_pipeline(mods):
     args = dict(sensor_hz=10.0, deskew=False, b_max=B_MAX, rho_ker=RHO_KER, p_th=0.8, b_min=B_MIN, b_ratio=B_RATIO,
                 num_keyframes=4, num_threads=4, realtime=False)
     gp = pypeline.Pipeline(**args)
+    assert gp.deviceFrontEnd()
+    if front_end == "host":
+        gp.setDeviceFrontEnd(False)
     op = O.Pipeline(*[args[k] for k in ("sensor_hz", "deskew", "b_max", "rho_ker", "p_th", "b_min", "b_ratio",
                                         "num_keyframes", "num_threads", "realtime")])
     n_updates = 0
@@ -183,7 +189,8 @@ def test_pipeline_matches_oracle_pipeline(mods):
         if i > 0:
             assert abs(gp.lastInliersRatio() - op.lastInliersRatio()) < 2e-3
         # currentLeaves / modelLeaves (pipeline.cpp:290-308): the leaf means of the current scan's tree / of every keyframe's
-        # tree, in getLeafs() order, in the map frame.  The trees are the oracle's bit for bit and the first frame's pose is
+        # tree, in getLeafs() order, in the map frame.  The trees are the oracle's bit for bit (host builder; the device
+        # builder's leaf representatives are the host builder's at every ordinal) and the first frame's pose is
         # the identity, so frame 0 is bitwise; later frames went through applyTransform (mad_tree.cpp:165-172) with poses
         # that agree to ~1e-15, so their leaves agree to 1e-9 m (not the 1e-4 of a shape check)
         gl, ol = np.asarray(gp.currentLeaves()), op.currentLeaves()
@@ -196,6 +203,7 @@ def test_pipeline_matches_oracle_pipeline(mods):
     assert gp.isInitialized() and len(gp.trajectory()) == n_frames
     # additive overload: the same drive fed as plain (N,3) arrays ends in the same pose, bit for bit
     ga = pypeline.Pipeline(**args)
+    ga.setDeviceFrontEnd(front_end != "host")
     for i, s in enumerate(scans):
         ga.compute(0.1 * i, s)
     assert np.array_equal(ga.currentPose(), gp.currentPose())
@@ -208,30 +216,36 @@ def test_pipeline_matches_oracle_pipeline(mods):
 @pytest.mark.gpu
 def test_pipeline_with_deskew_and_realtime_flags(mods):
     """deskew=True exercises the CPU motion compensation (pipeline.cpp:79-123); realtime=True with a generous
-    budget runs all rounds.  Tolerance note: with deskew the input of every tree build depends on the previous
-    poses, and MAD-tree construction is chaotic in the last bit of its input (a 1-ulp change of the cloud moves the
-    oracle's OWN pose by millimetres: nearest-point leaf representatives flip), so the two pipelines can only be
-    compared at the millimetre-centimetre level here — the 1e-5 bar applies where both sides see identical trees
+    budget runs all rounds.  Tolerance: with deskew the input of every tree build depends on the previous poses, and MAD-tree
+    construction turns a last-bit change of its input into other leaf representatives — the reference does not reproduce
+    ITSELF there (tests/test_oracle_sensitivity.py).  So the product is held inside the envelope the oracle pipeline shows
+    against itself (other thread counts, one coordinate of one point moved by one ulp: tests/envelope.py), and to 1e-5 on the
+    frames before anything has been amplified; the 1e-5 bar everywhere applies where both sides see the same clouds
     (test_pipeline_matches_oracle_pipeline, tests/test_gpu_parity.py)."""
+    import envelope as E
     import oracle_lib as O
     from mad_icp_amd import synth
 
     pypeline = mods[3]
     scene = synth.Scene(6)
-    scans = [synth.render_scan(scene, synth.path_pose(0.5 * i), 70 + i, n_beams=16, n_azimuth=500) for i in range(6)]
+    scans = [synth.render_scan(scene, synth.path_pose(0.5 * i), 70 + i, n_beams=16, n_azimuth=500) for i in range(8)]
+    base, _, dt, da = E.self_envelope(scans, deskew=True, base_threads=2, num_keyframes=4)
+    bt, ba = E.running_bound(dt), E.running_bound(da)
     gp = pypeline.Pipeline(10.0, True, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, 4, 2, True)
-    op = O.Pipeline(10.0, True, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, 4, 2, False)
+    assert not gp.deviceFrontEnd()
     for i, s in enumerate(scans):
         gp.compute(0.1 * i, pypeline.VectorEigen3d(s))
-        op.compute(0.1 * i, s)
-        d = np.linalg.inv(op.currentPose()) @ gp.currentPose()
-        assert np.linalg.norm(d[:3, 3]) <= (1e-5 if i < 2 else 2e-2), (i, d)
+        d_t, d_a = E.pose_dev(base[i], np.asarray(gp.currentPose()))
+        assert d_t <= 3.0 * bt[i] + 1e-5 and d_a <= 3.0 * ba[i] + 1e-5, (i, d_t, bt[i], d_a, ba[i])
+        if bt[i] <= 1e-9:
+            assert d_t <= 1e-5 and d_a <= 1e-5, (i, d_t, d_a)
     # (no ground-truth check: the synthetic scans are rendered instantaneously, so "deskewing" them distorts them)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("front_end", ["default", "host"])
 @pytest.mark.parametrize("scene_seed,step,p_th", [(1, 1.3, 0.85), (2, 0.6, 0.9), (7, 2.0, 0.8), (11, 1.0, 0.95)])
-def test_keyframe_decisions_match_oracle_over_seeded_drives(mods, scene_seed, step, p_th):
+def test_keyframe_decisions_match_oracle_over_seeded_drives(mods, scene_seed, step, p_th, front_end):
     """The keyframe weight is det(H^-1) of the last round's H (pipeline.cpp:223) and keyframes are chosen by `<` on it
     (:240).  The product's H differs from the reference's in two deliberate ways — the lower triangle is accumulated and
     mirrored, and the adders are summed in a fixed tree order — so the selection is re-checked here over several seeded
@@ -246,6 +260,8 @@ def test_keyframe_decisions_match_oracle_over_seeded_drives(mods, scene_seed, st
              for i in range(n_frames)]
     args = (10.0, False, B_MAX, RHO_KER, p_th, B_MIN, B_RATIO, 4, 4, False)
     gp, op = pypeline.Pipeline(*args), O.Pipeline(*args)
+    if front_end == "host":
+        gp.setDeviceFrontEnd(False)
     promotions = 0
     for i, s in enumerate(scans):
         gp.compute(0.1 * i, s)

@@ -44,8 +44,12 @@ lidar_to_base:
 """ + "".join("  - [%s]\n" % ", ".join("%.12e" % v for v in row) for row in LIDAR_TO_BASE)
 
 
+@pytest.mark.parametrize("gpu_build", [None, "1", "0"])
 @pytest.mark.parametrize("kitti", [False, True])
-def test_reference_bin_runner_against_the_product(natives, tmp_path, kitti):
+def test_reference_bin_runner_against_the_product(natives, tmp_path, kitti, gpu_build):
+    """`gpu_build`: the MAD_ICP_GPU_BUILD environment variable of the runner's process — the ONE switch an unmodified caller
+    has.  Unset: round 5's default (deskew: False in the dataset configuration -> MAD-tree construction on the device);
+    "1": the device front-end asked for; "0": the host builder.  All three within 1e-5 of the oracle pipeline."""
     if not os.path.exists(RUNNER):
         pytest.skip("oracle/_ref/bin_runner not built (oracle/build_bin_runner.sh needs /root/reference)")
     scene = synth.Scene(4)
@@ -71,7 +75,10 @@ def test_reference_bin_runner_against_the_product(natives, tmp_path, kitti):
            "-mad_icp_config", str(tmp_path / "default.cfg"), "-num_cores", "4", "-num_keyframes", "4"]
     if kitti:
         cmd.append("-kitti")
-    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "MAD_ICP_GPU_BUILD"}
+    if gpu_build is not None:
+        env["MAD_ICP_GPU_BUILD"] = gpu_build
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "Loading frame # 0" in run.stdout and ("Loading frame # %d" % (n_frames - 1)) in run.stdout
     est = np.loadtxt(str(out_dir / "estimate.txt")).reshape(-1, 3, 4)

@@ -28,7 +28,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from fixtures import B_MAX, B_MIN, PARAMS, street_problem
+from fixtures import B_MAX, B_MIN, PARAMS, full_scan, street_problem
 from mad_icp_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -411,25 +411,25 @@ def _jittered(scans, seed=0):
     return [sc + rng.normal(scale=1e-7, size=sc.shape) for sc in scans]
 
 
-@pytest.mark.parametrize("deskew,jitter", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("deskew,jitter", [(False, False)])
 def test_pipeline_with_device_front_end(natives, drive, deskew, jitter, capsys):
     """Pipeline.compute with tree construction (and deskew) on the device against the same Pipeline on the host path.
     The host path is the one held to 1e-5 against the oracle (tests/test_gpu_pipeline_fullsize.py).  Device-built trees
     have the host builder's member order and leaf representatives, and the nodes of at most 32 points — nearly all leaves —
     the host builder's centroid and covariance bit for bit (serial sums in member order); what differs is last bits of the
     larger nodes.  The two trajectories agree to 1e-9 m / 1e-6 rad at every frame (measured 8e-14 m over this drive; 4.5e-6
-    before the serial sums, 6e-4 before the member order), with the same keyframe decisions and inlier ratios within 1 %.  With deskew on the
-    bar is 1 cm, with or without azimuth ties (the jittered variant has none): the compensated cloud is a function of the
-    two previous POSES, which differ in their last bits between the two paths, and MAD-tree construction is chaotic in the
-    last bit of its input — a leaf of two points, whose members tie in distance to their midpoint up to rounding, flips its
-    representative; the oracle's own pose moves by millimetres under a 1-ulp change of the cloud — measured
-    4-5 mm here."""
+    before the serial sums, 6e-4 before the member order), with the same keyframe decisions and inlier ratios within 1 %.  (Round 5:
+    deskew = true is no longer held to a bar BETWEEN the product's two paths — the reference does not reproduce itself there
+    beyond millimetres — but each path against the oracle, inside the oracle's own measured envelope:
+    tests/test_gpu_frontend_oracle.py, tests/envelope.py.)"""
     import time
 
     from mad_icp.src.pybind import pypeline as m
 
     args = (10.0, deskew, B_MAX, 0.1, 0.8, B_MIN, 0.02, 16, 8, False)
     host, dev = m.Pipeline(*args), m.Pipeline(*args)
+    assert dev.deviceFrontEnd() == (not deskew)  # round 5: the default wherever the tree does not depend on the poses
+    host.setDeviceFrontEnd(False)
     dev.setDeviceFrontEnd(True)
     assert dev.deviceFrontEnd() and not host.deviceFrontEnd()
     worst = (0.0, 0.0)
@@ -464,7 +464,7 @@ def test_pipeline_with_device_front_end(natives, drive, deskew, jitter, capsys):
                  host.lastBuildMs()))
 
 
-@pytest.mark.parametrize("deskew,jitter,n_frames", [(False, False, 200), (True, False, 100), (True, True, 100)])
+@pytest.mark.parametrize("deskew,jitter,n_frames", [(False, False, 200)])
 def test_device_front_end_over_a_long_drive(natives, deskew, jitter, n_frames, capsys):
     """The acceptance bar of the device front-end over a long full-size drive (1 m
     per frame, 120 k-point scans), device front-end next to the host path — the one held to 1e-5 against the oracle:
@@ -473,22 +473,20 @@ def test_device_front_end_over_a_long_drive(natives, deskew, jitter, n_frames, c
         leaf representatives, and its centroids and covariances bit for bit for the nodes of at most 32 points;
       * final and RMS translation error against ground truth equal to the host path's to 1 mm;
       * the same keyframes promoted at the same frames.
-    With deskew on the two trajectories are only held to 5 cm of each other, with or without azimuth ties: the compensated
-    cloud depends on the previous poses' last bits and tree construction is chaotic in the last bit of its input (see
-    test_pipeline_with_device_front_end), so over 100 frames the two paths drift apart by 1-2 cm (measured 1.2 and 2.2 cm
-    with two builds of the device builder that differ only in the shape of their sums) while their errors against ground
-    truth stay equal to 2 % + 1 mm — which is what is asserted."""
+    (Round 5: the deskewed 100-frame drives moved to tests/test_gpu_frontend_oracle.py, where each path is held inside the
+    envelope the oracle pipeline shows against ITSELF under a thread-count or 1-ulp change, instead of to 5 cm of the other.)"""
     from mad_icp.src.pybind import pypeline as m
 
     scene = synth.Scene(0)
     args = (10.0, deskew, B_MAX, 0.1, 0.8, B_MIN, 0.02, 16, 16, False)
     host, dev = m.Pipeline(*args), m.Pipeline(*args)
+    host.setDeviceFrontEnd(False)
     dev.setDeviceFrontEnd(True)
     T0inv = np.linalg.inv(synth.path_pose(0.0))
     eh, ed, between, kf_h, kf_d = [], [], [], [], []
     rng = np.random.default_rng(3)
     for i in range(n_frames):
-        sc = synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i)
+        sc = full_scan(0, 1.0 * i, 100 + i)
         if jitter:
             sc = sc + rng.normal(scale=1e-7, size=sc.shape)
         host.compute(0.1 * i, sc)
@@ -681,6 +679,8 @@ def test_pipeline_device_front_end_look_ahead(natives, drive, capsys):
     assert late.lookAheadHits() == len(drive) - 1
     # ... and on the host path (keyed look-aheads)
     hp, hl = m.Pipeline(*args), m.Pipeline(*args)
+    hp.setDeviceFrontEnd(False)
+    hl.setDeviceFrontEnd(False)
     for i, s in enumerate(drive[:8]):
         hp.compute(0.1 * i, s)
         if i + 2 < 8:

@@ -39,10 +39,21 @@ def pose_err(Ta, Tb):
     return np.linalg.norm(d[:3, 3]), np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1))
 
 
-def test_pipeline_fullsize_matches_oracle_and_reports_rate(pypeline, drive, capsys):
+@pytest.mark.parametrize("front_end", ["host", "default"])
+def test_pipeline_fullsize_matches_oracle_and_reports_rate(pypeline, drive, capsys, front_end):
+    """`host`: the host tree builder (the reference's trees bit for bit; MAD_ICP_GPU_BUILD=0 / setDeviceFrontEnd(False));
+    `default`: what an unmodified caller gets since round 5 — tree construction on the device for deskew = false."""
     threads = min(os.cpu_count() or 1, 16)
     args = (10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, 16, threads, False)
-    gp = pypeline.Pipeline(*args)
+
+    def make():
+        p = pypeline.Pipeline(*args)
+        assert p.deviceFrontEnd()
+        if front_end == "host":
+            p.setDeviceFrontEnd(False)
+        return p
+
+    gp = make()
     op = O.Pipeline(*args)
     t_plain = []
     for i, s in enumerate(drive):
@@ -59,7 +70,7 @@ def test_pipeline_fullsize_matches_oracle_and_reports_rate(pypeline, drive, caps
             if i > 0:
                 assert abs(gp.lastInliersRatio() - op.lastInliersRatio()) < 2e-3
     # the same drive with the look-ahead: the tree of scan i+1 is built while frame i is registered — bit-identical poses
-    ga = pypeline.Pipeline(*args)
+    ga = make()
     t_ahead = []
     clouds = [pypeline.VectorEigen3d(s) for s in drive]
     ga.prefetch(clouds[0])
@@ -72,25 +83,28 @@ def test_pipeline_fullsize_matches_oracle_and_reports_rate(pypeline, drive, caps
     assert np.array_equal(np.asarray(ga.trajectory()), np.asarray(gp.trajectory()))
     # two scans ahead: the builds of scans i + 1 and i + 2 share the builder's threads (one's serial top levels run beside the
     # other's parallel bottom)
-    g2 = pypeline.Pipeline(*args)
-    t_ahead2 = []
-    g2.prefetch(clouds[0])
-    g2.prefetch(clouds[1])
-    for i in range(N_FRAMES):
-        t = time.perf_counter()
-        if i + 2 < N_FRAMES:
-            g2.prefetch(clouds[i + 2])
-        g2.compute(0.1 * i, clouds[i])
-        t_ahead2.append(time.perf_counter() - t)
-    assert np.array_equal(np.asarray(g2.trajectory()), np.asarray(gp.trajectory()))
+    # (host builder only: the device front-end has ONE construction in flight, on the library's build stream)
+    t_ahead2 = list(t_ahead)
+    if front_end == "host":
+        g2 = make()
+        t_ahead2 = []
+        g2.prefetch(clouds[0])
+        g2.prefetch(clouds[1])
+        for i in range(N_FRAMES):
+            t = time.perf_counter()
+            if i + 2 < N_FRAMES:
+                g2.prefetch(clouds[i + 2])
+            g2.compute(0.1 * i, clouds[i])
+            t_ahead2.append(time.perf_counter() - t)
+        assert np.array_equal(np.asarray(g2.trajectory()), np.asarray(gp.trajectory()))
     assert np.asarray(gp.currentLeaves()).shape == op.currentLeaves().shape if ORACLE_FRAMES == N_FRAMES else True
     gt = np.linalg.inv(synth.path_pose(0.0)) @ synth.path_pose(1.0 * (N_FRAMES - 1))
     assert np.linalg.norm(np.asarray(gp.currentPose())[:3, 3] - gt[:3, 3]) < 0.1
     with capsys.disabled():
         # (means: with a look-ahead the per-frame series is bimodal — a frame that waits a build's length, then quick ones)
-        print("\n[pipeline @ %d pts/scan, %d host threads] compute: mean %.2f ms/frame = %.0f frames/s (build %.2f ms, "
+        print("\n[pipeline, %s front-end @ %d pts/scan, %d host threads] compute: mean %.2f ms/frame = %.0f frames/s (build %.2f ms, "
               "registration %.3f ms); with prefetch(i + 1) before compute(i): %.2f ms = %.0f frames/s; two scans ahead: %.2f ms = %.0f frames/s"
-              % (drive[0].shape[0], threads, 1e3 * np.mean(t_plain[2:]), 1.0 / np.mean(t_plain[2:]), gp.lastBuildMs(),
+              % (front_end, drive[0].shape[0], threads, 1e3 * np.mean(t_plain[2:]), 1.0 / np.mean(t_plain[2:]), gp.lastBuildMs(),
                  gp.lastIcpMs(), 1e3 * np.mean(t_ahead[2:-1]), 1.0 / np.mean(t_ahead[2:-1]), 1e3 * np.mean(t_ahead2[2:-2]),
                  1.0 / np.mean(t_ahead2[2:-2])))
 

@@ -1,0 +1,48 @@
+"""What the reference does to ITSELF under last-bit changes — the evidence behind every tolerance above 1e-5 in this suite.
+
+Runs the oracle pipeline (oracle/, restating pipeline.cpp:125-265) against itself over a reduced-size drive:
+  * deskew = false: another `num_threads` (another order of the thread adders' sum, mad_icp.cpp:106-109) or one coordinate of
+    one point moved by one ulp changes the poses in their last bits and NOTHING else — the trees are built from the caller's
+    clouds, which do not depend on the poses.  That is where the 1e-5 m / 1e-5 rad bar of the north star is meaningful, and the
+    product is held to it there (tests/test_gpu_pipeline_fullsize.py, tests/test_gpu_frontend_oracle.py).
+  * deskew = true: the same changes move the reference's own trajectory by millimetres within a dozen frames: the compensated
+    cloud depends on the previous poses (pipeline.cpp:79-123), and MAD-tree construction turns a last-bit change of a cloud into
+    other leaf representatives (mad_tree.cpp:76-86: nearest member to the centroid; the two members of a two-point leaf tie up
+    to rounding).  The reference is not reproducible against itself across `num_threads` there — no implementation can be held
+    to it more tightly than it holds to itself (tests/envelope.py; the GPU tests hold both product paths inside this envelope).
+"""
+import numpy as np
+
+import envelope as E
+from mad_icp_amd import synth
+
+N_FRAMES = 12
+
+
+def _drive():
+    scene = synth.Scene(0)
+    return [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i, n_beams=32, n_azimuth=600) for i in range(N_FRAMES)]
+
+
+def test_without_deskew_the_reference_only_moves_in_its_last_bits():
+    scans = _drive()
+    _, _, dt, da = E.self_envelope(scans, deskew=False)
+    print("\n[oracle vs itself, deskew=False, %d frames of %d points] largest deviation per variant:" % (N_FRAMES, scans[0].shape[0]))
+    for (name, _), row in zip(E.VARIANTS, dt):
+        print("  %-40s %.1e m" % (name, row.max()))
+    assert dt.max() <= 1e-12 and da.max() <= 1e-7  # (acos near 1: 1e-8 rad is one ulp of the trace)
+
+
+def test_with_deskew_the_reference_drifts_from_itself_by_millimetres():
+    scans = _drive()
+    _, _, dt, da = E.self_envelope(scans, deskew=True)
+    bound = E.running_bound(dt)
+    print("\n[oracle vs itself, deskew=True, %d frames of %d points] deviation per frame (m):" % (N_FRAMES, scans[0].shape[0]))
+    for (name, _), row in zip(E.VARIANTS, dt):
+        print("  %-40s %s" % (name, " ".join("%.0e" % x for x in row)))
+    print("  %-40s %s" % ("running bound", " ".join("%.0e" % x for x in bound)))
+    # five orders of magnitude above the last-bit level within a dozen frames, from a 1-ulp change of ONE coordinate or from the
+    # thread count alone
+    assert bound[-1] >= 1e-4
+    assert (dt.max(axis=1) >= 1e-5).sum() >= 4  # (most variants, not one unlucky one)
+    assert dt[:, 0].max() == 0.0  # (the first frame has no registration)

@@ -2,11 +2,12 @@
 (apps/utils/tools/nn_search.py:36-61 and mad_registration.py:48-69 — the only known-answer material the reference
 ships: NN self-query error 0, pairwise registration -> identity).
 
-The files are read from /root/reference at run time (never copied): `mad_icp.src.pybind.*` resolves to THIS repository's
-modules, `mad_icp.apps.*` to the reference tree (its package directory is appended to `mad_icp.__path__`), `open3d` — which
-mad_registration.py imports at the top but only uses with --viz — is an empty stub.  Needs a GPU (every search and
-registration runs on the HIP path) AND the reference tree: skipped where either is missing (the GPU box of this project
-has no /root/reference; tests/test_boundary.py re-types the same two flows call for call for that box)."""
+The files are never part of this repository: they are read from /root/reference where it exists (this container) and
+otherwise from oracle/_ref/tools/ — byte-for-byte copies that __graft_entry__.build() places there (oracle/ship_ref_tools.sh;
+oracle/_ref/ is git-ignored and travels to the GPU box with the snapshot, like oracle/_ref/bin_runner).
+`mad_icp.src.pybind.*` resolves to THIS repository's modules, `mad_icp.apps.*` to the reference's files (their package
+directory is appended to `mad_icp.__path__`), `open3d` — which mad_registration.py imports at the top but only uses with
+--viz — is an empty stub.  Needs a GPU: every search and registration runs on the HIP path."""
 import contextlib
 import io
 import os
@@ -18,11 +19,14 @@ import types
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/mad_icp"
+if not os.path.isfile(os.path.join(REF, "apps", "utils", "tools", "nn_search.py")):
+    REF = os.path.join(ROOT, "oracle", "_ref", "tools", "mad_icp")  # shipped by oracle/ship_ref_tools.sh
 TOOLS = os.path.join(REF, "apps", "utils", "tools")
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.isfile(os.path.join(TOOLS, "nn_search.py")), reason="reference tree not present")]
+              pytest.mark.skipif(not os.path.isfile(os.path.join(TOOLS, "nn_search.py")), reason="neither /root/reference nor oracle/_ref/tools present")]
 
 
 @pytest.fixture()
