@@ -57,6 +57,17 @@ def self_envelope(scans, deskew, base_threads=4, variants=VARIANTS, **kw):
     return base, kf, dt, da
 
 
+RANGE = 10.0  # metres: a rotation of a rad moves a point at this range (the street's half width) by RANGE * a
+
+
+def combined(dt, da):
+    """One number per pose deviation: translation + the displacement the rotation gives a point at RANGE.  (Translation and
+    rotation deviations are NOT proportional from sample to sample — along the street the scene constrains translation
+    weakly, so a variant can move by millimetres without turning by 1e-8 rad — which is why the envelope is taken on this
+    sum and not on the two separately.)"""
+    return np.asarray(dt) + RANGE * np.asarray(da)
+
+
 def running_bound(dev):
     """What a path is held to at frame i: the largest deviation any variant has shown up to and including frame i."""
     return np.maximum.accumulate(dev.max(axis=0))

@@ -230,14 +230,14 @@ def test_pipeline_with_deskew_and_realtime_flags(mods):
     scene = synth.Scene(6)
     scans = [synth.render_scan(scene, synth.path_pose(0.5 * i), 70 + i, n_beams=16, n_azimuth=500) for i in range(8)]
     base, _, dt, da = E.self_envelope(scans, deskew=True, base_threads=2, num_keyframes=4)
-    bt, ba = E.running_bound(dt), E.running_bound(da)
+    bound = E.running_bound(E.combined(dt, da))  # translation + 10 m x rotation, metres
     gp = pypeline.Pipeline(10.0, True, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, 4, 2, True)
     assert not gp.deviceFrontEnd()
     for i, s in enumerate(scans):
         gp.compute(0.1 * i, pypeline.VectorEigen3d(s))
         d_t, d_a = E.pose_dev(base[i], np.asarray(gp.currentPose()))
-        assert d_t <= 3.0 * bt[i] + 1e-5 and d_a <= 3.0 * ba[i] + 1e-5, (i, d_t, bt[i], d_a, ba[i])
-        if bt[i] <= 1e-9:
+        assert E.combined(d_t, d_a) <= 3.0 * bound[i] + 2e-5, (i, d_t, d_a, bound[i])
+        if bound[i] <= 1e-9:
             assert d_t <= 1e-5 and d_a <= 1e-5, (i, d_t, d_a)
     # (no ground-truth check: the synthetic scans are rendered instantaneously, so "deskewing" them distorts them)
 
