@@ -3,7 +3,8 @@
 Runs the oracle pipeline (oracle/, restating pipeline.cpp:125-265) against itself over a reduced-size drive:
   * deskew = false: another `num_threads` (another order of the thread adders' sum, mad_icp.cpp:106-109) or one coordinate of
     one point moved by one ulp changes the poses in their last bits and NOTHING else — the trees are built from the caller's
-    clouds, which do not depend on the poses.  That is where the 1e-5 m / 1e-5 rad bar of the north star is meaningful, and the
+    clouds, which do not depend on the poses.  (Moving EVERY coordinate by an ulp is another matter: tree construction itself is
+    chaotic in its input, and the reference answers with a fraction of a millimetre at once.)  That is where the 1e-5 m / 1e-5 rad bar of the north star is meaningful, and the
     product is held to it there (tests/test_gpu_pipeline_fullsize.py, tests/test_gpu_frontend_oracle.py).
   * deskew = true: the same changes move the reference's own trajectory by millimetres within a dozen frames: the compensated
     cloud depends on the previous poses (pipeline.cpp:79-123), and MAD-tree construction turns a last-bit change of a cloud into
@@ -30,7 +31,15 @@ def test_without_deskew_the_reference_only_moves_in_its_last_bits():
     print("\n[oracle vs itself, deskew=False, %d frames of %d points] largest deviation per variant:" % (N_FRAMES, scans[0].shape[0]))
     for (name, _), row in zip(E.VARIANTS, dt):
         print("  %-40s %.1e m" % (name, row.max()))
-    assert dt.max() <= 1e-12 and da.max() <= 1e-7  # (acos near 1: 1e-8 rad is one ulp of the trace)
+    few = [v for v, (_, o) in enumerate(E.VARIANTS) if "ulp_all" not in o]
+    every = [v for v, (_, o) in enumerate(E.VARIANTS) if "ulp_all" in o]
+    # another thread count, or ONE coordinate by one ulp: the clouds the trees are built from stay what they were (but for that
+    # one coordinate), and the trajectory only moves in its last bits
+    assert dt[few].max() <= 1e-12 and da[few].max() <= 1e-7  # (acos near 1: 1e-8 rad is one ulp of the trace)
+    # EVERY coordinate by at most one ulp: MAD-tree construction itself turns that into other leaf representatives (two-point
+    # leaves tie up to rounding, mad_tree.cpp:76-86) and the reference moves by a fraction of a millimetre at once — the reason
+    # why the 1e-5 bar only means something between sides that build their trees from bit-identical clouds
+    assert dt[every, 1:].min(axis=1).max() >= 1e-6 and dt[every].max() >= 1e-4
 
 
 def test_with_deskew_the_reference_drifts_from_itself_by_millimetres():
