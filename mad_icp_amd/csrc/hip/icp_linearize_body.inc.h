@@ -28,7 +28,120 @@
     // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
     const int n_top_avail = (opt_lds_top && i_end - r * S >= opt_stage_min) ? min(td.n_top, kTopMax) : 0;
 
-    for (int base = r * S; base < i_end; base += QPT * kBlock) {
+#ifdef MADICP_QUEUE_WALK
+    // ---- QUEUED WALKS (round 5; icp_round only) -----------------------------------------------------------------------
+    // A unit of many passes (a batch shares the chip: BASELINE configs[4] has 26 passes per unit) in a round in which SOME
+    // pairs have to walk: with the walk inside the pass, a wavefront that holds ONE walker waits out a whole descent — at 2 %
+    // walkers three wavefronts in four do (0.98^64 = 0.27), and the per-round trace of configs[4] shows rounds 2-5 as slow as
+    // rounds 0-1 in which every pair walks (profiles/r5_k64_round_trace_before.md).  Here the unit is cut into chunks of
+    // kQueueChunk passes, and a chunk is done in three sweeps:
+    //   A  the reuse test of every pair (coordinates + cached margin, one coalesced round trip): pairs that pass get their
+    //      margin refreshed, the others are queued — per WAVEFRONT, in pass order then lane order (a ballot and a prefix
+    //      count: deterministic, no barrier), 2 bytes each in LDS;
+    //   B  the wavefront walks its queue DENSELY, 64 walkers per descent, and leaves leaf | depth and the fresh margin in the
+    //      correspondence cache;
+    //   C  the passes themselves, every pair's leaf now in the cache (a pair the cache cannot hold — depth > 63 — walks in
+    //      place): gate, e, J, accumulation in the SAME lane and pass order as without the queue.
+    // So the sums are the bits of the unqueued order whatever walked (tests: reuse on == off, queue on == off), and the
+    // number of descents a wavefront waits for is ceil(walkers / 64), not the number of passes that hold a walker.  Chosen per
+    // unit without a vote: round >= 2, somebody of this workgroup walked last round (the staging hint), at least
+    // kQueueMinPasses passes.  Speed only.
+    const bool qmode = QPT == 1 && reuse && round >= 2 && stage_hint && opt_queue &&
+                       (i_end - r * S) >= kQueueMinPasses * kBlock;  // (workgroup-uniform)
+    const int chunk_leaves = qmode ? kQueueChunk * kBlock : 0x40000000;
+#else
+    constexpr bool qmode = false;
+    const int chunk_leaves = 0x40000000;
+#endif
+    for (int cbase = r * S; cbase < i_end; cbase += min(chunk_leaves, i_end - cbase)) {
+    const int c_end = min(i_end, cbase + min(chunk_leaves, i_end - cbase));
+#ifdef MADICP_QUEUE_WALK
+    if (qmode) {
+      const int q_lane = MADICP_TID & 63, q_wave = MADICP_TID >> 6;
+      if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform; stage_hint holds in this mode) the tree's top levels into LDS
+        if (staged_tree >= 0) __syncthreads();
+        gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
+        gptr_u4 ge = (gptr_u4)(uintptr_t)td.top_exit;
+        for (int e = MADICP_TID; e < n_top_avail; e += kBlock) {
+          s_top[e] = gt[e];
+          reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
+        }
+        __syncthreads();
+        staged_tree = k;
+      }
+      // sweep A: who has to walk?
+      int qn = 0;  // entries in this wavefront's queue (wave-uniform)
+      int pc = 0;
+      for (int base = cbase; base < c_end; base += kBlock, ++pc) {
+        const int i = base + MADICP_TID;
+        const bool v = i < c_end;
+        vd4 p = vd4{0.0, 0.0, 0.0, 0.0};
+        float cm = 0.f;
+        if (u == u_first && base == r * S) {  // (workgroup-uniform) fetched before the solve prologue
+          p = pv0[0];
+          cm = cmar0[0];
+        } else if (v) {
+          p = ((gptr_d4)(uintptr_t)moving)[i];
+          cm = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[(long long)k * L + i];
+        }
+#ifdef MADICP_XFORM_HOMOGENEOUS
+        const double a0 = ((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0];
+        const double a1 = ((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1];
+        const double a2 = ((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2];
+#else
+        const double a0 = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
+        const double a1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
+        const double a2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+#endif
+        const double moved = moved_rot * p.w + moved_trans;
+        const double left_over = (double)cm - moved * (1.0 + 1e-12) -
+                                 1e-11 * ((fabs(a0) + fabs(a1) + fabs(a2)) + td.rho + fabs(td.origin[0]) +
+                                          fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
+        const bool keep = v && left_over > 0.0;
+        if (keep) cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
+        const bool w = v && !keep;
+        const unsigned long long wm = __ballot(w);
+        if (w) s_queue[q_wave][qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
+                   (unsigned short)(pc * 64 + q_lane);
+        qn += __popcll(wm);
+        walked |= w;
+      }
+      wave_lds_order();
+      // sweep B: the wavefront's walkers, 64 to a descent
+      const int n_top_q = (k == staged_tree) ? n_top_avail : 0;
+      for (int b = 0; b < qn; b += 64) {
+        const bool has = b + q_lane < qn;
+        const int e = has ? (int)s_queue[q_wave][b + q_lane] : 0;
+        const int i = cbase + (e >> 6) * kBlock + q_wave * 64 + (e & 63);
+        const vd4 p = has ? ((gptr_d4)(uintptr_t)moving)[i] : vd4{0.0, 0.0, 0.0, 0.0};
+#ifdef MADICP_XFORM_HOMOGENEOUS
+        const double a0[1] = {((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0]};
+        const double a1[1] = {((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1]};
+        const double a2[1] = {((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2]};
+#else
+        const double a0[1] = {t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z)};
+        const double a1[1] = {t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z)};
+        const double a2[1] = {t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z)};
+#endif
+        const bool wv[1] = {has};
+        int xi[1], xl[1], xd[1];
+        double xm[1] = {3.0e38};
+        descend_multi<1>(td, s_top, s_exit, n_top_q, a0, a1, a2, wv, xi, xl, xd, xm);
+        if (has) {
+          walked_visits += (unsigned int)xd[0];
+          const long long ci = (long long)k * L + i;
+          const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
+          cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
+          cache_margin[ci] = cacheable ? __double2float_rd(xm[0]) : 0.f;
+        }
+      }
+      // sweep C reads what sweeps A and B of this wavefront stored (other lanes' entries too)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+#endif
+    for (int base = cbase; base < c_end; base += QPT * kBlock) {
       double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
       bool valid[QPT], walk[QPT];
       int leaf[QPT], depth[QPT];
@@ -44,7 +157,7 @@
         pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
         cmar[j] = 0.f;
         cword[j] = 0u;
-        if (u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
+        if (!qmode && u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
           pv[j] = pv0[j];
           cmar[j] = cmar0[j];
           cword[j] = cword0[j];
@@ -80,7 +193,13 @@
         margin[j] = 3.0e38;
         leaf[j] = 0;
         depth[j] = 0;
-        if (reuse && valid[j]) {
+        if (qmode) {  // sweep C of a queued chunk: sweeps A / B left every pair's leaf in the cache, valid for THIS pose
+          if (valid[j] && cmar[j] > 0.f) {
+            leaf[j] = (int)(cword[j] & kCacheIdxMask);
+            depth[j] = (int)(cword[j] >> 26);
+            walk[j] = false;
+          }  // (margin 0: a pair the cache cannot hold, or whose margin rounded down to nothing — it walks in place)
+        } else if (reuse && valid[j]) {
           // how far can this leaf have moved since the previous round?  (bound from the update itself, see solve_pose;
           // the 1e-11 term covers the rounding of the two computed queries)
           const double moved = moved_rot * p.w + moved_trans;
@@ -136,7 +255,7 @@
           if (walk[j]) {
             leaf[j] = wleaf[j];
             depth[j] = wdepth[j];
-            walked_visits += (unsigned int)wdepth[j];
+            if (!qmode) walked_visits += (unsigned int)wdepth[j];  // (a queued chunk counted this pair's walk in sweep B)
             if (cache_leaf) {
               const long long ci = (long long)k * L + (base + j * kBlock + MADICP_TID);
               const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
@@ -165,7 +284,16 @@
         // gate (mad_icp.cpp:81-83)
         const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
         const double src_ball = min_ball + b_ratio * pn[j];
-        const bool rejected = sqrt(dotc(g0, g1, g2, g0, g1, g2)) > src_ball;
+        // The reference's test is sqrt(d2) > src_ball with a correctly rounded square root.  Squaring decides it without
+        // one whenever d2 is not within 2^-50 of src_ball^2 (relative): d2 > b2 (1 + 2^-50) implies RN(sqrt(d2)) > src_ball
+        // and d2 < b2 (1 - 2^-50) implies RN(sqrt(d2)) <= src_ball (b2 = RN(src_ball^2) is within 2^-53 of the square, the
+        // root of the remaining factor is beyond 1 +- 2^-52, and rounding is monotone) — the 17-instruction root is only
+        // evaluated when a lane of the wavefront falls in between, or its ball is not a positive normal number.
+        const double d2 = dotc(g0, g1, g2, g0, g1, g2);
+        const double b2 = src_ball * src_ball;
+        const bool surely_out = d2 > b2 * (1.0 + 0x1p-50), surely_in = d2 < b2 * (1.0 - 0x1p-50);
+        bool rejected = surely_out;
+        if (__any(!(surely_out || surely_in) || !(src_ball > 1e-140))) rejected = sqrt(d2) > src_ball;
         if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
         if (mark_matched) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)
@@ -247,4 +375,5 @@
       }
       if (u == u_first && base == r * S) { MADICP_STAMP(9); }
     }
+    }  // chunk
   }

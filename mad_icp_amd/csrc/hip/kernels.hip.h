@@ -196,6 +196,7 @@ struct Job {
 };
 constexpr int kFlagNoUpdate = 1;
 constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (option cache_correspondences = 0)
+constexpr int kFlagNoQueue = 2048; // never queue walks (option queue_walks = 0): every walk happens inside its pass
 constexpr int kFlagMatchAll = 1024;  // matched_ flags are the OR over ALL rounds (the host cleared them), not the last round's:
                                      // what the reference leaves behind when its realtime check ends the loop before
                                      // iteration MAX_ICP_ITS - 1, the only one that resets them (pipeline.cpp:167-176)
@@ -334,6 +335,10 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 // whole wave on the latency chain, so margins must not be thrown away).
 constexpr unsigned int kCacheIdxMask = 0x03ffffffu;
 constexpr int kCacheMaxDepth = 63;
+// queued walks (icp_linearize_body.inc.h): a unit of at least kQueueMinPasses passes is done in chunks of kQueueChunk passes
+// whose walkers are queued per wavefront (2 bytes each in LDS) and walked densely
+constexpr int kQueueChunk = 16;
+constexpr int kQueueMinPasses = 4;
 
 // QPT independent descents per lane advanced in lock-step (their loads are issued together).  Phase 1 walks the
 // LDS copy of the tree's top levels (s_top / s_exit, n_top entries), phase 2 continues in global memory.
@@ -1395,6 +1400,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int opt_stage_min = job->stage_min_leaves;
   const int L = job->L;
   const int flags = job->flags;
+  const bool opt_queue = !(flags & kFlagNoQueue);
+  __shared__ unsigned short s_queue[kWaves][kQueueChunk * 64];  // queued walks: per wavefront, pass-in-chunk * 64 + lane
   const bool last_round = (round == n_iters - 1);
   const bool mark_matched = last_round || (flags & kFlagMatchAll);
   const double* __restrict__ moving = job->moving;
@@ -1557,7 +1564,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 
 
 #define MADICP_TID threadIdx.x
+#define MADICP_QUEUE_WALK 1
 #include "icp_linearize_body.inc.h"
+#undef MADICP_QUEUE_WALK
 #undef MADICP_TID
 
   MADICP_STAMP(5);

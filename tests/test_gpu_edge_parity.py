@@ -163,3 +163,43 @@ def test_random_small_clouds_nearest_neighbour_and_linearisation(ctx):
         ctx.tree_release(tid)
         checked += 1
     assert checked == 60
+
+
+@pytest.mark.gpu
+def test_gate_within_ulps_of_its_threshold(ctx):
+    """The gate of mad_icp.cpp:81-83 is `(ml - f.mean).norm() > min_ball + b_ratio * |p|` with a correctly rounded square
+    root.  The kernel decides it from the SQUARES whenever they are more than 2^-50 apart (relative) and evaluates the root
+    only in between (icp_linearize_body.inc.h).  Here the pairs sit ON that threshold: a fixed cloud in the plane x ~ 0 (x = a
+    few ulps of 1.5), moving leaves straight above its leaf representatives at x = 1.5 + c ulps, b_ratio = 0 and min_ball =
+    1.5 — so the distance is 1.5 + (c - a) ulps EXACTLY, within 2^-49 of the ball for every pair, on both sides of it and on
+    it.  Gate decisions and correspondences against the oracle's, bit for bit; both outcomes must occur."""
+    rng = np.random.default_rng(12)
+    u = 2.0 ** -52
+    n = 3000
+    fixed = np.stack([rng.integers(0, 7, n) * u, rng.uniform(0, 1, n), rng.uniform(0, 1, n)], axis=1)
+    ht = capi.HostTree(fixed, 0.05, 0.01, 2)
+    ot = O.Tree(fixed, 0.05, 0.01, 2)
+    assert np.array_equal(ht.nodes["mean"], ot.export()["mean"])
+    reps = ht.leaf_means()
+    moving = reps.copy()
+    moving[:, 0] = 1.5 + rng.integers(-6, 13, reps.shape[0]) * u
+    qh = capi.HostTree(moving, 1e-5, 0.01, 2)
+    qo = O.Tree(moving, 1e-5, 0.01, 2)
+    assert qh.num_leaves == moving.shape[0]  # (every moving point its own leaf)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    mid = ctx.moving_upload(qh.leaf_means())
+    params = (1.5, RHO_KER, 0.0)
+    g = ctx.icp_linearize(mid, [tid], np.eye(4), params, qh.num_leaves)
+    _, _, corr, rej, mat, depth = O.icp_linearize(qo, ot, np.eye(4), 1.5, RHO_KER, 0.0)
+    assert np.array_equal(g["corr"][0] & 0x7FFFFFFF, corr)
+    assert np.array_equal((g["corr"][0] >> 31).astype(np.uint8), rej)
+    assert np.array_equal(g["matched"], mat) and g["visits"] == depth
+    # the pairs really are where the squares cannot decide: distance / ball - 1 within a few ulps, all three cases present
+    ml = qh.leaf_means()
+    d = np.sqrt(((ml - reps[corr]) ** 2).sum(axis=1))
+    near = np.abs(d / 1.5 - 1.0) <= 2.0 ** -49
+    assert near.mean() > 0.5
+    assert (d[near] > 1.5).any() and (d[near] < 1.5).any() and (d[near] == 1.5).any()
+    assert 0.2 < rej[near].mean() < 0.9
+    ctx.moving_release(mid)
+    ctx.tree_release(tid)

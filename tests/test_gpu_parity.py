@@ -374,6 +374,47 @@ def test_correspondence_reuse_is_exact(ctx, K):
     _teardown(ctx, tids, mids)
 
 
+def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
+    """Option "queue_walks" (default on; icp_linearize_body.inc.h, "QUEUED WALKS"): when a batch shares the chip a workgroup's
+    unit is many passes long, and from round 2 on the pairs that still have to walk are queued per wavefront and walked
+    densely before the passes run.  32 keyframes, 8 scans in flight (one range per tree: 11 passes per unit): final pose, H,
+    b, matched flags, matched counts and the visit counter bit for bit those of walking inside the pass, and those of walking
+    EVERY pair every round (no correspondence reuse, hence no queue) — the accumulation order does not depend on who walked.
+    And the poses are the oracle's (mad_icp.cpp:74-117 under pipeline.cpp:166-193)."""
+    pb = street_problem(32, n_queries=8)
+    tids, ots = [], []
+    for s_, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        ht, ot = build_pair(s_, T=T)
+        ots.append(ot)
+        tids.append(ctx.tree_upload(ht.nodes, ht.num_leaves))
+    qh = [capi.HostTree(s_, B_MAX, B_MIN, 2) for s_ in pb["query_scans"]]
+    mids = [ctx.moving_upload(h.leaf_means()) for h in qh]
+    X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
+    assert min(h.num_leaves for h in qh) >= 4 * 768  # (deep units: what the queue is for)
+    res = {}
+    for name, opts in (("queued", dict(queue_walks=1)), ("in pass", dict(queue_walks=0)),
+                       ("no reuse", dict(queue_walks=1, cache_correspondences=0))):
+        for k_, v_ in opts.items():
+            ctx.set_option(k_, v_)
+        r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+        r["matched"] = [ctx.icp_fetch_matched(i, h.num_leaves) for i, h in enumerate(qh)]
+        res[name] = r
+        ctx.set_option("queue_walks", 1)
+        ctx.set_option("cache_correspondences", 1)
+    for other in ("in pass", "no reuse"):
+        for key in ("X", "H", "b", "n_matched", "visits"):
+            assert np.array_equal(res["queued"][key], res[other][key]), (other, key)
+        for a, b in zip(res["queued"]["matched"], res[other]["matched"]):
+            assert np.array_equal(a, b), other
+    for q in (0, 5):
+        o = O.icp_register(O.Tree(pb["query_scans"][q], B_MAX, B_MIN, 2), ots, pb["query_guess"][q], 15, B_MAX, RHO_KER, B_RATIO,
+                           num_threads=4)
+        d = np.linalg.inv(o["T"]) @ capi.pose44(res["queued"]["X"][q])
+        assert np.linalg.norm(d[:3, 3]) <= 1e-5 and np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)) <= 1e-5
+        assert np.array_equal(res["queued"]["matched"][q], o["matched"])
+    _teardown(ctx, tids, mids)
+
+
 def test_register_is_deterministic_and_graph_equals_eager(ctx):
     pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 2)
     L = qh[0].num_leaves
