@@ -21,6 +21,19 @@ def pose_dev(Ta, Tb):
     return float(np.linalg.norm(d[:3, 3])), float(np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)))
 
 
+def ulp_jitter(a, rng, ulps=1):
+    """Every coordinate moved by -ulps .. +ulps units in the last place (np.nextafter steps: exact zeros become denormals, not
+    the NaN an integer view would make of them)."""
+    a = np.ascontiguousarray(a, dtype=np.float64).copy()
+    k = rng.integers(-ulps, ulps + 1, size=a.shape)
+    for _ in range(ulps):
+        up, dn = k > 0, k < 0
+        a[up] = np.nextafter(a[up], np.inf)
+        a[dn] = np.nextafter(a[dn], -np.inf)
+        k = k - np.sign(k)
+    return a
+
+
 def oracle_drive(scans, deskew, threads=4, ulp_at=None, ulp_all=None, num_keyframes=16, p_th=0.8):
     """Poses of the oracle pipeline over `scans`.  ulp_at = (frame, point, coordinate): that one double moved by one ulp;
     ulp_all = seed: EVERY coordinate of EVERY cloud moved by -1, 0 or +1 ulp (seeded)."""
@@ -30,10 +43,10 @@ def oracle_drive(scans, deskew, threads=4, ulp_at=None, ulp_all=None, num_keyfra
     for i, s in enumerate(scans):
         if ulp_at is not None and ulp_at[0] == i:
             s = np.ascontiguousarray(s, dtype=np.float64).copy()
-            s.view(np.int64)[ulp_at[1] % s.shape[0], ulp_at[2]] += 1
+            j = ulp_at[1] % s.shape[0]
+            s[j, ulp_at[2]] = np.nextafter(s[j, ulp_at[2]], np.inf)
         if rng is not None:
-            s = np.ascontiguousarray(s, dtype=np.float64).copy()
-            s.view(np.int64)[...] += rng.integers(-1, 2, size=s.shape)
+            s = ulp_jitter(s, rng)
         p.compute(0.1 * i, s)
         poses.append(p.currentPose().copy())
         kf.append(p.keyframeID())

@@ -219,8 +219,8 @@ def test_pipeline_with_deskew_and_realtime_flags(mods):
     budget runs all rounds.  Tolerance: with deskew the input of every tree build depends on the previous poses, and MAD-tree
     construction turns a last-bit change of its input into other leaf representatives — the reference does not reproduce
     ITSELF there (tests/test_oracle_sensitivity.py).  So the product is held inside the envelope the oracle pipeline shows
-    against itself (other thread counts, one coordinate of one point moved by one ulp: tests/envelope.py), and to 1e-5 on the
-    frames before anything has been amplified; the 1e-5 bar everywhere applies where both sides see the same clouds
+    against itself (other thread counts, coordinates moved by one ulp: tests/envelope.py), and to 1e-5 on the two frames
+    that are not deskewed; the 1e-5 bar everywhere applies where both sides see the same clouds
     (test_pipeline_matches_oracle_pipeline, tests/test_gpu_parity.py)."""
     import envelope as E
     import oracle_lib as O
@@ -237,7 +237,7 @@ def test_pipeline_with_deskew_and_realtime_flags(mods):
         gp.compute(0.1 * i, pypeline.VectorEigen3d(s))
         d_t, d_a = E.pose_dev(base[i], np.asarray(gp.currentPose()))
         assert E.combined(d_t, d_a) <= 3.0 * bound[i] + 2e-5, (i, d_t, d_a, bound[i])
-        if bound[i] <= 1e-9:
+        if i < 2:  # (frames 0 and 1 are not deskewed — pipeline.cpp:138-139 needs two poses —: the north-star bar itself)
             assert d_t <= 1e-5 and d_a <= 1e-5, (i, d_t, d_a)
     # (no ground-truth check: the synthetic scans are rendered instantaneously, so "deskewing" them distorts them)
 

@@ -115,7 +115,11 @@ def _hold_inside_envelope(tag, scans, pypeline, capsys, variants=E.VARIANTS, gt=
     bound_all, bound_few = np.maximum.accumulate(m_all), np.maximum.accumulate(m_few)  # metres: translation + 10 m x rotation
     bt = np.maximum.accumulate(t_all)
     rows = []
-    for name, device, bound in (("host path", False, bound_few), ("device front-end", True, bound_all)):
+    # (Both paths are held to the envelope of ALL variants.  Holding the host path to the thread / single-coordinate variants
+    # alone — the kind of change it makes — was tried: its deviations sit in that envelope from frame ~4 on, but the ONSET of
+    # the amplification is heavy-tailed — one drive showed 3e-3 m at frame 2 where eight such variants showed at most 3e-4 at
+    # frame 2 and 7e-3 at frame 3 — and eight samples do not bound it; both envelopes are printed.)
+    for name, device, bound in (("host path", False, bound_all), ("device front-end", True, bound_all)):
         poses, kf = _product_drive(pypeline, scans, device)
         d = np.array([E.pose_dev(a, b) for a, b in zip(base, poses)])
         rows.append((name, d, poses, kf, bound))
@@ -189,17 +193,21 @@ def _same_topology(nodes, ht):
     return nodes.shape[0] == ht.nodes.shape[0] and np.array_equal(nodes["right"], ht.nodes["right"])
 
 
-def _reference_keeps_its_topology(pts, b_max, b_min, seed, trials=8):
-    """Does the reference's OWN tree (host builder == oracle) survive a change of every coordinate by -1 / 0 / +1 ulp?"""
+def _reference_keeps_its_topology(pts, b_max, b_min, seed, trials=8, ulps=(1, 4, 16)):
+    """Does the reference's OWN tree (host builder == oracle) survive a change of every coordinate by a few ulps?  The device
+    builder adds the members of a node of more than 32 points in another shape than the reference's serial chain
+    (tree_build.hip.h): its centroids differ from the reference's by the rounding of a sum — a few ulps, nine on a 246-point
+    node whose members share a coordinate.  Returns [(ulps, trees kept, trials)]."""
     base = capi.HostTree(pts, b_max, b_min, 2).nodes["right"]
-    rng = np.random.default_rng(seed)
-    kept = 0
-    for _ in range(trials):
-        q = np.ascontiguousarray(pts, dtype=np.float64).copy()
-        q.view(np.int64)[...] += rng.integers(-1, 2, size=q.shape)
-        r = capi.HostTree(q, b_max, b_min, 2).nodes["right"]
-        kept += int(r.shape == base.shape and np.array_equal(r, base))
-    return kept, trials
+    out = []
+    for u in ulps:
+        rng = np.random.default_rng(seed + 7919 * u)
+        kept = 0
+        for _ in range(trials):
+            r = capi.HostTree(E.ulp_jitter(pts, rng, u), b_max, b_min, 2).nodes["right"]
+            kept += int(r.shape == base.shape and np.array_equal(r, base))
+        out.append((u, kept, trials))
+    return out
 
 
 def test_device_builder_on_deskewed_clouds(ctx, capsys):
@@ -241,9 +249,11 @@ def test_device_builder_on_deskewed_clouds(ctx, capsys):
 def test_device_builder_topology_on_random_small_clouds_exactly(ctx, capsys):
     """The sixty random small clouds of tests/test_gpu_frontend.py (blobs, sheets, lines, duplicates; 1 .. 400 points; random
     thresholds), topology compared EXACTLY.  The device builder may only differ from the reference's tree where the reference's
-    tree is itself not determined by the input to better than an ulp: every cloud that differs is listed with what a 1-ulp
-    change of the input does to the HOST builder's (== the oracle's) topology, and a cloud whose reference topology survives
-    all such changes while the device's differs fails the test."""
+    tree is itself not determined by the input to better than a few ulps: every cloud that differs is listed with what a change
+    of every coordinate by up to 1, 4 and 16 ulps does to the HOST builder's (== the oracle's) topology, and a cloud whose
+    reference topology survives all of them while the device's differs fails the test.  (What differs on these clouds, measured:
+    exactly collinear points — the SIGN of the split direction, an eigenvector of a covariance with two zero eigenvalues, is left
+    to the rounding of the centroid, and with the opposite sign the two children swap places.)"""
     r2 = np.random.default_rng(77)
     listing, unexplained = [], []
     n_same = 0
@@ -264,15 +274,17 @@ def test_device_builder_topology_on_random_small_clouds_exactly(ctx, capsys):
         if _same_topology(nodes, ht):
             n_same += 1
             continue
-        kept, trials = _reference_keeps_its_topology(c, b_max, b_min, 1000 + i)
-        first = int(np.flatnonzero(nodes["right"][: min(nodes.shape[0], ht.nodes.shape[0])] !=
-                                   ht.nodes["right"][: min(nodes.shape[0], ht.nodes.shape[0])])[:1].sum()) \
-            if nodes.shape[0] and ht.nodes.shape[0] else 0
-        listing.append("cloud %2d: %3d points, kind %s, b_max %g, b_min %g: device %d leaves, reference %d; first differing node %d; "
-                       "the reference keeps its own topology in %d of %d 1-ulp perturbations"
+        kept = _reference_keeps_its_topology(c, b_max, b_min, 1000 + i)
+        m = min(nodes.shape[0], ht.nodes.shape[0])
+        neq = np.flatnonzero(nodes["right"][:m] != ht.nodes["right"][:m])
+        first = int(neq[0]) if neq.size else m
+        mirrored = first < m and bool(np.dot(nodes["dir"][first], ht.nodes["dir"][first]) < 0)
+        listing.append("cloud %2d: %3d points, %s, b_max %g, b_min %g: device %d leaves, reference %d; first differing node %d%s; the "
+                       "reference keeps its own topology in %s perturbations of every coordinate"
                        % (i, c.shape[0], ("blob", "sheet", "line", "duplicates")[kind], b_max, b_min, (nodes.shape[0] + 1) // 2,
-                          ht.num_leaves, first, kept, trials))
-        if kept == trials:
+                          ht.num_leaves, first, " (split direction of opposite SIGN: the children are mirrored)" if mirrored else "",
+                          ", ".join("%d of %d +-%d-ulp" % (k_, t_, u_) for u_, k_, t_ in kept)))
+        if all(k_ == t_ for _, k_, t_ in kept):
             unexplained.append(i)
     with capsys.disabled():
         print("\n[device vs host builder, 60 random small clouds, exact topology] identical on %d; differing:" % n_same)
