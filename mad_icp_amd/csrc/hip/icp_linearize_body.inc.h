@@ -43,11 +43,12 @@
     //   C  the passes themselves, every pair's leaf now in the cache (a pair the cache cannot hold — depth > 63 — walks in
     //      place): gate, e, J, accumulation in the SAME lane and pass order as without the queue.
     // So the sums are the bits of the unqueued order whatever walked (tests: reuse on == off, queue on == off), and the
-    // number of descents a wavefront waits for is ceil(walkers / 64), not the number of passes that hold a walker.  Chosen per
-    // unit without a vote: round >= 2, somebody of this workgroup walked last round (the staging hint), at least
-    // kQueueMinPasses passes.  Speed only.
-    const bool qmode = QPT == 1 && reuse && round >= 2 && stage_hint && opt_queue &&
-                       (i_end - r * S) >= kQueueMinPasses * kBlock;  // (workgroup-uniform)
+    // number of descents a wavefront waits for is ceil(walkers / 64), not the number of passes that hold a walker.  Sweep A
+    // costs a coalesced round trip per pass (0.67 us measured), so the mode is chosen per round without a vote from what
+    // the workgroup walked in the PREVIOUS round (the hint it left behind its partials: nodes walked): at least `queue_nodes`
+    // per pass (option "queue_walks", default 32 — the walkers of a round are a tenth of the round before, GN converges
+    // quadratically), round >= 2, units of at least kQueueMinPasses passes.  Speed only.
+    const bool qmode = QPT == 1 && reuse && queue_hint && (i_end - r * S) >= kQueueMinPasses * kBlock;  // (workgroup-uniform)
     const int chunk_leaves = qmode ? kQueueChunk * kBlock : 0x40000000;
 #else
     constexpr bool qmode = false;

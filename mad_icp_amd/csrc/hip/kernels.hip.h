@@ -183,6 +183,8 @@ struct Job {
   int32_t ranges_per_tree;  // launch geometry: every tree's moving leaves are cut into this many ranges
   int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
   int32_t lds_top;          // 1 when the launch carries kTopLdsBytes of dynamic LDS
+  int32_t queue_nodes;      // queued walks: a unit is queued when the workgroup walked at least this many nodes per pass in the
+                            // previous round (0: never; option "queue_walks")
   int32_t seq;              // streamed registrations: what icp_final leaves in HostResult::seq when everything is written
   uint32_t epoch;           // icp_persist: distinguishes this launch's exchange granules from every earlier launch's (host counter)
   int32_t error;            // icp_persist: non-zero when a bounded in-launch wait ran out (results invalid)
@@ -196,7 +198,6 @@ struct Job {
 };
 constexpr int kFlagNoUpdate = 1;
 constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (option cache_correspondences = 0)
-constexpr int kFlagNoQueue = 2048; // never queue walks (option queue_walks = 0): every walk happens inside its pass
 constexpr int kFlagMatchAll = 1024;  // matched_ flags are the OR over ALL rounds (the host cleared them), not the last round's:
                                      // what the reference leaves behind when its realtime check ends the loop before
                                      // iteration MAX_ICP_ITS - 1, the only one that resets them (pipeline.cpp:167-176)
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int opt_stage_min = job->stage_min_leaves;
   const int L = job->L;
   const int flags = job->flags;
-  const bool opt_queue = !(flags & kFlagNoQueue);
+  const int opt_queue = job->queue_nodes;
   __shared__ unsigned short s_queue[kWaves][kQueueChunk * 64];  // queued walks: per wavefront, pass-in-chunk * 64 + lane
   const bool last_round = (round == n_iters - 1);
   const bool mark_matched = last_round || (flags & kFlagMatchAll);
@@ -1560,7 +1561,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = wave_uniform(s_X[9 + k]);
   const double moved_rot = wave_uniform(s_X[12]), moved_trans = wave_uniform(s_X[13]);
-  const bool stage_hint = round == 0 || wave_uniform(s_X[14]) > 0.0;
+  const double hint_nodes = wave_uniform(s_X[14]);  // nodes this workgroup walked in the previous round
+  const bool stage_hint = round == 0 || hint_nodes > 0.0;
+  // passes this workgroup makes in a round (every unit the same length but the last range of a tree)
+  const int wg_passes = have_first ? ((hi - u_first + nslots - 1) / nslots) * ((S + kBlock - 1) / kBlock) : 0;
+  const bool queue_hint = opt_queue > 0 && round >= 2 && hint_nodes >= (double)opt_queue * (double)wg_passes;
 
 
 #define MADICP_TID threadIdx.x
@@ -1588,8 +1593,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
                         2 * threadIdx.x, tag_now, s);
     else
       partials[(round & 1) * pstride + ((long long)blockIdx.y * prows + blockIdx.x) * kAcc + threadIdx.x] = s;
+    // the walk hint of the next round: the nodes this workgroup walked (> 0: stage the tree's top; per pass: queue the walks)
+    if (threadIdx.x == 29) hints[(round & 1) * hint_stride + hint_slot] = fmax(s, static_cast<double>(n_walked));
   }
-  if (threadIdx.x == 0) hints[(round & 1) * hint_stride + hint_slot] = static_cast<double>(n_walked);
   MADICP_STAMP(6);
   if (TAIL) {
     __shared__ int s_last;

@@ -205,7 +205,8 @@ struct madicp_ctx {
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
-  int queue_walks = 1; // option "queue_walks": units of many passes queue their walkers per wavefront and walk them densely
+  int queue_walks = 32; // option "queue_walks": units of many passes queue their walkers per wavefront and walk them densely in a
+                        // round that follows one in which the workgroup walked at least this many nodes per pass (0: never)
   int nn_lds_top = 0;  // option "nn_lds_top": nn_search batches of >= 16 k queries walk the tree's top levels from LDS
                        // (nn_descend_top).  Off: measured SLOWER for one 120 k-query launch (8.7 vs 6.6 us against a
                        // 20 k-leaf tree, 10.7 vs 9.2 us against a 120 k-leaf tree) — staging 48 KiB per workgroup costs
@@ -787,8 +788,8 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
   j.epoch = ++ctx->epoch;  // (24 bits of it reach the granule tags: a tag recurs after 16 M registrations, far beyond
                            // the life of any granule of a geometry in use)
   j.error = 0;
-  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse) | (ctx->match_all ? kFlagMatchAll : 0) |
-            (ctx->queue_walks ? 0 : kFlagNoQueue);
+  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse) | (ctx->match_all ? kFlagMatchAll : 0);
+  j.queue_nodes = ctx->queue_walks;
   std::memcpy(j.X, X0, 12 * sizeof(double));
   std::memcpy(j.Xring[0], X0, 12 * sizeof(double));
   std::memcpy(j.Xring[1], X0, 12 * sizeof(double));
@@ -1109,7 +1110,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "cache_correspondences") {
     ctx->cache_corr = value ? 1 : 0;
   } else if (k == "queue_walks") {
-    ctx->queue_walks = value ? 1 : 0;
+    if (value < 0 || value > (1 << 20)) return fail(MADICP_ERR_INVALID, "queue_walks must be 0 (never) or a node count per pass");
+    ctx->queue_walks = (int)value;
   } else if (k == "lds_stage_min_leaves") {
     if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
     ctx->stage_min_leaves = (int)std::min<int64_t>(value, 1 << 30);

@@ -375,9 +375,10 @@ def test_correspondence_reuse_is_exact(ctx, K):
 
 
 def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
-    """Option "queue_walks" (default on; icp_linearize_body.inc.h, "QUEUED WALKS"): when a batch shares the chip a workgroup's
-    unit is many passes long, and from round 2 on the pairs that still have to walk are queued per wavefront and walked
-    densely before the passes run.  32 keyframes, 8 scans in flight (one range per tree: 11 passes per unit): final pose, H,
+    """Option "queue_walks" (icp_linearize_body.inc.h, "QUEUED WALKS"): when a batch shares the chip a workgroup's
+    unit is many passes long, and from round 2 on — while the previous round still walked enough (1: any walk at all; the
+    default asks for 32 nodes per pass) — the pairs that still have to walk are queued per wavefront and walked densely
+    before the passes run.  32 keyframes, 8 scans in flight (one range per tree: 11 passes per unit): final pose, H,
     b, matched flags, matched counts and the visit counter bit for bit those of walking inside the pass, and those of walking
     EVERY pair every round (no correspondence reuse, hence no queue) — the accumulation order does not depend on who walked.
     And the poses are the oracle's (mad_icp.cpp:74-117 under pipeline.cpp:166-193)."""
@@ -392,16 +393,17 @@ def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
     X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
     assert min(h.num_leaves for h in qh) >= 4 * 768  # (deep units: what the queue is for)
     res = {}
-    for name, opts in (("queued", dict(queue_walks=1)), ("in pass", dict(queue_walks=0)),
+    assert ctx.get_option("queue_walks") == 32  # the default: queue after a round that walked >= 32 nodes per pass
+    for name, opts in (("queued", dict(queue_walks=1)), ("in pass", dict(queue_walks=0)), ("queued by default", dict(queue_walks=32)),
                        ("no reuse", dict(queue_walks=1, cache_correspondences=0))):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
         r["matched"] = [ctx.icp_fetch_matched(i, h.num_leaves) for i, h in enumerate(qh)]
         res[name] = r
-        ctx.set_option("queue_walks", 1)
+        ctx.set_option("queue_walks", 32)
         ctx.set_option("cache_correspondences", 1)
-    for other in ("in pass", "no reuse"):
+    for other in ("in pass", "queued by default", "no reuse"):
         for key in ("X", "H", "b", "n_matched", "visits"):
             assert np.array_equal(res["queued"][key], res[other][key]), (other, key)
         for a, b in zip(res["queued"]["matched"], res[other]["matched"]):
