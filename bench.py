@@ -98,6 +98,19 @@ def pose_error(Tgt, T):
     return float(np.linalg.norm(err[:3, 3]))
 
 
+# the gather calibration of the PMC sub-runs (madicp_debug_gather16): region, gathers per launch, seed, launches
+GATHER_REGION, GATHER_N, GATHER_SEED, GATHER_REPS = 2 << 30, 1 << 22, 7, 3
+
+
+def gather_lines(region_bytes=GATHER_REGION, n=GATHER_N, seed=GATHER_SEED):
+    """distinct 64-byte and 128-byte lines ONE launch of the gather probe touches (the library's hash, restated)"""
+    g = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = g * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+    idx = h % np.uint64(region_bytes // 16)
+    return int(np.unique(idx >> np.uint64(2)).size), int(np.unique(idx >> np.uint64(3)).size)
+
+
 def streamed_loop(ctx, capi, leaves, guesses, tids, n, results=None, stamps=None):
     """n registrations, each a new scan in / results out, one submission ahead of the collection."""
     nq = len(leaves)
@@ -128,6 +141,8 @@ def pmc_child(path):
     K = int(z["K"])
     ctx = capi.Context(0)
     ctx.stream_copy_gbs(int(z["copy_bytes"]), 3)
+    # icp_round's own access pattern with a known line count: random 16-byte gathers over 2 GiB (beyond the Infinity Cache)
+    ctx.gather16_us(GATHER_REGION, GATHER_N, seed=GATHER_SEED, reps=GATHER_REPS)
     tids = []
     for k in range(K):
         tids.append(ctx.tree_upload(z["nodes%d" % k].view(capi.NODE_DTYPE).reshape(-1), int(z["leaves%d" % k])))
@@ -136,6 +151,8 @@ def pmc_child(path):
     for _ in range(int(z["regs"])):
         ctx.icp_register_batch_enqueue([mid], tids, X0, PARAMS, N_ITERS)
     ctx.synchronize()
+    if "nn_queries" in z.files:  # nn_descend (the pymadtree path) against the last keyframe tree
+        ctx.nn_time_descend(tids[K - 1], z["nn_queries"], 6)
     if "K2" in z.files:  # the stress configuration in the same profiler pass: its launches FOLLOW the headline's
         K2, B2 = int(z["K2"]), int(z["B2"])
         for k in range(K, K2):
@@ -148,7 +165,7 @@ def pmc_child(path):
     ctx.close()
 
 
-def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stress=None, regs2=3):
+def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stress=None, regs2=3, nn_queries=None):
     """HBM-side traffic of icp_round per launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE, TCC requests: one
     pass each, --kernel-trace only).  Each pass also runs a device-to-device copy of `copy_bytes`: the known byte
     count FETCH_SIZE / WRITE_SIZE are calibrated on (the guide: FETCH_SIZE reads half of a wide streaming read)."""
@@ -158,6 +175,8 @@ def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stre
     tmp = tempfile.mkdtemp(prefix="madicp_pmc_", dir="/tmp")
     try:
         arrays = dict(K=len(tids_trees), moving=moving, X0=X0, copy_bytes=copy_bytes, regs=regs)
+        if nn_queries is not None:
+            arrays["nn_queries"] = np.ascontiguousarray(nn_queries, dtype=np.float64)
         all_trees = list(tids_trees)
         if stress is not None:  # (trees 0..K-1 are the headline's map: the stress map extends it)
             all_trees = stress["trees"]
@@ -189,7 +208,8 @@ def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stre
                 seen_rounds = {}
                 for row in rows:
                     kn = row.get("Kernel_Name", "")
-                    key = "copy" if "stream_copy" in kn else ("round" if "icp_round" in kn else None)
+                    key = ("copy" if "stream_copy" in kn else "gather" if "gather16_probe" in kn else
+                           "nn" if "nn_descend" in kn else "round" if "icp_round" in kn else None)
                     if key == "round":
                         c = seen_rounds.get(row["Counter_Name"], 0)
                         seen_rounds[row["Counter_Name"]] = c + 1
@@ -198,7 +218,7 @@ def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stre
                     if key:
                         acc.setdefault((key, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
             for (key, cname), vals in acc.items():
-                if key == "copy":
+                if key in ("copy", "gather"):
                     vals = vals[1:] or vals  # first launch touches cold pages
                 out[(key, cname)] = float(np.mean(vals))
                 out[(key, cname, "n")] = len(vals)
@@ -411,10 +431,31 @@ def traffic_from_counters(m, key, layout_bytes, avg_us):
     cf, cw = m.get(("copy", "FETCH_SIZE"), 0.0) * 1024, m.get(("copy", "WRITE_SIZE"), 0.0) * 1024
     kf = copy_bytes / cf if cf > 0 else 1.0   # the guide says 2.0 for wide streaming reads on gfx950
     kw = copy_bytes / cw if cw > 0 else 1.0
-    traffic = f_raw * kf + w_raw * kw
+    traffic_stream = f_raw * kf + w_raw * kw
+    traffic = traffic_stream
+    gather = None
+    g_raw = m.get(("gather", "FETCH_SIZE"), 0.0) * 1024
+    if g_raw > 0:
+        # FETCH_SIZE calibrated in THIS kernel's access pattern: one 16-byte gather per lane, every lane another line, over a
+        # region the Infinity Cache cannot hold — the probe's launches touch a known number of distinct lines
+        d64, d128 = gather_lines()
+        kg64, kg128 = 64.0 * d64 / g_raw, 128.0 * d128 / g_raw
+        gather = {"probe": "%d random 16-byte gathers over %d MiB per launch (madicp_debug_gather16)" % (GATHER_N, GATHER_REGION >> 20),
+                  "distinct_64B_lines": d64, "distinct_128B_lines": d128, "fetch_size_bytes_raw": int(g_raw),
+                  "raw_bytes_per_distinct_64B_line": round(g_raw / d64, 2),
+                  "fetch_calibration_64B_lines": round(kg64, 3), "fetch_calibration_128B_lines": round(kg128, 3)}
+        traffic = f_raw * kg64 + w_raw * kw
     detail = {
         "fetch_size_bytes_raw": int(f_raw), "write_size_bytes_raw": int(w_raw),
         "fetch_calibration": round(kf, 3), "write_calibration": round(kw, 3),
+        "calibration_used": ("gather64: FETCH_SIZE x (64 B x distinct lines / FETCH_SIZE) of the 16-byte gather probe in the same "
+                             "pass — this kernel's access pattern; WRITE_SIZE x the streaming copy's factor" if gather else
+                             "streaming copy (the gather probe did not run)"),
+        "gather_probe": gather,
+        "traffic_with_streaming_calibration": int(traffic_stream),
+        "traffic_raw_counters": int(f_raw + w_raw),
+        "infinity_cache": "FETCH_SIZE counts requests on the L2's memory side: hits in the 256 MB Infinity Cache are included, so "
+                          "this is an UPPER bound of the HBM traffic wherever the working set fits that cache",
         "calibrated_on": "a 1 GiB device-to-device copy in the same rocprofv3 pass (known 1 GiB read + 1 GiB written)",
         "launches_averaged": int(m.get((key, "FETCH_SIZE", "n"), 0)),
         "traffic_frac_of_hbm_peak": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
@@ -502,9 +543,10 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         "bound": "latency", "roof": "hbm", "kernel": "icp_round",
         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
         "traffic": None,
-        "what_achieved_counts": "HBM bytes per launch from the memory counters (FETCH_SIZE, WRITE_SIZE; rocprofv3 --pmc sub-runs "
-                                "of this script, calibrated on a 1 GiB copy in the same pass) / avg launch time.  The kernel is "
-                                "not bandwidth-bound: see latency_budget",
+        "what_achieved_counts": "bytes per launch on the L2's memory side from the counters (FETCH_SIZE calibrated on random 16-byte "
+                                "gathers with a known line count — this kernel's access pattern —, WRITE_SIZE on a 1 GiB copy; "
+                                "rocprofv3 --pmc sub-runs of this script) / avg launch time; Infinity-Cache hits are counted, so "
+                                "an upper bound of the HBM rate.  The kernel is not bandwidth-bound: see latency_budget",
         "limiter": "latency, not bandwidth: a chain of dependent steps per round at 3 waves/SIMD — see latency_budget",
         "avg_launch_us": round(avg_us, 2), "first_round_launch_us": round(first_us, 2), "final_launch_us": round(final_us, 2),
         "rounds": N_ITERS, "pairs_per_launch": pairs,
@@ -543,8 +585,11 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         except Exception as e:  # noqa: BLE001 — a secondary figure never takes the bench line down
             stress, st = {"error": str(e)[:200]}, None
 
+    pmc_m = None
     if args.pmc == "auto":
-        m = measure_traffic(pb, kf_trees, leaves[0], X0[0], stress=st)
+        q_map_pmc = (pb["query_scans"][0] @ pb["query_gt"][0][:3, :3].T) + pb["query_gt"][0][:3, 3]
+        m = measure_traffic(pb, kf_trees, leaves[0], X0[0], stress=st, nn_queries=q_map_pmc)
+        pmc_m = m
         if "error" in m:
             roofline["traffic_error"] = m["error"]
         else:
@@ -574,6 +619,14 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                                     "mqueries_per_s": round(nq / us_b, 1), "mean_depth": round(depth_b / nq, 2),
                                     "layout_gbs": round(nq * (24 + 16.0 * depth_b / nq + 64 + 16) / (us_b * 1e-6) / 1e9, 1)},
           "note": "queries and outputs resident; one launch = all queries against one tree (pymadtree searchCloud)"}
+    if pmc_m and ("nn", "FETCH_SIZE") in pmc_m:
+        # counter traffic of nn_descend against the keyframe tree (the PMC sub-runs launch it behind the registrations)
+        lay = nq * (24 + 16.0 * depth_a / nq + 64 + 16)  # query + a 16-byte record per level + the leaf record + outputs
+        tr, det, l2n = traffic_from_counters(pmc_m, "nn", lay, us_a)
+        nn["keyframe_tree_b_max_0.2"]["roofline"] = {
+            "bound": "latency", "roof": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": int(tr),
+            "achieved": round(tr / (us_a * 1e-6) / 1e9, 1), "frac": round(tr / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "layout_bytes": int(lay), "traffic_detail": det, "l2": l2n}
     ctx.tree_release(dense_id)
 
     # ---- the device front-end: the query scan's MAD-tree built on the device ----------------
@@ -817,7 +870,11 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                 "shard_split": ("two half-batches on two streams (one half's all-reduce under the other half's round)" if B >= 4
                                 else "off (fewer than four scans in flight)"),
                 "shard_tail": "off (the round kernel folding its own rows is measured slower: profiles/r4_c_shard_probe.md)"}
-            out_extra["all_reduces_per_registration"] = N_ITERS + 1
+            # per BATCH of B scans: one sum all-reduce per round (two of B/2 scans each with the batch split in halves) and one
+            # max-all-reduce of the matched flags per scan
+            n_sum = N_ITERS * (2 if B >= 4 else 1)
+            out_extra["all_reduces_per_batch"] = {"sum_f64": n_sum, "max_u8_matched_flags": B, "scans_per_batch": B,
+                                                  "per_registration": round((n_sum + B) / B, 2)}
             out_extra["all_reduce_payload_bytes_per_round"] = 240 * B
             out_extra["max_translation_error_m"] = round(terr, 5)
             for m in mids:
@@ -894,11 +951,67 @@ def cpu_baseline(pb, K, budget_s):
     n = int(max(3, min(40, budget_s / max(first, 1e-3))))
     ms = [O.icp_register(q, trees, T0, N_ITERS, B_MAX, RHO_KER, B_RATIO, num_threads=threads)["ms"] for _ in range(n)]
     med = float(np.median(ms)) * 1e-3
-    return {"value": round(1.0 / med, 3), "unit": "registrations/s", "cores": threads, "host_cores": cores,
-            "kind": "port",
-            "sample": "%d registrations of the same workload (K=%d, L=%d, 15 rounds), median; GN loop only "
-                      "(the region the reference stopwatches, pipeline.cpp:171-192)" % (n, K, q.num_leaves),
-            "ms_per_registration": round(med * 1e3, 2)}
+    out = {"value": round(1.0 / med, 3), "unit": "registrations/s", "cores": threads, "host_cores": cores,
+           "kind": "port",
+           "sample": "%d registrations of the same workload (K=%d, L=%d, 15 rounds), median; GN loop only "
+                     "(the region the reference stopwatches, pipeline.cpp:171-192)" % (n, K, q.num_leaves),
+           "ms_per_registration": round(med * 1e3, 2)}
+    out["ref_tus"] = cpu_baseline_ref_tus(pb, K, threads, max(6.0, budget_s / 2))
+    return out
+
+
+REF_TUS_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle_lib as O
+z = np.load(sys.argv[2])
+K, threads, budget = int(z["K"]), int(z["threads"]), float(z["budget"])
+trees = []
+for k in range(K):
+    tr = O.Tree(z["scan%d" % k], 0.2, 0.1, 3)
+    T = z["pose%d" % k]
+    tr.transform(T[:3, :3], T[:3, 3])
+    trees.append(tr)
+q = O.Tree(z["query"], 0.2, 0.1, 3)
+first = O.icp_register(q, trees, z["guess"], 15, 0.2, 0.1, 0.02, num_threads=threads)["ms"] * 1e-3
+n = int(max(3, min(40, budget / max(first, 1e-3))))
+ms = [O.icp_register(q, trees, z["guess"], 15, 0.2, 0.1, 0.02, num_threads=threads)["ms"] for _ in range(n)]
+print(json.dumps({"ms": float(np.median(ms)), "n": n, "leaves": int(q.num_leaves)}))
+"""
+
+
+def cpu_baseline_ref_tus(pb, K, threads, budget_s):
+    """The same registrations through the REFERENCE'S OWN translation units — tools/mad_tree.cpp, odometry/mad_icp.cpp ...
+    compiled from /root/reference against the Eigen stand-in (oracle/_ref/libmad_ref_standin.so, built where the reference
+    is and shipped as a file; oracle/build_ref_standin.sh): the reference's control flow, loops and data structures
+    (heap-allocated pointer tree, omp parallel for over keyframes) with the oracle's arithmetic primitives in place of
+    Eigen's.  Runs in a subprocess (the ctypes binding holds one library per process).  None where the file is missing."""
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "_ref", "libmad_ref_standin.so")
+    if not os.path.exists(so):
+        return None
+    tmp = tempfile.mkdtemp(prefix="madicp_ref_", dir="/tmp")
+    try:
+        arrays = dict(K=K, threads=threads, budget=budget_s, query=pb["query_scans"][0], guess=pb["query_guess"][0])
+        for k in range(K):
+            arrays["scan%d" % k] = pb["keyframe_scans"][k]
+            arrays["pose%d" % k] = pb["keyframe_poses"][k]
+        npz = os.path.join(tmp, "pb.npz")
+        np.savez(npz, **arrays)
+        root = os.path.dirname(os.path.abspath(__file__))
+        r = subprocess.run([sys.executable, "-c", REF_TUS_SCRIPT, root, npz], env=dict(os.environ, MADICP_ORACLE_SO=so),
+                           capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": round(1e3 / d["ms"], 3), "unit": "registrations/s", "cores": threads,
+                "kind": "reference translation units + Eigen stand-in",
+                "sample": "%d registrations of the same workload, median; GN loop only" % d["n"],
+                "ms_per_registration": round(d["ms"], 2),
+                "note": "the reference's own mad_tree.cpp / mad_icp.cpp compiled from /root/reference with its flags against "
+                        "oracle/eigen_standin (no Eigen in this image): its loops and data structures, the oracle's arithmetic"}
+    except Exception as e:  # noqa: BLE001 — a secondary figure
+        return {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -108,7 +108,8 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * "persistent" (0/1, default 0: all rounds of a single-GPU registration as ONE launch; bit-identical, measured slower —
  * profiles/r3_b_persist_negative.md), "shard_split" (0/1/2, default 1: with a communicator, a batch of >= 4 scans (2: of >= 2
  * scans) runs as two halves on two streams, so that one half's per-round all-reduce is in flight under the other half's round
- * kernel; collectives are enqueued in one order on every rank), "shard_tail" (0/1, default 0: the sharded round kernel leaves
+ * kernel; collectives are enqueued in one order on every rank — the option decides how many collectives a round makes, so it MUST
+ * have the same value on every rank of the communicator, as must the batch sizes the ranks submit), "shard_tail" (0/1, default 0: the sharded round kernel leaves
  * the rank's adders itself instead of a separate icp_reduce launch; bit-identical, measured slower —
  * profiles/r4_c_shard_probe.md), "xcd_fold" (0/1, default 0: per-round launches with the XCD-hierarchical join at the
  * end of each launch; bit-identical, measured slower — profiles/r3_j_xcd_fold_negative.md), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
@@ -237,6 +238,11 @@ int madicp_nn_time_descend(madicp_ctx* ctx, int tree_id, const double* queries, 
  * written bytes per second / 1e9.  The measured HBM rate of this box, and the known byte count on which bench.py
  * calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE. */
 int madicp_debug_stream_copy(madicp_ctx* ctx, int64_t bytes, int reps, double* out_gbs);
+/* Measurement aid: `reps` launches of n_gathers random 16-byte loads over a region of region_bytes (gather g of launch r reads
+ * the 16 bytes at 16 * ((g * 0x9E3779B97F4A7C15 + seed + r) mod (region_bytes / 16)): a set of lines the caller can enumerate).
+ * icp_round's own access pattern with a known byte count — what bench.py calibrates rocprofv3's FETCH_SIZE on for that
+ * kernel.  out_avg_us per launch. */
+int madicp_debug_gather16(madicp_ctx* ctx, int64_t region_bytes, int64_t n_gathers, uint64_t seed, int reps, double* out_avg_us);
 
 /* ---- device front-end: scans resident in HBM, ingest + deskew, MAD-tree build (row f-1) -- */
 /* Additive (the reference has no such interface: its Pipeline takes a host vector and builds on the CPU).  A "cloud" is

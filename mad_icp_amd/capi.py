@@ -80,6 +80,7 @@ def hip_lib():
         L.madicp_stream_collect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _u8p, _i32p, _u64p]
         L.madicp_nn_time_descend.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, _dp, _u64p]
         L.madicp_debug_stream_copy.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp]
+        L.madicp_debug_gather16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int, _dp]
         L.madicp_icp_linearize.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), _dp, _dp,
                                            _u32p, _u8p, _u64p]
         L.madicp_icp_register.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _dp,
@@ -496,6 +497,12 @@ class Context:
         _check(hip_lib().madicp_nn_time_descend(self._h, tid, q.ctypes.data_as(_dp), q.shape[0], reps, C.byref(us),
                                                 C.byref(depth)))
         return us.value, depth.value
+
+    def gather16_us(self, region_bytes, n_gathers, seed=1, reps=3):
+        """avg microseconds per launch of n_gathers random 16-byte loads over a region (madicp_debug_gather16)."""
+        g = C.c_double(0.0)
+        _check(hip_lib().madicp_debug_gather16(self._h, int(region_bytes), int(n_gathers), int(seed), int(reps), C.byref(g)))
+        return g.value
 
     def stream_copy_gbs(self, nbytes=1 << 30, reps=10):
         g = C.c_double(0.0)

@@ -52,6 +52,7 @@ struct FrontScratch {
     DevCloud cloud;        // look-ahead only
   } fly;
   int last_depth = -1;     // deepest level of the previous build on this scratch (consecutive scans: the same +- 1)
+  int64_t last_n = 0;      // ... and that build's point count (the hint is for consecutive scans of one sensor, not for any cloud)
 };
 
 constexpr int kDeskewTableMax = 1040;  // > CHUNKS + a few: thresholds fall below -pi after ~1024 steps
@@ -590,7 +591,11 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   f.n_tiles = static_cast<int>((n + 1 + tb::kScanTile - 1) / tb::kScanTile);
   // a 120 k-point scan at b_max = 0.2 is 17 levels deep; deeper trees (dense maps, b_max -> 0) take the loop in the second half
   f.levels_done = 20;
-  f.quiet_from = fs.last_depth >= 0 ? fs.last_depth + 1 : -1;
+  // (a STEP lags the level it finishes by up to kChipLevels - 1: a small node born while the chip regime runs waits for step
+  // first_step, and its descendants follow one step per level — so the steps up to last_depth + kChipLevels can hold real
+  // queues and keep their grid; and a build on another cloud size than the last one forgets the hint)
+  f.quiet_from = (fs.last_depth >= 0 && fs.last_n > 0 && n >= fs.last_n - fs.last_n / 8 && n <= fs.last_n + fs.last_n / 8)
+                     ? fs.last_depth + tb::kChipLevels : -1;
   RC_TRY(tb_run_levels(fs, 0, f.levels_done));
   HIP_TRY(hipGetLastError());
   RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
@@ -616,6 +621,7 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   }
   fs.state_stale = true;
   fs.last_depth = hl.error == 0 ? hl.max_level : -1;
+  fs.last_n = f.n;
   if (hl.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
   if (hl.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
   const int32_t n_leaves = hl.n_leaves, n_nodes = 2 * hl.n_leaves - 1;

@@ -945,10 +945,15 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     q.totals[0] += (size_t)n_first * kAcc;
     q.totals[1] += (size_t)n_first * kAcc;
     q.tickets += n_first;
-    if (madicp::xch_granules(halves[0].batch, halves[0].grid) + madicp::xch_granules(halves[1].batch, halves[1].grid) >
-        kXchRowsMax * 2 * madicp::kRowGranules)
-      q.xch = nullptr;  // (no room for two sets of exchange rows: see use_tail — never with MADICP_MAX_BATCH scans at this chip's grids)
-    if (!q.xch) return fail(MADICP_ERR_CAPACITY, "sharded batch too large for the exchange rows of its two halves");
+    // the exchange rows are only read by the TAIL variant of the round kernel (option "shard_tail"): only then do the two
+    // halves need disjoint regions of them that both fit
+    const bool rows_used = use_tail(ctx, halves[0]) || use_tail(ctx, halves[1]);
+    if (!rows_used) {
+      q.xch = ctx->d_xch;
+    } else if (madicp::xch_granules(halves[0].batch, halves[0].grid) + madicp::xch_granules(halves[1].batch, halves[1].grid) >
+               kXchRowsMax * 2 * madicp::kRowGranules) {
+      return fail(MADICP_ERR_CAPACITY, "sharded batch too large for the exchange rows of its two halves");
+    }
     return enqueue_rounds_split(ctx, halves, parts, ctx->last_moving.data());
   }
   // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
@@ -1971,6 +1976,57 @@ int madicp_debug_stream_copy(madicp_ctx* ctx, int64_t bytes, int reps, double* o
   hipFree(b);
   if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("stream copy: ") + hipGetErrorString(e));
   *out_gbs = 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9;  // read + write
+  return MADICP_OK;
+}
+
+// Random 16-byte gathers over a large region: the access pattern of icp_round's dependent loads (one 16-byte screening
+// record or quarter leaf record per lane, every lane another line), with a KNOWN set of lines — gather g reads the 16 bytes at
+// 16 * ((g * 0x9E3779B97F4A7C15 + seed) mod n16), which the caller can enumerate — so that rocprofv3's FETCH_SIZE can be
+// calibrated in the kernel's own access pattern instead of on a wide streaming copy (MI355X_MICROARCH.md, HBM section: "other
+// access widths are uncalibrated: calibrate in your own access pattern").
+namespace madicp_detail {
+__global__ void gather16_probe(const uint4* __restrict__ src, size_t n16, unsigned long long n_gathers, unsigned long long seed,
+                               unsigned int* __restrict__ sink) {
+  unsigned int acc = 0;
+  for (unsigned long long g = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; g < n_gathers;
+       g += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long h = g * 0x9E3779B97F4A7C15ull + seed;
+    const uint4 v = src[h % n16];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;  // (never true for the memset pattern: keeps the loads alive)
+}
+}  // namespace madicp_detail
+
+int madicp_debug_gather16(madicp_ctx* ctx, int64_t region_bytes, int64_t n_gathers, uint64_t seed, int reps, double* out_avg_us) {
+  if (!ctx || !out_avg_us) return fail(MADICP_ERR_INVALID, "null argument");
+  if (region_bytes < 4096 || n_gathers < 1 || reps < 1) return fail(MADICP_ERR_INVALID, "region_bytes >= 4096, n_gathers >= 1, reps >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->ev_t0) {
+    HIP_TRY(hipEventCreate(&ctx->ev_t0));
+    HIP_TRY(hipEventCreate(&ctx->ev_t1));
+  }
+  const size_t n16 = (size_t)region_bytes / 16;
+  void* a = nullptr;
+  unsigned int* sink = nullptr;
+  HIP_TRY(hipMalloc(&a, n16 * 16));
+  hipError_t e = hipMalloc(&sink, 64);
+  if (e == hipSuccess) e = hipMemsetAsync(a, 1, n16 * 16, ctx->stream);
+  const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n_gathers + 255) / 256, (size_t)ctx->n_cus * 16);
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_t0, ctx->stream);
+  for (int r = 0; r < reps && e == hipSuccess; ++r) {
+    hipLaunchKernelGGL(madicp_detail::gather16_probe, dim3(blocks), dim3(256), 0, ctx->stream, (const uint4*)a, n16,
+                       (unsigned long long)n_gathers, (unsigned long long)seed + (unsigned long long)r, sink);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipEventRecord(ctx->ev_t1, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1);
+  hipFree(a);
+  if (sink) hipFree(sink);
+  if (e != hipSuccess) return fail(MADICP_ERR_DEVICE, std::string("gather probe: ") + hipGetErrorString(e));
+  *out_avg_us = 1e3 * ms / reps;
   return MADICP_OK;
 }
 

@@ -1606,7 +1606,8 @@ __global__ __launch_bounds__(256) void tb_chip_scatter(const Params P, int level
       nvalid += ok ? 1 : 0;
     }
     int shift = 0;
-    while ((cm.n_chunks >> shift) > kPrefMax) ++shift;
+    // (the ROUNDED-UP granule count must fit: 8 193 chunks at shift 1 are 4 097 granules, and s_pref[n_gran] is written below)
+    while (((cm.n_chunks + (1 << shift) - 1) >> shift) > kPrefMax) ++shift;
     const int n_gran = (cm.n_chunks + (1 << shift) - 1) >> shift;
     if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0.0; s_hi[threadIdx.x] = 0.0; }
     if (threadIdx.x == 3) { s_before = 0; s_carry = 0; }

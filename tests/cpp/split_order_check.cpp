@@ -65,10 +65,13 @@ static bool check_tables(const std::vector<uint8_t>& left, int chunk_points, int
       }
       cnt[c] = lb;
     }
+    // the coarse table of tb_chip_scatter (tree_build.hip.h): the ROUNDED-UP granule count must fit the table — the rule
+    // "(n_chunks >> shift) <= max" lets 2 * max + 1 chunks through as max + 1 granules, one entry past the LDS array
     int shift = 0;
-    while ((n_chunks >> shift) > max_gran) ++shift;
+    while (((n_chunks + (1 << shift) - 1) >> shift) > max_gran) ++shift;
     const int n_gran = (n_chunks + (1 << shift) - 1) >> shift;
-    std::vector<int> pref(n_gran + 1);
+    if (n_gran > max_gran) return false;
+    std::vector<int> pref(max_gran + 1);  // (the kernel's array: s_pref[kPrefMax + 1])
     {
       int run = 0;
       for (int c = 0; c < n_chunks; ++c) {
@@ -158,6 +161,18 @@ int main() {
     }
     ++checked;
   }
+  for (int gran = 1; gran <= 6; ++gran)  // chunk counts around every multiple of the table size: 2 g + 1 chunks at shift 1 are g + 1 granules
+    for (int chunks = 1; chunks <= 8 * gran + 3; ++chunks)
+      for (int tail = 1; tail <= 5; tail += 2) {
+        const int n = (chunks - 1) * 5 + tail;
+        std::vector<uint8_t> left(n);
+        for (int p = 0; p < n; ++p) left[p] = (rng() % 3) ? 1 : 0;
+        if (!check_tables(left, 5, gran)) {
+          std::printf("coarse table: chunks=%d gran=%d n=%d differs\n", chunks, gran, n);
+          return 1;
+        }
+        ++checked;
+      }
   std::printf("split order ok: %ld patterns\n", checked);
   return 0;
 }
