@@ -291,10 +291,14 @@
         // root of the remaining factor is beyond 1 +- 2^-52, and rounding is monotone) — the 17-instruction root is only
         // evaluated when a lane of the wavefront falls in between, or its ball is not a positive normal number.
         const double d2 = dotc(g0, g1, g2, g0, g1, g2);
+#ifdef MADICP_GATE_SQRT  // (development A/B: the root every time)
+        const bool rejected = sqrt(d2) > src_ball;
+#else
         const double b2 = src_ball * src_ball;
         const bool surely_out = d2 > b2 * (1.0 + 0x1p-50), surely_in = d2 < b2 * (1.0 - 0x1p-50);
         bool rejected = surely_out;
         if (__any(!(surely_out || surely_in) || !(src_ball > 1e-140))) rejected = sqrt(d2) > src_ball;
+#endif
         if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
         if (mark_matched) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)

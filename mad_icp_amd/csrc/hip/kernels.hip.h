@@ -1569,7 +1569,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 
 
 #define MADICP_TID threadIdx.x
+#ifndef MADICP_NO_QUEUE  // (development A/B: the queued-walk sweeps compiled out)
 #define MADICP_QUEUE_WALK 1
+#endif
 #include "icp_linearize_body.inc.h"
 #undef MADICP_QUEUE_WALK
 #undef MADICP_TID
