@@ -78,7 +78,9 @@ int madicp_ctx_destroy(madicp_ctx* ctx);
 int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
- * "queue_walks" (0: never; n > 0, default 32: units of many passes — a batch sharing the chip — queue the pairs that still have
+ * "cache_gate" (0/1, default 1: a pair that keeps its leaf and was rejected by the gate of mad_icp.cpp:81-83 with more slack than it
+ * has moved since is not evaluated again — its leaf record is not fetched; same bits either way),
+ * "queue_walks" (0: never; n > 0, default 12: units of many passes — a batch sharing the chip — queue the pairs that still have
  * to walk per wavefront and walk them densely, in a round that follows one in which the workgroup walked at least n nodes per
  * pass; same bits either way),
  * "publish_side" (0/1, default 1: a streamed registration leaves its results in a device-resident outbox and a one-workgroup

@@ -4,8 +4,8 @@
 // launch) so that both kernels run the same instructions in the same order; not a translation unit of its own.
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
-// s_td; per round: round, reuse, mark_matched, stage_hint, R[9], t[3], moved_rot, moved_trans, pv0 / cmar0 / cword0 (the
-// first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
+// s_td, cache_gate; per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], moved_rot, moved_trans, pv0 / cmar0 /
+// cgate0 / cword0 (the first pass's pose-independent loads, already issued); MADICP_HAS_QUEUE 1: also QUEUE, queue_hint, s_queue; state it updates: desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
   int k = k_first, r = r_first;
@@ -28,7 +28,7 @@
     // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
     const int n_top_avail = (opt_lds_top && i_end - r * S >= opt_stage_min) ? min(td.n_top, kTopMax) : 0;
 
-#ifdef MADICP_QUEUE_WALK
+#if MADICP_HAS_QUEUE
     // ---- QUEUED WALKS (round 5; icp_round only) -----------------------------------------------------------------------
     // A unit of many passes (a batch shares the chip: BASELINE configs[4] has 26 passes per unit) in a round in which SOME
     // pairs have to walk: with the walk inside the pass, a wavefront that holds ONE walker waits out a whole descent — at 2 %
@@ -48,15 +48,14 @@
     // the workgroup walked in the PREVIOUS round (the hint it left behind its partials: nodes walked): at least `queue_nodes`
     // per pass (option "queue_walks", default 32 — the walkers of a round are a tenth of the round before, GN converges
     // quadratically), round >= 2, units of at least kQueueMinPasses passes.  Speed only.
-    const bool qmode = QPT == 1 && reuse && queue_hint && (i_end - r * S) >= kQueueMinPasses * kBlock;  // (workgroup-uniform)
-    const int chunk_leaves = qmode ? kQueueChunk * kBlock : 0x40000000;
+    const bool qmode = QUEUE && QPT == 1 && reuse && queue_hint && (i_end - r * S) >= kQueueMinPasses * kBlock;  // (workgroup-uniform)
 #else
     constexpr bool qmode = false;
-    const int chunk_leaves = 0x40000000;
 #endif
+    const int chunk_leaves = qmode ? kQueueChunk * kBlock : 0x40000000;
     for (int cbase = r * S; cbase < i_end; cbase += min(chunk_leaves, i_end - cbase)) {
     const int c_end = min(i_end, cbase + min(chunk_leaves, i_end - cbase));
-#ifdef MADICP_QUEUE_WALK
+#if MADICP_HAS_QUEUE
     if (qmode) {
       const int q_lane = MADICP_TID & 63, q_wave = MADICP_TID >> 6;
       if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform; stage_hint holds in this mode) the tree's top levels into LDS
@@ -134,6 +133,7 @@
           const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
           cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
           cache_margin[ci] = cacheable ? __double2float_rd(xm[0]) : 0.f;
+          cache_gate[ci] = 0.f;  // (the slack on file belongs to the OLD leaf: sweep C evaluates this pair)
         }
       }
       // sweep C reads what sweeps A and B of this wavefront stored (other lanes' entries too)
@@ -149,18 +149,22 @@
       // every load of this pass that does not depend on another one is issued first — the leaf's coordinates and
       // its cached correspondence — so a walk-free pass is two memory round trips (these, then the leaf record)
       vd4 pv[QPT];
-      float cmar[QPT];
+      float cmar[QPT], cgate[QPT];
       unsigned int cword[QPT];
+      bool skip[QPT];  // gate reuse: the pair keeps its leaf and is still rejected — nothing to fetch, nothing to add
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         const int i = base + j * kBlock + MADICP_TID;
         valid[j] = i < i_end;
         pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
         cmar[j] = 0.f;
+        cgate[j] = 0.f;
         cword[j] = 0u;
+        skip[j] = false;
         if (!qmode && u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
           pv[j] = pv0[j];
           cmar[j] = cmar0[j];
+          cgate[j] = cgate0[j];
           cword[j] = cword0[j];
         } else if (valid[j]) {
           pv[j] = ((gptr_d4)(uintptr_t)moving)[i];
@@ -168,6 +172,7 @@
             const long long ci = (long long)k * L + i;
             cmar[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
             cword[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
+            if (gate_reuse) cgate[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_gate)[ci];
           }
         }
       }
@@ -194,6 +199,11 @@
         margin[j] = 3.0e38;
         leaf[j] = 0;
         depth[j] = 0;
+        // how far can this leaf have moved since the previous round?  (bound from the update itself, see solve_pose; the
+        // 1e-11 term covers the rounding of the computed queries, distances and balls)
+        const double wear = (moved_rot * p.w + moved_trans) * (1.0 + 1e-12) +
+                            1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
+                                     fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
         if (qmode) {  // sweep C of a queued chunk: sweeps A / B left every pair's leaf in the cache, valid for THIS pose
           if (valid[j] && cmar[j] > 0.f) {
             leaf[j] = (int)(cword[j] & kCacheIdxMask);
@@ -201,17 +211,19 @@
             walk[j] = false;
           }  // (margin 0: a pair the cache cannot hold, or whose margin rounded down to nothing — it walks in place)
         } else if (reuse && valid[j]) {
-          // how far can this leaf have moved since the previous round?  (bound from the update itself, see solve_pose;
-          // the 1e-11 term covers the rounding of the two computed queries)
-          const double moved = moved_rot * p.w + moved_trans;
-          const double left_over = (double)cmar[j] - moved * (1.0 + 1e-12) -
-                                   1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
-                                            fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
+          const double left_over = (double)cmar[j] - wear;
           if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
             leaf[j] = (int)(cword[j] & kCacheIdxMask);
             depth[j] = (int)(cword[j] >> 26);
             cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
             walk[j] = false;
+          }
+        }
+        if (gate_reuse && valid[j] && !walk[j]) {  // same leaf as when the slack was measured: is the pair still outside its ball?
+          const double slack = (double)cgate[j] - wear;
+          if (slack > 0.0) {
+            skip[j] = true;
+            cache_gate[(long long)k * L + i] = __double2float_rd(slack);
           }
         }
       }
@@ -275,6 +287,10 @@
       for (int j = 0; j < QPT; ++j) {
         if (!valid[j]) continue;
         const int i = base + j * kBlock + MADICP_TID;
+        if (skip[j]) {  // still rejected (gate reuse): mad_icp.cpp:83 `continue`
+          if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | 0x80000000u;
+          continue;
+        }
         // the matched leaf's record: one 64-byte line, its four 16-byte loads issued together (one round trip)
         gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + leaf[j]);
         const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
@@ -285,20 +301,12 @@
         // gate (mad_icp.cpp:81-83)
         const double g0 = q0[j] - la.x, g1 = q1[j] - la.y, g2 = q2[j] - lb.x;
         const double src_ball = min_ball + b_ratio * pn[j];
-        // The reference's test is sqrt(d2) > src_ball with a correctly rounded square root.  Squaring decides it without
-        // one whenever d2 is not within 2^-50 of src_ball^2 (relative): d2 > b2 (1 + 2^-50) implies RN(sqrt(d2)) > src_ball
-        // and d2 < b2 (1 - 2^-50) implies RN(sqrt(d2)) <= src_ball (b2 = RN(src_ball^2) is within 2^-53 of the square, the
-        // root of the remaining factor is beyond 1 +- 2^-52, and rounding is monotone) — the 17-instruction root is only
-        // evaluated when a lane of the wavefront falls in between, or its ball is not a positive normal number.
-        const double d2 = dotc(g0, g1, g2, g0, g1, g2);
-#ifdef MADICP_GATE_SQRT  // (development A/B: the root every time)
-        const bool rejected = sqrt(d2) > src_ball;
-#else
-        const double b2 = src_ball * src_ball;
-        const bool surely_out = d2 > b2 * (1.0 + 0x1p-50), surely_in = d2 < b2 * (1.0 - 0x1p-50);
-        bool rejected = surely_out;
-        if (__any(!(surely_out || surely_in) || !(src_ball > 1e-140))) rejected = sqrt(d2) > src_ball;
-#endif
+        // (deciding from the squares and taking the root only within 2^-50 of the threshold was built and measured: +4.6 us per
+        // launch at BASELINE configs[4], nothing at the headline — the wave-wide vote costs more than the root; profiles/r5_e_ab.md)
+        const double dist = sqrt(dotc(g0, g1, g2, g0, g1, g2));
+        const bool rejected = dist > src_ball;
+        // gate reuse: how far outside its ball the pair is (0: inside — it is evaluated every round)
+        if (cache_gate) cache_gate[(long long)k * L + i] = rejected ? __double2float_rd(dist - src_ball) : 0.f;
         if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
         if (mark_matched) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)

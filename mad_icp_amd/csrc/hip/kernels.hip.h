@@ -198,6 +198,7 @@ struct Job {
 };
 constexpr int kFlagNoUpdate = 1;
 constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (option cache_correspondences = 0)
+constexpr int kFlagNoGateReuse = 2048;  // never skip a pair on its cached gate slack (option cache_gate = 0)
 constexpr int kFlagMatchAll = 1024;  // matched_ flags are the OR over ALL rounds (the host cleared them), not the last round's:
                                      // what the reference leaves behind when its realtime check ends the loop before
                                      // iteration MAX_ICP_ITS - 1, the only one that resets them (pipeline.cpp:167-176)
@@ -334,6 +335,16 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 // is per (tree, leaf): leaf ordinal | depth << 26, and the margin as a float rounded DOWN.  Levels decided by the
 // exact fallback contribute |s| minus a generous bound on its rounding error (a lane that keeps walking keeps its
 // whole wave on the latency chain, so margins must not be thrown away).
+// Gate reuse (round 5; exact like the correspondence reuse it rides on).  The reference rejects a pair when
+// sqrt(|ml - f.mean|^2) > min_ball + b_ratio |p| (mad_icp.cpp:81-83).  The ball depends on the leaf alone, and while a pair
+// keeps its leaf (margin > displacement, above) the distance changes by at most the displacement.  So a pair rejected with
+// slack g = distance - ball stays rejected as long as the leaf has moved by less than g since — and a rejected pair
+// contributes NOTHING (mad_icp.cpp:83 `continue`), so it needs neither its leaf record (four 16-byte gathers: what a converged
+// pass is bound by) nor the gate nor the Jacobian.  The slack is cached per (tree, leaf) as a float rounded down (0: not
+// rejected, evaluate), in the second half of the margin array, and wears off with the same per-round displacement bound and
+// rounding floor as the margin.  At BASELINE configs[4] 79 % of the pairs are rejected at the converged pose, at the headline's
+// 16 keyframes 44 % (oracle count) — whole wavefronts of a far keyframe's unit skip their gathers.  Same bits on or off: the
+// pairs that are evaluated are accumulated in the same order.
 constexpr unsigned int kCacheIdxMask = 0x03ffffffu;
 constexpr int kCacheMaxDepth = 63;
 // queued walks (icp_linearize_body.inc.h): a unit of at least kQueueMinPasses passes is done in chunks of kQueueChunk passes
@@ -1320,7 +1331,9 @@ constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100
 // there) and takes a ticket; the workgroup that draws the last one folds the scan's rows in the canonical order (stage 1 by
 // all its threads, stage 2 by wave 0: the bits of icp_reduce) and resets the ticket.  `totals` (the reduced sums of the
 // PREVIOUS round, read in the prologue) and `totals_out` are the two parity halves of one buffer, never the same memory.
-template <int QPT, bool TRACE, bool FOLD = false, bool TAIL = false>
+// QUEUE: the variant with the queued-walk sweeps compiled in (icp_linearize_body.inc.h) — launched only when a unit is at
+// least kQueueMinPasses passes long; their mere presence costs the one-scan launch 0.45 us (measured, profiles/r5_e_ab.md)
+template <int QPT, bool TRACE, bool FOLD = false, bool TAIL = false, bool QUEUE = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
     const Job* __restrict__ jobs, Job* __restrict__ jobs_out, double* __restrict__ partials,
     const double* __restrict__ totals, int round, int n_iters, int K, int RPT, unsigned long long* __restrict__ xch,
@@ -1401,8 +1414,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int opt_stage_min = job->stage_min_leaves;
   const int L = job->L;
   const int flags = job->flags;
-  const int opt_queue = job->queue_nodes;
-  __shared__ unsigned short s_queue[kWaves][kQueueChunk * 64];  // queued walks: per wavefront, pass-in-chunk * 64 + lane
+  const int opt_queue = QUEUE ? job->queue_nodes : 0;
+  __shared__ unsigned short s_queue[QUEUE ? kWaves : 1][QUEUE ? kQueueChunk * 64 : 1];  // queued walks: per wavefront, pass-in-chunk * 64 + lane
   const bool last_round = (round == n_iters - 1);
   const bool mark_matched = last_round || (flags & kFlagMatchAll);
   const double* __restrict__ moving = job->moving;
@@ -1415,6 +1428,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   uint32_t* __restrict__ cache_leaf = job->cache_leaf;
   float* __restrict__ cache_margin = job->cache_margin;
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
+  float* __restrict__ cache_gate = cache_margin ? cache_margin + (long long)K * L : nullptr;  // (second half of the margin array)
+  const bool gate_reuse = reuse && !(flags & kFlagNoGateReuse);
   const int S = (L + RPT - 1) / RPT;  // leaves per range
 
   // The first pass's loads that do not depend on the pose (leaf coordinates, cached correspondence) are issued NOW,
@@ -1422,7 +1437,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // divergent region would wait for its loads where it ends.  (Also touching the second pass's lines and the cached
   // leaf records here was measured: no gain.)
   vd4 pv0[QPT];
-  float cmar0[QPT];
+  float cmar0[QPT], cgate0[QPT];
   unsigned int cword0[QPT];
   {
     const int i_end = have_first ? min(L, (r_first + 1) * S) : 0;
@@ -1432,11 +1447,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       const int i = min(r_first * S + j * kBlock + threadIdx.x, i_last);
       pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
       cmar0[j] = 0.f;
+      cgate0[j] = 0.f;
       cword0[j] = 0u;
       if (reuse) {  // (uniform)
         const long long ci = (long long)k_first * L + i;
         cmar0[j] = ((gptr_f1)(uintptr_t)cache_margin)[ci];
         cword0[j] = ((gptr_u1)(uintptr_t)cache_leaf)[ci];
+        if (gate_reuse) cgate0[j] = ((gptr_f1)(uintptr_t)cache_gate)[ci];
       }
     }
   }
@@ -1565,15 +1582,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const bool stage_hint = round == 0 || hint_nodes > 0.0;
   // passes this workgroup makes in a round (every unit the same length but the last range of a tree)
   const int wg_passes = have_first ? ((hi - u_first + nslots - 1) / nslots) * ((S + kBlock - 1) / kBlock) : 0;
-  const bool queue_hint = opt_queue > 0 && round >= 2 && hint_nodes >= (double)opt_queue * (double)wg_passes;
+  const bool queue_hint = QUEUE && opt_queue > 0 && round >= 2 && hint_nodes >= (double)opt_queue * (double)wg_passes;
 
 
 #define MADICP_TID threadIdx.x
-#ifndef MADICP_NO_QUEUE  // (development A/B: the queued-walk sweeps compiled out)
-#define MADICP_QUEUE_WALK 1
-#endif
+#define MADICP_HAS_QUEUE 1  // (the sweeps are dead code in the QUEUE = false instantiations)
 #include "icp_linearize_body.inc.h"
-#undef MADICP_QUEUE_WALK
+#undef MADICP_HAS_QUEUE
 #undef MADICP_TID
 
   MADICP_STAMP(5);
@@ -1802,6 +1817,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const bool last_round = (round == n_iters - 1);
     const bool mark_matched = last_round || (flags & kFlagMatchAll);
     const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
+    float* __restrict__ cache_gate = cache_margin ? cache_margin + (long long)K * L : nullptr;
+    const bool gate_reuse = reuse && !(flags & kFlagNoGateReuse);
     const unsigned tag_prev = tag0 + (unsigned)round;  // rows of round - 1 carry (round - 1) + 1
     const unsigned tag_now = tag_prev + 1u;
     // exchange rows of this scan
@@ -1813,7 +1830,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     // the first pass's pose-independent loads (leaf coordinates, cached correspondence: L1/L2 hits from the second round
     // on): in flight during the wait below
     vd4 pv0[QPT];
-    float cmar0[QPT];
+    float cmar0[QPT], cgate0[QPT];
     unsigned int cword0[QPT];
     {
       const int i_end0 = have_first ? min(L, (r_first + 1) * S) : 0;
@@ -1823,11 +1840,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         const int i = min(r_first * S + j * kBlock + tid, i_last0);
         pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
         cmar0[j] = 0.f;
+        cgate0[j] = 0.f;
         cword0[j] = 0u;
         if (reuse) {  // (uniform)
           const long long ci = (long long)k_first * L + i;
           cmar0[j] = ((gptr_f1)(uintptr_t)cache_margin)[ci];
           cword0[j] = ((gptr_u1)(uintptr_t)cache_leaf)[ci];
+          if (gate_reuse) cgate0[j] = ((gptr_f1)(uintptr_t)cache_gate)[ci];
         }
       }
     }
@@ -1915,7 +1934,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const bool stage_hint = stage_hint_next;
 
 #define MADICP_TID tid
+#define MADICP_HAS_QUEUE 0
 #include "icp_linearize_body.inc.h"
+#undef MADICP_HAS_QUEUE
 #undef MADICP_TID
 
     MADICP_STAMP(5);

@@ -124,6 +124,7 @@ struct Geometry {
   int ranges_per_tree;  // units per tree
   int qpt;              // leaves a lane walks at once: 1, 2 or 4
   int lds_bytes;        // dynamic LDS of the launch: kTopLdsBytes when units are big enough to stage a tree's top, else 0
+  int queue;            // 1: units are long enough for queued walks (the QUEUE instantiation of icp_round is launched)
 };
 
 // one streamed registration in flight (madicp_stream_submit .. madicp_stream_collect)
@@ -205,7 +206,9 @@ struct madicp_ctx {
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
-  int queue_walks = 32; // option "queue_walks": units of many passes queue their walkers per wavefront and walk them densely in a
+  int cache_gate = 1;   // option "cache_gate": a pair that keeps its leaf and was rejected with more slack than it has moved since is
+                        // not evaluated again (kernels.hip.h, "Gate reuse")
+  int queue_walks = 12; // option "queue_walks": units of many passes queue their walkers per wavefront and walk them densely in a
                         // round that follows one in which the workgroup walked at least this many nodes per pass (0: never)
   int nn_lds_top = 0;  // option "nn_lds_top": nn_search batches of >= 16 k queries walk the tree's top levels from LDS
                        // (nn_descend_top).  Off: measured SLOWER for one 120 k-query launch (8.7 vs 6.6 us against a
@@ -447,11 +450,12 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   }
   const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
   g.lds_bytes = (K > 0 && per_range >= ctx->stage_min_leaves) ? kTopLdsBytes : 0;
+  g.queue = (K > 0 && ctx->queue_walks > 0 && g.qpt == 1 && per_range >= madicp::kQueueMinPasses * madicp::kBlock) ? 1 : 0;
   return g;
 }
 
 struct Launch {  // one registration's launch shape
-  int grid, batch, iters, qpt, lds, K, rpt, trace;
+  int grid, batch, iters, qpt, lds, K, rpt, trace, queue;
 };
 
 constexpr size_t kXchRowsMax = 1024 + 8 * MADICP_MAX_BATCH;  // level-1 rows + level-2 rows of the largest admissible launch
@@ -505,6 +509,7 @@ void launch_round(madicp_ctx* ctx, const Launch& l, const Part& p, int round, co
   void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int, unsigned long long*, double*, unsigned int*) =
       l.trace ? (l.qpt == 2 ? icp_round<2, true> : icp_round<1, true>) : (l.qpt == 2 ? icp_round<2, false> : icp_round<1, false>);
   if (use_fold(ctx, l)) kern = icp_round<1, false, true>;
+  else if (l.queue && !l.trace && l.qpt == 1) kern = icp_round<1, false, false, false, true>;  // units of many passes: queued walks
   hipLaunchKernelGGL(kern, g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials, totals, round, l.iters, l.K, l.rpt, p.xch,
                      (double*)nullptr, (unsigned int*)nullptr);
 }
@@ -595,7 +600,8 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
   // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
-  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot, use_persist(ctx, l) ? 1 : (use_fold(ctx, l) ? 2 : 0)};
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot,
+                     (use_persist(ctx, l) ? 1 : (use_fold(ctx, l) ? 2 : 0)) + 4 * l.queue};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
     auto instantiate = [&](Job* jobs, const GraphKey& k) -> int {
@@ -684,7 +690,7 @@ int reserve_cache(madicp_ctx* ctx, DevMoving& m, int K) {
   void* p = nullptr;
   RC_TRY(pool_alloc(ctx, sizeof(uint32_t) * need, ctx->stream, &p));
   m.cache_leaf = static_cast<uint32_t*>(p);
-  RC_TRY(pool_alloc(ctx, sizeof(float) * need, ctx->stream, &p));
+  RC_TRY(pool_alloc(ctx, sizeof(float) * 2 * need, ctx->stream, &p));  // margins, then the gate slacks (kernels.hip.h, "Gate reuse")
   m.cache_margin = static_cast<float*>(p);
   m.cache_cap = need;
   return MADICP_OK;
@@ -788,7 +794,8 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
   j.epoch = ++ctx->epoch;  // (24 bits of it reach the granule tags: a tag recurs after 16 M registrations, far beyond
                            // the life of any granule of a geometry in use)
   j.error = 0;
-  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse) | (ctx->match_all ? kFlagMatchAll : 0);
+  j.flags = flags | ((ctx->cache_corr && is_rigid(X0)) ? 0 : kFlagNoReuse) | (ctx->match_all ? kFlagMatchAll : 0) |
+            (ctx->cache_gate ? 0 : kFlagNoGateReuse);
   j.queue_nodes = ctx->queue_walks;
   std::memcpy(j.X, X0, 12 * sizeof(double));
   std::memcpy(j.Xring[0], X0, 12 * sizeof(double));
@@ -886,7 +893,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   for (int h = 0; h < (split ? 2 : 1); ++h) {
     const int first = h ? n_first : 0, count = h ? a.n_scans - n_first : n_first;
     if (h) geo = pick_geometry(ctx, max_L, a.K, count);
-    halves[h] = Launch{geo.grid, count, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree, a.d_corr ? 1 : 0};
+    halves[h] = Launch{geo.grid, count, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree, a.d_corr ? 1 : 0, geo.queue};
     for (int s = first; s < first + count; ++s) {
       h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
       h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
@@ -1114,6 +1121,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->comm_graph = value ? 1 : 0;
   } else if (k == "cache_correspondences") {
     ctx->cache_corr = value ? 1 : 0;
+  } else if (k == "cache_gate") {
+    ctx->cache_gate = value ? 1 : 0;
   } else if (k == "queue_walks") {
     if (value < 0 || value > (1 << 20)) return fail(MADICP_ERR_INVALID, "queue_walks must be 0 (never) or a node count per pass");
     ctx->queue_walks = (int)value;
@@ -1169,6 +1178,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "use_graph") v = ctx->use_graph;
   else if (k == "comm_graph") v = ctx->comm_graph;
   else if (k == "cache_correspondences") v = ctx->cache_corr;
+  else if (k == "cache_gate") v = ctx->cache_gate;
   else if (k == "queue_walks") v = ctx->queue_walks;
   else if (k == "lds_stage_min_leaves") v = ctx->stage_min_leaves;
   else if (k == "eager_when_busy") v = ctx->eager_when_busy;
@@ -1600,7 +1610,7 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   // — or the rounds need the whole chip to themselves: icp_persist / the xcd_fold variant wait INSIDE a launch for workgroups
   // that must all be resident, at 3 x 168 registers per SIMD lane nothing fits beside them, and an icp_publish workgroup that got
   // its CU first (the compute stream is still waiting for the feed) would keep one of them out until their bounded waits expire
-  const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0};
+  const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0, geo.queue};
   const bool side = ctx->publish_side && ctx->seq_completion && !ctx->sharded() && !use_persist(ctx, launch) && !use_fold(ctx, launch);
   j.outbox = side ? sl.d_outbox : nullptr;
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, K);

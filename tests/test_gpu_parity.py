@@ -364,6 +364,15 @@ def test_correspondence_reuse_is_exact(ctx, K):
     for key in ("X", "X_iters", "H", "b", "matched"):
         assert np.array_equal(res[1][key], res[0][key]), key
     assert res[1]["visits"] == res[0]["visits"]
+    # ... and the gate reuse that rides on it (round 5: a pair that keeps its leaf and was rejected with more slack than it has
+    # moved since is not evaluated again — no leaf record, no gate; mad_icp.cpp:81-83): the same bits without it
+    assert ctx.get_option("cache_gate") == 1
+    ctx.set_option("cache_gate", 0)
+    res[2] = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, 15, L)
+    ctx.set_option("cache_gate", 1)
+    for key in ("X", "X_iters", "H", "b", "matched"):
+        assert np.array_equal(res[1][key], res[2][key]), ("cache_gate", key)
+    assert res[1]["visits"] == res[2]["visits"]
     # a second registration of the same scan from a different start must not see stale cache entries
     T2 = pb["query_gt"][0]
     a = ctx.icp_register(mids[0], tids, T2, PARAMS, 15, L)
@@ -377,7 +386,7 @@ def test_correspondence_reuse_is_exact(ctx, K):
 def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
     """Option "queue_walks" (icp_linearize_body.inc.h, "QUEUED WALKS"): when a batch shares the chip a workgroup's
     unit is many passes long, and from round 2 on — while the previous round still walked enough (1: any walk at all; the
-    default asks for 32 nodes per pass) — the pairs that still have to walk are queued per wavefront and walked densely
+    default asks for 12 nodes per pass) — the pairs that still have to walk are queued per wavefront and walked densely
     before the passes run.  32 keyframes, 8 scans in flight (one range per tree: 11 passes per unit): final pose, H,
     b, matched flags, matched counts and the visit counter bit for bit those of walking inside the pass, and those of walking
     EVERY pair every round (no correspondence reuse, hence no queue) — the accumulation order does not depend on who walked.
@@ -393,17 +402,19 @@ def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
     X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
     assert min(h.num_leaves for h in qh) >= 4 * 768  # (deep units: what the queue is for)
     res = {}
-    assert ctx.get_option("queue_walks") == 32  # the default: queue after a round that walked >= 32 nodes per pass
-    for name, opts in (("queued", dict(queue_walks=1)), ("in pass", dict(queue_walks=0)), ("queued by default", dict(queue_walks=32)),
+    assert ctx.get_option("queue_walks") == 12  # the default: queue after a round that walked >= 12 nodes per pass
+    for name, opts in (("queued", dict(queue_walks=1)), ("in pass", dict(queue_walks=0)), ("queued by default", dict(queue_walks=12)),
+                       ("no gate reuse", dict(queue_walks=1, cache_gate=0)), ("in pass, no gate reuse", dict(queue_walks=0, cache_gate=0)),
                        ("no reuse", dict(queue_walks=1, cache_correspondences=0))):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
         r["matched"] = [ctx.icp_fetch_matched(i, h.num_leaves) for i, h in enumerate(qh)]
         res[name] = r
-        ctx.set_option("queue_walks", 32)
+        ctx.set_option("queue_walks", 12)
         ctx.set_option("cache_correspondences", 1)
-    for other in ("in pass", "queued by default", "no reuse"):
+        ctx.set_option("cache_gate", 1)
+    for other in ("in pass", "queued by default", "no gate reuse", "in pass, no gate reuse", "no reuse"):
         for key in ("X", "H", "b", "n_matched", "visits"):
             assert np.array_equal(res["queued"][key], res[other][key]), (other, key)
         for a, b in zip(res["queued"]["matched"], res[other]["matched"]):
