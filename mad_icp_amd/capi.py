@@ -80,7 +80,8 @@ def hip_lib():
         L.madicp_stream_collect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _u8p, _i32p, _u64p]
         L.madicp_nn_time_descend.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, _dp, _u64p]
         L.madicp_debug_stream_copy.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp]
-        L.madicp_debug_gather16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int, _dp]
+        if hasattr(L, "madicp_debug_gather16"):  # (absent from an older build loaded through MADICP_HIP_LIB for an A/B)
+            L.madicp_debug_gather16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int, _dp]
         L.madicp_icp_linearize.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), _dp, _dp,
                                            _u32p, _u8p, _u64p]
         L.madicp_icp_register.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _dp,
