@@ -299,6 +299,22 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
 int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n);
 
 /* ---- multi-GPU: keyframe trees sharded across ranks, one all-reduce of (H,b) per GN round ---------- */
+/* Peer-mapped mailboxes: keyframe sharding WITHOUT a collective between two rounds (option "shard_p2p" = 1, default 0; additive,
+ * one node, at most 8 ranks).  The per-round join of the ranks' adders — the reference's serial sum of mad_icp.cpp:106-109, 30
+ * doubles per scan — is then done inside the next round kernel's prologue: workgroup 0 writes this rank's sums as tagged
+ * granules into every peer's mailbox, every workgroup polls the peers' rows in the own mailbox and adds them in rank order
+ * (all ranks the same bits).  The launch sequence of a sharded registration becomes the single-GPU one; the matched flags are
+ * still OR-ed once per registration through the communicator.
+ *   madicp_p2p_export: allocates this rank's mailbox (once) and returns its 64-byte hipIpcMemHandle_t.
+ *   madicp_p2p_attach: `handles` = n_ranks x 64 bytes in rank order (gathered by the caller — torch.distributed, MPI ...);
+ *                      needs madicp_comm_init / madicp_comm_init_host first, with the same n_ranks / rank.
+ *   madicp_p2p_detach: unmaps the peers' mailboxes (madicp_comm_destroy does it too).
+ * A peer whose row does not arrive within "comm_timeout_ms" fails the registration with MADICP_ERR_COMM.  Every rank must
+ * submit the same sequence of sharded registrations (as with any collective). */
+int madicp_p2p_export(madicp_ctx* ctx, uint8_t out_handle[64]);
+int madicp_p2p_attach(madicp_ctx* ctx, const uint8_t* handles, int n_ranks, int rank);
+int madicp_p2p_detach(madicp_ctx* ctx);
+
 /* Replaces the serial sum of per-thread adders at mad_icp.cpp:106-109.  unique_id: the 128-byte
  * ncclUniqueId produced by madicp_comm_unique_id on rank 0 and distributed by the caller (e.g. a
  * torch.distributed broadcast).  After this call every registration on the context all-reduces

@@ -114,6 +114,10 @@ def hip_lib():
         L.madicp_comm_init.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
         L.madicp_comm_destroy.argtypes = [C.c_void_p]
         L.madicp_comm_init_host.argtypes = [C.c_void_p, C.c_int, C.c_int, HOST_ALLREDUCE_FN, C.c_void_p]
+        if hasattr(L, "madicp_p2p_export"):
+            L.madicp_p2p_export.argtypes = [C.c_void_p, _u8p]
+            L.madicp_p2p_attach.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
+            L.madicp_p2p_detach.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -584,6 +588,23 @@ class Context:
 
         self._host_ar_cb = HOST_ALLREDUCE_FN(_cb)  # (kept alive as long as the library may call it)
         _check(hip_lib().madicp_comm_init_host(self._h, n_ranks, rank, self._host_ar_cb, None))
+
+    def p2p_export(self):
+        """This rank's mailbox as a 64-byte hipIpcMemHandle_t (madicp_p2p_export; allocated on first call)."""
+        buf = (C.c_uint8 * 64)()
+        _check(hip_lib().madicp_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_attach(self, handles, n_ranks, rank):
+        """Map every rank's mailbox: `handles` = the ranks' 64-byte handles in rank order (madicp_p2p_attach)."""
+        blob = b"".join(handles)
+        if len(blob) != 64 * n_ranks:
+            raise ValueError("expected %d handles of 64 bytes" % n_ranks)
+        buf = (C.c_uint8 * len(blob))(*blob)
+        _check(hip_lib().madicp_p2p_attach(self._h, buf, n_ranks, rank))
+
+    def p2p_detach(self):
+        _check(hip_lib().madicp_p2p_detach(self._h))
 
     def comm_destroy(self):
         _check(hip_lib().madicp_comm_destroy(self._h))

@@ -4,7 +4,7 @@
 // launch) so that both kernels run the same instructions in the same order; not a translation unit of its own.
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
-// s_td, cache_gate; per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], moved_rot, moved_trans, pv0 / cmar0 /
+// s_td, cache_gate; per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
 // cgate0 / cword0 (the first pass's pose-independent loads, already issued); MADICP_HAS_QUEUE 1: also QUEUE, queue_hint, s_queue; state it updates: desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
@@ -27,6 +27,8 @@
     // staging costs ~2 x n_top lane-loads per workgroup: only worth it when the unit walks many leaves — and only
     // when somebody actually has to walk (with correspondence reuse most rounds need no walk at all)
     const int n_top_avail = (opt_lds_top && i_end - r * S >= opt_stage_min) ? min(td.n_top, kTopMax) : 0;
+    // wear of a pair of this tree up to this round: A = |p| wear_alpha + wear_k (kernels.hip.h, "Bookkeeping without a store")
+    const double wear_k = wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) + fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0));
 
 #if MADICP_HAS_QUEUE
     // ---- QUEUED WALKS (round 5; icp_round only) -----------------------------------------------------------------------
@@ -84,21 +86,7 @@
           p = ((gptr_d4)(uintptr_t)moving)[i];
           cm = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[(long long)k * L + i];
         }
-#ifdef MADICP_XFORM_HOMOGENEOUS
-        const double a0 = ((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0];
-        const double a1 = ((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1];
-        const double a2 = ((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2];
-#else
-        const double a0 = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
-        const double a1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
-        const double a2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
-#endif
-        const double moved = moved_rot * p.w + moved_trans;
-        const double left_over = (double)cm - moved * (1.0 + 1e-12) -
-                                 1e-11 * ((fabs(a0) + fabs(a1) + fabs(a2)) + td.rho + fabs(td.origin[0]) +
-                                          fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
-        const bool keep = v && left_over > 0.0;
-        if (keep) cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
+        const bool keep = v && (double)cm > __builtin_fma(p.w, wear_alpha, wear_k);
         const bool w = v && !keep;
         const unsigned long long wm = __ballot(w);
         if (w) s_queue[q_wave][qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
@@ -132,7 +120,7 @@
           const long long ci = (long long)k * L + i;
           const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
           cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
-          cache_margin[ci] = cacheable ? __double2float_rd(xm[0]) : 0.f;
+          cache_margin[ci] = cacheable ? __double2float_rd(xm[0] + __builtin_fma(p.w, wear_alpha, wear_k)) : 0.f;
           cache_gate[ci] = 0.f;  // (the slack on file belongs to the OLD leaf: sweep C evaluates this pair)
         }
       }
@@ -152,6 +140,7 @@
       float cmar[QPT], cgate[QPT];
       unsigned int cword[QPT];
       bool skip[QPT];  // gate reuse: the pair keeps its leaf and is still rejected — nothing to fetch, nothing to add
+      double wearv[QPT];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         const int i = base + j * kBlock + MADICP_TID;
@@ -199,33 +188,25 @@
         margin[j] = 3.0e38;
         leaf[j] = 0;
         depth[j] = 0;
-        // how far can this leaf have moved since the previous round?  (bound from the update itself, see solve_pose; the
-        // 1e-11 term covers the rounding of the computed queries, distances and balls)
-        const double wear = (moved_rot * p.w + moved_trans) * (1.0 + 1e-12) +
-                            1e-11 * ((fabs(q0[j]) + fabs(q1[j]) + fabs(q2[j])) + td.rho + fabs(td.origin[0]) +
-                                     fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0);
+        // everything this leaf can have moved against this tree since round 0, rounding included (an upper bound that only
+        // grows: thresholds measured against it are never rewritten while they hold)
+        const double wear = __builtin_fma(p.w, wear_alpha, wear_k);
+        wearv[j] = wear;
         if (qmode) {  // sweep C of a queued chunk: sweeps A / B left every pair's leaf in the cache, valid for THIS pose
-          if (valid[j] && cmar[j] > 0.f) {
+          if (valid[j] && (double)cmar[j] > wear) {
             leaf[j] = (int)(cword[j] & kCacheIdxMask);
             depth[j] = (int)(cword[j] >> 26);
             walk[j] = false;
-          }  // (margin 0: a pair the cache cannot hold, or whose margin rounded down to nothing — it walks in place)
+          }  // (threshold 0: a pair the cache cannot hold — it walks in place)
         } else if (reuse && valid[j]) {
-          const double left_over = (double)cmar[j] - wear;
-          if (left_over > 0.0) {  // every side test of the old path keeps its sign: same leaf, same depth
+          if ((double)cmar[j] > wear) {  // every side test of the old path keeps its sign: same leaf, same depth
             leaf[j] = (int)(cword[j] & kCacheIdxMask);
             depth[j] = (int)(cword[j] >> 26);
-            cache_margin[(long long)k * L + i] = __double2float_rd(left_over);
             walk[j] = false;
           }
         }
-        if (gate_reuse && valid[j] && !walk[j]) {  // same leaf as when the slack was measured: is the pair still outside its ball?
-          const double slack = (double)cgate[j] - wear;
-          if (slack > 0.0) {
-            skip[j] = true;
-            cache_gate[(long long)k * L + i] = __double2float_rd(slack);
-          }
-        }
+        // same leaf as when the slack was measured, and still further outside its ball than it can have moved since?
+        skip[j] = gate_reuse && valid[j] && !walk[j] && (double)cgate[j] > wear;
       }
       if (u == u_first && base == r * S) { MADICP_STAMP(3); }
       if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP(11); }
@@ -273,7 +254,7 @@
               const long long ci = (long long)k * L + (base + j * kBlock + MADICP_TID);
               const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
               cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
-              cache_margin[ci] = cacheable ? __double2float_rd(margin[j]) : 0.f;
+              cache_margin[ci] = cacheable ? __double2float_rd(margin[j] + wearv[j]) : 0.f;
             }
           }
         }
@@ -306,7 +287,11 @@
         const double dist = sqrt(dotc(g0, g1, g2, g0, g1, g2));
         const bool rejected = dist > src_ball;
         // gate reuse: how far outside its ball the pair is (0: inside — it is evaluated every round)
-        if (cache_gate) cache_gate[(long long)k * L + i] = rejected ? __double2float_rd(dist - src_ball) : 0.f;
+        // (as a threshold on the pair's wear; stored only when it changes — an accepted pair stays 0 and is never written)
+        if (cache_gate) {
+          const float slack = rejected ? __double2float_rd((dist - src_ball) + wearv[j]) : 0.f;
+          if (walk[j] || slack != cgate[j]) cache_gate[(long long)k * L + i] = slack;
+        }
         if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;
         if (mark_matched) matched[i] = 1;  // idempotent byte store (mad_icp.cpp:85)

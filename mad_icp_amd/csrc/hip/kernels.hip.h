@@ -176,6 +176,7 @@ struct Job {
   unsigned long long walked;  // of those, the ones this registration really walked (the rest: correspondence reuse)
   double X[12];          // final pose (R row-major, t), written by icp_final
   double Xring[2][12];   // pose of round r lives in Xring[r & 1]; Xring[0] = initial guess (host)
+  double wear_ring[2][2];  // [r & 1]: the cumulative wear coefficients (alpha, beta) of round r — see "Correspondence reuse"
   double min_ball, rho, b_ratio;
   double H[36];          // row-major, of the last round
   double b[6];
@@ -335,6 +336,18 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 // is per (tree, leaf): leaf ordinal | depth << 26, and the margin as a float rounded DOWN.  Levels decided by the
 // exact fallback contribute |s| minus a generous bound on its rounding error (a lane that keeps walking keeps its
 // whole wave on the latency chain, so margins must not be thrown away).
+// Bookkeeping without a store (round 5).  Margins and slacks used to be rewritten every round (left over = old - this
+// round's displacement bound): 8 bytes written per pair and round, 96 MB per launch at BASELINE configs[4], on top of the 12
+// read.  Now they are kept as THRESHOLDS on a per-pair wear that only grows:
+//     A_ik(r) = |p_i| alpha(r) + beta(r) + r gamma_k
+//     alpha(r) = sum over rounds j <= r of (rotation bound of update j) (1 + 1e-12) + 1.75e-11
+//     beta(r)  = sum of (translation bound of update j) (1 + 1e-12) + 1e-11 |t_j|_1,     gamma_k = 1e-11 (rho_k + |o_k|_1 + 1)
+// — an upper bound of everything leaf i can have moved against tree k since round 0, the rounding of the computed queries,
+// distances and balls included (|q|_1 <= 1.75 |p| + |t|_1).  A walk at round r0 with margin M stores T = fl32_down(M + A(r0)),
+// and the pair keeps its leaf while A(r) < T; a slack g is stored the same way.  Reused pairs are READ-ONLY; alpha and beta
+// come out of the round's solve (two doubles beside the pose, Job::wear_ring).  fl32 of a threshold near 1 resolves 6e-8 m:
+// margins below that are lost to rounding down (such a pair walks).
+//
 // Gate reuse (round 5; exact like the correspondence reuse it rides on).  The reference rejects a pair when
 // sqrt(|ml - f.mean|^2) > min_ball + b_ratio |p| (mad_icp.cpp:81-83).  The ball depends on the leaf alone, and while a pair
 // keeps its leaf (margin > displacement, above) the distance changes by at most the displacement.  So a pair rejected with
@@ -1320,6 +1333,71 @@ __device__ __forceinline__ bool granule_try(gptr_g64 g, unsigned tag, double& v)
 }
 constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
 
+// ---- keyframe sharding without a collective between rounds: peer-mapped mailboxes (option "shard_p2p") ------------------------
+// The join of mad_icp.cpp:106-109 over the ranks of a sharded registration is 30 doubles per scan and round.  As an
+// ncclAllReduce it is a kernel of its own behind an icp_reduce launch, strictly between two rounds (13.4 us of
+// round + 4.5 + 10-25 us).  Here every rank owns a MAILBOX — device memory every peer has mapped (hipIpc) — with one row of
+// tagged 16-byte granules per (slot, scan, sending rank).  The round kernel joins its own partials as on one GPU; workgroup 0
+// then WRITES the rank's 30 sums into its row of every peer's mailbox (one xGMI store each way, no fence: the tag in each
+// half says that the value is there), and wave 0 of every workgroup polls the other ranks' rows in its OWN mailbox (local
+// memory) and adds all N rows in rank order — every rank the same order, so every rank solves from the same bits.  No launch,
+// no collective and no host between two rounds.  Slots: (registration parity, round parity) — a rank can be at most one
+// exchange ahead of the slowest one, and never a whole registration.  Bounded spins (Job::error = 4 -> MADICP_ERR_COMM).
+constexpr int kMaxRanks = 8;
+constexpr int kP2pSlots = 4;
+struct PeerBox {
+  unsigned long long* box[kMaxRanks];  // box[q]: rank q's mailbox as mapped in THIS process (box[rank]: the own one)
+  int n_ranks, rank;
+  unsigned int epoch;                  // registration counter of the communicator (the same on every rank)
+  int scan0;                           // first mailbox scan row of this launch (a batch's second half: its first scan)
+  unsigned long long spin_ticks;       // 100 MHz ticks a poll may take before the registration is declared lost
+};
+__host__ __device__ constexpr size_t p2p_row(int slot, int scan, int q) {
+  return (((size_t)slot * MADICP_MAX_BATCH + (size_t)scan) * kMaxRanks + (size_t)q) * kRowGranules;
+}
+constexpr size_t kP2pBoxWords = (size_t)kP2pSlots * MADICP_MAX_BATCH * kMaxRanks * kRowGranules;
+__device__ __forceinline__ void granule_store_sys(gptr_g64 g, unsigned tag, double v) {
+  const unsigned long long t = (unsigned long long)tag << 32;
+  __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(g + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool granule_try_sys(gptr_g64 g, unsigned tag, double& v) {
+  const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  v = __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+  return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
+}
+// Wave 0 of a workgroup (all 64 lanes): total[] (LDS) holds this rank's adders of round `r_done` of mailbox scan row `scan`;
+// on return it holds the sum over the ranks, in rank order.  `publish`: this workgroup is the one that sends the rank's row.
+__device__ __forceinline__ bool p2p_exchange(const PeerBox& pb, int scan, int r_done, bool publish, double* total /*LDS kAcc*/) {
+  const int lane = threadIdx.x & 63;
+  const unsigned tag = (pb.epoch << 8) + (unsigned)r_done + 1u;
+  const int slot = (int)((pb.epoch & 1u) << 1) | (r_done & 1);
+  const double mine = lane < kAcc ? total[lane] : 0.0;
+  if (publish && lane < kAcc) {
+    for (int q = 0; q < pb.n_ranks; ++q)
+      if (q != pb.rank) granule_store_sys((gptr_g64)(uintptr_t)pb.box[q] + p2p_row(slot, scan, pb.rank) + 2 * lane, tag, mine);
+  }
+  bool ok = true;
+  double tot = 0.0;
+  const unsigned long long t0 = wall_clock64();
+  for (int q = 0; q < pb.n_ranks; ++q) {
+    double v = mine;
+    if (q != pb.rank && lane < kAcc) {
+      gptr_g64 g = (gptr_g64)(uintptr_t)pb.box[pb.rank] + p2p_row(slot, scan, q) + 2 * lane;
+      for (unsigned spins = 1; !granule_try_sys(g, tag, v); ++spins) {
+        if ((spins & 63u) == 0u && wall_clock64() - t0 > pb.spin_ticks) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    tot = (q == 0) ? v : tot + v;
+  }
+  wave_lds_order();  // (every lane has read total[])
+  if (lane < kAcc) total[lane] = tot;
+  wave_lds_order();
+  return __all(ok);
+}
+
 // TRACE: also write the per-pair correspondence trace (Job::corr) — the single-round debugging entry point only
 // FOLD (option "xcd_fold", an experiment kept for its measurement — profiles/r3_j_xcd_fold.md): the XCD-hierarchical join
 // WITHOUT the persistent launch.  Every workgroup publishes its row as granules; the leader of each group x = blockIdx.x & 7
@@ -1333,11 +1411,13 @@ constexpr unsigned long long kSpinLimitTicks = 20000000ull;  // 0.2 s of the 100
 // PREVIOUS round, read in the prologue) and `totals_out` are the two parity halves of one buffer, never the same memory.
 // QUEUE: the variant with the queued-walk sweeps compiled in (icp_linearize_body.inc.h) — launched only when a unit is at
 // least kQueueMinPasses passes long; their mere presence costs the one-scan launch 0.45 us (measured, profiles/r5_e_ab.md)
-template <int QPT, bool TRACE, bool FOLD = false, bool TAIL = false, bool QUEUE = false>
+// P2P (multi-GPU, option "shard_p2p"): the join over the ranks happens INSIDE the prologue, over the peer-mapped mailboxes
+// (p2p_exchange above) — the launch sequence of a sharded registration is then the single-GPU one.
+template <int QPT, bool TRACE, bool FOLD = false, bool TAIL = false, bool QUEUE = false, bool P2P = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void icp_round(
     const Job* __restrict__ jobs, Job* __restrict__ jobs_out, double* __restrict__ partials,
     const double* __restrict__ totals, int round, int n_iters, int K, int RPT, unsigned long long* __restrict__ xch,
-    double* __restrict__ totals_out = nullptr, unsigned int* __restrict__ tickets = nullptr) {
+    double* __restrict__ totals_out, unsigned int* __restrict__ tickets, const PeerBox pb) {
   // (n_iters, K and ranges_per_tree are the same for every scan of the launch: as kernel arguments they are known
   // one memory round trip before anything read through `job`)
   // `jobs` and `jobs_out` are the SAME array: everything this kernel reads goes through the const restrict view, the
@@ -1358,7 +1438,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int prows = join_rows(gridDim.x);                          // rows stored per scan (>= gridDim.x, zero padded)
   const long long pstride = (long long)gridDim.y * prows * kAcc;  // one parity's worth of partials
   const double* __restrict__ prev_partials = partials + ((round - 1) & 1) * pstride + (long long)blockIdx.y * prows * kAcc;
-  double Xp[12];
+  double Xp[12], wear_prev[2] = {0.0, 0.0};
   JoinLoads jl;
   if (!FOLD && round > 0 && !totals) join_issue(prev_partials, jl);
   // FOLD: the eight folded rows of the previous round (level 2 of the exchange), four values per lane of wave 0
@@ -1387,7 +1467,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     gptr_d1 xr = (gptr_d1)(uintptr_t)job->Xring[(round > 0 ? round - 1 : 0) & 1];
 #pragma unroll
     for (int i = 0; i < 12; ++i) Xp[i] = xr[i];
-    if (round > 0) prev_hint = ((gptr_d1)(uintptr_t)hints)[((round - 1) & 1) * hint_stride + hint_slot];
+    if (round > 0) {
+      prev_hint = ((gptr_d1)(uintptr_t)hints)[((round - 1) & 1) * hint_stride + hint_slot];
+      gptr_d1 wr = (gptr_d1)(uintptr_t)job->wear_ring[(round - 1) & 1];
+      wear_prev[0] = wr[0];
+      wear_prev[1] = wr[1];
+    }
   }
   MADICP_STAMP(15);
   const int U = K * RPT;  // <= MADICP_MAX_TREES x workgroups: 32-bit arithmetic (a 64-bit division is ~100 instructions)
@@ -1523,6 +1608,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       } else {
         join_stage2_wave0(s_seg, s_total);
       }
+      if (P2P) {  // this rank's adders -> every peer's mailbox; the other ranks' rows <- the own mailbox; sum in rank order
+        if (!p2p_exchange(pb, pb.scan0 + (int)blockIdx.y, round - 1, blockIdx.x == 0, s_total) && threadIdx.x == 0) jout->error = 4;
+      }
       MADICP_STAMP(1);
       double H[36], b[6];
       solve_pose(s_total, Xp, !(flags & kFlagNoUpdate), Xn, H, b, moved, threadIdx.x & 63);
@@ -1543,15 +1631,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 #pragma unroll
       for (int i = 0; i < 12; ++i) Xn[i] = Xp[i];
     }
+    // cumulative wear of the correspondence / gate thresholds up to THIS round's pose ("Bookkeeping without a store")
+    double wear_a = 0.0, wear_b = 0.0;
+    if (round > 0) {
+      wear_a = wear_prev[0] + (moved[0] * (1.0 + 1e-12) + 1.75e-11);
+      wear_b = wear_prev[1] + (moved[1] * (1.0 + 1e-12) + 1e-11 * (fabs(Xn[9]) + fabs(Xn[10]) + fabs(Xn[11])));
+    }
     if (threadIdx.x == 0) {
+      if (blockIdx.x == 0) {
+        jout->wear_ring[round & 1][0] = wear_a;
+        jout->wear_ring[round & 1][1] = wear_b;
+      }
       if (blockIdx.x == 0 && job->x_iters) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) job->x_iters[(long long)round * 12 + i] = Xn[i];  // the pose this round linearises at
       }
 #pragma unroll
       for (int i = 0; i < 12; ++i) s_X[i] = Xn[i];
-      s_X[12] = moved[0];
-      s_X[13] = moved[1];
+      s_X[12] = wear_a;
+      s_X[13] = wear_b;
       s_X[14] = prev_hint;
     }
   }
@@ -1577,7 +1675,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   for (int k = 0; k < 9; ++k) R[k] = wave_uniform(s_X[k]);
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = wave_uniform(s_X[9 + k]);
-  const double moved_rot = wave_uniform(s_X[12]), moved_trans = wave_uniform(s_X[13]);
+  const double wear_alpha = wave_uniform(s_X[12]), wear_beta = wave_uniform(s_X[13]);
   const double hint_nodes = wave_uniform(s_X[14]);  // nodes this workgroup walked in the previous round
   const bool stage_hint = round == 0 || hint_nodes > 0.0;
   // passes this workgroup makes in a round (every unit the same length but the last range of a tree)
@@ -1908,8 +2006,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
           s_cnt[1] += static_cast<unsigned long long>(s_total[29]);
 #pragma unroll
           for (int i = 0; i < 12; ++i) s_X[i] = Xn[i];
-          s_X[12] = moved[0];
-          s_X[13] = moved[1];
+          s_X[12] += moved[0] * (1.0 + 1e-12) + 1.75e-11;  // cumulative wear ("Bookkeeping without a store"): alpha, beta
+          s_X[13] += moved[1] * (1.0 + 1e-12) + 1e-11 * (fabs(Xn[9]) + fabs(Xn[10]) + fabs(Xn[11]));
         }
       }
     }
@@ -1930,7 +2028,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     for (int k = 0; k < 9; ++k) R[k] = wave_uniform(s_X[k]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = wave_uniform(s_X[9 + k]);
-    const double moved_rot = wave_uniform(s_X[12]), moved_trans = wave_uniform(s_X[13]);
+    const double wear_alpha = wave_uniform(s_X[12]), wear_beta = wave_uniform(s_X[13]);
     const bool stage_hint = stage_hint_next;
 
 #define MADICP_TID tid
@@ -2036,7 +2134,7 @@ __device__ __forceinline__ void count_matched(Job* job) {
 // (pipeline.cpp:195-204,223).  grid = n_scans, block = kBlock (the join order depends on it).  nblocks = workgroups per scan of icp_round.
 __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, const double* __restrict__ partials,
                                                           const double* __restrict__ totals, int nblocks, int n_scans,
-                                                          const unsigned long long* __restrict__ xch) {
+                                                          const unsigned long long* __restrict__ xch, const PeerBox pb) {
   __shared__ double s_total[kAcc];
   Job* job = jobs + blockIdx.x;
   const int n = job->n_iters;
@@ -2068,6 +2166,9 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     const int prows = join_rows(nblocks);
     const long long pstride = (long long)n_scans * prows * kAcc;
     join_partials(partials + ((n - 1) & 1) * pstride + (long long)blockIdx.x * prows * kAcc, prows, s_total);
+    // sharded over peer-mapped mailboxes (option "shard_p2p"): the last round's join over the ranks
+    if (pb.n_ranks > 0 && threadIdx.x < 64 && !p2p_exchange(pb, pb.scan0 + (int)blockIdx.x, n - 1, true, s_total) && threadIdx.x == 0)
+      job->error = 4;
   }
   count_matched(job);
   if (threadIdx.x < 64) {  // wave 0, every lane the same values (solve_pose is wave-uniform)

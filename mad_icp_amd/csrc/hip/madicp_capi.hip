@@ -225,6 +225,13 @@ struct madicp_ctx {
                            // launch.  Off: built, bit-identical, measured SLOWER (profiles/r4_c_shard_probe.md: the 256 tickets
                            // on one address and the cross-XCD read of the rows cost ~8 us at the end of every round; the
                            // separate icp_reduce launch costs 4.5 us and no gap)
+  int shard_p2p = 0;       // sharded rounds join over peer-mapped mailboxes inside the round kernel (madicp_p2p_attach) instead
+                           // of icp_reduce + a collective between two rounds
+  unsigned long long* p2p_box = nullptr;                  // this rank's mailbox (kP2pBoxWords; fine-grained device memory)
+  unsigned long long* p2p_peer[madicp::kMaxRanks] = {};   // every rank's mailbox as mapped here ([rank] = p2p_box)
+  bool p2p_opened[madicp::kMaxRanks] = {};                // ... opened through hipIpcOpenMemHandle (to be closed)
+  bool p2p_attached = false;
+  unsigned int p2p_epoch = 0;                             // sharded registrations so far (the same count on every rank)
   int shard_split = 1;     // a sharded batch of >= 4 scans runs as two halves on two streams: one half's all-reduce under the
                            // other half's round (profiles/r4_c_shard_probe.md: -14 % per registration at 8 scans with a 15 us
                            // collective; a loss without one, and with halves of one scan)
@@ -480,6 +487,7 @@ struct Part {
   unsigned long long* xch = nullptr;
   double* totals[2] = {nullptr, nullptr};  // round parity: written by round r (or icp_reduce), all-reduced, read by round r + 1
   unsigned int* tickets = nullptr;
+  int scan0 = 0;  // first scan of the part within the registration's batch (its rows of the peer mailboxes)
 };
 Part whole_part(madicp_ctx* ctx, Job* d_jobs) {
   Part p;
@@ -499,19 +507,47 @@ bool use_tail(const madicp_ctx* ctx, const Launch& l) {
          madicp::xch_level1(l.batch, l.grid) <= kXchRowsMax * 2 * madicp::kRowGranules;
 }
 
+// sharded rounds that join over the peer-mapped mailboxes inside the round kernel (option "shard_p2p", madicp_p2p_attach)
+bool use_p2p(const madicp_ctx* ctx, const Launch& l) {
+  return ctx->sharded() && ctx->shard_p2p && ctx->p2p_attached && !l.trace && l.qpt == 1 && l.iters <= 250;
+}
+madicp::PeerBox peer_box(const madicp_ctx* ctx, int scan0, bool on) {
+  madicp::PeerBox pb{};
+  if (!on) return pb;  // (n_ranks = 0: not a mailbox launch)
+  for (int q = 0; q < madicp::kMaxRanks; ++q) pb.box[q] = ctx->p2p_peer[q];
+  pb.n_ranks = ctx->n_ranks;
+  pb.rank = ctx->rank;
+  pb.epoch = ctx->p2p_epoch;
+  pb.scan0 = scan0;
+  pb.spin_ticks = (unsigned long long)std::max(1, ctx->comm_timeout_ms) * 100000ull;  // 100 MHz ticks
+  return pb;
+}
+
 void launch_round(madicp_ctx* ctx, const Launch& l, const Part& p, int round, const double* totals) {
   dim3 g(l.grid, l.batch), b(kBlock);
-  if (use_tail(ctx, l)) {
-    hipLaunchKernelGGL((icp_round<1, false, false, true>), g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials, totals, round,
-                       l.iters, l.K, l.rpt, p.xch, p.totals[round & 1], p.tickets);
+  const madicp::PeerBox none{};
+  if (use_p2p(ctx, l)) {
+    const madicp::PeerBox pb = peer_box(ctx, p.scan0, true);
+    if (l.queue)
+      hipLaunchKernelGGL((icp_round<1, false, false, false, true, true>), g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials,
+                         (const double*)nullptr, round, l.iters, l.K, l.rpt, p.xch, (double*)nullptr, (unsigned int*)nullptr, pb);
+    else
+      hipLaunchKernelGGL((icp_round<1, false, false, false, false, true>), g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials,
+                         (const double*)nullptr, round, l.iters, l.K, l.rpt, p.xch, (double*)nullptr, (unsigned int*)nullptr, pb);
     return;
   }
-  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int, unsigned long long*, double*, unsigned int*) =
+  if (use_tail(ctx, l)) {
+    hipLaunchKernelGGL((icp_round<1, false, false, true>), g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials, totals, round,
+                       l.iters, l.K, l.rpt, p.xch, p.totals[round & 1], p.tickets, none);
+    return;
+  }
+  void (*kern)(const Job*, Job*, double*, const double*, int, int, int, int, unsigned long long*, double*, unsigned int*,
+               const madicp::PeerBox) =
       l.trace ? (l.qpt == 2 ? icp_round<2, true> : icp_round<1, true>) : (l.qpt == 2 ? icp_round<2, false> : icp_round<1, false>);
   if (use_fold(ctx, l)) kern = icp_round<1, false, true>;
   else if (l.queue && !l.trace && l.qpt == 1) kern = icp_round<1, false, false, false, true>;  // units of many passes: queued walks
   hipLaunchKernelGGL(kern, g, b, l.lds, p.s, (const Job*)p.jobs, p.jobs, p.partials, totals, round, l.iters, l.K, l.rpt, p.xch,
-                     (double*)nullptr, (unsigned int*)nullptr);
+                     (double*)nullptr, (unsigned int*)nullptr, none);
 }
 
 // (experiment, option "xcd_fold") per-round launches with the XCD-hierarchical join: same admission rules as icp_persist
@@ -525,6 +561,10 @@ bool use_fold(const madicp_ctx* ctx, const Launch& l) {
 // one round of a part, and what a sharded round needs behind it: this rank's share of the adders (a rank that owns no tree
 // contributes zeros) -> one all-reduce of [H(21) b(6) n v w] per scan over xGMI: the serial sum of mad_icp.cpp:106-109
 int enqueue_round(madicp_ctx* ctx, const Launch& l, const Part& p, int it) {
+  if (use_p2p(ctx, l)) {  // the join over the ranks is inside the round kernel's prologue: the single-GPU launch sequence
+    launch_round(ctx, l, p, it, nullptr);
+    return MADICP_OK;
+  }
   launch_round(ctx, l, p, it, (ctx->sharded() && it > 0) ? p.totals[(it - 1) & 1] : nullptr);
   if (ctx->sharded()) {
     if (!use_tail(ctx, l))
@@ -536,16 +576,22 @@ int enqueue_round(madicp_ctx* ctx, const Launch& l, const Part& p, int it) {
 // what closes a part: the matched flags OR-ed over the ranks, then icp_final
 int enqueue_close(madicp_ctx* ctx, const Launch& l, const Part& p, const int* moving_ids) {
   if (ctx->sharded()) {
-    // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204)
-    for (int s = 0; s < l.batch; ++s) {
+    // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204): the scans' flag
+    // arrays as ONE grouped RCCL operation (one launch for the batch, not one per scan)
+    if (ctx->comm && l.batch > 1) NCCL_TRY(ncclGroupStart());
+    int rc = MADICP_OK;
+    for (int s = 0; s < l.batch && rc == MADICP_OK; ++s) {
       const DevMoving& mv = ctx->movings.at(moving_ids[s]);
-      RC_TRY(all_reduce(ctx, mv.matched, (size_t)mv.L, MADICP_REDUCE_MAX_U8, p.s));
+      rc = all_reduce(ctx, mv.matched, (size_t)mv.L, MADICP_REDUCE_MAX_U8, p.s);
     }
+    if (ctx->comm && l.batch > 1) NCCL_TRY(ncclGroupEnd());
+    if (rc != MADICP_OK) return rc;
   }
   // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
+  const bool p2p = use_p2p(ctx, l);
   hipLaunchKernelGGL(icp_final, dim3(l.batch), dim3(kBlock), 0, p.s, p.jobs, p.partials,
-                     ctx->sharded() ? (const double*)p.totals[(l.iters - 1) & 1] : (const double*)nullptr, l.grid, l.batch,
-                     use_fold(ctx, l) ? (const unsigned long long*)p.xch : (const unsigned long long*)nullptr);
+                     (ctx->sharded() && !p2p) ? (const double*)p.totals[(l.iters - 1) & 1] : (const double*)nullptr, l.grid, l.batch,
+                     use_fold(ctx, l) ? (const unsigned long long*)p.xch : (const unsigned long long*)nullptr, peer_box(ctx, p.scan0, p2p));
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -558,7 +604,7 @@ int enqueue_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, const std::vec
     void (*kern)(const Job*, Job*, unsigned long long*, int, int, int) = l.qpt == 2 ? icp_persist<2> : icp_persist<1>;
     hipLaunchKernelGGL(kern, g, b, l.lds, ctx->stream, (const Job*)d_jobs, d_jobs, ctx->d_xch, iters, l.K, l.rpt);
     hipLaunchKernelGGL(icp_final, dim3(batch), dim3(kBlock), 0, ctx->stream, d_jobs, ctx->d_partials, (const double*)nullptr,
-                       grid, batch, (const unsigned long long*)ctx->d_xch);
+                       grid, batch, (const unsigned long long*)ctx->d_xch, madicp::PeerBox{});
     HIP_TRY(hipGetLastError());
     return MADICP_OK;
   }
@@ -595,7 +641,9 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
   // with a communicator the RCCL calls are captured only on request (option "comm_graph"): it could not be
   // exercised on more than one rank where this was developed
   // (a host-staged transport makes a host round trip per round: never capturable)
-  const bool graph_ok = ctx->use_graph && !ctx->host_ar && (!ctx->comm || ctx->comm_graph) &&
+  const bool p2p = use_p2p(ctx, l);
+  if (p2p) ++ctx->p2p_epoch;  // (every rank submits the same sequence of sharded registrations: the tags of this one's rows)
+  const bool graph_ok = ctx->use_graph && !ctx->host_ar && (!ctx->comm || ctx->comm_graph) && !p2p &&
                         !(queued_behind && ctx->eager_when_busy && !ctx->comm);
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
@@ -885,8 +933,9 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   }
   // a sharded batch of two or more scans goes as two halves on two streams (enqueue_rounds_split): each half is a launch
   // shape of its own — its scans share the chip among themselves, not with the other half's
+  // (option value 2: split from two scans on — tests, probes; never over the peer mailboxes: there is no collective to hide)
   const bool split = ctx->sharded() && a.n_scans >= (ctx->shard_split >= 2 ? 2 : 4) && ctx->shard_split && !a.time_launches &&
-                     !a.d_corr && !a.d_x_iters;  // (option value 2: split from two scans on — tests, probes)
+                     !a.d_corr && !a.d_x_iters && !(ctx->shard_p2p && ctx->p2p_attached);
   const int n_first = split ? a.n_scans / 2 : a.n_scans;
   Launch halves[2];
   Geometry geo = pick_geometry(ctx, max_L, a.K, n_first);
@@ -928,7 +977,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     HIP_TRY(hipEventRecord(ctx->ev_t1, ctx->stream));
     // fold the last launch's partials (round parity 0) into job->visits / H / b: icp_final with n_iters = 1 semantics
     hipLaunchKernelGGL(icp_final, dim3(a.n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                       (const double*)nullptr, grid, a.n_scans, (const unsigned long long*)nullptr);
+                       (const double*)nullptr, grid, a.n_scans, (const unsigned long long*)nullptr, madicp::PeerBox{});
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
@@ -994,7 +1043,26 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   if (stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // MADICP_CU_MASK=lo|hi (development / tests): the compute stream only gets the lower / upper half of the device's CUs, so
+    // that two processes sharing ONE GPU can have their round kernels resident side by side — what two ranks polling each
+    // other's mailboxes need (tests/test_sharded.py: on real hardware every rank has a GPU of its own)
+    const char* cu_half = std::getenv("MADICP_CU_MASK");
+    if (cu_half && (cu_half[0] == 'l' || cu_half[0] == 'h')) {
+      const int words = (ctx->n_cus + 31) / 32;
+      std::vector<uint32_t> mask((size_t)words, 0u);
+      for (int cu = 0; cu < ctx->n_cus; ++cu) {
+        const bool lower = cu < ctx->n_cus / 2;
+        if (lower == (cu_half[0] == 'l')) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+      }
+      e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, mask.data());
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        std::fprintf(stderr, "madicp: MADICP_CU_MASK ignored (hipExtStreamCreateWithCUMask: %s)\n", hipGetErrorString(e));
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+      }
+    } else {
+      e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) {
       delete ctx;
       return fail(MADICP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -1033,6 +1101,7 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   return MADICP_OK;
 }
 
+int madicp_p2p_detach(madicp_ctx* ctx);
 int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (!ctx) return MADICP_OK;
   hipSetDevice(ctx->device);
@@ -1040,6 +1109,8 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->copy) hipStreamSynchronize(ctx->copy);
   if (ctx->build) hipStreamSynchronize(ctx->build);
   if (ctx->pub) hipStreamSynchronize(ctx->pub);
+  if (ctx->p2p_attached) madicp_p2p_detach(ctx);
+  if (ctx->p2p_box) hipFree(ctx->p2p_box);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   if (ctx->h_comm) hipHostFree(ctx->h_comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
@@ -1141,6 +1212,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->debug_collective_us = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1000));
   } else if (k == "shard_tail") {
     ctx->shard_tail = value ? 1 : 0;
+  } else if (k == "shard_p2p") {
+    ctx->shard_p2p = value ? 1 : 0;
   } else if (k == "shard_split") {
     ctx->shard_split = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
   } else if (k == "match_all_rounds") {
@@ -1187,6 +1260,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "xcd_fold") v = ctx->xcd_fold;
   else if (k == "debug_collective_us") v = ctx->debug_collective_us;
   else if (k == "shard_tail") v = ctx->shard_tail;
+  else if (k == "shard_p2p") v = ctx->shard_p2p;
   else if (k == "shard_split") v = ctx->shard_split;
   else if (k == "match_all_rounds") v = ctx->match_all;
   else if (k == "persistent") v = ctx->persistent;
@@ -1715,6 +1789,7 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
   const HostResult& r = *sl.h_out;
   if (r.error) {
     sl.pending = false;
+    if (r.error == 4) return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
     return fail(MADICP_ERR_DEVICE, r.error == 3 ? std::string("registration never left its results in the outbox (icp_publish timed out)")
                                                 : "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(r.error) + ")");
   }
@@ -1745,6 +1820,7 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
   RC_TRY(bounded_sync(ctx, ctx->stream));
   for (int s = 0; s < n_scans; ++s) {
     const Job& j = ctx->h_fetch[s];
+    if (j.error == 4) return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
     if (j.error) return fail(MADICP_ERR_DEVICE, "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(j.error) + ")");
     if (out_X) std::memcpy(out_X + 12 * s, j.X, 12 * sizeof(double));
     if (out_H) std::memcpy(out_H + 36 * s, j.H, 36 * sizeof(double));
@@ -1876,7 +1952,7 @@ int madicp_icp_time_registration(madicp_ctx* ctx, int n_scans, const int* moving
   HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   for (int r = 0; r < reps; ++r)
     hipLaunchKernelGGL(icp_final, dim3(n_scans), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_partials,
-                       (const double*)nullptr, geo.grid, n_scans, (const unsigned long long*)nullptr);
+                       (const double*)nullptr, geo.grid, n_scans, (const unsigned long long*)nullptr, madicp::PeerBox{});
   HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
   HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   {
@@ -2081,8 +2157,83 @@ int madicp_comm_init_host(madicp_ctx* ctx, int n_ranks, int rank, madicp_host_al
   return MADICP_OK;
 }
 
+// ---- peer-mapped mailboxes (option "shard_p2p"; kernels.hip.h, "keyframe sharding without a collective between rounds") ----
+int madicp_p2p_export(madicp_ctx* ctx, uint8_t out_handle[64]) {
+  if (!ctx || !out_handle) return fail(MADICP_ERR_INVALID, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = madicp::kP2pBoxWords * sizeof(unsigned long long);
+  hipIpcMemHandle_t h;
+  if (!ctx->p2p_box) {
+    // fine-grained device memory first: peers write it while kernels of this device poll it (coarse-grained memory promises
+    // no cross-device visibility during a kernel); plain hipMalloc where the runtime has no fine-grained device pool or will
+    // not export one
+    for (int attempt = 0; attempt < 2 && !ctx->p2p_box; ++attempt) {
+      void* p = nullptr;
+      hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
+      if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+      if (e == hipSuccess) {
+        ctx->p2p_box = static_cast<unsigned long long*>(p);
+      } else {
+        (void)hipGetLastError();
+        if (p) hipFree(p);
+        if (attempt == 1) return fail(MADICP_ERR_DEVICE, std::string("mailbox: ") + hipGetErrorString(e));
+      }
+    }
+  }
+  HIP_TRY(hipIpcGetMemHandle(&h, ctx->p2p_box));
+  std::memcpy(out_handle, &h, 64);
+  return MADICP_OK;
+}
+
+int madicp_p2p_detach(madicp_ctx* ctx) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->stream) HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int q = 0; q < madicp::kMaxRanks; ++q) {
+    if (ctx->p2p_opened[q] && ctx->p2p_peer[q]) hipIpcCloseMemHandle(ctx->p2p_peer[q]);
+    ctx->p2p_opened[q] = false;
+    ctx->p2p_peer[q] = nullptr;
+  }
+  ctx->p2p_attached = false;
+  return MADICP_OK;
+}
+
+int madicp_p2p_attach(madicp_ctx* ctx, const uint8_t* handles, int n_ranks, int rank) {
+  if (!ctx || !handles) return fail(MADICP_ERR_INVALID, "null argument");
+  if (!ctx->sharded()) return fail(MADICP_ERR_INVALID, "madicp_p2p_attach needs a communicator (madicp_comm_init / madicp_comm_init_host) first");
+  if (n_ranks != ctx->n_ranks || rank != ctx->rank) return fail(MADICP_ERR_INVALID, "n_ranks / rank differ from the communicator's");
+  if (n_ranks > madicp::kMaxRanks) return fail(MADICP_ERR_CAPACITY, "peer mailboxes serve at most 8 ranks (one node)");
+  if (!ctx->p2p_box) return fail(MADICP_ERR_INVALID, "madicp_p2p_export first: this rank's own mailbox does not exist yet");
+  if (ctx->p2p_attached) RC_TRY(madicp_p2p_detach(ctx));
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (int q = 0; q < n_ranks; ++q) {
+    if (q == rank) {
+      ctx->p2p_peer[q] = ctx->p2p_box;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + 64 * (size_t)q, 64);
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      madicp_p2p_detach(ctx);
+      return fail(MADICP_ERR_COMM, "rank " + std::to_string(q) + "'s mailbox could not be mapped: " + hipGetErrorString(e));
+    }
+    ctx->p2p_peer[q] = static_cast<unsigned long long*>(p);
+    ctx->p2p_opened[q] = true;
+  }
+  ctx->p2p_epoch = 0;
+  ctx->p2p_attached = true;
+  return MADICP_OK;
+}
+
 int madicp_comm_destroy(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (ctx->p2p_attached) RC_TRY(madicp_p2p_detach(ctx));
   if (ctx->host_ar) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->host_ar = nullptr;

@@ -6,7 +6,9 @@ sharded across ranks — round-robin by keyframe index — the moving leaves and
 round ends with ONE small all-reduce of [H, b]; the matched flags are OR-ed (MAX) once, after the last round.
 Every rank then solves the 6x6 redundantly and holds the same pose.
 
-Three transports:
+Three transports (and, on top of native or host, the peer MAILBOXES of `attach_peer_mailboxes`: option "shard_p2p" moves the
+per-round join into the round kernel itself — stores into the peers' hipIpc-mapped mailboxes, polls of the own one — so that
+only the matched flags still go through the transport, once per registration):
   * native  — `init_native_comm(ctx)`: the all-reduces are RCCL calls enqueued by libmadicp_hip.so on its own HIP
               stream between the kernels of a round (no host round trip); torch.distributed only carries the
               128-byte ncclUniqueId once.  This is what bench.py --gpus N uses.
@@ -66,6 +68,21 @@ def init_host_comm(ctx, group=None):
             dist.all_reduce(t, op=op, group=group)
 
     ctx.comm_init_host(world, rank, all_reduce)
+    return rank, world
+
+
+def attach_peer_mailboxes(ctx, group=None):
+    """Option "shard_p2p": every rank exports its mailbox, torch.distributed gathers the 64-byte handles, every rank maps the
+    others' (madicp_p2p_export / madicp_p2p_attach).  Needs a communicator in `ctx` already (init_native_comm /
+    init_host_comm); ranks on one node (hipIpc).  After this, `ctx.set_option("shard_p2p", 1)` makes the per-round join of the
+    ranks' adders happen inside the round kernel — no collective between two rounds."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = ctx.p2p_export()
+    handles = [None] * world
+    dist.all_gather_object(handles, mine, group=group)
+    ctx.p2p_attach(handles, world, rank)
     return rank, world
 
 
