@@ -877,6 +877,39 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                                                   "per_registration": round((n_sum + B) / B, 2)}
             out_extra["all_reduce_payload_bytes_per_round"] = 240 * B
             out_extra["max_translation_error_m"] = round(terr, 5)
+            # ---- the same sharding with the per-round join over peer-mapped mailboxes instead of a collective (option
+            # "shard_p2p"): side by side with the RCCL figure above, same batch, same trees
+            p2p_err = None
+            try:
+                from mad_icp_amd import sharded as _sh
+                _sh.attach_peer_mailboxes(ctx)
+            except Exception as e:  # noqa: BLE001
+                p2p_err = "%s: %s" % (type(e).__name__, str(e)[:200])
+            bad = torch.tensor([1.0 if p2p_err else 0.0], device=small)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if bad.item() > 0:
+                out_extra["shard_p2p"] = {"error": p2p_err or "a peer could not map the mailboxes"}
+            else:
+                try:
+                    ctx.set_option("shard_p2p", 1)
+                    e1p, _ = batched(1, tids, max(20, args.steps // 4), 5, mids[:1])
+                    ep, lastp = batched(B, tids, args.steps, args.warmup, mids)
+                    terr_p = max(pose_error(pb["query_gt"][q], capi.pose44(lastp[1]["X"][s])) for s, q in enumerate(lastp[0]))
+                    out_extra["shard_p2p"] = {
+                        "registrations_per_s": round(args.steps * B / ep, 1), "scans_in_flight": B,
+                        "one_scan_registrations_per_s": round(max(20, args.steps // 4) / e1p, 1),
+                        "vs_shard_rccl": round((args.steps * B / ep) / value, 3),
+                        "max_translation_error_m": round(terr_p, 5),
+                        "sequence": "icp_round only: workgroup 0 stores the rank's 30 sums per scan into every peer's hipIpc-mapped "
+                                    "mailbox, every workgroup polls its own mailbox in the next round's prologue and adds the rows in "
+                                    "rank order; no icp_reduce, no collective between rounds; matched flags OR-ed once (RCCL, grouped)",
+                        "note": "developed and tested with two ranks on ONE GPU (half of the CUs each): %s" %
+                                ("this is a world of one — nothing crossed xGMI" if world == 1 else
+                                 "this line is its first measurement over xGMI")}
+                except Exception as e:  # noqa: BLE001 — (a rank that fails here leaves its peers to their bounded waits)
+                    out_extra["shard_p2p"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+                finally:
+                    ctx.set_option("shard_p2p", 0)
             for m in mids:
                 ctx.moving_release(m)
             for t in tids:

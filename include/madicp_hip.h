@@ -80,9 +80,11 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
  * "cache_gate" (0/1, default 1: a pair that keeps its leaf and was rejected by the gate of mad_icp.cpp:81-83 with more slack than it
  * has moved since is not evaluated again — its leaf record is not fetched; same bits either way),
- * "queue_walks" (0: never; n > 0, default 12: units of many passes — a batch sharing the chip — queue the pairs that still have
- * to walk per wavefront and walk them densely, in a round that follows one in which the workgroup walked at least n nodes per
- * pass; same bits either way),
+ * "leaf_major" (0: never; n > 0, default 2048: when a batch shares the chip — more keyframe trees than workgroups per XCD piece —
+ * every workgroup gets one range of the scan's leaves and all the trees of its piece, and a round that follows one in which the
+ * workgroup walked fewer than n nodes per pass runs LEAF-MAJOR: the moving leaf is read and transformed once per pass for all
+ * those trees, and the pairs that still have to walk are queued per wavefront and walked densely.  Same decisions — leaf,
+ * depth, gate, matched flags, visit count — bit for bit; H and b in another summation order, ~1e-16 relative),
  * "publish_side" (0/1, default 1: a streamed registration leaves its results in a device-resident outbox and a one-workgroup
  * kernel on a side stream carries them, and the matched flags, to the caller's pinned block while the compute stream is already
  * running the next registration — the two PCIe round trips of that hand-over were 5 us of every registration; off: the

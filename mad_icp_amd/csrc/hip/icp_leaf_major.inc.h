@@ -1,0 +1,216 @@
+// LEAF-MAJOR ROUNDS — the round of a DEEP launch (a batch shares the chip: few workgroups per scan, every workgroup owns
+// several keyframe trees) in which the pairs that still have to walk are few.  TEXTUALLY included by icp_round in front of the
+// tree-major body (icp_linearize_body.inc.h), live only in the DEEP = true instantiation; same names in scope.
+//
+// What the per-round trace of BASELINE configs[4] (64 keyframes, 8 scans in flight) said about the tree-major order
+// (profiles/r5_k64_rounds.md): a round in which NOTHING walks costs 90-100 us and neither skipping the rejected pairs' leaf
+// records (gate reuse) nor dropping the per-round margin stores moved it — it reads 44 bytes per (leaf, tree) pair, 529 MB per
+// launch = 5.9 TB/s: the moving leaf (x, y, z, |p|: 32 B) once per TREE, and 12 B of cached correspondence.  And a round in
+// which 0.1-10 % of the pairs walk costs 150-300 us, because a wavefront that holds ONE walker waits out a whole descent.
+//
+// Here the launch geometry gives every workgroup ONE range of the scan's leaves and ALL the trees of its XCD piece
+// (ranges_per_tree = workgroups per piece, pick_geometry), and the loops are turned inside out:
+//     for every pass of 768 leaves:  p, |p|, q = X p ONCE;  for every tree of the piece:  cached correspondence (12 B, the
+//     loads of four trees in flight together) -> reuse test -> gate reuse or leaf record, gate, e, J, accumulation
+// so the moving leaf is read and transformed once per 8 trees (32 + 18 flops -> 4 B + 2 flops per pair at 64 keyframes), and
+// a pair that has to walk is not walked in place but QUEUED — per wavefront, 2 bytes in LDS — and the queue is walked DENSELY
+// (64 walkers per descent, from global memory: the LDS-staged top belongs to one tree) when it is full or the range is done;
+// the walker's leaf record, gate and accumulation follow its descent.  The number of descents a wavefront waits for is
+// ceil(walkers / 64), not the number of passes that hold one.
+//
+// The ACCUMULATION ORDER is another one than the tree-major body's (pass-major, walkers last), so H and b differ from it in
+// their last bits (~1e-16 relative; the pose contract is 1e-5 and the reference's own order depends on its thread count) —
+// every DECISION (leaf, depth, gate, matched flag, visit count) is the same, bit for bit, and the launch is deterministic: which
+// rounds run leaf-major is decided from the hint the previous round left (nodes walked), itself a function of the inputs.
+// tests/test_gpu_parity.py::test_deep_launches_* hold exactly that.  Chosen per round, per workgroup, without a vote: round
+// >= 2, the workgroup walked fewer than `leaf_major_nodes` nodes per pass last round (option "leaf_major", default 2048 of
+// ~10 000: less than a fifth of its pairs), every unit of the workgroup is the same range (geometry), at most kDeepTrees trees
+// and kDeepPasses passes.
+  if (DEEP && QPT == 1 && leaf_major) {
+    const int q_lane = MADICP_TID & 63, q_wave = MADICP_TID >> 6;
+    const int n_my = (hi - u_first + nslots - 1) / nslots;  // trees of this workgroup: k_first .. k_first + n_my - 1
+    // their descriptors -> LDS (11 eight-byte words each)
+    for (int w = MADICP_TID; w < n_my * 11; w += kBlock) {
+      const int tt = w / 11, ww = w - 11 * tt;
+      reinterpret_cast<long long*>(&s_tds[tt])[ww] =
+          ((const __attribute__((address_space(1))) long long*)(uintptr_t)&job->trees[k_first + tt])[ww];
+    }
+    __syncthreads();
+    const int i_lo = r_first * S, i_hi = min(L, (r_first + 1) * S);
+    int qn = 0;  // entries in this wavefront's queue (wave-uniform)
+
+    // the evaluation of one pair whose leaf is known: record, gate (mad_icp.cpp:81-83), e, J, weights, accumulation
+    // (mad_icp.cpp:59-101) — the arithmetic of the tree-major body, statement for statement
+    auto evaluate = [&](const TreeDesc& td, int kk, int i, int lf, bool walked_now, float slack_on_file, double wear, double px,
+                        double py, double pz, double pnorm, double q0, double q1, double q2) {
+      gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + lf);
+      const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+      const double g0 = q0 - la.x, g1 = q1 - la.y, g2 = q2 - lb.x;
+      const double src_ball = min_ball + b_ratio * pnorm;
+      const double dist = sqrt(dotc(g0, g1, g2, g0, g1, g2));
+      const bool rejected = dist > src_ball;
+      {
+        const float slack = rejected ? __double2float_rd((dist - src_ball) + wear) : 0.f;
+        if (walked_now || slack != slack_on_file) cache_gate[(long long)kk * L + i] = slack;
+      }
+      if (rejected) return;
+      if (mark_matched) matched[i] = 1;
+      const double bbox0 = ld.x;
+      const double n0 = lb.y, n1 = lc.x, n2 = lc.y;
+#ifndef MADICP_EXACT_SOLVE
+      {
+#pragma clang fp contract(fast)
+        const double e = g0 * n0 + g1 * n1 + g2 * n2;
+        double J[6];
+        J[0] = n0 * R[0] + n1 * R[3] + n2 * R[6];
+        J[1] = n0 * R[1] + n1 * R[4] + n2 * R[7];
+        J[2] = n0 * R[2] + n1 * R[5] + n2 * R[8];
+        J[3] = J[2] * py - J[1] * pz;
+        J[4] = J[0] * pz - J[2] * px;
+        J[5] = J[1] * px - J[0] * py;
+        double scale = 1.0;
+        const double chi = fabs(e);
+        if (chi > rho) scale = fast_div(rho, chi, fast_rcp(chi));
+        const double w = 1.0 - fast_div(bbox0, min_ball, inv_min_ball);
+        scale *= w * w;
+        double sJ[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
+        int v = 0;
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+          for (int rr = cc; rr < 6; ++rr) {
+            acc[v] = __builtin_fma(sJ[rr], J[cc], acc[v]);
+            ++v;
+          }
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) acc[21 + rr] = __builtin_fma(sJ[rr], e, acc[21 + rr]);
+      }
+#else
+      const double e = dotc(g0, g1, g2, n0, n1, n2);
+      double J[6];
+      J[0] = dotc(n0, n1, n2, R[0], R[3], R[6]);
+      J[1] = dotc(n0, n1, n2, R[1], R[4], R[7]);
+      J[2] = dotc(n0, n1, n2, R[2], R[5], R[8]);
+      const double a0 = -J[0], a1 = -J[1], a2 = -J[2];
+      J[3] = dotc(a0, a1, a2, 0.0, pz, -py);
+      J[4] = dotc(a0, a1, a2, -pz, 0.0, px);
+      J[5] = dotc(a0, a1, a2, py, -px, 0.0);
+      double scale = 1.0;
+      const double chi = fabs(e);
+      if (chi > rho) scale = rho / chi;
+      const double w = 1.0 - bbox0 / min_ball;
+      scale *= w * w;
+      double sJ[6];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) sJ[rr] = scale * J[rr];
+      int v = 0;
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+        for (int rr = cc; rr < 6; ++rr) acc[v++] += sJ[rr] * J[cc];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += sJ[rr] * e;
+#endif
+      acc[27] += 1.0;
+    };
+
+    // the queue of this wavefront, walked densely: every lane one queued pair (pass, tree, lane of origin)
+    auto drain = [&]() {
+      wave_lds_order();
+      for (int b = 0; b < qn; b += 64) {
+        const bool has = b + q_lane < qn;
+        const int e = has ? (int)s_queue[q_wave][b + q_lane] : 0;
+        const int tt = (e >> 6) & (kDeepTrees - 1), pc = e >> (6 + kDeepTreesLog2);
+        const int i = i_lo + pc * kBlock + q_wave * 64 + (e & 63);
+        const TreeDesc& td = s_tds[has ? tt : 0];
+        const vd4 p = has ? ((gptr_d4)(uintptr_t)moving)[i] : vd4{0.0, 0.0, 0.0, 0.0};
+#ifdef MADICP_XFORM_HOMOGENEOUS
+        const double a0[1] = {((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0]};
+        const double a1[1] = {((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1]};
+        const double a2[1] = {((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2]};
+#else
+        const double a0[1] = {t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z)};
+        const double a1[1] = {t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z)};
+        const double a2[1] = {t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z)};
+#endif
+        const bool wv[1] = {has};
+        int xi[1], xl[1], xd[1];
+        double xm[1] = {3.0e38};
+        descend_multi<1>(td, s_top, s_exit, 0, a0, a1, a2, wv, xi, xl, xd, xm);  // (global memory: no staged top here)
+        if (has) {
+          const int kk = k_first + tt;
+          const double wear = __builtin_fma(p.w, wear_alpha, wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) +
+                                                                                                    fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0)));
+          visits += (unsigned int)xd[0];
+          walked_visits += (unsigned int)xd[0];
+          const long long ci = (long long)kk * L + i;
+          const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
+          cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
+          cache_margin[ci] = cacheable ? __double2float_rd(xm[0] + wear) : 0.f;
+          evaluate(td, kk, i, xl[0], true, 0.f, wear, p.x, p.y, p.z, p.w, a0[0], a1[0], a2[0]);
+        }
+      }
+      qn = 0;
+      wave_lds_order();
+    };
+
+    int pc = 0;
+    for (int base = i_lo; base < i_hi; base += kBlock, ++pc) {
+      // (a pass queues at most 64 walkers per tree and wavefront: room is made HERE, where no pair is in registers)
+      if (qn + 64 * n_my > kQueueCap) drain();
+      const int i = base + MADICP_TID;
+      const bool valid = i < i_hi;
+      vd4 p = vd4{0.0, 0.0, 0.0, 0.0};
+      if (pc == 0) p = pv0[0];  // (fetched before the solve prologue; clamped index: harmless for an invalid lane)
+      else if (valid) p = ((gptr_d4)(uintptr_t)moving)[i];
+#ifdef MADICP_XFORM_HOMOGENEOUS
+      const double q0 = ((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0];
+      const double q1 = ((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1];
+      const double q2 = ((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2];
+#else
+      const double q0 = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
+      const double q1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
+      const double q2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+#endif
+      const double wear_p = __builtin_fma(p.w, wear_alpha, wear_beta);
+      for (int t0 = 0; t0 < n_my; t0 += 4) {  // the trees of this workgroup, four at a time: their cached records in flight together
+        unsigned int cw[4];
+        float cm[4], cg[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          cw[a] = 0u; cm[a] = 0.f; cg[a] = 0.f;
+          if (valid && t0 + a < n_my) {
+            const long long ci = (long long)(k_first + t0 + a) * L + i;
+            cw[a] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
+            cm[a] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
+            if (gate_reuse) cg[a] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_gate)[ci];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (t0 + a >= n_my) break;  // (uniform)
+          const int tt = t0 + a;
+          const TreeDesc& td = s_tds[tt];
+          const double wear = wear_p + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) + fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0));
+          const bool keep = valid && (double)cm[a] > wear;
+          const bool w = valid && !keep;
+          // queue the walkers: pass, tree, lane — in pass, tree, lane order (a ballot and a prefix count: deterministic)
+          const unsigned long long wm = __ballot(w);
+          if (wm) {  // (wave-uniform)
+            if (w) s_queue[q_wave][qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
+                       (unsigned short)((pc << (6 + kDeepTreesLog2)) | (tt << 6) | q_lane);
+            qn += __popcll(wm);
+            walked |= w;
+          }
+          if (keep) {
+            visits += cw[a] >> 26;
+            if (!(gate_reuse && (double)cg[a] > wear))
+              evaluate(td, k_first + tt, i, (int)(cw[a] & kCacheIdxMask), false, cg[a], wear, p.x, p.y, p.z, p.w, q0, q1, q2);
+          }
+        }
+      }
+    }
+    drain();
+  } else

@@ -5,7 +5,7 @@
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
 // s_td, cache_gate; per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
-// cgate0 / cword0 (the first pass's pose-independent loads, already issued); MADICP_HAS_QUEUE 1: also QUEUE, queue_hint, s_queue; state it updates: desc_tree, staged_tree, acc[kAcc], visits,
+// cgate0 / cword0 (the first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
   int k = k_first, r = r_first;
@@ -30,107 +30,7 @@
     // wear of a pair of this tree up to this round: A = |p| wear_alpha + wear_k (kernels.hip.h, "Bookkeeping without a store")
     const double wear_k = wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) + fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0));
 
-#if MADICP_HAS_QUEUE
-    // ---- QUEUED WALKS (round 5; icp_round only) -----------------------------------------------------------------------
-    // A unit of many passes (a batch shares the chip: BASELINE configs[4] has 26 passes per unit) in a round in which SOME
-    // pairs have to walk: with the walk inside the pass, a wavefront that holds ONE walker waits out a whole descent — at 2 %
-    // walkers three wavefronts in four do (0.98^64 = 0.27), and the per-round trace of configs[4] shows rounds 2-5 as slow as
-    // rounds 0-1 in which every pair walks (profiles/r5_k64_round_trace_before.md).  Here the unit is cut into chunks of
-    // kQueueChunk passes, and a chunk is done in three sweeps:
-    //   A  the reuse test of every pair (coordinates + cached margin, one coalesced round trip): pairs that pass get their
-    //      margin refreshed, the others are queued — per WAVEFRONT, in pass order then lane order (a ballot and a prefix
-    //      count: deterministic, no barrier), 2 bytes each in LDS;
-    //   B  the wavefront walks its queue DENSELY, 64 walkers per descent, and leaves leaf | depth and the fresh margin in the
-    //      correspondence cache;
-    //   C  the passes themselves, every pair's leaf now in the cache (a pair the cache cannot hold — depth > 63 — walks in
-    //      place): gate, e, J, accumulation in the SAME lane and pass order as without the queue.
-    // So the sums are the bits of the unqueued order whatever walked (tests: reuse on == off, queue on == off), and the
-    // number of descents a wavefront waits for is ceil(walkers / 64), not the number of passes that hold a walker.  Sweep A
-    // costs a coalesced round trip per pass (0.67 us measured), so the mode is chosen per round without a vote from what
-    // the workgroup walked in the PREVIOUS round (the hint it left behind its partials: nodes walked): at least `queue_nodes`
-    // per pass (option "queue_walks", default 32 — the walkers of a round are a tenth of the round before, GN converges
-    // quadratically), round >= 2, units of at least kQueueMinPasses passes.  Speed only.
-    const bool qmode = QUEUE && QPT == 1 && reuse && queue_hint && (i_end - r * S) >= kQueueMinPasses * kBlock;  // (workgroup-uniform)
-#else
-    constexpr bool qmode = false;
-#endif
-    const int chunk_leaves = qmode ? kQueueChunk * kBlock : 0x40000000;
-    for (int cbase = r * S; cbase < i_end; cbase += min(chunk_leaves, i_end - cbase)) {
-    const int c_end = min(i_end, cbase + min(chunk_leaves, i_end - cbase));
-#if MADICP_HAS_QUEUE
-    if (qmode) {
-      const int q_lane = MADICP_TID & 63, q_wave = MADICP_TID >> 6;
-      if (n_top_avail > 0 && k != staged_tree) {  // (workgroup-uniform; stage_hint holds in this mode) the tree's top levels into LDS
-        if (staged_tree >= 0) __syncthreads();
-        gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-        gptr_u4 ge = (gptr_u4)(uintptr_t)td.top_exit;
-        for (int e = MADICP_TID; e < n_top_avail; e += kBlock) {
-          s_top[e] = gt[e];
-          reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
-        }
-        __syncthreads();
-        staged_tree = k;
-      }
-      // sweep A: who has to walk?
-      int qn = 0;  // entries in this wavefront's queue (wave-uniform)
-      int pc = 0;
-      for (int base = cbase; base < c_end; base += kBlock, ++pc) {
-        const int i = base + MADICP_TID;
-        const bool v = i < c_end;
-        vd4 p = vd4{0.0, 0.0, 0.0, 0.0};
-        float cm = 0.f;
-        if (u == u_first && base == r * S) {  // (workgroup-uniform) fetched before the solve prologue
-          p = pv0[0];
-          cm = cmar0[0];
-        } else if (v) {
-          p = ((gptr_d4)(uintptr_t)moving)[i];
-          cm = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[(long long)k * L + i];
-        }
-        const bool keep = v && (double)cm > __builtin_fma(p.w, wear_alpha, wear_k);
-        const bool w = v && !keep;
-        const unsigned long long wm = __ballot(w);
-        if (w) s_queue[q_wave][qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
-                   (unsigned short)(pc * 64 + q_lane);
-        qn += __popcll(wm);
-        walked |= w;
-      }
-      wave_lds_order();
-      // sweep B: the wavefront's walkers, 64 to a descent
-      const int n_top_q = (k == staged_tree) ? n_top_avail : 0;
-      for (int b = 0; b < qn; b += 64) {
-        const bool has = b + q_lane < qn;
-        const int e = has ? (int)s_queue[q_wave][b + q_lane] : 0;
-        const int i = cbase + (e >> 6) * kBlock + q_wave * 64 + (e & 63);
-        const vd4 p = has ? ((gptr_d4)(uintptr_t)moving)[i] : vd4{0.0, 0.0, 0.0, 0.0};
-#ifdef MADICP_XFORM_HOMOGENEOUS
-        const double a0[1] = {((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0]};
-        const double a1[1] = {((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1]};
-        const double a2[1] = {((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2]};
-#else
-        const double a0[1] = {t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z)};
-        const double a1[1] = {t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z)};
-        const double a2[1] = {t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z)};
-#endif
-        const bool wv[1] = {has};
-        int xi[1], xl[1], xd[1];
-        double xm[1] = {3.0e38};
-        descend_multi<1>(td, s_top, s_exit, n_top_q, a0, a1, a2, wv, xi, xl, xd, xm);
-        if (has) {
-          walked_visits += (unsigned int)xd[0];
-          const long long ci = (long long)k * L + i;
-          const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
-          cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
-          cache_margin[ci] = cacheable ? __double2float_rd(xm[0] + __builtin_fma(p.w, wear_alpha, wear_k)) : 0.f;
-          cache_gate[ci] = 0.f;  // (the slack on file belongs to the OLD leaf: sweep C evaluates this pair)
-        }
-      }
-      // sweep C reads what sweeps A and B of this wavefront stored (other lanes' entries too)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-#endif
-    for (int base = cbase; base < c_end; base += QPT * kBlock) {
+    for (int base = r * S; base < i_end; base += QPT * kBlock) {
       double px[QPT], py[QPT], pz[QPT], pn[QPT], q0[QPT], q1[QPT], q2[QPT], margin[QPT];
       bool valid[QPT], walk[QPT];
       int leaf[QPT], depth[QPT];
@@ -150,7 +50,7 @@
         cgate[j] = 0.f;
         cword[j] = 0u;
         skip[j] = false;
-        if (!qmode && u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
+        if (u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
           pv[j] = pv0[j];
           cmar[j] = cmar0[j];
           cgate[j] = cgate0[j];
@@ -192,18 +92,10 @@
         // grows: thresholds measured against it are never rewritten while they hold)
         const double wear = __builtin_fma(p.w, wear_alpha, wear_k);
         wearv[j] = wear;
-        if (qmode) {  // sweep C of a queued chunk: sweeps A / B left every pair's leaf in the cache, valid for THIS pose
-          if (valid[j] && (double)cmar[j] > wear) {
-            leaf[j] = (int)(cword[j] & kCacheIdxMask);
-            depth[j] = (int)(cword[j] >> 26);
-            walk[j] = false;
-          }  // (threshold 0: a pair the cache cannot hold — it walks in place)
-        } else if (reuse && valid[j]) {
-          if ((double)cmar[j] > wear) {  // every side test of the old path keeps its sign: same leaf, same depth
-            leaf[j] = (int)(cword[j] & kCacheIdxMask);
-            depth[j] = (int)(cword[j] >> 26);
-            walk[j] = false;
-          }
+        if (reuse && valid[j] && (double)cmar[j] > wear) {  // every side test of the old path keeps its sign: same leaf, same depth
+          leaf[j] = (int)(cword[j] & kCacheIdxMask);
+          depth[j] = (int)(cword[j] >> 26);
+          walk[j] = false;
         }
         // same leaf as when the slack was measured, and still further outside its ball than it can have moved since?
         skip[j] = gate_reuse && valid[j] && !walk[j] && (double)cgate[j] > wear;
@@ -249,7 +141,7 @@
           if (walk[j]) {
             leaf[j] = wleaf[j];
             depth[j] = wdepth[j];
-            if (!qmode) walked_visits += (unsigned int)wdepth[j];  // (a queued chunk counted this pair's walk in sweep B)
+            walked_visits += (unsigned int)wdepth[j];
             if (cache_leaf) {
               const long long ci = (long long)k * L + (base + j * kBlock + MADICP_TID);
               const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
@@ -373,5 +265,4 @@
       }
       if (u == u_first && base == r * S) { MADICP_STAMP(9); }
     }
-    }  // chunk
   }

@@ -184,8 +184,8 @@ struct Job {
   int32_t ranges_per_tree;  // launch geometry: every tree's moving leaves are cut into this many ranges
   int32_t stage_min_leaves; // stage a tree's top levels into LDS only for units with at least this many leaves
   int32_t lds_top;          // 1 when the launch carries kTopLdsBytes of dynamic LDS
-  int32_t queue_nodes;      // queued walks: a unit is queued when the workgroup walked at least this many nodes per pass in the
-                            // previous round (0: never; option "queue_walks")
+  int32_t queue_nodes;      // DEEP launches: a round is done leaf-major when the workgroup walked FEWER than this many nodes per
+                            // pass in the previous round (0: never; option "leaf_major")
   int32_t seq;              // streamed registrations: what icp_final leaves in HostResult::seq when everything is written
   uint32_t epoch;           // icp_persist: distinguishes this launch's exchange granules from every earlier launch's (host counter)
   int32_t error;            // icp_persist: non-zero when a bounded in-launch wait ran out (results invalid)
@@ -360,10 +360,13 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 // pairs that are evaluated are accumulated in the same order.
 constexpr unsigned int kCacheIdxMask = 0x03ffffffu;
 constexpr int kCacheMaxDepth = 63;
-// queued walks (icp_linearize_body.inc.h): a unit of at least kQueueMinPasses passes is done in chunks of kQueueChunk passes
-// whose walkers are queued per wavefront (2 bytes each in LDS) and walked densely
-constexpr int kQueueChunk = 16;
-constexpr int kQueueMinPasses = 4;
+// DEEP launches (a batch shares the chip) and their leaf-major rounds (icp_leaf_major.inc.h): ranges of at least
+// kQueueMinPasses passes; at most kDeepTrees trees per workgroup and 64 passes per range (a queue entry is pass | tree | lane in
+// 16 bits); kQueueCap queued walkers per wavefront before the queue is walked
+constexpr int kQueueMinPasses = 2;
+constexpr int kDeepTreesLog2 = 4, kDeepTrees = 1 << kDeepTreesLog2;
+constexpr int kDeepPasses = 64;
+constexpr int kQueueCap = 1024;
 
 // QPT independent descents per lane advanced in lock-step (their loads are issued together).  Phase 1 walks the
 // LDS copy of the tree's top levels (s_top / s_exit, n_top entries), phase 2 continues in global memory.
@@ -1409,8 +1412,9 @@ __device__ __forceinline__ bool p2p_exchange(const PeerBox& pb, int scan, int r_
 // there) and takes a ticket; the workgroup that draws the last one folds the scan's rows in the canonical order (stage 1 by
 // all its threads, stage 2 by wave 0: the bits of icp_reduce) and resets the ticket.  `totals` (the reduced sums of the
 // PREVIOUS round, read in the prologue) and `totals_out` are the two parity halves of one buffer, never the same memory.
-// QUEUE: the variant with the queued-walk sweeps compiled in (icp_linearize_body.inc.h) — launched only when a unit is at
-// least kQueueMinPasses passes long; their mere presence costs the one-scan launch 0.45 us (measured, profiles/r5_e_ab.md)
+// QUEUE (= DEEP): the variant with the leaf-major rounds compiled in (icp_leaf_major.inc.h) — launched only for the geometry
+// they are for (a batch sharing the chip: pick_geometry); code of that size in the one-scan kernel costs its launch 0.45 us
+// by its mere presence (measured with the first form of the queue, profiles/r5_e_ab.md)
 // P2P (multi-GPU, option "shard_p2p"): the join over the ranks happens INSIDE the prologue, over the peer-mapped mailboxes
 // (p2p_exchange above) — the launch sequence of a sharded registration is then the single-GPU one.
 template <int QPT, bool TRACE, bool FOLD = false, bool TAIL = false, bool QUEUE = false, bool P2P = false>
@@ -1499,8 +1503,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int opt_stage_min = job->stage_min_leaves;
   const int L = job->L;
   const int flags = job->flags;
-  const int opt_queue = QUEUE ? job->queue_nodes : 0;
-  __shared__ unsigned short s_queue[QUEUE ? kWaves : 1][QUEUE ? kQueueChunk * 64 : 1];  // queued walks: per wavefront, pass-in-chunk * 64 + lane
+  constexpr bool DEEP = QUEUE;
+  const int opt_leaf_major = DEEP ? job->queue_nodes : 0;
+  __shared__ unsigned short s_queue[DEEP ? kWaves : 1][DEEP ? kQueueCap : 1];  // leaf-major rounds: queued walkers per wavefront
+  __shared__ __attribute__((aligned(16))) TreeDesc s_tds[DEEP ? kDeepTrees : 1];  // ... and the descriptors of the workgroup's trees
   const bool last_round = (round == n_iters - 1);
   const bool mark_matched = last_round || (flags & kFlagMatchAll);
   const double* __restrict__ moving = job->moving;
@@ -1680,13 +1686,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const bool stage_hint = round == 0 || hint_nodes > 0.0;
   // passes this workgroup makes in a round (every unit the same length but the last range of a tree)
   const int wg_passes = have_first ? ((hi - u_first + nslots - 1) / nslots) * ((S + kBlock - 1) / kBlock) : 0;
-  const bool queue_hint = QUEUE && opt_queue > 0 && round >= 2 && hint_nodes >= (double)opt_queue * (double)wg_passes;
-
+  // leaf-major round (DEEP launches, icp_leaf_major.inc.h)?  Workgroup-uniform, no vote: the geometry gives every unit of the
+  // workgroup the same range, the trees and passes fit a queue entry, and last round the workgroup walked few nodes per pass
+  const int wg_units = have_first ? (hi - u_first + nslots - 1) / nslots : 0;
+  const bool leaf_major = DEEP && reuse && round >= 2 && opt_leaf_major > 0 && RPT == nslots && wg_units >= 1 &&
+                          wg_units <= kDeepTrees && (S + kBlock - 1) / kBlock <= kDeepPasses &&
+                          hint_nodes < (double)opt_leaf_major * (double)wg_passes;
 
 #define MADICP_TID threadIdx.x
-#define MADICP_HAS_QUEUE 1  // (the sweeps are dead code in the QUEUE = false instantiations)
+#include "icp_leaf_major.inc.h"  // (ends in `else`: the tree-major body below is the other branch)
+  {
 #include "icp_linearize_body.inc.h"
-#undef MADICP_HAS_QUEUE
+  }
 #undef MADICP_TID
 
   MADICP_STAMP(5);
@@ -2032,9 +2043,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const bool stage_hint = stage_hint_next;
 
 #define MADICP_TID tid
-#define MADICP_HAS_QUEUE 0
 #include "icp_linearize_body.inc.h"
-#undef MADICP_HAS_QUEUE
 #undef MADICP_TID
 
     MADICP_STAMP(5);

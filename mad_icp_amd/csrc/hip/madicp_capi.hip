@@ -208,8 +208,9 @@ struct madicp_ctx {
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
   int cache_gate = 1;   // option "cache_gate": a pair that keeps its leaf and was rejected with more slack than it has moved since is
                         // not evaluated again (kernels.hip.h, "Gate reuse")
-  int queue_walks = 12; // option "queue_walks": units of many passes queue their walkers per wavefront and walk them densely in a
-                        // round that follows one in which the workgroup walked at least this many nodes per pass (0: never)
+  int queue_walks = 2048; // option "leaf_major": a DEEP launch (a batch shares the chip) runs a round leaf-major — moving leaf once per
+                        // pass for all the workgroup's trees, walkers queued and walked densely — when the workgroup walked fewer
+                        // than this many nodes per pass in the previous round (0: never; icp_leaf_major.inc.h)
   int nn_lds_top = 0;  // option "nn_lds_top": nn_search batches of >= 16 k queries walk the tree's top levels from LDS
                        // (nn_descend_top).  Off: measured SLOWER for one 120 k-query launch (8.7 vs 6.6 us against a
                        // 20 k-leaf tree, 10.7 vs 9.2 us against a 120 k-leaf tree) — staging 48 KiB per workgroup costs
@@ -455,9 +456,17 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
     const long long cap = std::max<long long>(1, max_L / 256);  // (a range of fewer than 256 leaves is not worth a descriptor)
     g.ranges_per_tree = static_cast<int>(std::max<long long>(g.ranges_per_tree, std::min(want, cap)));
   }
+  // DEEP launches: more trees than workgroups per XCD piece (a batch shares the chip).  Every workgroup then gets ONE range
+  // of the scan and ALL the trees of its piece — ranges_per_tree = workgroups per piece, so that its units u_first, u_first +
+  // nslots, ... are the same range of consecutive trees — which is what the leaf-major rounds need (icp_leaf_major.inc.h)
+  const int nslots = g.grid / 8;
+  if (K >= 8 && ctx->queue_walks > 0 && g.qpt == 1 && g.ranges_per_tree < nslots &&
+      max_L / nslots >= madicp::kQueueMinPasses * madicp::kBlock && (K + 7) / 8 + 1 <= madicp::kDeepTrees)
+    g.ranges_per_tree = nslots;
   const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
   g.lds_bytes = (K > 0 && per_range >= ctx->stage_min_leaves) ? kTopLdsBytes : 0;
-  g.queue = (K > 0 && ctx->queue_walks > 0 && g.qpt == 1 && per_range >= madicp::kQueueMinPasses * madicp::kBlock) ? 1 : 0;
+  g.queue = (K >= 8 && ctx->queue_walks > 0 && g.qpt == 1 && g.ranges_per_tree == nslots &&
+             per_range >= madicp::kQueueMinPasses * madicp::kBlock) ? 1 : 0;
   return g;
 }
 
@@ -1194,8 +1203,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->cache_corr = value ? 1 : 0;
   } else if (k == "cache_gate") {
     ctx->cache_gate = value ? 1 : 0;
-  } else if (k == "queue_walks") {
-    if (value < 0 || value > (1 << 20)) return fail(MADICP_ERR_INVALID, "queue_walks must be 0 (never) or a node count per pass");
+  } else if (k == "leaf_major") {
+    if (value < 0 || value > (1 << 20)) return fail(MADICP_ERR_INVALID, "leaf_major must be 0 (never) or a node count per pass");
     ctx->queue_walks = (int)value;
   } else if (k == "lds_stage_min_leaves") {
     if (value < 0) return fail(MADICP_ERR_INVALID, "lds_stage_min_leaves must be >= 0");
@@ -1252,7 +1261,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "comm_graph") v = ctx->comm_graph;
   else if (k == "cache_correspondences") v = ctx->cache_corr;
   else if (k == "cache_gate") v = ctx->cache_gate;
-  else if (k == "queue_walks") v = ctx->queue_walks;
+  else if (k == "leaf_major") v = ctx->queue_walks;
   else if (k == "lds_stage_min_leaves") v = ctx->stage_min_leaves;
   else if (k == "eager_when_busy") v = ctx->eager_when_busy;
   else if (k == "seq_completion") v = ctx->seq_completion;

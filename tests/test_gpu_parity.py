@@ -383,14 +383,15 @@ def test_correspondence_reuse_is_exact(ctx, K):
     _teardown(ctx, tids, mids)
 
 
-def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
-    """Option "queue_walks" (icp_linearize_body.inc.h, "QUEUED WALKS"): when a batch shares the chip a workgroup's
-    unit is many passes long, and from round 2 on — while the previous round still walked enough (1: any walk at all; the
-    default asks for 12 nodes per pass) — the pairs that still have to walk are queued per wavefront and walked densely
-    before the passes run.  32 keyframes, 8 scans in flight (one range per tree: 11 passes per unit): final pose, H,
-    b, matched flags, matched counts and the visit counter bit for bit those of walking inside the pass, and those of walking
-    EVERY pair every round (no correspondence reuse, hence no queue) — the accumulation order does not depend on who walked.
-    And the poses are the oracle's (mad_icp.cpp:74-117 under pipeline.cpp:166-193)."""
+def test_deep_launches_leaf_major_rounds(ctx):
+    """A batch that shares the chip (32 keyframes, 8 scans in flight: 32 workgroups per scan, four trees per workgroup) is a
+    DEEP launch: every workgroup gets one range of the scan and all the trees of its XCD piece, and the rounds that follow a
+    round with few walkers run LEAF-MAJOR (icp_leaf_major.inc.h; option "leaf_major"): the moving leaf once per pass for all
+    the workgroup's trees, the pairs that still walk queued per wavefront and walked densely.  Same DECISIONS as the tree-major
+    order, bit for bit — matched flags, matched counts, the visit counter (the reference's count: mad_tree.cpp:144-152 per pair)
+    — whatever the threshold (default, every round from round 2, never), with and without gate reuse, and as without any
+    correspondence reuse; H, b and the pose agree to 1e-12 (another summation order, nothing else); bit-reproducible; and the
+    poses are the oracle's (mad_icp.cpp:74-117 under pipeline.cpp:166-193)."""
     pb = street_problem(32, n_queries=8)
     tids, ots = [], []
     for s_, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
@@ -400,31 +401,40 @@ def test_queued_walks_give_the_bits_of_in_pass_walks(ctx):
     qh = [capi.HostTree(s_, B_MAX, B_MIN, 2) for s_ in pb["query_scans"]]
     mids = [ctx.moving_upload(h.leaf_means()) for h in qh]
     X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
-    assert min(h.num_leaves for h in qh) >= 4 * 768  # (deep units: what the queue is for)
+    assert min(h.num_leaves for h in qh) >= 2 * 4 * 768  # (ranges of at least two passes with four workgroups per XCD piece: a DEEP launch)
+    assert ctx.get_option("leaf_major") == 2048
     res = {}
-    assert ctx.get_option("queue_walks") == 12  # the default: queue after a round that walked >= 12 nodes per pass
-    for name, opts in (("queued", dict(queue_walks=1)), ("in pass", dict(queue_walks=0)), ("queued by default", dict(queue_walks=12)),
-                       ("no gate reuse", dict(queue_walks=1, cache_gate=0)), ("in pass, no gate reuse", dict(queue_walks=0, cache_gate=0)),
-                       ("no reuse", dict(queue_walks=1, cache_correspondences=0))):
+    for name, opts in (("default", dict()), ("default again", dict()), ("every round", dict(leaf_major=1 << 20)),
+                       ("every round, no gate reuse", dict(leaf_major=1 << 20, cache_gate=0)), ("never", dict(leaf_major=0)),
+                       ("never, no gate reuse", dict(leaf_major=0, cache_gate=0)), ("no reuse", dict(cache_correspondences=0))):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
         r["matched"] = [ctx.icp_fetch_matched(i, h.num_leaves) for i, h in enumerate(qh)]
         res[name] = r
-        ctx.set_option("queue_walks", 12)
+        ctx.set_option("leaf_major", 2048)
         ctx.set_option("cache_correspondences", 1)
         ctx.set_option("cache_gate", 1)
-    for other in ("in pass", "queued by default", "no gate reuse", "in pass, no gate reuse", "no reuse"):
-        for key in ("X", "H", "b", "n_matched", "visits"):
-            assert np.array_equal(res["queued"][key], res[other][key]), (other, key)
-        for a, b in zip(res["queued"]["matched"], res[other]["matched"]):
+    ref = res["default"]
+    for key in ("X", "H", "b", "n_matched", "visits"):
+        assert np.array_equal(ref[key], res["default again"][key]), key  # deterministic
+        assert np.array_equal(res["never"][key], res["never, no gate reuse"][key]), key  # gate reuse: the same bits
+        assert np.array_equal(res["every round"][key], res["every round, no gate reuse"][key]), key
+    for other in ("every round", "every round, no gate reuse", "never", "never, no gate reuse", "no reuse"):
+        o = res[other]
+        assert np.array_equal(ref["n_matched"], o["n_matched"]) and np.array_equal(ref["visits"], o["visits"]), other
+        for a, b in zip(ref["matched"], o["matched"]):
             assert np.array_equal(a, b), other
+        assert np.abs(ref["X"] - o["X"]).max() <= 1e-12, (other, np.abs(ref["X"] - o["X"]).max())
+        assert np.abs(ref["H"] - o["H"]).max() <= 1e-12 * np.abs(ref["H"]).max(), other
+        assert np.abs(ref["b"] - o["b"]).max() <= 1e-10 * max(1.0, np.abs(ref["b"]).max()), other
     for q in (0, 5):
         o = O.icp_register(O.Tree(pb["query_scans"][q], B_MAX, B_MIN, 2), ots, pb["query_guess"][q], 15, B_MAX, RHO_KER, B_RATIO,
                            num_threads=4)
-        d = np.linalg.inv(o["T"]) @ capi.pose44(res["queued"]["X"][q])
+        d = np.linalg.inv(o["T"]) @ capi.pose44(ref["X"][q])
         assert np.linalg.norm(d[:3, 3]) <= 1e-5 and np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)) <= 1e-5
-        assert np.array_equal(res["queued"]["matched"][q], o["matched"])
+        assert np.array_equal(ref["matched"][q], o["matched"])
+        assert ref["visits"][q] == o["depth_sum"]
     _teardown(ctx, tids, mids)
 
 

@@ -19,7 +19,7 @@ if has small; then
   timeout 300 python tools/small_cloud_diff.py > $OUT/small_cloud_diff.log 2>&1; grep -c "=== cloud" $OUT/small_cloud_diff.log
 fi
 if has k64; then
-  MADICP_AB="queue_walks=0;queue_walks=1" timeout 600 python tools/k64_probe.py > $OUT/k64_ab.log 2>&1; grep "K=64" $OUT/k64_ab.log
+  MADICP_AB="leaf_major=0;leaf_major=2048" timeout 600 python tools/k64_probe.py > $OUT/k64_ab.log 2>&1; grep "K=64" $OUT/k64_ab.log
   K64_ONLY8=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/k64trace -o t -- python tools/k64_probe.py > $OUT/k64_probe.log 2>&1
   python tools/k64_trace.py $(find $OUT/k64trace -name "t_kernel_trace.csv" | head -1) > $OUT/k64_round_trace.md; rm -rf $OUT/k64trace; cat $OUT/k64_round_trace.md
 fi
