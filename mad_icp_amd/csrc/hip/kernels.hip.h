@@ -1689,7 +1689,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // leaf-major round (DEEP launches, icp_leaf_major.inc.h)?  Workgroup-uniform, no vote: the geometry gives every unit of the
   // workgroup the same range, the trees and passes fit a queue entry, and last round the workgroup walked few nodes per pass
   const int wg_units = have_first ? (hi - u_first + nslots - 1) / nslots : 0;
-  const bool leaf_major = DEEP && reuse && round >= 2 && opt_leaf_major > 0 && RPT == nslots && wg_units >= 1 &&
+  const bool leaf_major = DEEP && reuse && round >= 1 && opt_leaf_major > 0 && RPT == nslots && wg_units >= 1 &&
                           wg_units <= kDeepTrees && (S + kBlock - 1) / kBlock <= kDeepPasses &&
                           hint_nodes < (double)opt_leaf_major * (double)wg_passes;
 

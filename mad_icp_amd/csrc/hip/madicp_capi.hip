@@ -208,7 +208,7 @@ struct madicp_ctx {
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
   int cache_gate = 1;   // option "cache_gate": a pair that keeps its leaf and was rejected with more slack than it has moved since is
                         // not evaluated again (kernels.hip.h, "Gate reuse")
-  int queue_walks = 2048; // option "leaf_major": a DEEP launch (a batch shares the chip) runs a round leaf-major — moving leaf once per
+  int queue_walks = 8192; // option "leaf_major": a DEEP launch (a batch shares the chip) runs a round leaf-major — moving leaf once per
                         // pass for all the workgroup's trees, walkers queued and walked densely — when the workgroup walked fewer
                         // than this many nodes per pass in the previous round (0: never; icp_leaf_major.inc.h)
   int nn_lds_top = 0;  // option "nn_lds_top": nn_search batches of >= 16 k queries walk the tree's top levels from LDS

@@ -402,7 +402,7 @@ def test_deep_launches_leaf_major_rounds(ctx):
     mids = [ctx.moving_upload(h.leaf_means()) for h in qh]
     X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
     assert min(h.num_leaves for h in qh) >= 2 * 4 * 768  # (ranges of at least two passes with four workgroups per XCD piece: a DEEP launch)
-    assert ctx.get_option("leaf_major") == 2048
+    assert ctx.get_option("leaf_major") == 8192
     res = {}
     for name, opts in (("default", dict()), ("default again", dict()), ("every round", dict(leaf_major=1 << 20)),
                        ("every round, no gate reuse", dict(leaf_major=1 << 20, cache_gate=0)), ("never", dict(leaf_major=0)),
@@ -412,7 +412,7 @@ def test_deep_launches_leaf_major_rounds(ctx):
         r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
         r["matched"] = [ctx.icp_fetch_matched(i, h.num_leaves) for i, h in enumerate(qh)]
         res[name] = r
-        ctx.set_option("leaf_major", 2048)
+        ctx.set_option("leaf_major", 8192)
         ctx.set_option("cache_correspondences", 1)
         ctx.set_option("cache_gate", 1)
     ref = res["default"]
