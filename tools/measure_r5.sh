@@ -1,7 +1,8 @@
 #!/bin/bash
 # round-5 measurement pass.  usage (GPU box): tools/measure_r5.sh <tag> [what...]
 #   what: kernel (parity tests of the round kernel)  oracle (front-end vs oracle tests)  small (small-cloud listing)
-#         k64 (configs[4] A/B + per-round trace)  bench  tests (whole GPU suite)
+#         k64 (configs[4] A/B + per-round trace)  pmc (configs[4] SQ / cache counters)  trace (headline per-round kernel trace)
+#         world1 (bench.py's N > 1 branch with a world of one: shard over RCCL and over the mailboxes)  bench  tests (whole GPU suite)
 set -u
 TAG=$1; shift
 WHAT="${*:-kernel oracle small k64 bench}"
@@ -25,6 +26,19 @@ if has k64; then
 fi
 if has bench; then
   timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench.err; python tools/show_bench.py $OUT/bench_n1.json | head -40
+fi
+if has pmc; then
+  timeout 600 tools/k64_pmc.sh $OUT/k64_pmc > $OUT/k64_pmc.log 2>&1; cp $OUT/k64_pmc/summary.md $OUT/k64_pmc_summary.md 2>/dev/null; rm -rf $OUT/k64_pmc; grep -A 24 "icp_round" $OUT/k64_pmc_summary.md | head -30
+fi
+if has trace; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python tools/round_trace.py run 200 > /dev/null 2> $OUT/trace.err
+  python tools/round_trace.py split $(find $OUT/trace -name "t_kernel_trace.csv" | head -1) > $OUT/round_trace.md
+  cp $(find $OUT/trace -name "t_kernel_stats.csv" | head -1) $OUT/round_trace_kernel_stats.csv
+  rm -rf $OUT/trace
+  cat $OUT/round_trace.md
+fi
+if has world1; then
+  timeout 300 tools/shard_world1.sh $OUT/shard_world1.json; timeout 300 tools/shard_world1.sh $OUT/shard_world1_scans8.json --scans 8
 fi
 if has tests; then
   timeout 1500 python -m pytest tests -m gpu -q 2>&1 > $OUT/pytest_gpu.log; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -3
