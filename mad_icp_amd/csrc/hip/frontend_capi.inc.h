@@ -701,7 +701,23 @@ int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, doubl
   if (n < 1 || n > 0x3fffffff) return fail(MADICP_ERR_INVALID, "a cloud holds 1 .. 2^30 points");
   RC_TRY(busy_with_lookahead(ctx));
   HIP_TRY(hipSetDevice(ctx->device));
-  if (!ctx->build) HIP_TRY(hipStreamCreateWithFlags(&ctx->build, hipStreamNonBlocking));
+  if (!ctx->build) {
+    // MADICP_BUILD_CUS=<n> (experiment): the look-ahead construction only gets the first n CUs, so that its level
+    // kernels cannot spread over the CUs a registration round wants all of — whatever hardware queues the runtime maps the two
+    // streams to
+    const char* e = std::getenv("MADICP_BUILD_CUS");
+    const int n_build = e ? std::atoi(e) : 0;
+    if (n_build > 0 && n_build < ctx->n_cus) {
+      const int words = (ctx->n_cus + 31) / 32;
+      std::vector<uint32_t> mask((size_t)words, 0u);
+      for (int cu = 0; cu < n_build; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+      if (hipExtStreamCreateWithCUMask(&ctx->build, (uint32_t)words, mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->build = nullptr;
+      }
+    }
+    if (!ctx->build) HIP_TRY(hipStreamCreateWithFlags(&ctx->build, hipStreamNonBlocking));
+  }
   FrontScratch* fs = nullptr;
   RC_TRY(ensure_scratch(ctx, n, &fs));
   hipStream_t s = ctx->build;

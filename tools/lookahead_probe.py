@@ -19,7 +19,10 @@ drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in ra
 clouds = [pypeline.VectorEigen3d(s) for s in drive]
 threads = min(os.cpu_count() or 1, 16)
 ref = None
-for device, depth in ((False, 0), (False, 1), (False, 2), (False, 3), (True, 0), (True, 1)):
+CASES = ((False, 0), (False, 1), (False, 2), (False, 3), (True, 0), (True, 1))
+if os.environ.get("LOOKAHEAD_ONLY") == "device":
+    CASES = ((True, 0), (True, 1))
+for device, depth in CASES:
     if device and depth == 0:
         ref = None  # (device-built trees: their own reference trajectory)
     pl = pypeline.Pipeline(10.0, False, 0.2, 0.1, 0.8, 0.1, 0.02, 16, threads, False)
