@@ -226,6 +226,8 @@ struct madicp_ctx {
                            // launch.  Off: built, bit-identical, measured SLOWER (profiles/r4_c_shard_probe.md: the 256 tickets
                            // on one address and the cross-XCD read of the rows cost ~8 us at the end of every round; the
                            // separate icp_reduce launch costs 4.5 us and no gap)
+  int build_after_registration = 1;  // option: a look-ahead construction's kernels wait for the registration in flight (frontend_capi.inc.h)
+  hipEvent_t ev_build_gate = nullptr;
   int shard_p2p = 0;       // sharded rounds join over peer-mapped mailboxes inside the round kernel (madicp_p2p_attach) instead
                            // of icp_reduce + a collective between two rounds
   unsigned long long* p2p_box = nullptr;                  // this rank's mailbox (kP2pBoxWords; fine-grained device memory)
@@ -1120,6 +1122,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
   if (ctx->pub) hipStreamSynchronize(ctx->pub);
   if (ctx->p2p_attached) madicp_p2p_detach(ctx);
   if (ctx->p2p_box) hipFree(ctx->p2p_box);
+  if (ctx->ev_build_gate) hipEventDestroy(ctx->ev_build_gate);
   if (ctx->comm) ncclCommDestroy(ctx->comm);
   if (ctx->h_comm) hipHostFree(ctx->h_comm);
   for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
@@ -1221,6 +1224,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->debug_collective_us = (int)std::max<int64_t>(0, std::min<int64_t>(value, 1000));
   } else if (k == "shard_tail") {
     ctx->shard_tail = value ? 1 : 0;
+  } else if (k == "build_after_registration") {
+    ctx->build_after_registration = value ? 1 : 0;
   } else if (k == "shard_p2p") {
     ctx->shard_p2p = value ? 1 : 0;
   } else if (k == "shard_split") {
@@ -1269,6 +1274,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "xcd_fold") v = ctx->xcd_fold;
   else if (k == "debug_collective_us") v = ctx->debug_collective_us;
   else if (k == "shard_tail") v = ctx->shard_tail;
+  else if (k == "build_after_registration") v = ctx->build_after_registration;
   else if (k == "shard_p2p") v = ctx->shard_p2p;
   else if (k == "shard_split") v = ctx->shard_split;
   else if (k == "match_all_rounds") v = ctx->match_all;
