@@ -756,13 +756,11 @@ int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, doubl
     }
   }
   CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], s));
-  // The construction's KERNELS wait for whatever the compute stream holds right now — the registration this look-ahead was
-  // begun beside (Pipeline::compute begins it the moment its registration is submitted).  A registration round wants every CU
-  // and a level kernel's workgroups hold theirs for 10-20 us: overlapping, both take 2.5 x as long (1.6 ms per frame instead of
-  // 0.67); run one after the other the device is busy 0.22 + 0.43 ms per frame whatever hardware queues the runtime gives the
-  // two streams.  (Round 4's 0.63-0.67 ms needed four hardware queues AND the side-publishing kernel: the construction then
-  // happened to share a queue with that kernel, which spins until the registration is over — profiles/r5_lookahead_matrix.md.)
-  // The host side of the construction (staging copy above, ~60 launches below) still runs beside the registration.
+  // Option "build_after_registration" (experiment, default off): the construction's KERNELS wait for whatever the compute stream
+  // holds right now — the registration this look-ahead was begun beside.  Built to test the hypothesis that the look-ahead
+  // cliff (0.67 ms per frame in one process configuration, 1.5 in the others) is the two kernel sets fighting for the CUs;
+  // measured: it is not — with the construction strictly behind the registration the other configurations stay at 1.5-2.1 ms
+  // (profiles/r5_lookahead_matrix.md).
   if (ctx->build_after_registration) {
     if (!ctx->ev_build_gate) CLOUD_TRY(hipEventCreateWithFlags(&ctx->ev_build_gate, hipEventDisableTiming));
     CLOUD_TRY(hipEventRecord(ctx->ev_build_gate, ctx->stream));

@@ -226,7 +226,8 @@ struct madicp_ctx {
                            // launch.  Off: built, bit-identical, measured SLOWER (profiles/r4_c_shard_probe.md: the 256 tickets
                            // on one address and the cross-XCD read of the rows cost ~8 us at the end of every round; the
                            // separate icp_reduce launch costs 4.5 us and no gap)
-  int build_after_registration = 1;  // option: a look-ahead construction's kernels wait for the registration in flight (frontend_capi.inc.h)
+  int build_after_registration = 0;  // option (experiment, default off): a look-ahead construction's kernels wait for the registration in
+                                     // flight (frontend_capi.inc.h; measured: does not remove the look-ahead cliff, profiles/r5_lookahead_matrix.md)
   hipEvent_t ev_build_gate = nullptr;
   int shard_p2p = 0;       // sharded rounds join over peer-mapped mailboxes inside the round kernel (madicp_p2p_attach) instead
                            // of icp_reduce + a collective between two rounds
