@@ -707,6 +707,23 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                          "ms_per_frame_median": round(float(np.median(ts[2:])) * 1e3, 3),
                          "tree_ms": round(pl.lastBuildMs(), 3), "registration_ms": round(pl.lastIcpMs(), 3),
                          "end_translation_error_m": round(float(np.linalg.norm(np.asarray(pl.currentPose())[:3, 3] - gt[:3, 3])), 4)}
+        # the look-ahead frame depends on the process it runs in (hardware queues, which streams exist: profiles/
+        # r5_lookahead_matrix.md) and this process sets GPU_MAX_HW_QUEUES=8 for itself: the same drive in PLAIN processes, with the
+        # runtime's default queues and with eight
+        plain = {}
+        for label, qs in (("hw_queues_default", None), ("hw_queues_8", "8")):
+            env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+            if qs:
+                env["GPU_MAX_HW_QUEUES"] = qs
+            env["LOOKAHEAD_ONLY"] = "device"
+            try:
+                r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "lookahead_probe.py"), "24"],
+                                   env=env, capture_output=True, text=True, timeout=120)
+                ms = [float(l.split("mean")[1].split("ms")[0]) for l in r.stdout.splitlines() if l.startswith("device front-end")]
+                plain[label] = {"no_lookahead_ms_per_frame": ms[0], "lookahead_ms_per_frame": ms[1]}
+            except Exception as e:  # noqa: BLE001
+                plain[label] = {"error": str(e)[:120]}
+        pipe["lookahead_in_a_plain_process"] = plain
         pipe["default_is_device_front_end"] = bool(pm.Pipeline(10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False).deviceFrontEnd())
         pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: default = what an UNMODIFIED caller gets "
                         "(no setDeviceFrontEnd call, MAD_ICP_GPU_BUILD unset; round 5: the device front-end for deskew = false); "
@@ -715,7 +732,9 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                         "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "
                         "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU; "
                         "device_front_end_lookahead = the same with prefetch(scan i + 1) before compute(scan i): the next scan's "
-                        "construction runs on the library's build stream beside this scan's registration, same poses bit for bit; "
+                        "construction runs on the library's build stream beside this scan's registration, same poses bit for bit — a "
+                        "figure of THIS process (GPU_MAX_HW_QUEUES=8, framework stream): lookahead_in_a_plain_process has the same "
+                        "drive in plain processes, where the look-ahead frame can be SLOWER than the plain one; "
                         "host_path_deskew / device_front_end_deskew = deskew on (scans with distinct azimuths; the synthetic scans are "
                         "instantaneous, so compensating them moves them: timing keys, not accuracy keys), the host one with the "
                         "azimuth order computed ahead by prefetch(scan i + 1)")
