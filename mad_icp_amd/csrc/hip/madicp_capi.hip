@@ -7,6 +7,7 @@
 // device memory comes from a small in-context pool (a released buffer is reused once the event recorded at its
 // release has passed), pinned staging is grow-only, results are written by the last kernel of a registration straight
 // into a pinned host block (Job::host_out) that the caller reads after one event wait.
+#include "madicp_hip_measure.h"
 #include "kernels.hip.h"
 #include "frontend.hip.h"  // + tree_build.hip.h: device front-end
 
