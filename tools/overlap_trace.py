@@ -86,6 +86,21 @@ def report(path):
              length(busy) / 1e3 / frames, (span - length(busy) / 1e3) / frames))
     print("\nper frame; `both at once` = %.0f %% of the registration's kernel time ran while a builder kernel was running"
           % (100.0 * length(both) / max(1, length(reg))))
+    # where the kernel time goes, family by family (launches and microseconds per steady frame), and on which queues
+    fam = {}
+    for r in rows:
+        n, s_, e_ = r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if s_ < t0 or e_ > t1:
+            continue
+        key = next((f for f in ("icp_round", "icp_final", "icp_publish", "tb_chip_stats", "tb_chip_scatter", "tb_level", "tb_init",
+                                "tb_finish", "tb_emit", "tree_compact", "moving_from_leaves", "tree_transform") if f in n), "other")
+        d = fam.setdefault(key, [0, 0.0, set()])
+        d[0] += 1
+        d[1] += (e_ - s_) / 1e3
+        d[2].add(r.get("Queue_Id", "?"))
+    print("\n| kernels | launches per frame | us per frame | avg us | queues |\n|---|---|---|---|---|")
+    for key, (c, us, qs) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        print("| %s | %.1f | %.1f | %.2f | %s |" % (key, c / frames, us / frames, us / c, ",".join(sorted(qs))))
 
 
 if __name__ == "__main__":
