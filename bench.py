@@ -682,7 +682,8 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         # synthetic scans share 64 points per azimuth column, so the deskew keys run on a copy with 1e-7 m of jitter
         jitter = np.random.default_rng(0)
         drive_j = [sc + jitter.normal(scale=1e-7, size=sc.shape) for sc in drive]
-        for key, dev, ahead, dsk in (("default", None, 0, False), ("host_path", False, 0, False), ("host_path_lookahead", False, 2, False),
+        # ("default" is not run first: the first drive of a process also pays for the pool's and the builder's first allocations)
+        for key, dev, ahead, dsk in (("host_path", False, 0, False), ("default", None, 0, False), ("host_path_lookahead", False, 2, False),
                                      ("device_front_end", True, 0, False), ("device_front_end_lookahead", True, 1, False),
                                      ("host_path_deskew", False, 1, True), ("device_front_end_deskew", True, 0, True)):
             pl = pm.Pipeline(10.0, dsk, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)

@@ -13,6 +13,11 @@ from mad_icp_amd import _build, synth  # noqa: E402
 _build.build_pybind()
 from mad_icp.src.pybind import pypeline  # noqa: E402
 
+if os.environ.get("LOOKAHEAD_IMPORT_TORCH") == "1":  # (is it the framework's presence in the process that makes the look-ahead fast?)
+    import torch
+
+    torch.cuda.init()
+    torch.zeros(8, device="cuda").sum().item()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 scene = synth.Scene(0)
 drive = [synth.render_scan(scene, synth.path_pose(1.0 * i), 100 + i) for i in range(N)]
