@@ -2256,7 +2256,8 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
 // XCD's L2 — hence the acquire) and releases the sequence number at system scope.  On a time-out the caller finds
 // HostResult::error = 3 behind the sequence number.
 __global__ __launch_bounds__(256) void icp_publish(const Outbox* __restrict__ ob, const uint8_t* __restrict__ matched, int L, int seq,
-                                                   HostResult* __restrict__ ho, uint8_t* __restrict__ hm) {
+                                                   HostResult* __restrict__ ho, uint8_t* __restrict__ hm,
+                                                   unsigned long long spin_ticks) {
   __shared__ int s_bad;
   __shared__ double s_v[kOutboxGranules];
   if (threadIdx.x == 0) s_bad = 0;
@@ -2269,7 +2270,7 @@ __global__ __launch_bounds__(256) void icp_publish(const Outbox* __restrict__ ob
     while (!ok) {
       __builtin_amdgcn_s_sleep(32);
       ok = granule_try(g, (unsigned)seq, v);
-      if (!ok && wall_clock64() - t0 > 50ull * kSpinLimitTicks) break;  // 10 s: the registration never finished
+      if (!ok && wall_clock64() - t0 > spin_ticks) break;  // the registration never finished (>= 10 s; the caller's time-outs if longer)
     }
     if (!ok) s_bad = 1;
     s_v[threadIdx.x] = v;

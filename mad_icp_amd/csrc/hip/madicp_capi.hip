@@ -1727,8 +1727,11 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   const std::vector<int> ids{sl.moving_id};
   RC_TRY(run_rounds(ctx, launch, sl.d_job, ticket % madicp_ctx::kStreamSlots, ids, busy));
   if (side) {
+    // (its wait is bounded by the longest the CALLER is prepared to wait, never less than 10 s: a compute stream legitimately
+    // stalled for longer than a fixed bound would otherwise lose a registration that later completes)
+    const unsigned long long spin_ms = (unsigned long long)std::max(10000, std::max(ctx->wait_timeout_ms, ctx->comm_timeout_ms));
     hipLaunchKernelGGL(icp_publish, dim3(1), dim3(256), 0, ctx->pub, (const Outbox*)sl.d_outbox, (const uint8_t*)mv.matched, L, ticket + 1,
-                       j.host_out, j.host_matched);
+                       j.host_out, j.host_matched, spin_ms * 100000ull);
     HIP_TRY(hipGetLastError());
   }
   sl.side = side;
