@@ -13,10 +13,10 @@
 //     for every pass of 768 leaves:  p, |p|, q = X p ONCE;  for every tree of the piece:  cached correspondence (12 B, the
 //     loads of four trees in flight together) -> reuse test -> gate reuse or leaf record, gate, e, J, accumulation
 // so the moving leaf is read and transformed once per 8 trees (32 + 18 flops -> 4 B + 2 flops per pair at 64 keyframes), and
-// a pair that has to walk is not walked in place but QUEUED — per wavefront and tree, 2 bytes in LDS — and the queues are walked
-// DENSELY, tree by tree with that tree's top levels staged in LDS, 64 walkers per descent, when one of them is full (a workgroup
-// vote per pass) or the range is done; the walker's leaf record, gate and accumulation follow its descent.  The number of
-// descents a wavefront waits for is the sum over its trees of ceil(walkers / 64), not the number of passes that hold one.
+// a pair that has to walk is not walked in place but QUEUED — per wavefront, 2 bytes in LDS — and the queue is walked DENSELY
+// (64 walkers per descent, from global memory: the LDS-staged top belongs to one tree) when it is full or the range is done;
+// the walker's leaf record, gate and accumulation follow its descent.  The number of descents a wavefront waits for is
+// ceil(walkers / 64), not the number of passes that hold one.
 //
 // The ACCUMULATION ORDER is another one than the tree-major body's (pass-major, walkers last), so H and b differ from it in
 // their last bits (~1e-16 relative; the pose contract is 1e-5 and the reference's own order depends on its thread count) —
@@ -38,6 +38,7 @@
     }
     __syncthreads();
     const int i_lo = r_first * S, i_hi = min(L, (r_first + 1) * S);
+    int qn = 0;  // entries in this wavefront's queue (wave-uniform)
 
     // the evaluation of one pair whose leaf is known: record, gate (mad_icp.cpp:81-83), e, J, weights, accumulation
     // (mad_icp.cpp:59-101) — the arithmetic of the tree-major body, statement for statement
@@ -116,74 +117,50 @@
       acc[27] += 1.0;
     };
 
-    // The queues — one per wavefront and TREE (kSubCap entries of pass | lane) — walked densely, tree by tree, by the whole
-    // workgroup: a tree in which any wavefront has a walker gets its top levels staged into LDS (as in the tree-major body: the
-    // walk of the staged levels costs a third of the same levels from L1 / L2), then every wavefront walks its own entries of
-    // that tree, 64 to a descent.  Called by ALL threads (it contains barriers); the caller's trigger is a workgroup vote.
+    // the queue of this wavefront, walked densely: every lane one queued pair (pass, tree, lane of origin)
     auto drain = [&]() {
       wave_lds_order();
-      for (int tt = 0; tt < n_my; ++tt) {
-        const int n_t = s_qn[q_wave][tt];  // (wave-uniform)
-        if (!__syncthreads_or(n_t > 0 ? 1 : 0)) continue;  // (a barrier: nobody still walks the tree staged before)
-        const TreeDesc& td = s_tds[tt];
-        const int n_top = opt_lds_top ? min(td.n_top, kTopMax) : 0;
-        {
-          gptr_u4 gt = (gptr_u4)(uintptr_t)td.top;
-          gptr_u4 ge = (gptr_u4)(uintptr_t)td.top_exit;
-          for (int e = MADICP_TID; e < n_top; e += kBlock) {
-            s_top[e] = gt[e];
-            reinterpret_cast<vu4*>(s_exit)[e] = ge[e];
-          }
-        }
-        __syncthreads();
-        const int kk = k_first + tt;
-        const double wear_t = wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) + fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0));
-        for (int b = 0; b < n_t; b += 64) {
-          const bool has = b + q_lane < n_t;
-          const int e = has ? (int)s_queue[q_wave][tt][b + q_lane] : 0;
-          const int i = i_lo + (e >> 6) * kBlock + q_wave * 64 + (e & 63);
-          const vd4 p = has ? ((gptr_d4)(uintptr_t)moving)[i] : vd4{0.0, 0.0, 0.0, 0.0};
+      for (int b = 0; b < qn; b += 64) {
+        const bool has = b + q_lane < qn;
+        const int e = has ? (int)s_queue[q_wave][b + q_lane] : 0;
+        const int tt = (e >> 6) & (kDeepTrees - 1), pc = e >> (6 + kDeepTreesLog2);
+        const int i = i_lo + pc * kBlock + q_wave * 64 + (e & 63);
+        const TreeDesc& td = s_tds[has ? tt : 0];
+        const vd4 p = has ? ((gptr_d4)(uintptr_t)moving)[i] : vd4{0.0, 0.0, 0.0, 0.0};
 #ifdef MADICP_XFORM_HOMOGENEOUS
-          const double a0[1] = {((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0]};
-          const double a1[1] = {((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1]};
-          const double a2[1] = {((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2]};
+        const double a0[1] = {((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0]};
+        const double a1[1] = {((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1]};
+        const double a2[1] = {((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2]};
 #else
-          const double a0[1] = {t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z)};
-          const double a1[1] = {t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z)};
-          const double a2[1] = {t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z)};
+        const double a0[1] = {t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z)};
+        const double a1[1] = {t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z)};
+        const double a2[1] = {t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z)};
 #endif
-          const bool wv[1] = {has};
-          int xi[1], xl[1], xd[1];
-          double xm[1] = {3.0e38};
-          descend_multi<1>(td, s_top, s_exit, n_top, a0, a1, a2, wv, xi, xl, xd, xm);
-          if (has) {
-            const double wear = __builtin_fma(p.w, wear_alpha, wear_t);
-            visits += (unsigned int)xd[0];
-            walked_visits += (unsigned int)xd[0];
-            const long long ci = (long long)kk * L + i;
-            const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
-            cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
-            cache_margin[ci] = cacheable ? __double2float_rd(xm[0] + wear) : 0.f;
-            evaluate(td, kk, i, xl[0], true, 0.f, wear, p.x, p.y, p.z, p.w, a0[0], a1[0], a2[0]);
-          }
+        const bool wv[1] = {has};
+        int xi[1], xl[1], xd[1];
+        double xm[1] = {3.0e38};
+        descend_multi<1>(td, s_top, s_exit, 0, a0, a1, a2, wv, xi, xl, xd, xm);  // (global memory: no staged top here)
+        if (has) {
+          const int kk = k_first + tt;
+          const double wear = __builtin_fma(p.w, wear_alpha, wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) +
+                                                                                                    fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0)));
+          visits += (unsigned int)xd[0];
+          walked_visits += (unsigned int)xd[0];
+          const long long ci = (long long)kk * L + i;
+          const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
+          cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
+          cache_margin[ci] = cacheable ? __double2float_rd(xm[0] + wear) : 0.f;
+          evaluate(td, kk, i, xl[0], true, 0.f, wear, p.x, p.y, p.z, p.w, a0[0], a1[0], a2[0]);
         }
-        if (q_lane == 0) s_qn[q_wave][tt] = 0;
       }
-      staged_tree = -1;  // (the staged top is whatever tree was drained last: the tree-major body must not trust it)
+      qn = 0;
       wave_lds_order();
     };
 
-    if (MADICP_TID < kWaves * kDeepTrees) (&s_qn[0][0])[MADICP_TID] = 0;
-    __syncthreads();
-    int qmax = 0;  // the fullest of this wavefront's queues (wave-uniform)
     int pc = 0;
     for (int base = i_lo; base < i_hi; base += kBlock, ++pc) {
-      // (a pass queues at most 64 walkers per tree and wavefront: room is made HERE, where no pair is in registers — by every
-      // wavefront together, as soon as one of them needs it)
-      if (__syncthreads_or(qmax + 64 > kSubCap ? 1 : 0)) {
-        drain();
-        qmax = 0;
-      }
+      // (a pass queues at most 64 walkers per tree and wavefront: room is made HERE, where no pair is in registers)
+      if (qn + 64 * n_my > kQueueCap) drain();
       const int i = base + MADICP_TID;
       const bool valid = i < i_hi;
       vd4 p = vd4{0.0, 0.0, 0.0, 0.0};
@@ -202,10 +179,8 @@
       for (int t0 = 0; t0 < n_my; t0 += 4) {  // the trees of this workgroup, four at a time: their cached records in flight together
         unsigned int cw[4];
         float cm[4], cg[4];
-        int qc[4];  // this wavefront's queue lengths of the four trees (wave-uniform)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          qc[a] = t0 + a < n_my ? s_qn[q_wave][t0 + a] : 0;
           cw[a] = 0u; cm[a] = 0.f; cg[a] = 0.f;
           if (valid && t0 + a < n_my) {
             const long long ci = (long long)(k_first + t0 + a) * L + i;
@@ -222,14 +197,12 @@
           const double wear = wear_p + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) + fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0));
           const bool keep = valid && (double)cm[a] > wear;
           const bool w = valid && !keep;
-          // queue the walkers of this tree: pass | lane, in pass then lane order (a ballot and a prefix count: deterministic)
+          // queue the walkers: pass, tree, lane — in pass, tree, lane order (a ballot and a prefix count: deterministic)
           const unsigned long long wm = __ballot(w);
           if (wm) {  // (wave-uniform)
-            if (w) s_queue[q_wave][tt][qc[a] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
-                       (unsigned short)((pc << 6) | q_lane);
-            qc[a] += __popcll(wm);
-            if (q_lane == 0) s_qn[q_wave][tt] = qc[a];
-            qmax = max(qmax, qc[a]);
+            if (w) s_queue[q_wave][qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u))] =
+                       (unsigned short)((pc << (6 + kDeepTreesLog2)) | (tt << 6) | q_lane);
+            qn += __popcll(wm);
             walked |= w;
           }
           if (keep) {
@@ -239,7 +212,6 @@
           }
         }
       }
-      wave_lds_order();  // (this pass's queue lengths are in LDS before the next pass reads them)
     }
     drain();
   } else

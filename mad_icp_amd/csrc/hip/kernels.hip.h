@@ -361,12 +361,12 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 constexpr unsigned int kCacheIdxMask = 0x03ffffffu;
 constexpr int kCacheMaxDepth = 63;
 // DEEP launches (a batch shares the chip) and their leaf-major rounds (icp_leaf_major.inc.h): ranges of at least
-// kQueueMinPasses passes; at most kDeepTrees trees per workgroup and kDeepPasses passes per range (a queue entry is pass | lane in
-// 16 bits)
+// kQueueMinPasses passes; at most kDeepTrees trees per workgroup and 64 passes per range (a queue entry is pass | tree | lane in
+// 16 bits); kQueueCap queued walkers per wavefront before the queue is walked
 constexpr int kQueueMinPasses = 2;
 constexpr int kDeepTreesLog2 = 4, kDeepTrees = 1 << kDeepTreesLog2;
 constexpr int kDeepPasses = 64;
-constexpr int kSubCap = 128;  // queued walkers per wavefront and tree before the queues are walked
+constexpr int kQueueCap = 1024;
 
 // QPT independent descents per lane advanced in lock-step (their loads are issued together).  Phase 1 walks the
 // LDS copy of the tree's top levels (s_top / s_exit, n_top entries), phase 2 continues in global memory.
@@ -1505,8 +1505,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int flags = job->flags;
   constexpr bool DEEP = QUEUE;
   const int opt_leaf_major = DEEP ? job->queue_nodes : 0;
-  __shared__ unsigned short s_queue[DEEP ? kWaves : 1][DEEP ? kDeepTrees : 1][DEEP ? kSubCap : 1];  // leaf-major rounds: queued walkers per wavefront and tree
-  __shared__ int s_qn[DEEP ? kWaves : 1][DEEP ? kDeepTrees : 1];                                       // ... and the queues' lengths
+  __shared__ unsigned short s_queue[DEEP ? kWaves : 1][DEEP ? kQueueCap : 1];  // leaf-major rounds: queued walkers per wavefront
   __shared__ __attribute__((aligned(16))) TreeDesc s_tds[DEEP ? kDeepTrees : 1];  // ... and the descriptors of the workgroup's trees
   const bool last_round = (round == n_iters - 1);
   const bool mark_matched = last_round || (flags & kFlagMatchAll);
