@@ -1,5 +1,7 @@
 #include "mad_icp.h"
 
+#include <chrono>
+
 #include <cstring>
 
 #include "device.h"
@@ -67,6 +69,10 @@ void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool trunc
   std::memcpy(X + 9, X_.t, sizeof(X_.t));
   const madicp_icp_params p{min_ball_, rho_ker_, b_ratio_};
   int ticket = -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point from) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - from).count();
+  };
   if (moving_tree_) {
     check(madicp_stream_submit_tree(ctx, moving_tree_->deviceId(), ids.data(), static_cast<int>(ids.size()), X, &p, n_iters,
                                     &ticket),
@@ -76,6 +82,8 @@ void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool trunc
                                &ticket),
           "madicp_stream_submit");
   }
+  phase_ms_[0] = since(t0);
+  const auto t1 = std::chrono::steady_clock::now();
   if (while_in_flight) {
     try {
       while_in_flight();
@@ -85,9 +93,12 @@ void MADicp::compute(const std::vector<MADtree*>& fixed, int n_iters, bool trunc
       throw;
     }
   }
+  phase_ms_[1] = since(t1);
+  const auto t2 = std::chrono::steady_clock::now();
   int32_t n_matched = 0;
   check(madicp_stream_collect(ctx, ticket, X, H_adder_, b_adder_, matched_.data(), &n_matched, &visits_),
         "madicp_stream_collect");
+  phase_ms_[2] = since(t2);
   n_matched_ = n_matched;
   std::memcpy(X_.R, X, sizeof(X_.R));
   std::memcpy(X_.t, X + 9, sizeof(X_.t));

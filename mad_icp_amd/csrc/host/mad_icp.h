@@ -47,6 +47,7 @@ class MADicp {
   double b_adder_[6];
   std::vector<uint8_t> matched_;
   uint64_t visits_ = 0;  // internal nodes visited by the last compute() (instrumentation)
+  double phase_ms_[3] = {0., 0., 0.};  // last compute(): submission, the caller's work beside it, the wait for the result (instrumentation)
 
   double rho_ker_;  // as given by the caller (the sqrt of mad_icp.cpp:32 is taken inside the library)
   double min_ball_;

@@ -72,8 +72,8 @@ void Pipeline::waitPrefetched() {
 // A look-ahead result belongs to the scan it was computed from: size, end points and a digest of a strided sample of the
 // points (up to 1024 of them, every coordinate's bit pattern) — a re-filtered, jittered or padded copy with the same size
 // and end points does not get another scan's tree.
-static uint64_t cloud_digest(const ContainerType& c) {
-  const size_t n = c.size(), step = std::max<size_t>(1, n / 1024);
+static uint64_t cloud_digest(const Vector3d* c, size_t n) {
+  const size_t step = std::max<size_t>(1, n / 1024);
   uint64_t h = 0x9e3779b97f4a7c15ull ^ n;
   for (size_t i = 0; i < n; i += step) {
     uint64_t w[3];
@@ -85,20 +85,22 @@ static uint64_t cloud_digest(const ContainerType& c) {
   }
   return h;
 }
-Pipeline::DevKey Pipeline::DevKey::of(const ContainerType& c) {
+Pipeline::DevKey Pipeline::DevKey::of(const Vector3d* c, size_t n) {
   DevKey k;
-  k.n = c.size();
-  if (!c.empty()) {
-    k.first = c.front();
-    k.last = c.back();
-    k.digest = cloud_digest(c);
+  k.n = n;
+  if (n) {
+    k.first = c[0];
+    k.last = c[n - 1];
+    k.digest = cloud_digest(c, n);
   }
   return k;
 }
-bool Pipeline::DevKey::matches(const ContainerType& c) const {
-  return n == c.size() && n > 0 && std::memcmp(first.data(), c.front().data(), 24) == 0 &&
-         std::memcmp(last.data(), c.back().data(), 24) == 0 && digest == cloud_digest(c);
+bool Pipeline::DevKey::matches(const Vector3d* c, size_t count) const {
+  return n == count && n > 0 && std::memcmp(first.data(), c[0].data(), 24) == 0 &&
+         std::memcmp(last.data(), c[n - 1].data(), 24) == 0 && digest == cloud_digest(c, n);
 }
+Pipeline::DevKey Pipeline::DevKey::of(const ContainerType& c) { return of(c.data(), c.size()); }
+bool Pipeline::DevKey::matches(const ContainerType& c) const { return matches(c.data(), c.size()); }
 
 void Pipeline::collectDeviceLookAhead() {
   if (!dev_pending_) return;
@@ -110,17 +112,16 @@ void Pipeline::collectDeviceLookAhead() {
 }
 
 void Pipeline::beginStagedLookAhead() {
-  if (dev_next_cloud_.empty()) return;
-  ContainerType cloud = std::move(dev_next_cloud_);
-  dev_next_cloud_.clear();
+  if (!dev_next_staged_) return;
+  dev_next_staged_ = false;  // (the buffer keeps its memory for the next scan: see prefetchView)
   collectDeviceLookAhead();  // (the one slot: whatever was in flight is collected first)
-  dev_pending_ = MADtree::beginDeviceBuild(cloud, b_max_, b_min_);
+  dev_pending_ = MADtree::beginDeviceBuild(dev_next_cloud_, b_max_, b_min_);
   if (!dev_pending_) return;
-  dev_pending_key_ = DevKey::of(cloud);
+  dev_pending_key_ = DevKey::of(dev_next_cloud_);
 }
 
 void Pipeline::dropDeviceLookAhead(bool staged_too) {
-  if (staged_too) dev_next_cloud_.clear();
+  if (staged_too) dev_next_staged_ = false;
   if (dev_pending_) {
     MADtree::cancelDeviceBuild(dev_pending_);
     dev_pending_ = 0;
@@ -169,14 +170,29 @@ void Pipeline::initialize(const double& curr_stamp, ContainerType& cloud) {
   seq_++;
 }
 
-void Pipeline::prefetch(ContainerType next_cloud) {
-  if (next_cloud.empty()) return;
+// The scan as a VIEW (the bindings' entry point: pybind hands a by-value ContainerType over as a fresh 3 MB allocation + copy
+// per call, and fresh pages cost ~1 us each — 0.35 ms per cloud, twice per look-ahead frame, which is what the "look-ahead
+// cliff" of rounds 3-5 was: profiles/r5_u_lookahead_canary.md).  The memory is only read during the call.
+void Pipeline::prefetchView(const Vector3d* next_cloud, size_t n) {
+  if (!next_cloud || n == 0) return;
   if (device_frontend_) {
     // the tree is built on the GPU — a host build would only compete for the CPU — and the look-ahead is the library's:
     // collect the construction in flight (the scan about to be consumed), start this one beside the coming registration
     if (deskew_) return;  // (the tree needs the previous pose)
-    dev_next_cloud_ = std::move(next_cloud);  // begun by the next compute(), behind its registration's submission
+    // begun by the next compute(), behind its registration's submission; assign() into a buffer that lives as long as the
+    // Pipeline: after the first frames no allocation, no fresh pages
+    dev_next_cloud_.assign(next_cloud, next_cloud + n);
+    dev_next_staged_ = true;
     if (!is_initialized_ || (!dev_pending_ && !dev_ready_)) beginStagedLookAhead();  // (nothing to hide behind yet)
+    return;
+  }
+  prefetch(ContainerType(next_cloud, next_cloud + n));
+}
+
+void Pipeline::prefetch(ContainerType next_cloud) {
+  if (next_cloud.empty()) return;
+  if (device_frontend_) {
+    prefetchView(next_cloud.data(), next_cloud.size());
     return;
   }
   // with deskew the tree is built from the motion-compensated cloud, which needs the pose of the frame before it — but the
@@ -247,36 +263,52 @@ void Pipeline::computeRecords(const double& curr_stamp, const float* records, si
   computeWithTree(curr_stamp, buildOnDevice(cloud_id), nullptr, t_pre);
 }
 
-// pipeline.cpp:125-265
-void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
+// pipeline.cpp:125-265, the device front-end's half: the scan is only READ (key of a look-ahead, or the upload), so a view does
+void Pipeline::computeView(const double& curr_stamp, const Vector3d* curr_cloud, size_t n) {
+  if (!curr_cloud || n == 0) throw std::invalid_argument("Pipeline::compute: empty cloud");
+  if (!device_frontend_) {  // the host builder takes the points over: it needs its own copy
+    compute(curr_stamp, ContainerType(curr_cloud, curr_cloud + n));
+    return;
+  }
   is_map_updated_ = false;
-  if (curr_cloud.empty()) throw std::invalid_argument("Pipeline::compute: empty cloud");
   // a tree built ahead for exactly this scan?
   std::unique_ptr<MADtree> current_tree;
   const double t_pre = now_ms();
+  waitPrefetched();
+  if (dev_ready_ && dev_ready_key_.matches(curr_cloud, n)) {
+    current_tree = std::move(dev_ready_);  // collected when the next look-ahead was begun
+  } else if (dev_pending_ && dev_pending_key_.matches(curr_cloud, n)) {
+    collectDeviceLookAhead();
+    current_tree = std::move(dev_ready_);
+  }
+  if (current_tree) ++look_ahead_hits_;
+  if (!current_tree) {
+    // Nothing looked ahead for THIS scan.  A construction in flight is then most likely for the NEXT one (a caller whose
+    // first scan came without a prefetch stays one ahead from there on): it is collected and kept — the synchronous build
+    // below needs the builder's scratch, so it has to be finished either way — not thrown away.
+    collectDeviceLookAhead();
+    int cloud_id = -1;
+    {
+      DeviceLock lock(Device::mutex());
+      check(madicp_cloud_upload(Device::ctx(), curr_cloud[0].data(), static_cast<int64_t>(n), &cloud_id), "madicp_cloud_upload");
+    }
+    current_tree = buildOnDevice(cloud_id);
+  }
+  computeWithTree(curr_stamp, std::move(current_tree), nullptr, t_pre);
+}
+
+// pipeline.cpp:125-265
+void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud) {
+  if (curr_cloud.empty()) throw std::invalid_argument("Pipeline::compute: empty cloud");
   if (device_frontend_) {
-    waitPrefetched();
-    if (dev_ready_ && dev_ready_key_.matches(curr_cloud)) {
-      current_tree = std::move(dev_ready_);  // collected when the next look-ahead was begun
-    } else if (dev_pending_ && dev_pending_key_.matches(curr_cloud)) {
-      collectDeviceLookAhead();
-      current_tree = std::move(dev_ready_);
-    }
-    if (current_tree) ++look_ahead_hits_;
-    if (!current_tree) {
-      // Nothing looked ahead for THIS scan.  A construction in flight is then most likely for the NEXT one (a caller whose
-      // first scan came without a prefetch stays one ahead from there on): it is collected and kept — the synchronous build
-      // below needs the builder's scratch, so it has to be finished either way — not thrown away.
-      collectDeviceLookAhead();
-      int cloud_id = -1;
-      {
-        DeviceLock lock(Device::mutex());
-        check(madicp_cloud_upload(Device::ctx(), curr_cloud.front().data(), static_cast<int64_t>(curr_cloud.size()), &cloud_id),
-              "madicp_cloud_upload");
-      }
-      current_tree = buildOnDevice(cloud_id);
-    }
-  } else if (!prefetched_.empty() && !(deskew_ && is_initialized_ && trajectory_.size() > 1)) {
+    computeView(curr_stamp, curr_cloud.data(), curr_cloud.size());
+    return;
+  }
+  is_map_updated_ = false;
+  // a tree built ahead for exactly this scan?
+  std::unique_ptr<MADtree> current_tree;
+  const double t_pre = now_ms();
+  if (!prefetched_.empty() && !(deskew_ && is_initialized_ && trajectory_.size() > 1)) {
     // the look-ahead built for exactly this scan, if there is one; older look-aheads are for scans that never came
     for (size_t q = 0; q < prefetched_.size(); ++q) {
       const Prefetched& p = prefetched_[q];
@@ -376,7 +408,7 @@ void Pipeline::computeWithTree(const double& curr_stamp, std::unique_ptr<MADtree
     for (auto& f : keyframes_) fixed.push_back(f->tree_.get());
     // (cut short: the matched flags are the OR over the rounds that ran — the reference resets them in iteration
     // MAX_ICP_ITS - 1 only — and the launch goes kernel by kernel, no graph is instantiated for an odd round count)
-    const bool looking_ahead = device_frontend_ && (dev_pending_ || !dev_next_cloud_.empty());
+    const bool looking_ahead = device_frontend_ && (dev_pending_ || dev_next_staged_);
     icp_.compute(fixed, rounds, rounds < MAX_ICP_ITS, [this]() {
       if (device_frontend_) beginStagedLookAhead();
     }, looking_ahead);

@@ -26,6 +26,7 @@
 // deskewed datasets the tree needs the previous poses: prefetch() then computes the pose-independent half of deskew ahead —
 // the azimuth of every point and their order (deskew.h).
 #pragma once
+#include <array>
 #include <cstddef>
 #include <deque>
 #include <future>
@@ -74,6 +75,10 @@ class Pipeline {
 
   // additive (not in the reference): start building the tree of the scan that the NEXT compute() will be given
   void prefetch(ContainerType next_cloud);
+  // additive: the same two calls on a VIEW of the caller's points (n x 3 doubles, only read during the call) — what the
+  // Python bindings use, so that a frame does not begin with a 3 MB allocation + copy of its by-value argument
+  void computeView(const double& curr_stamp, const Vector3d* curr_cloud, size_t n);
+  void prefetchView(const Vector3d* next_cloud, size_t n);
 
   // additive, opt-in: the device front-end.  When on, compute() uploads the scan once and
   // deskew (pipeline.cpp:79-123) and MADtree::build (mad_tree.cpp:47-130) run on the MI355X; the tree never exists on
@@ -103,6 +108,8 @@ class Pipeline {
   void setTimingForTest(double pre_ms, double round_ms) { virtual_pre_ms_ = pre_ms; virtual_round_ms_ = round_ms; }
   double lastIcpMs() const { return last_icp_ms_; }
   double lastBuildMs() const { return last_build_ms_; }
+  // the last frame's registration split: submission, the look-ahead begun beside it, the wait for the result (ms)
+  std::array<double, 3> lastIcpPhasesMs() const { return {icp_.phase_ms_[0], icp_.phase_ms_[1], icp_.phase_ms_[2]}; }
   size_t numKeyframes() const { return keyframes_.size(); }
   size_t lookAheadHits() const { return look_ahead_hits_; }  // frames whose tree had been built ahead (prefetch)
 
@@ -132,6 +139,8 @@ class Pipeline {
     uint64_t digest = 0;
     static DevKey of(const ContainerType& c);
     bool matches(const ContainerType& c) const;
+    static DevKey of(const Vector3d* c, size_t n);
+    bool matches(const Vector3d* c, size_t n) const;
   };
   // look-ahead builds: up to three scans ahead of the one being consumed (kMaxLookAhead), each matched to its scan by its
   // key (a prefetch(i + 1) issued BEFORE compute(i) must not cost scan i its tree)
@@ -156,6 +165,7 @@ class Pipeline {
   ContainerType dev_next_cloud_;  // the scan prefetch() was given, staged and begun by compute() WHILE its registration is in
                                   // flight (the host side of a begin — 3 MB into pinned memory, ~60 launches — is a third of
                                   // a millisecond that would otherwise sit in front of the registration)
+  bool dev_next_staged_ = false;  // dev_next_cloud_ holds a scan that has not been begun (the vector keeps its memory between scans)
   void beginStagedLookAhead();
   DevKey dev_pending_key_, dev_ready_key_;
   std::unique_ptr<MADtree> dev_ready_;

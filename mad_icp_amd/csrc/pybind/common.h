@@ -78,6 +78,13 @@ inline ContainerType container_from_array(py::array_t<double, py::array::c_style
   return out;
 }
 
+// an (N,3) float64 C-contiguous array read in place as N points (same shape rule as container_from_array)
+inline const Vector3d* points_of_array(const py::array_t<double, py::array::c_style | py::array::forcecast>& array) {
+  static_assert(sizeof(Vector3d) == 3 * sizeof(double), "a point is three packed doubles");
+  if (array.ndim() != 2 || array.shape(1) != 3) throw py::cast_error();
+  return reinterpret_cast<const Vector3d*>(array.data());
+}
+
 template <typename... Extra>
 inline void bind_vector_eigen3d(py::module_& m, const Extra&... extra) {
   // same recipe as the reference (eigen_stl_bindings.h:25-35,64-97): a plain class_ with the buffer protocol,

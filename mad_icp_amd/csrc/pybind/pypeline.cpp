@@ -19,18 +19,24 @@ PYBIND11_MODULE(pypeline, m) {
     .def("keyframeID", &Pipeline::keyframeID)
     .def("modelLeaves", &Pipeline::modelLeaves)
     .def("currentLeaves", &Pipeline::currentLeaves)
-    .def("compute", &Pipeline::compute)
-    // additive: an (N,3) float64 array directly — one copy instead of the two of VectorEigen3d(points) + by-value call
+    // compute(stamp, VectorEigen3d): the reference binds the by-value member (pypeline.cpp:69), which has pybind copy the whole
+    // container per call; bound here on a reference and handed on as a view — the same call for Python, no 3 MB allocation +
+    // copy in front of every frame (the host path makes the one copy its tree keeps, inside)
+    .def("compute", [](Pipeline& self, double stamp, const ContainerType& cloud) { self.computeView(stamp, cloud.data(), cloud.size()); })
+    // additive: an (N,3) float64 array directly (C-contiguous float64 input is read in place)
     .def("compute",
          [](Pipeline& self, double stamp, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {
-           self.compute(stamp, container_from_array(std::move(cloud)));
+           const Vector3d* pts = points_of_array(cloud);
+           self.computeView(stamp, pts, static_cast<size_t>(cloud.shape(0)));
          })
     // additive look-ahead: start building the next scan's MAD-tree while this frame is registered
     .def("lookAheadHits", &Pipeline::lookAheadHits)
-    .def("prefetch", &Pipeline::prefetch, py::arg("next_cloud"))
+    .def("prefetch", [](Pipeline& self, const ContainerType& cloud) { self.prefetchView(cloud.data(), cloud.size()); },
+         py::arg("next_cloud"))
     .def("prefetch",
          [](Pipeline& self, py::array_t<double, py::array::c_style | py::array::forcecast> cloud) {
-           self.prefetch(container_from_array(std::move(cloud)));
+           const Vector3d* pts = points_of_array(cloud);
+           self.prefetchView(pts, static_cast<size_t>(cloud.shape(0)));
          })
     // additive, opt-in: deskew + MAD-tree construction on the device; env MAD_ICP_GPU_BUILD=1
     .def("setDeviceFrontEnd", &Pipeline::setDeviceFrontEnd, py::arg("on"))
@@ -51,5 +57,6 @@ PYBIND11_MODULE(pypeline, m) {
     .def("setTimingForTest", &Pipeline::setTimingForTest, py::arg("pre_ms"), py::arg("round_ms"))
     .def("lastIcpMs", &Pipeline::lastIcpMs)
     .def("lastBuildMs", &Pipeline::lastBuildMs)
+    .def("lastIcpPhasesMs", &Pipeline::lastIcpPhasesMs)
     .def("numKeyframes", &Pipeline::numKeyframes);
 }
