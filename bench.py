@@ -46,12 +46,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# This process holds more HIP streams than a runner would (torch's, this script's context with two, the Pipeline block's
-# context with three): with the runtime's default of four hardware queues some of them share a queue and the look-ahead
-# build serialises behind the registration it is meant to run beside (pipeline_end_to_end.device_front_end_lookahead:
-# 0.81 ms per frame with 4 queues, 0.63 with 8; the headline is unchanged within its box-to-box noise).  Read by the HIP
-# runtime when it initialises, so it is set before anything imports torch.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (Rounds 4-5 set GPU_MAX_HW_QUEUES=8 here because the look-ahead frame seemed to depend on the runtime's queue map.  It did
+# not: the slow frames were the bindings' by-value copy of the cloud on the HOST — profiles/r5_u_lookahead_canary.md — and with
+# that gone the runtime's default is the better setting for the look-ahead, 0.65-0.69 against 0.86-0.88 ms.  This process now
+# runs with whatever the caller's environment says, like any embedder; pipeline_end_to_end.lookahead_in_a_plain_process still
+# reports both settings.)
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
 PARAMS = (B_MAX, RHO_KER, B_RATIO)
@@ -708,9 +707,9 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                          "ms_per_frame_median": round(float(np.median(ts[2:])) * 1e3, 3),
                          "tree_ms": round(pl.lastBuildMs(), 3), "registration_ms": round(pl.lastIcpMs(), 3),
                          "end_translation_error_m": round(float(np.linalg.norm(np.asarray(pl.currentPose())[:3, 3] - gt[:3, 3])), 4)}
-        # the look-ahead frame depends on the process it runs in (hardware queues, which streams exist: profiles/
-        # r5_lookahead_matrix.md) and this process sets GPU_MAX_HW_QUEUES=8 for itself: the same drive in PLAIN processes, with the
-        # runtime's default queues and with eight
+        # the same drive in PLAIN processes (no framework, one context), with the runtime's default hardware queues and with eight
+        # (eight: the next scan's upload and construction really run beside the registration, and both lose — profiles/
+        # r5_u_lookahead_canary.md)
         plain = {}
         for label, qs in (("hw_queues_default", None), ("hw_queues_8", "8")):
             env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
@@ -733,9 +732,9 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                         "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "
                         "device_front_end = setDeviceFrontEnd(True): upload, MAD-tree build and registration on the GPU; "
                         "device_front_end_lookahead = the same with prefetch(scan i + 1) before compute(scan i): the next scan's "
-                        "construction runs on the library's build stream beside this scan's registration, same poses bit for bit — a "
-                        "figure of THIS process (GPU_MAX_HW_QUEUES=8, framework stream): lookahead_in_a_plain_process has the same "
-                        "drive in plain processes, where the look-ahead frame can be SLOWER than the plain one; "
+                        "construction is submitted on the library's build stream behind this scan's registration, same poses bit for bit; "
+                        "lookahead_in_a_plain_process has the same drive in plain processes under the runtime's default hardware queues "
+                        "and under GPU_MAX_HW_QUEUES=8 (where the look-ahead does not pay); "
                         "host_path_deskew / device_front_end_deskew = deskew on (scans with distinct azimuths; the synthetic scans are "
                         "instantaneous, so compensating them moves them: timing keys, not accuracy keys), the host one with the "
                         "azimuth order computed ahead by prefetch(scan i + 1)")
