@@ -704,3 +704,53 @@ def test_pipeline_device_front_end_look_ahead(natives, drive, capsys):
         print("\n[pipeline, device front-end] mean per frame %.2f ms = %.0f frames/s; with prefetch(next) before compute: %.2f ms "
               "= %.0f frames/s" % (1e3 * np.mean(t_plain[3:]), 1.0 / np.mean(t_plain[3:]),
                                    1e3 * np.mean(t_ahead[3:-1]), 1.0 / np.mean(t_ahead[3:-1])))
+
+
+def test_bindings_read_the_callers_points_only_during_the_call(natives, drive):
+    """compute / prefetch are bound on a VIEW of the caller's points (Pipeline::computeView / prefetchView; the reference's
+    by-value binding, pypeline.cpp:69, copies the container per call).  What the caller may rely on is what a by-value call
+    gave: the memory is read during the call only — a scan handed to prefetch() and overwritten afterwards is still the scan the
+    look-ahead was built from, whatever form it came in (VectorEigen3d, float64 array, float32 / strided array through
+    forcecast) — and every form lands on the same trajectory, bit for bit."""
+    from mad_icp.src.pybind import pypeline as m
+
+    args = (10.0, False, B_MAX, 0.1, 0.8, B_MIN, 0.02, 16, 8, False)
+    frames = drive[:8]
+    ref = m.Pipeline(*args)
+    for i, s in enumerate(frames):
+        ref.compute(0.1 * i, m.VectorEigen3d(s))
+    want = np.asarray(ref.trajectory())
+
+    def run(wrap):
+        pl = m.Pipeline(*args)
+        pl.prefetch(wrap(frames[0]))
+        for i, s in enumerate(frames):
+            if i + 1 < len(frames):
+                nxt = wrap(frames[i + 1])
+                pl.prefetch(nxt)
+                if isinstance(nxt, np.ndarray):
+                    nxt[...] = 0.0  # the caller's buffer is the caller's again
+                else:
+                    nxt.clear()
+            cur = wrap(s)
+            pl.compute(0.1 * i, cur)
+        assert pl.lookAheadHits() == len(frames)
+        return np.asarray(pl.trajectory())
+
+    assert np.array_equal(run(lambda s: s.copy()), want)  # float64 array, read in place
+    assert np.array_equal(run(lambda s: m.VectorEigen3d(s)), want)  # the reference's container
+    wide = lambda s: np.concatenate([s, np.ones((len(s), 1))], axis=1)[:, :3]  # noqa: E731  (a strided view: forcecast copies)
+    assert np.array_equal(run(wide), want)
+    # float32 input is converted by the binding (as pybind's forcecast always did): another cloud, so only self-consistency
+    f32 = [s.astype(np.float32) for s in frames]
+    a, b = m.Pipeline(*args), m.Pipeline(*args)
+    for i, s in enumerate(f32):
+        a.compute(0.1 * i, s)
+        b.compute(0.1 * i, s.astype(np.float64))
+    assert np.array_equal(np.asarray(a.trajectory()), np.asarray(b.trajectory()))
+    with pytest.raises(Exception):
+        m.Pipeline(*args).compute(0.0, m.VectorEigen3d())
+    with pytest.raises(Exception):
+        m.Pipeline(*args).compute(0.0, np.zeros((0, 3)))
+    with pytest.raises(Exception):
+        m.Pipeline(*args).compute(0.0, np.zeros((5, 4)))
