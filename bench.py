@@ -51,6 +51,13 @@ sys.path.insert(0, ROOT)
 # that gone the runtime's default is the better setting for the look-ahead, 0.65-0.69 against 0.86-0.88 ms.  This process now
 # runs with whatever the caller's environment says, like any embedder; pipeline_end_to_end.lookahead_in_a_plain_process still
 # reports both settings.)
+# The MULTI-RANK branch is different: a process that also holds an RCCL communicator (its streams, torch's) has more streams than
+# the runtime's default four hardware queues, and the streamed loop's upload / rounds / read-back then share queues — measured on
+# one GPU with a world of one (tools/shard_world1.sh, two repetitions, same box): replica 4 027 -> 4 440, shard 3 487 -> 3 750,
+# shard_p2p 3 928 -> 4 290 registrations/s with eight queues; the one-process bench does not care (4 684 / 4 623).  Read by the
+# HIP runtime when it initialises, so it is set before anything imports torch; an explicit setting in the environment wins.
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("MADICP_BENCH_FORCE_MULTI") == "1":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
 PARAMS = (B_MAX, RHO_KER, B_RATIO)
@@ -331,7 +338,7 @@ def base_line(args, world, value, elapsed, workload, extra_config, warmup_run=No
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": dict({"workload": workload}, **extra_config),
+        "config": dict({"workload": workload, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default")}, **extra_config),
     }
 
 
