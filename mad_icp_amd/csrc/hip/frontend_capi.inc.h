@@ -818,6 +818,7 @@ int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t
 // every leaf's members in the order the splits above it produced (reference: the caller's container after MADtree::build,
 // mad_tree.cpp:95-97 with utils.h:37-52, except that the reference also overwrites a leaf's first member with its
 // representative, mad_tree.cpp:76-84).  Valid until the next build, ingest or deskew on the context.
+#ifndef MADICP_NO_MEASURE
 int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n) {
   if (!ctx || !out_xyz) return fail(MADICP_ERR_INVALID, "null argument");
   if (!ctx->front || !ctx->front->scratch.block || !ctx->front->scratch.h_line) return fail(MADICP_ERR_INVALID, "no build yet");
@@ -838,6 +839,7 @@ int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n) 
     return fail(MADICP_ERR_DEVICE, std::string("tree build points: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return MADICP_OK;
 }
+#endif  // MADICP_NO_MEASURE
 
 // per-level node counts of the last build on this context (diagnostics for tests / tools): out[0] = levels reached,
 // out[1] = lane-regime sub-trees, then 2 x 64 ints: wave-regime and chip-regime nodes per level

@@ -1923,6 +1923,7 @@ int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, in
   return rc;
 }
 
+#ifndef MADICP_NO_MEASURE  // ---- measurement / test aids (include/madicp_hip_measure.h): a product build leaves them out
 int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
                               const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
                               uint64_t* out_visits_per_launch) {
@@ -2135,6 +2136,8 @@ int madicp_debug_gather16(madicp_ctx* ctx, int64_t region_bytes, int64_t n_gathe
   *out_avg_us = 1e3 * ms / reps;
   return MADICP_OK;
 }
+
+#endif  // MADICP_NO_MEASURE
 
 // ---- multi-GPU --------------------------------------------------------------------------------------
 int madicp_comm_unique_id(uint8_t out_id[128]) {

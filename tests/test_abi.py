@@ -57,3 +57,34 @@ def test_product_never_imports_oracle():
                     if re.search(r"oracle_lib|libmad_oracle|mad_oracle", code):
                         bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_product_build_leaves_the_measurement_and_test_aids_out(natives, tmp_path):
+    """-DMADICP_NO_MEASURE (MADICP_EXTRA_DEFINES, built into a scratch directory through MADICP_NATIVE_DIR): the library still
+    exports every symbol of the drop-in header and NONE of include/madicp_hip_measure.h, and pypeline is compiled without the
+    realtime rule's test seam.  (The in-tree build keeps them: bench.py and the tests call them.)"""
+    import subprocess
+    import sys
+
+    d = str(tmp_path)
+    env = dict(os.environ, MADICP_NATIVE_DIR=d, MADICP_EXTRA_DEFINES="-DMADICP_NO_MEASURE",
+               PYTHONPATH=os.pathsep.join([ROOT] + sys.path))
+    r = subprocess.run([sys.executable, "-c", "from mad_icp_amd import _build; print(_build.build_hip())"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(d, "libmadicp_hip.so")], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\b(madicp_[a-z0-9_]+)\b", out))
+    missing = [s for s in declared_symbols("madicp_hip.h") if s not in exported]
+    assert not missing, missing
+    leaked = [s for s in declared_symbols("madicp_hip_measure.h") if s in exported]
+    assert not leaked, leaked
+    assert not [s for s in exported if s.startswith("madicp_debug_")]
+    # the binding: the preprocessed translation unit no longer registers the seam
+    import pybind11
+
+    pp = subprocess.run(["g++", "-E", "-std=c++17", "-DMADICP_NO_MEASURE", "-I" + os.path.join(ROOT, "include"),
+                         "-I" + os.path.join(ROOT, "mad_icp_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "mad_icp_amd", "csrc", "pybind"),
+                         "-I" + pybind11.get_include(), "-I" + __import__("sysconfig").get_paths()["include"],
+                         os.path.join(ROOT, "mad_icp_amd", "csrc", "pybind", "pypeline.cpp")], capture_output=True, text=True)
+    assert pp.returncode == 0, pp.stderr[-2000:]
+    assert '"setTimingForTest"' not in pp.stdout and '"compute"' in pp.stdout
