@@ -254,9 +254,14 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible — the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    # MADICP_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a box with fewer GPUs than ranks (ranks then
-    # share devices; the shard figures are skipped — RCCL refuses two ranks on one GPU)
+    # MADICP_BENCH_BACKEND=gloo lets the N>1 code path be EXECUTED on a box with fewer GPUs than ranks: the ranks share devices,
+    # every rank's compute stream gets its own slice of the CU mask (MADICP_CU_MASK=rank/world, so that all ranks' round kernels
+    # are resident side by side), the `shard` key runs over the library's host-staged transport (RCCL refuses two ranks on one
+    # GPU: same kernels and ordering, the all-reduce itself over gloo) and `shard_p2p` over the peer mailboxes.  The line then
+    # says "N ranks on one GPU: functional, not a scaling number".
     backend = os.environ.get("MADICP_BENCH_BACKEND", "nccl")
+    if backend != "nccl" and world > 1:
+        os.environ.setdefault("MADICP_CU_MASK", "%d/%d" % (rank, world))
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     small = torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu")
@@ -292,7 +297,8 @@ def main():
 
     K = args.keyframes
     stream = torch.cuda.Stream()
-    ctx = capi.Context(device_index, stream.cuda_stream)
+    # (ranks sharing a device: the library creates the compute stream itself — the one the CU-mask slice applies to)
+    ctx = capi.Context(device_index) if (backend != "nccl" and world > 1) else capi.Context(device_index, stream.cuda_stream)
     for kv in args.option:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -868,7 +874,8 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
         gc.enable()
         return max_over_ranks(dt), last
 
-    shard_ok = backend == "nccl"
+    native = backend == "nccl"  # RCCL inside the library; otherwise its host-staged transport over torch.distributed
+    shard_ok = True
     value = elapsed = None
     n_local = 0
     shard_error = None
@@ -880,11 +887,15 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
             my = [k for k in range(K) if k % world == rank]
             tids, n_nodes = upload_map(ctx, capi, pb, my)
             n_local = len(tids)
-            uid = torch.zeros(128, dtype=torch.uint8, device=small)
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+            from mad_icp_amd import sharded as _sh
+            if native:
+                uid = torch.zeros(128, dtype=torch.uint8, device=small)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(capi.Context.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+            else:
+                _sh.init_host_comm(ctx)
             if os.environ.get("MADICP_BENCH_FAIL_SHARD") == "1":  # (development: exercises the fall-back below)
                 raise RuntimeError("injected failure of the sharded path")
             if os.environ.get("MADICP_COMM_GRAPH") == "1":
@@ -895,11 +906,12 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
             # few hundred collectives (channel set-up) are out of the way before the headline is timed
             e1, _ = batched(1, tids, max(20, args.steps // 4), 5, mids[:1])
             out_extra["shard_one_scan"] = {"registrations_per_s": round(max(20, args.steps // 4) / e1, 1), "scaling": "strong",
-                                           "note": "one scan in flight, 16 trees over %d GPUs, %d all-reduces of 240 B" % (world, N_ITERS)}
+                                           "note": "one scan in flight, 16 trees over %d %s, %d all-reduces of 240 B" % (
+                                               world, "GPUs" if native else "ranks on one GPU", N_ITERS)}
             elapsed, last = batched(B, tids, args.steps, args.warmup, mids)
             value = args.steps * B / elapsed
             terr = max(pose_error(pb["query_gt"][q], capi.pose44(last[1]["X"][s])) for s, q in enumerate(last[0]))
-            out_extra["shard_note"] = (
+            shard_note = (
                 "keyframe sharding was developed on ONE GPU (RCCL with one rank; two ranks through a host-staged transport): this line "
                 "is the first multi-GPU measurement of it.  A round is ~14 us of device work per scan and every sharded round adds "
                 "icp_reduce (4.5 us) and one %d-byte RCCL all-reduce, so the shard keys are bound by all-reduce latency, not by "
@@ -907,8 +919,16 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                 "collective is in flight under the other half's round (measured on one GPU with a 15 us stand-in collective: -14 %% "
                 "per registration at 8 scans); `replica` (no collective) is the key that scales with the GPU count"
                 % (240 * (args.scans if args.scans > 0 else world)))
+            out_extra["shard_note"] = shard_note if native else (
+                "%d ranks on ONE GPU (each rank's compute stream on its own slice of the CU mask), (H,b) all-reduced over the "
+                "library's host-staged transport: this exercises every line of the world = %d sharded path — partition, zero-tree "
+                "ranks, launch sequence, collectives per round, flags — and says NOTHING about scaling: the ranks share one chip "
+                "and every round makes a host round trip" % (world, world))
             out_extra["shard_mode"] = {
-                "sequence": "icp_round -> icp_reduce -> ncclAllReduce(30 f64 per scan) per round; matched flags OR-ed once",
+                "transport": "RCCL (ncclAllReduce enqueued by the library between its kernels)" if native else
+                             "host-staged (madicp_comm_init_host): the RCCL path's kernels and ordering, the all-reduce itself over gloo "
+                             "on pinned host memory — one host round trip per round",
+                "sequence": "icp_round -> icp_reduce -> all-reduce(30 f64 per scan) per round; matched flags OR-ed once",
                 "shard_split": ("two half-batches on two streams (one half's all-reduce under the other half's round)" if B >= 4
                                 else "off (fewer than four scans in flight)"),
                 "shard_tail": "off (the round kernel folding its own rows is measured slower: profiles/r4_c_shard_probe.md)"}
@@ -923,8 +943,7 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
             # "shard_p2p"): side by side with the RCCL figure above, same batch, same trees
             p2p_err = None
             try:
-                from mad_icp_amd import sharded as _sh
-                _sh.attach_peer_mailboxes(ctx)
+                _sh.attach_peer_mailboxes(ctx, allow_coarse=not native)  # (coarse-grained memory only between ranks of ONE device)
             except Exception as e:  # noqa: BLE001
                 p2p_err = "%s: %s" % (type(e).__name__, str(e)[:200])
             bad = torch.tensor([1.0 if p2p_err else 0.0], device=small)
@@ -942,12 +961,16 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                         "one_scan_registrations_per_s": round(max(20, args.steps // 4) / e1p, 1),
                         "vs_shard_rccl": round((args.steps * B / ep) / value, 3),
                         "max_translation_error_m": round(terr_p, 5),
+                        "mailbox_memory": "fine-grained" if ctx.get_option("p2p_fine_grained") else "coarse-grained (ranks of one device)",
                         "sequence": "icp_round only: workgroup 0 stores the rank's 30 sums per scan into every peer's hipIpc-mapped "
                                     "mailbox, every workgroup polls its own mailbox in the next round's prologue and adds the rows in "
-                                    "rank order; no icp_reduce, no collective between rounds; matched flags OR-ed once (RCCL, grouped)",
-                        "note": "developed and tested with two ranks on ONE GPU (half of the CUs each): %s" %
+                                    "rank order; icp_final exchanges the matched flags the same way (32 per tagged word): no icp_reduce, "
+                                    "no collective, no host step — the single-GPU launch sequence, captured in a hipGraph, results out "
+                                    "through the side stream",
+                        "note": "developed and tested with up to eight ranks on ONE GPU (an eighth of the CU mask each): %s" %
                                 ("this is a world of one — nothing crossed xGMI" if world == 1 else
-                                 "this line is its first measurement over xGMI")}
+                                 "this line is its first measurement over xGMI" if native else
+                                 "%d ranks on one GPU — nothing crossed xGMI" % world)}
                 except Exception as e:  # noqa: BLE001 — (a rank that fails here leaves its peers to their bounded waits)
                     out_extra["shard_p2p"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
                 finally:
@@ -991,14 +1014,21 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                             "note": "every rank holds all %d trees and streams its own scans; no data-path collective" % K}
     if value is None or args.mode == "replica":
         value, elapsed = replica, r_elapsed
-        why = "the sharded path failed, see shard_error" if "shard_error" in out_extra else ("--mode replica" if shard_ok else "gloo backend")
+        why = "the sharded path failed, see shard_error" if "shard_error" in out_extra else "--mode replica"
         workload = "replicas of BASELINE configs[2] (no shard figure: %s)" % why
         par = "replicas"
     else:
         B = args.scans if args.scans > 0 else world
-        workload = ("BASELINE configs[3]: %d keyframe MAD-trees sharded %d per GPU over %d x MI355X, %d scans in flight (one per "
-                    "GPU), RCCL all-reduce of (H,b) over xGMI after every one of the %d GN rounds; a step = %d new scans' leaves in "
-                    "-> registration -> %d results out" % (K, n_local, world, B, N_ITERS, B, B))
+        if native:
+            workload = ("BASELINE configs[3]: %d keyframe MAD-trees sharded %d per GPU over %d x MI355X, %d scans in flight (one per "
+                        "GPU), RCCL all-reduce of (H,b) over xGMI after every one of the %d GN rounds; a step = %d new scans' leaves in "
+                        "-> registration -> %d results out" % (K, n_local, world, B, N_ITERS, B, B))
+        else:
+            workload = ("BASELINE configs[3] EXECUTED with %d ranks on ONE GPU — functional, not a scaling number: %d keyframe "
+                        "MAD-trees sharded %d per rank, every rank's compute stream on its own slice of the CU mask "
+                        "(MADICP_CU_MASK=rank/%d), %d scans in flight, all-reduce of (H,b) over the library's host-staged transport "
+                        "(gloo) after every one of the %d GN rounds; a step = %d new scans' leaves in -> registration -> %d results "
+                        "out" % (world, K, n_local, world, B, N_ITERS, B, B))
         par = "keyframes sharded %d/rank + all-reduce(H,b) per round" % n_local
     out = base_line(args, world, value, elapsed, workload,
                     {"keyframes": K, "scans_in_flight": (args.scans if args.scans > 0 else world), "moving_leaves": Ls,

@@ -268,14 +268,24 @@ int madicp_tree_build_stats(madicp_ctx* ctx, int32_t out[130]);
  * one node, at most 8 ranks).  The per-round join of the ranks' adders — the reference's serial sum of mad_icp.cpp:106-109, 30
  * doubles per scan — is then done inside the next round kernel's prologue: workgroup 0 writes this rank's sums as tagged
  * granules into every peer's mailbox, every workgroup polls the peers' rows in the own mailbox and adds them in rank order
- * (all ranks the same bits).  The launch sequence of a sharded registration becomes the single-GPU one; the matched flags are
- * still OR-ed once per registration through the communicator.
- *   madicp_p2p_export: allocates this rank's mailbox (once) and returns its 64-byte hipIpcMemHandle_t.
+ * (all ranks the same bits).  The matched flags of the last round (a leaf is an inlier if ANY keyframe on ANY rank matched it:
+ * mad_icp.cpp:85, pipeline.cpp:197-204) travel the same way, 32 flags per tagged word, OR-ed by the closing kernel — for moving
+ * sets of up to 131 072 leaves; larger ones OR them through the communicator as before.  A sharded registration is then the
+ * single-GPU launch sequence with NO collective and no host step: it is captured in a hipGraph and streams its results out like
+ * a single-GPU one.
+ *   madicp_p2p_export: allocates this rank's mailbox (the first time), ZEROES it and returns its 64-byte hipIpcMemHandle_t.
+ *                      Fine-grained device memory; where the runtime cannot export that, the call fails unless option
+ *                      "p2p_allow_coarse" = 1 (coarse-grained memory promises no visibility of a peer's stores to a running
+ *                      kernel: acceptable only for ranks that share ONE device).  get_option "p2p_fine_grained" says which.
  *   madicp_p2p_attach: `handles` = n_ranks x 64 bytes in rank order (gathered by the caller — torch.distributed, MPI ...);
- *                      needs madicp_comm_init / madicp_comm_init_host first, with the same n_ranks / rank.
+ *                      needs madicp_comm_init / madicp_comm_init_host first, with the same n_ranks / rank, and an export SINCE
+ *                      the last attach: a session is export -> gather (a point every rank passes) -> attach, so that every
+ *                      mailbox is clean before any rank can begin a registration of the session, whose counter restarts at 0.
  *   madicp_p2p_detach: unmaps the peers' mailboxes (madicp_comm_destroy does it too).
- * A peer whose row does not arrive within "comm_timeout_ms" fails the registration with MADICP_ERR_COMM.  Every rank must
- * submit the same sequence of sharded registrations (as with any collective). */
+ * A peer whose row does not arrive within "comm_timeout_ms" fails the registration with MADICP_ERR_COMM — once per
+ * registration, not once per round — and the session is over (the ranks' counters may disagree from there on): later sharded
+ * registrations fail with MADICP_ERR_COMM until every rank has exported and attached again.  Every rank must submit the same
+ * sequence of sharded registrations (as with any collective). */
 int madicp_p2p_export(madicp_ctx* ctx, uint8_t out_handle[64]);
 int madicp_p2p_attach(madicp_ctx* ctx, const uint8_t* handles, int n_ranks, int rank);
 int madicp_p2p_detach(madicp_ctx* ctx);

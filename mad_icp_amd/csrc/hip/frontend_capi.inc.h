@@ -705,8 +705,13 @@ int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, doubl
     // MADICP_BUILD_CUS=<n> (experiment): the look-ahead construction only gets the first n CUs, so that its level
     // kernels cannot spread over the CUs a registration round wants all of — whatever hardware queues the runtime maps the two
     // streams to
+    // (a measurement aid: compiled out of product builds, -DMADICP_NO_MEASURE)
+#ifndef MADICP_NO_MEASURE
     const char* e = std::getenv("MADICP_BUILD_CUS");
     const int n_build = e ? std::atoi(e) : 0;
+#else
+    const int n_build = 0;
+#endif
     if (n_build > 0 && n_build < ctx->n_cus) {
       const int words = (ctx->n_cus + 31) / 32;
       std::vector<uint32_t> mask((size_t)words, 0u);

@@ -188,6 +188,7 @@ struct Job {
                             // pass in the previous round (0: never; option "leaf_major")
   int32_t seq;              // streamed registrations: what icp_final leaves in HostResult::seq when everything is written
   uint32_t epoch;           // icp_persist: distinguishes this launch's exchange granules from every earlier launch's (host counter)
+  uint32_t p2p_epoch;       // option "shard_p2p": the mailbox session's registration counter (the same on every rank): tags + slot parity
   int32_t error;            // icp_persist: non-zero when a bounded in-launch wait ran out (results invalid)
 #ifdef MADICP_ABLATE
   unsigned long long* dbg;  // profiling builds: per-workgroup phase time stamps of the last launch
@@ -1351,14 +1352,26 @@ constexpr int kP2pSlots = 4;
 struct PeerBox {
   unsigned long long* box[kMaxRanks];  // box[q]: rank q's mailbox as mapped in THIS process (box[rank]: the own one)
   int n_ranks, rank;
-  unsigned int epoch;                  // registration counter of the communicator (the same on every rank)
+  int flags_in_box;                    // icp_final: the matched flags travel over the mailboxes too (every scan's L <= kP2pFlagLeaves)
   int scan0;                           // first mailbox scan row of this launch (a batch's second half: its first scan)
   unsigned long long spin_ticks;       // 100 MHz ticks a poll may take before the registration is declared lost
 };
+// (the registration counter that tags the rows — the same on every rank — is Job::p2p_epoch, not a kernel argument: a captured
+// launch sequence then serves every registration of its shape, like a single-GPU one)
+constexpr size_t kP2pSumWords = (size_t)kP2pSlots * MADICP_MAX_BATCH * kMaxRanks * kRowGranules;
 __host__ __device__ constexpr size_t p2p_row(int slot, int scan, int q) {
   return (((size_t)slot * MADICP_MAX_BATCH + (size_t)scan) * kMaxRanks + (size_t)q) * kRowGranules;
 }
-constexpr size_t kP2pBoxWords = (size_t)kP2pSlots * MADICP_MAX_BATCH * kMaxRanks * kRowGranules;
+// Behind the sums: the matched flags of a registration's last round (mad_icp.cpp:85; a leaf is an inlier if ANY keyframe on ANY
+// rank matched it, pipeline.cpp:197-204), 32 flags per tagged 8-byte word, one row per (registration parity, scan, sending
+// rank).  Two parities are enough: no rank can finish registration e + 1 before every rank has started its icp_final — i.e.
+// has left registration e's behind, flags read — so a row of parity e & 1 is never rewritten (by e + 2) while it is still unread.
+constexpr int kP2pFlagLeaves = 131072;  // moving sets beyond this OR their flags through the communicator, as before
+constexpr int kP2pFlagWords = kP2pFlagLeaves / 32;
+__host__ __device__ constexpr size_t p2p_flag_row(int parity, int scan, int q) {
+  return kP2pSumWords + (((size_t)parity * MADICP_MAX_BATCH + (size_t)scan) * kMaxRanks + (size_t)q) * kP2pFlagWords;
+}
+constexpr size_t kP2pBoxWords = kP2pSumWords + (size_t)2 * MADICP_MAX_BATCH * kMaxRanks * kP2pFlagWords;
 __device__ __forceinline__ void granule_store_sys(gptr_g64 g, unsigned tag, double v) {
   const unsigned long long t = (unsigned long long)tag << 32;
   __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1372,24 +1385,31 @@ __device__ __forceinline__ bool granule_try_sys(gptr_g64 g, unsigned tag, double
 }
 // Wave 0 of a workgroup (all 64 lanes): total[] (LDS) holds this rank's adders of round `r_done` of mailbox scan row `scan`;
 // on return it holds the sum over the ranks, in rank order.  `publish`: this workgroup is the one that sends the rank's row.
-__device__ __forceinline__ bool p2p_exchange(const PeerBox& pb, int scan, int r_done, bool publish, double* total /*LDS kAcc*/) {
+// `err_word` (Job::error): once ANY workgroup of the registration has given up on a peer — in this launch or an earlier one —
+// nobody waits out the bound again (a lost peer costs the registration one comm_timeout_ms, not one per workgroup and round).
+__device__ __forceinline__ bool p2p_exchange(const PeerBox& pb, unsigned epoch, int scan, int r_done, bool publish,
+                                             double* total /*LDS kAcc*/, int* err_word) {
   const int lane = threadIdx.x & 63;
-  const unsigned tag = (pb.epoch << 8) + (unsigned)r_done + 1u;
-  const int slot = (int)((pb.epoch & 1u) << 1) | (r_done & 1);
+  const unsigned tag = (epoch << 8) + (unsigned)r_done + 1u;
+  const int slot = (int)((epoch & 1u) << 1) | (r_done & 1);
   const double mine = lane < kAcc ? total[lane] : 0.0;
   if (publish && lane < kAcc) {
     for (int q = 0; q < pb.n_ranks; ++q)
       if (q != pb.rank) granule_store_sys((gptr_g64)(uintptr_t)pb.box[q] + p2p_row(slot, scan, pb.rank) + 2 * lane, tag, mine);
   }
-  bool ok = true;
+  bool ok = pb.n_ranks <= 1 || __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
   double tot = 0.0;
   const unsigned long long t0 = wall_clock64();
   for (int q = 0; q < pb.n_ranks; ++q) {
     double v = mine;
-    if (q != pb.rank && lane < kAcc) {
+    if (q != pb.rank && lane < kAcc && ok) {
       gptr_g64 g = (gptr_g64)(uintptr_t)pb.box[pb.rank] + p2p_row(slot, scan, q) + 2 * lane;
       for (unsigned spins = 1; !granule_try_sys(g, tag, v); ++spins) {
-        if ((spins & 63u) == 0u && wall_clock64() - t0 > pb.spin_ticks) { ok = false; break; }
+        if ((spins & 63u) == 0u && (wall_clock64() - t0 > pb.spin_ticks ||
+                                    __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          ok = false;
+          break;
+        }
         __builtin_amdgcn_s_sleep(2);
       }
     }
@@ -1399,6 +1419,80 @@ __device__ __forceinline__ bool p2p_exchange(const PeerBox& pb, int scan, int r_
   if (lane < kAcc) total[lane] = tot;
   wave_lds_order();
   return __all(ok);
+}
+
+// Job::error = 4 (a peer was lost), unless the registration already carries an error
+__device__ __forceinline__ void p2p_mark_lost(int* err_word) {
+  if (__hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    __hip_atomic_store(err_word, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the matched flags over the mailboxes (icp_final, whole workgroup) ----
+// 32 flag bytes (0 / 1) of the moving set <-> one 32-bit payload.  `matched` is 256-byte aligned and its capacity a multiple of
+// 256 bytes, so the two 16-byte loads of a word never leave the allocation; bytes at and beyond L are not flags.
+__device__ __forceinline__ unsigned p2p_pack_nibble(unsigned x) { return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu; }
+__device__ __forceinline__ unsigned p2p_unpack_nibble(unsigned n) { return (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21); }
+__device__ __forceinline__ unsigned p2p_pack32(const uint8_t* __restrict__ matched, int w, int L) {
+  const uint4 a = reinterpret_cast<const uint4*>(matched)[2 * w], b = reinterpret_cast<const uint4*>(matched)[2 * w + 1];
+  unsigned bits = p2p_pack_nibble(a.x) | (p2p_pack_nibble(a.y) << 4) | (p2p_pack_nibble(a.z) << 8) | (p2p_pack_nibble(a.w) << 12) |
+                  (p2p_pack_nibble(b.x) << 16) | (p2p_pack_nibble(b.y) << 20) | (p2p_pack_nibble(b.z) << 24) | (p2p_pack_nibble(b.w) << 28);
+  const int left = L - 32 * w;  // flags in this word
+  if (left < 32) bits &= (1u << left) - 1u;
+  return bits;
+}
+// this rank's flags -> its row in every peer's mailbox (stores only: they are in flight while wave 0 exchanges the sums)
+__device__ __forceinline__ void p2p_flags_publish(const PeerBox& pb, unsigned epoch, int scan, const uint8_t* __restrict__ matched, int L) {
+  const unsigned long long t = (unsigned long long)((epoch << 8) + 255u) << 32;
+  const int W = (L + 31) >> 5;
+  for (int w = threadIdx.x; w < W; w += blockDim.x) {
+    const unsigned long long word = t | p2p_pack32(matched, w, L);
+    for (int q = 0; q < pb.n_ranks; ++q)
+      if (q != pb.rank)
+        __hip_atomic_store((gptr_g64)(uintptr_t)pb.box[q] + p2p_flag_row((int)(epoch & 1u), scan, pb.rank) + w, word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// the peers' rows <- the own mailbox, OR-ed into `matched` (every rank ends with the same flags: OR has no order).  False when
+// a peer's row never came.  Ends with an agent-scope release by every thread: icp_publish reads `matched` from another XCD.
+__device__ __forceinline__ bool p2p_flags_join(const PeerBox& pb, unsigned epoch, int scan, uint8_t* __restrict__ matched, int L, int* err_word) {
+  const unsigned tag = (epoch << 8) + 255u;
+  const int W = (L + 31) >> 5;
+  bool ok = __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+  const unsigned long long t0 = wall_clock64();
+  for (int w = threadIdx.x; w < W && ok; w += blockDim.x) {
+    const unsigned own = p2p_pack32(matched, w, L);
+    unsigned bits = own;
+    for (int q = 0; q < pb.n_ranks && ok; ++q) {
+      if (q == pb.rank) continue;
+      gptr_g64 g = (gptr_g64)(uintptr_t)pb.box[pb.rank] + p2p_flag_row((int)(epoch & 1u), scan, q) + w;
+      unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (unsigned spins = 1; (unsigned)(v >> 32) != tag; ++spins) {
+        if ((spins & 63u) == 0u && (wall_clock64() - t0 > pb.spin_ticks ||
+                                    __hip_atomic_load(err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      bits |= (unsigned)v;
+    }
+    if (ok && bits != own) {
+      if (L - 32 * w >= 32) {
+        uint4 a, b;
+        a.x = p2p_unpack_nibble(bits & 15u); a.y = p2p_unpack_nibble((bits >> 4) & 15u);
+        a.z = p2p_unpack_nibble((bits >> 8) & 15u); a.w = p2p_unpack_nibble((bits >> 12) & 15u);
+        b.x = p2p_unpack_nibble((bits >> 16) & 15u); b.y = p2p_unpack_nibble((bits >> 20) & 15u);
+        b.z = p2p_unpack_nibble((bits >> 24) & 15u); b.w = p2p_unpack_nibble(bits >> 28);
+        reinterpret_cast<uint4*>(matched)[2 * w] = a;
+        reinterpret_cast<uint4*>(matched)[2 * w + 1] = b;
+      } else {
+        for (int i = 32 * w; i < L; ++i) matched[i] = (uint8_t)((bits >> (i - 32 * w)) & 1u);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  return ok;
 }
 
 // TRACE: also write the per-pair correspondence trace (Job::corr) — the single-round debugging entry point only
@@ -1503,6 +1597,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const int opt_stage_min = job->stage_min_leaves;
   const int L = job->L;
   const int flags = job->flags;
+  const unsigned p2p_epoch = P2P ? job->p2p_epoch : 0u;
   constexpr bool DEEP = QUEUE;
   const int opt_leaf_major = DEEP ? job->queue_nodes : 0;
   __shared__ unsigned short s_queue[DEEP ? kWaves : 1][DEEP ? kQueueCap : 1];  // leaf-major rounds: queued walkers per wavefront
@@ -1615,7 +1710,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         join_stage2_wave0(s_seg, s_total);
       }
       if (P2P) {  // this rank's adders -> every peer's mailbox; the other ranks' rows <- the own mailbox; sum in rank order
-        if (!p2p_exchange(pb, pb.scan0 + (int)blockIdx.y, round - 1, blockIdx.x == 0, s_total) && threadIdx.x == 0) jout->error = 4;
+        if (!p2p_exchange(pb, p2p_epoch, pb.scan0 + (int)blockIdx.y, round - 1, blockIdx.x == 0, s_total, &jout->error) && threadIdx.x == 0)
+          p2p_mark_lost(&jout->error);
       }
       MADICP_STAMP(1);
       double H[36], b[6];
@@ -2172,12 +2268,21 @@ __global__ __launch_bounds__(kBlock) void icp_final(Job* __restrict__ jobs, cons
     }
     __syncthreads();
   } else {
+    // sharded over peer-mapped mailboxes (option "shard_p2p"): this rank's matched flags go out first — plain stores, in flight
+    // while the sums are joined — then the last round's join over the ranks, then the peers' flags are OR-ed in
+    const bool box_flags = pb.n_ranks > 1 && pb.flags_in_box;
+    const unsigned p2p_epoch = job->p2p_epoch;
+    if (box_flags) p2p_flags_publish(pb, p2p_epoch, pb.scan0 + (int)blockIdx.x, job->matched, job->L);
     const int prows = join_rows(nblocks);
     const long long pstride = (long long)n_scans * prows * kAcc;
     join_partials(partials + ((n - 1) & 1) * pstride + (long long)blockIdx.x * prows * kAcc, prows, s_total);
-    // sharded over peer-mapped mailboxes (option "shard_p2p"): the last round's join over the ranks
-    if (pb.n_ranks > 0 && threadIdx.x < 64 && !p2p_exchange(pb, pb.scan0 + (int)blockIdx.x, n - 1, true, s_total) && threadIdx.x == 0)
-      job->error = 4;
+    if (pb.n_ranks > 0 && threadIdx.x < 64 &&
+        !p2p_exchange(pb, p2p_epoch, pb.scan0 + (int)blockIdx.x, n - 1, true, s_total, &job->error) && threadIdx.x == 0)
+      p2p_mark_lost(&job->error);
+    if (box_flags) {
+      if (!p2p_flags_join(pb, p2p_epoch, pb.scan0 + (int)blockIdx.x, job->matched, job->L, &job->error)) p2p_mark_lost(&job->error);
+      __syncthreads();  // (count_matched below reads what other threads have just OR-ed in)
+    }
   }
   count_matched(job);
   if (threadIdx.x < 64) {  // wave 0, every lane the same values (solve_pose is wave-uniform)

@@ -236,6 +236,10 @@ struct madicp_ctx {
   unsigned long long* p2p_peer[madicp::kMaxRanks] = {};   // every rank's mailbox as mapped here ([rank] = p2p_box)
   bool p2p_opened[madicp::kMaxRanks] = {};                // ... opened through hipIpcOpenMemHandle (to be closed)
   bool p2p_attached = false;
+  bool p2p_fresh = false;    // the own mailbox has been zeroed and exported since the last attach (madicp_p2p_export)
+  bool p2p_fine = false;     // ... and it is fine-grained device memory (peers' stores are visible to a running kernel)
+  bool p2p_broken = false;   // a registration of this mailbox session lost a peer: the ranks' counters may disagree from here on
+  int p2p_allow_coarse = 0;  // option "p2p_allow_coarse": accept a coarse-grained mailbox (ranks that share ONE device only)
   unsigned int p2p_epoch = 0;                             // sharded registrations so far (the same count on every rank)
   int shard_split = 1;     // a sharded batch of >= 4 scans runs as two halves on two streams: one half's all-reduce under the
                            // other half's round (profiles/r4_c_shard_probe.md: -14 % per registration at 8 scans with a 15 us
@@ -524,16 +528,39 @@ bool use_tail(const madicp_ctx* ctx, const Launch& l) {
 bool use_p2p(const madicp_ctx* ctx, const Launch& l) {
   return ctx->sharded() && ctx->shard_p2p && ctx->p2p_attached && !l.trace && l.qpt == 1 && l.iters <= 250;
 }
-madicp::PeerBox peer_box(const madicp_ctx* ctx, int scan0, bool on) {
+// ... and whose matched flags travel over the mailboxes too (icp_final): the whole registration is then free of collectives —
+// the single-GPU launch sequence, capturable, results out through the side stream.  Every scan's leaves must fit a flag row
+// (every rank holds the same moving sets, so every rank decides the same way).
+bool p2p_flags_fit(const madicp_ctx* ctx, const int* moving_ids, int n) {
+  for (int s = 0; s < n; ++s) {
+    auto it = ctx->movings.find(moving_ids[s]);
+    if (it == ctx->movings.end() || it->second.L > madicp::kP2pFlagLeaves) return false;
+  }
+  return true;
+}
+madicp::PeerBox peer_box(const madicp_ctx* ctx, int scan0, bool on, bool flags_in_box = false) {
   madicp::PeerBox pb{};
   if (!on) return pb;  // (n_ranks = 0: not a mailbox launch)
   for (int q = 0; q < madicp::kMaxRanks; ++q) pb.box[q] = ctx->p2p_peer[q];
   pb.n_ranks = ctx->n_ranks;
   pb.rank = ctx->rank;
-  pb.epoch = ctx->p2p_epoch;
+  pb.flags_in_box = flags_in_box ? 1 : 0;
   pb.scan0 = scan0;
   pb.spin_ticks = (unsigned long long)std::max(1, ctx->comm_timeout_ms) * 100000ull;  // 100 MHz ticks
   return pb;
+}
+
+// The registration counter of the mailbox session: every rank submits the same sequence of sharded registrations, so every
+// rank's counter names the same registration — it tags the rows and picks their slot.  Taken once per registration (all scans of
+// a batch), after every check that can refuse the submission and right before the Jobs are uploaded.
+int next_p2p_epoch(madicp_ctx* ctx, const Launch& l, unsigned* out) {
+  *out = 0;
+  if (!use_p2p(ctx, l)) return MADICP_OK;
+  if (ctx->p2p_broken)
+    return fail(MADICP_ERR_COMM, "this mailbox session lost a peer in an earlier registration: the ranks' registration counters may "
+                                 "disagree — madicp_p2p_export + madicp_p2p_attach again on every rank (or switch shard_p2p off)");
+  *out = ++ctx->p2p_epoch;
+  return MADICP_OK;
 }
 
 void launch_round(madicp_ctx* ctx, const Launch& l, const Part& p, int round, const double* totals) {
@@ -588,7 +615,9 @@ int enqueue_round(madicp_ctx* ctx, const Launch& l, const Part& p, int it) {
 }
 // what closes a part: the matched flags OR-ed over the ranks, then icp_final
 int enqueue_close(madicp_ctx* ctx, const Launch& l, const Part& p, const int* moving_ids) {
-  if (ctx->sharded()) {
+  const bool p2p = use_p2p(ctx, l);
+  const bool box_flags = p2p && p2p_flags_fit(ctx, moving_ids, l.batch);  // (icp_final ORs them over the mailboxes itself)
+  if (ctx->sharded() && !box_flags) {
     // a leaf is an inlier if ANY keyframe on ANY rank matched it (mad_icp.cpp:85, pipeline.cpp:197-204): the scans' flag
     // arrays as ONE grouped RCCL operation (one launch for the batch, not one per scan)
     if (ctx->comm && l.batch > 1) NCCL_TRY(ncclGroupStart());
@@ -601,10 +630,10 @@ int enqueue_close(madicp_ctx* ctx, const Launch& l, const Part& p, const int* mo
     if (rc != MADICP_OK) return rc;
   }
   // (icp_reduce / icp_final join with kBlock threads, like icp_round: same summation order with and without ranks)
-  const bool p2p = use_p2p(ctx, l);
   hipLaunchKernelGGL(icp_final, dim3(l.batch), dim3(kBlock), 0, p.s, p.jobs, p.partials,
                      (ctx->sharded() && !p2p) ? (const double*)p.totals[(l.iters - 1) & 1] : (const double*)nullptr, l.grid, l.batch,
-                     use_fold(ctx, l) ? (const unsigned long long*)p.xch : (const unsigned long long*)nullptr, peer_box(ctx, p.scan0, p2p));
+                     use_fold(ctx, l) ? (const unsigned long long*)p.xch : (const unsigned long long*)nullptr,
+                     peer_box(ctx, p.scan0, p2p, box_flags));
   HIP_TRY(hipGetLastError());
   return MADICP_OK;
 }
@@ -654,14 +683,16 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
   // with a communicator the RCCL calls are captured only on request (option "comm_graph"): it could not be
   // exercised on more than one rank where this was developed
   // (a host-staged transport makes a host round trip per round: never capturable)
+  // over the peer mailboxes with the flags in them (p2p_free) nothing of the registration is a collective or a host step: it
+  // is captured like a single-GPU one (the tags come from Job::p2p_epoch, not from a kernel argument)
   const bool p2p = use_p2p(ctx, l);
-  if (p2p) ++ctx->p2p_epoch;  // (every rank submits the same sequence of sharded registrations: the tags of this one's rows)
-  const bool graph_ok = ctx->use_graph && !ctx->host_ar && (!ctx->comm || ctx->comm_graph) && !p2p &&
-                        !(queued_behind && ctx->eager_when_busy && !ctx->comm);
+  const bool p2p_free = p2p && p2p_flags_fit(ctx, moving_ids.data(), l.batch);
+  const bool graph_ok = ctx->use_graph && (p2p_free || (!ctx->host_ar && (!ctx->comm || ctx->comm_graph) && !p2p)) &&
+                        !(queued_behind && ctx->eager_when_busy && (!ctx->comm || p2p_free));
   if (!graph_ok) return enqueue_rounds(ctx, l, d_jobs, moving_ids);
   // (with a communicator the matched-flag all-reduce bakes the moving buffer's address: key on the slot only — the
   // batch path never takes the graph route with a communicator unless every scan's buffer is stable, see below)
-  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, ctx->comm ? 1 : 0, l.lds, l.K, l.rpt, l.trace, slot,
+  const GraphKey key{l.grid, l.batch, l.iters, l.qpt, (ctx->comm ? 1 : 0) + (p2p_free ? 2 : 0), l.lds, l.K, l.rpt, l.trace, slot,
                      (use_persist(ctx, l) ? 1 : (use_fold(ctx, l) ? 2 : 0)) + 4 * l.queue};
   auto it = ctx->graphs.find(key);
   if (it == ctx->graphs.end()) {
@@ -681,7 +712,7 @@ int run_rounds(madicp_ctx* ctx, const Launch& l, Job* d_jobs, int slot, const st
       ctx->graphs.emplace(k, exec);
       return MADICP_OK;
     };
-    if (slot >= 0 && !ctx->comm) {
+    if (slot >= 0 && (!ctx->comm || p2p_free)) {
       // a streamed registration: instantiate this shape for EVERY slot now (a few ms each, once), so that the first
       // lap around the ring costs the same as every later one
       for (int s = 0; s < madicp_ctx::kStreamSlots; ++s) {
@@ -966,6 +997,11 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   const int grid = launch.grid;
   size_t part_doubles[2] = {0, 0};
   RC_TRY(prepare_partials(ctx, halves, split ? 2 : 1, part_doubles));
+  if (!a.time_launches) {
+    unsigned reg_epoch = 0;
+    RC_TRY(next_p2p_epoch(ctx, launch, &reg_epoch));
+    for (int s = 0; s < a.n_scans; ++s) h_jobs[s].p2p_epoch = reg_epoch;
+  }
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
   for (int s = 0; s < a.n_scans; ++s)
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1026,8 +1062,9 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     return enqueue_rounds_split(ctx, halves, parts, ctx->last_moving.data());
   }
   // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
+  // (over the mailboxes with the flags in them there is no collective: captured like a single-GPU batch)
   const int saved = ctx->use_graph;
-  if (ctx->sharded()) ctx->use_graph = 0;
+  if (ctx->sharded() && !(use_p2p(ctx, launch) && p2p_flags_fit(ctx, ctx->last_moving.data(), a.n_scans))) ctx->use_graph = 0;
   const bool queued_behind = ctx->use_graph && ctx->eager_when_busy && hipStreamQuery(ctx->stream) == hipErrorNotReady;
   const int rc = run_rounds(ctx, launch, ctx->d_jobs, -1, ctx->last_moving, queued_behind);
   ctx->use_graph = saved;
@@ -1056,22 +1093,33 @@ int madicp_ctx_create(int device_id, void* stream, madicp_ctx** out) {
   if (stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {
-    // MADICP_CU_MASK=lo|hi (development / tests): the compute stream only gets the lower / upper half of the device's CUs, so
-    // that two processes sharing ONE GPU can have their round kernels resident side by side — what two ranks polling each
-    // other's mailboxes need (tests/test_sharded.py: on real hardware every rank has a GPU of its own)
-    const char* cu_half = std::getenv("MADICP_CU_MASK");
-    if (cu_half && (cu_half[0] == 'l' || cu_half[0] == 'h')) {
+    // MADICP_CU_MASK=i/n (also lo = 0/2, hi = 1/2): the compute stream only gets slice i of n of the device's CU mask, so that n
+    // processes sharing ONE GPU can have their round kernels resident side by side — what ranks polling each other's mailboxes
+    // need (tests/test_sharded_world8.py, bench.py --gpus N under MADICP_BENCH_BACKEND=gloo: BASELINE configs[3] executed with
+    // eight ranks on a one-GPU box; on real hardware every rank has a GPU of its own).  The driver deals the mask's bits over
+    // the XCDs, so every slice holds CUs of all eight.  Said once on stderr when it takes effect: a stray setting costs CUs.
+    int cu_i = -1, cu_n = 0;
+    if (const char* cm = std::getenv("MADICP_CU_MASK")) {
+      if (cm[0] == 'l') { cu_i = 0; cu_n = 2; }
+      else if (cm[0] == 'h') { cu_i = 1; cu_n = 2; }
+      else if (std::sscanf(cm, "%d/%d", &cu_i, &cu_n) != 2 || cu_n < 1 || cu_i < 0 || cu_i >= cu_n || ctx->n_cus / cu_n < 1) {
+        std::fprintf(stderr, "madicp: MADICP_CU_MASK=%s ignored (expected lo, hi or i/n with 0 <= i < n <= %d)\n", cm, ctx->n_cus);
+        cu_i = -1;
+      }
+    }
+    if (cu_i >= 0) {
       const int words = (ctx->n_cus + 31) / 32;
       std::vector<uint32_t> mask((size_t)words, 0u);
-      for (int cu = 0; cu < ctx->n_cus; ++cu) {
-        const bool lower = cu < ctx->n_cus / 2;
-        if (lower == (cu_half[0] == 'l')) mask[(size_t)cu / 32] |= 1u << (cu % 32);
-      }
+      const int first = (int)((long long)ctx->n_cus * cu_i / cu_n), last = (int)((long long)ctx->n_cus * (cu_i + 1) / cu_n);
+      for (int cu = first; cu < last; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
       e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words, mask.data());
       if (e != hipSuccess) {
         (void)hipGetLastError();
         std::fprintf(stderr, "madicp: MADICP_CU_MASK ignored (hipExtStreamCreateWithCUMask: %s)\n", hipGetErrorString(e));
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+      } else {
+        std::fprintf(stderr, "madicp: MADICP_CU_MASK=%d/%d in effect: the compute stream of this context runs on CUs %d..%d of %d\n", cu_i,
+                     cu_n, first, last - 1, ctx->n_cus);
       }
     } else {
       e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -1245,6 +1293,13 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "comm_timeout_ms") {
     if (value < 1) return fail(MADICP_ERR_INVALID, "comm_timeout_ms must be >= 1");
     ctx->comm_timeout_ms = (int)std::min<int64_t>(value, 1 << 30);
+    if (ctx->p2p_attached) {  // (captured mailbox launches carry the bound of their polls as a kernel argument)
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);
+      ctx->graphs.clear();
+    }
+  } else if (k == "p2p_allow_coarse") {
+    ctx->p2p_allow_coarse = value ? 1 : 0;
   } else if (k == "nn_lds_top") {
     ctx->nn_lds_top = value ? 1 : 0;
   } else if (k == "queries_per_lane") {
@@ -1284,6 +1339,8 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "wait_mode") v = ctx->wait_mode;
   else if (k == "wait_timeout_ms") v = ctx->wait_timeout_ms;
   else if (k == "comm_timeout_ms") v = ctx->comm_timeout_ms;
+  else if (k == "p2p_allow_coarse") v = ctx->p2p_allow_coarse;
+  else if (k == "p2p_fine_grained") v = (ctx->p2p_box && ctx->p2p_fine) ? 1 : 0;  // (read-only: what madicp_p2p_export obtained)
   else if (k == "nn_lds_top") v = ctx->nn_lds_top;
   else if (k == "queries_per_lane") v = ctx->qpt_override;
   else return fail(MADICP_ERR_INVALID, "unknown option: " + k);
@@ -1702,8 +1759,11 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   // that must all be resident, at 3 x 168 registers per SIMD lane nothing fits beside them, and an icp_publish workgroup that got
   // its CU first (the compute stream is still waiting for the feed) would keep one of them out until their bounded waits expire
   const Launch launch{geo.grid, 1, n_iters, geo.qpt, geo.lds_bytes, K, geo.ranges_per_tree, 0, geo.queue};
-  const bool side = ctx->publish_side && ctx->seq_completion && !ctx->sharded() && !use_persist(ctx, launch) && !use_fold(ctx, launch);
+  const bool p2p_free = use_p2p(ctx, launch) && L <= madicp::kP2pFlagLeaves;  // (sharded, yet no collective and no host step)
+  const bool side = ctx->publish_side && ctx->seq_completion && (!ctx->sharded() || p2p_free) && !use_persist(ctx, launch) &&
+                    !use_fold(ctx, launch);
   j.outbox = side ? sl.d_outbox : nullptr;
+  RC_TRY(next_p2p_epoch(ctx, launch, &j.p2p_epoch));
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, K);
   j.seq = ticket + 1;
   sl.h_out->seq = 0;
@@ -1809,7 +1869,10 @@ int madicp_stream_collect(madicp_ctx* ctx, int ticket, double out_X[12], double 
   const HostResult& r = *sl.h_out;
   if (r.error) {
     sl.pending = false;
-    if (r.error == 4) return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
+    if (r.error == 4) {
+      ctx->p2p_broken = true;
+      return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
+    }
     return fail(MADICP_ERR_DEVICE, r.error == 3 ? std::string("registration never left its results in the outbox (icp_publish timed out)")
                                                 : "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(r.error) + ")");
   }
@@ -1840,7 +1903,10 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
   RC_TRY(bounded_sync(ctx, ctx->stream));
   for (int s = 0; s < n_scans; ++s) {
     const Job& j = ctx->h_fetch[s];
-    if (j.error == 4) return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
+    if (j.error == 4) {
+      ctx->p2p_broken = true;
+      return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
+    }
     if (j.error) return fail(MADICP_ERR_DEVICE, "registration aborted on the device: an in-launch wait of the persistent round kernel ran out (code " + std::to_string(j.error) + ")");
     if (out_X) std::memcpy(out_X + 12 * s, j.X, 12 * sizeof(double));
     if (out_H) std::memcpy(out_H + 36 * s, j.H, 36 * sizeof(double));
@@ -2181,24 +2247,31 @@ int madicp_comm_init_host(madicp_ctx* ctx, int n_ranks, int rank, madicp_host_al
 }
 
 // ---- peer-mapped mailboxes (option "shard_p2p"; kernels.hip.h, "keyframe sharding without a collective between rounds") ----
+// A mailbox SESSION is export -> (the caller gathers every rank's handle: a point every rank passes) -> attach.  The export
+// zeroes the own mailbox, so that no row of an earlier session can carry a tag the new one expects (the registration counter
+// restarts at 0 with every attach), and it does so BEFORE the handle leaves this rank: no peer can have begun a registration of
+// the new session — it needs every rank's handle first, this one's included.  An attach therefore insists on a fresh export.
 int madicp_p2p_export(madicp_ctx* ctx, uint8_t out_handle[64]) {
   if (!ctx || !out_handle) return fail(MADICP_ERR_INVALID, "null argument");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   HIP_TRY(hipSetDevice(ctx->device));
+  if (ctx->p2p_attached) return fail(MADICP_ERR_INVALID, "madicp_p2p_detach first: peers of the running session still write this mailbox");
   const size_t bytes = madicp::kP2pBoxWords * sizeof(unsigned long long);
   hipIpcMemHandle_t h;
   if (!ctx->p2p_box) {
-    // fine-grained device memory first: peers write it while kernels of this device poll it (coarse-grained memory promises
-    // no cross-device visibility during a kernel); plain hipMalloc where the runtime has no fine-grained device pool or will
-    // not export one
+    // Fine-grained device memory: peers write it while kernels of this device poll it.  Coarse-grained memory promises no
+    // cross-device visibility while a kernel runs — over xGMI the polls could spin until comm_timeout_ms — so it is only taken
+    // on request (option "p2p_allow_coarse": ranks that share ONE device, where the same L2 / memory serves writer and reader).
     for (int attempt = 0; attempt < 2 && !ctx->p2p_box; ++attempt) {
+      if (attempt == 1 && !ctx->p2p_allow_coarse)
+        return fail(MADICP_ERR_DEVICE, "mailbox: no exportable fine-grained device memory on this runtime (option p2p_allow_coarse = 1 "
+                                       "accepts coarse-grained memory, for ranks that share one device only)");
       void* p = nullptr;
       hipError_t e = attempt == 0 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
-      if (e == hipSuccess) e = hipMemset(p, 0, bytes);
-      if (e == hipSuccess) e = hipDeviceSynchronize();
       if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
       if (e == hipSuccess) {
         ctx->p2p_box = static_cast<unsigned long long*>(p);
+        ctx->p2p_fine = attempt == 0;
       } else {
         (void)hipGetLastError();
         if (p) hipFree(p);
@@ -2206,8 +2279,12 @@ int madicp_p2p_export(madicp_ctx* ctx, uint8_t out_handle[64]) {
       }
     }
   }
+  if (ctx->stream) HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipMemset(ctx->p2p_box, 0, bytes));
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipIpcGetMemHandle(&h, ctx->p2p_box));
   std::memcpy(out_handle, &h, 64);
+  ctx->p2p_fresh = true;
   return MADICP_OK;
 }
 
@@ -2215,12 +2292,16 @@ int madicp_p2p_detach(madicp_ctx* ctx) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   HIP_TRY(hipSetDevice(ctx->device));
   if (ctx->stream) HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->pub) HIP_TRY(hipStreamSynchronize(ctx->pub));
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);  // (captured launches carry the peers' mappings)
+  ctx->graphs.clear();
   for (int q = 0; q < madicp::kMaxRanks; ++q) {
     if (ctx->p2p_opened[q] && ctx->p2p_peer[q]) hipIpcCloseMemHandle(ctx->p2p_peer[q]);
     ctx->p2p_opened[q] = false;
     ctx->p2p_peer[q] = nullptr;
   }
   ctx->p2p_attached = false;
+  ctx->p2p_broken = false;
   return MADICP_OK;
 }
 
@@ -2230,8 +2311,13 @@ int madicp_p2p_attach(madicp_ctx* ctx, const uint8_t* handles, int n_ranks, int 
   if (n_ranks != ctx->n_ranks || rank != ctx->rank) return fail(MADICP_ERR_INVALID, "n_ranks / rank differ from the communicator's");
   if (n_ranks > madicp::kMaxRanks) return fail(MADICP_ERR_CAPACITY, "peer mailboxes serve at most 8 ranks (one node)");
   if (!ctx->p2p_box) return fail(MADICP_ERR_INVALID, "madicp_p2p_export first: this rank's own mailbox does not exist yet");
+  if (!ctx->p2p_fresh)
+    return fail(MADICP_ERR_INVALID, "madicp_p2p_export again before re-attaching: the mailbox still holds the rows of the previous "
+                                    "session, whose tags the new session's registration counter would meet again");
   if (ctx->p2p_attached) RC_TRY(madicp_p2p_detach(ctx));
   HIP_TRY(hipSetDevice(ctx->device));
+  for (auto& g : ctx->graphs) hipGraphExecDestroy(g.second);  // (captured without the join over the ranks)
+  ctx->graphs.clear();
   for (int q = 0; q < n_ranks; ++q) {
     if (q == rank) {
       ctx->p2p_peer[q] = ctx->p2p_box;
@@ -2250,6 +2336,8 @@ int madicp_p2p_attach(madicp_ctx* ctx, const uint8_t* handles, int n_ranks, int 
     ctx->p2p_opened[q] = true;
   }
   ctx->p2p_epoch = 0;
+  ctx->p2p_fresh = false;
+  ctx->p2p_broken = false;
   ctx->p2p_attached = true;
   return MADICP_OK;
 }

@@ -71,18 +71,33 @@ def init_host_comm(ctx, group=None):
     return rank, world
 
 
-def attach_peer_mailboxes(ctx, group=None):
-    """Option "shard_p2p": every rank exports its mailbox, torch.distributed gathers the 64-byte handles, every rank maps the
-    others' (madicp_p2p_export / madicp_p2p_attach).  Needs a communicator in `ctx` already (init_native_comm /
-    init_host_comm); ranks on one node (hipIpc).  After this, `ctx.set_option("shard_p2p", 1)` makes the per-round join of the
-    ranks' adders happen inside the round kernel — no collective between two rounds."""
+def attach_peer_mailboxes(ctx, group=None, allow_coarse=False):
+    """Option "shard_p2p": every rank exports its (freshly zeroed) mailbox, torch.distributed gathers the 64-byte handles — the
+    point every rank passes between zeroing its mailbox and the first registration of the session — every rank maps the others'
+    (madicp_p2p_export / madicp_p2p_attach).  Needs a communicator in `ctx` already (init_native_comm / init_host_comm); ranks
+    on one node (hipIpc).  After this, `ctx.set_option("shard_p2p", 1)` makes the per-round join of the ranks' adders AND the
+    OR of the matched flags happen inside the registration's own kernels — no collective at all.  Call it again to start a
+    new session (after a MADICP_ERR_COMM, or with other ranks).  A rank whose export fails does not leave its peers waiting:
+    the ranks agree and every one raises.  `allow_coarse`: accept a coarse-grained mailbox (ranks that share ONE device: the
+    one-GPU tests and bench.py under MADICP_BENCH_BACKEND=gloo)."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    mine = ctx.p2p_export()
-    handles = [None] * world
-    dist.all_gather_object(handles, mine, group=group)
-    ctx.p2p_attach(handles, world, rank)
+    err = None
+    mine = b""
+    try:
+        if allow_coarse:
+            ctx.set_option("p2p_allow_coarse", 1)
+        ctx.p2p_detach()  # (a no-op without a running session)
+        mine = ctx.p2p_export()
+    except capi.MadIcpError as e:
+        err = "rank %d: %s" % (rank, e)
+    got = [None] * world
+    dist.all_gather_object(got, (err, mine), group=group)
+    errs = [e for e, _ in got if e]
+    if errs:
+        raise capi.MadIcpError("peer mailboxes: " + "; ".join(errs))
+    ctx.p2p_attach([h for _, h in got], world, rank)
     return rank, world
 
 

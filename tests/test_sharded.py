@@ -410,10 +410,10 @@ def _p2p_worker(rank, world, port, K, out):
         L = qh[0].num_leaves
         mids = [ctx.moving_upload(q.leaf_means()) for q in qh]
         guess = pb["query_guess"][0]
-        sharded.init_host_comm(ctx)                 # the matched flags still go through a transport, once per registration
+        sharded.init_host_comm(ctx)                 # (the mailboxes need a communicator; moving sets beyond 131 072 leaves OR their flags through it)
         ctx.set_option("comm_timeout_ms", 20000)
         ref = ctx.icp_register(mids[0], tids, guess, PARAMS, 15, L)  # icp_reduce + host all-reduce per round
-        sharded.attach_peer_mailboxes(ctx)
+        sharded.attach_peer_mailboxes(ctx, allow_coarse=True)  # (the two ranks share ONE device)
         ctx.set_option("shard_p2p", 1)
         res = []
         for rep in range(3):                        # (several registrations: the slots' registration parity alternates)
@@ -507,9 +507,12 @@ def test_peer_mailboxes_with_one_rank_and_a_missing_peer(natives):
         mid = c.moving_upload(qh.leaf_means())
         ref = c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
         c.comm_init_host(1, 0, lambda arr, kind: None)
+        c.set_option("p2p_allow_coarse", 1)
         h = c.p2p_export()
         assert len(h) == 64
         c.p2p_attach([h], 1, 0)
+        with pytest.raises(capi.MadIcpError, match="detach first"):
+            c.p2p_export()  # (peers of a running session still write the mailbox)
         c.set_option("shard_p2p", 1)
         solo = c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
         assert np.array_equal(solo["X"], ref["X"]) and np.array_equal(solo["H"], ref["H"])
@@ -522,6 +525,9 @@ def test_peer_mailboxes_with_one_rank_and_a_missing_peer(natives):
         # of rank 1's row run out
         c.comm_init_host(2, 0, lambda arr, kind: None)
         c.set_option("comm_timeout_ms", 300)
+        with pytest.raises(capi.MadIcpError, match="export again"):
+            c.p2p_attach([h, h], 2, 0)  # (a session starts with a fresh — zeroed — export)
+        h = c.p2p_export()
         try:
             c.p2p_attach([h, h], 2, 0)
             attached = True
@@ -529,6 +535,8 @@ def test_peer_mailboxes_with_one_rank_and_a_missing_peer(natives):
             attached = False  # (this runtime refuses to open the process's own handle: nothing to test here)
         if attached:
             with pytest.raises(capi.MadIcpError, match="error -3"):
+                c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
+            with pytest.raises(capi.MadIcpError, match="lost a peer"):  # the session is over: refused before anything is launched
                 c.icp_register(mid, tids, pb["query_guess"][0], PARAMS, 15, qh.num_leaves)
         c.set_option("shard_p2p", 0)
         c.set_option("comm_timeout_ms", 60000)

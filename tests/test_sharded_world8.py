@@ -1,0 +1,278 @@
+"""BASELINE configs[3] executed end to end — 16 keyframe MAD-trees sharded 2 per rank over EIGHT ranks (and 4 per rank over
+four; and K = 4 over eight: four ranks own no tree) — on the ONE GPU of the test box: eight processes on device 0, each its
+own capi.Context whose compute stream runs on its own eighth of the CU mask (MADICP_CU_MASK=i/n), so that all ranks' round
+kernels are resident side by side like on eight GPUs.  Full-size problem: 119 725-point scans, default parameters, 15 rounds.
+
+Two transports, the same registrations over both:
+  host-staged  icp_round -> icp_reduce -> all-reduce over gloo -> next round (madicp_comm_init_host): the RCCL path's
+               kernels and ordering, only the all-reduce itself differs (RCCL refuses several ranks on one GPU)
+  mailboxes    option "shard_p2p": the per-round join of the ranks' adders AND the OR of the matched flags inside the
+               registration's own kernels, over hipIpc-mapped mailboxes — no collective, no host step, captured graphs
+
+What the reference does there: the serial sum of the per-thread adders, mad_icp.cpp:106-109, under the fan-out over keyframes,
+pipeline.cpp:180-183.  Bars: every rank bit-equal to every other; <= 1e-9 of the single-context registration; <= 1e-5 m /
+1e-5 rad of the oracle; matched flags equal; streamed and batched; a rank that never shows up -> MADICP_ERR_COMM within ONE
+comm_timeout_ms, the session then refuses further registrations until every rank has exported and attached again.
+NOTHING here crossed xGMI: functional coverage of the world = 8 code, not a scaling measurement.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from fixtures import B_MAX, B_MIN, B_RATIO, PARAMS, RHO_KER
+from mad_icp_amd import capi, sharded, synth
+
+pytestmark = pytest.mark.gpu
+N_ITERS = 15
+
+
+def _pose_err(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    ang = np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1))
+    return float(np.linalg.norm(d[:3, 3])), float(ang)
+
+
+@pytest.fixture(scope="module")
+def problem(tmp_path_factory):
+    """The full-size scene once, on disk for the workers: 16 keyframe scans + 2 query scans."""
+    pb = synth.make_problem(16, seed=1, n_queries=2)
+    path = str(tmp_path_factory.mktemp("world8") / "problem.npz")
+    arrays = {"n_kf": 16, "n_q": 2}
+    for k in range(16):
+        arrays["kf%d" % k] = pb["keyframe_scans"][k]
+        arrays["kfT%d" % k] = pb["keyframe_poses"][k]
+    for q in range(2):
+        arrays["q%d" % q] = pb["query_scans"][q]
+        arrays["g%d" % q] = pb["query_guess"][q]
+    np.savez(path, **arrays)
+    return pb, path
+
+
+def _setup_rank(rank, world, port, K, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MADICP_CU_MASK"] = "%d/%d" % (rank, world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = capi.Context(0)
+    z = np.load(path)
+    tids = []
+    for k in sharded.shard_keyframes(K, world, rank):
+        T = z["kfT%d" % k]
+        ht = capi.HostTree(z["kf%d" % k], B_MAX, B_MIN, 3)
+        ht.transform(T[:3, :3], T[:3, 3])
+        tids.append(ctx.upload(ht))
+    qh = [capi.HostTree(z["q%d" % q], B_MAX, B_MIN, 3) for q in range(2)]
+    leaves = [q.leaf_means() for q in qh]
+    guesses = [z["g0"], z["g1"]]
+    return ctx, tids, leaves, guesses
+
+
+def _worker(rank, world, port, K, path, out):
+    ctx, tids, leaves, guesses = _setup_rank(rank, world, port, K, path)
+    try:
+        L = [a.shape[0] for a in leaves]
+        mids = [ctx.moving_upload(a) for a in leaves]
+        X2 = np.stack([capi.pose12(g) for g in guesses])
+        res = {"n_local": len(tids)}
+
+        def run(tag):
+            r = ctx.icp_register(mids[0], tids, guesses[0], PARAMS, N_ITERS, L[0])
+            res[tag + "_X"], res[tag + "_H"], res[tag + "_b"] = r["X"], r["H"], r["b"]
+            res[tag + "_m"], res[tag + "_Xi"] = r["matched"], r["X_iters"]
+            tk = ctx.stream_submit(leaves[0], tids, guesses[0], PARAMS, N_ITERS)
+            tk2 = ctx.stream_submit(leaves[1], tids, guesses[1], PARAMS, N_ITERS)  # (two in flight: the ring, the busy path)
+            s0 = ctx.stream_collect(tk, L[0])
+            s1 = ctx.stream_collect(tk2, L[1])
+            res[tag + "_sX"], res[tag + "_sm"], res[tag + "_sn"] = s0["X"], s0["matched"], s0["n_matched"]
+            res[tag + "_s1X"], res[tag + "_s1m"] = s1["X"], s1["matched"]
+            bt = ctx.icp_register_batch(mids, tids, X2, PARAMS, N_ITERS)
+            res[tag + "_bX"], res[tag + "_bn"] = bt["X"], bt["n_matched"]
+            res[tag + "_bm0"], res[tag + "_bm1"] = ctx.icp_fetch_matched(0, L[0]), ctx.icp_fetch_matched(1, L[1])
+
+        # (i) host-staged transport: the library's sharded launch sequence, all-reduce over gloo
+        sharded.init_host_comm(ctx)
+        ctx.set_option("comm_timeout_ms", 60000)
+        ctx.set_option("shard_split", 0)
+        run("host")
+        # (ii) the peer mailboxes (ranks share ONE device here: a coarse-grained mailbox is acceptable if that is all there is)
+        sharded.attach_peer_mailboxes(ctx, allow_coarse=True)
+        res["fine_grained"] = ctx.get_option("p2p_fine_grained")
+        ctx.set_option("shard_p2p", 1)
+        run("p2p")
+        again = ctx.icp_register(mids[0], tids, guesses[0], PARAMS, N_ITERS, L[0])  # (the other registration parity)
+        res["p2p_again_X"] = again["X"]
+        ctx.set_option("use_graph", 0)  # eager launches instead of the captured sequence: the same registration
+        tk = ctx.stream_submit(leaves[0], tids, guesses[0], PARAMS, N_ITERS)
+        e0 = ctx.stream_collect(tk, L[0])
+        res["p2p_eager_X"], res["p2p_eager_m"] = e0["X"], e0["matched"]
+        ctx.set_option("use_graph", 1)
+        ctx.set_option("shard_p2p", 0)
+        ctx.comm_destroy()
+        np.savez(out % rank, **res)
+    finally:
+        ctx.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K", [(8, 16), (4, 16), (8, 4)])
+def test_configs3_sharded_over_world_ranks_one_gpu(ctx, problem, tmp_path, world, K):
+    pb, path = problem
+    out = str(tmp_path / "rank%d.npz")
+    port = 23500 + ((os.getpid() * 7 + world * 13 + K) % 4000)
+    mp.spawn(_worker, args=(world, port, K, path, out), nprocs=world, join=True)
+    R = [np.load(out % r) for r in range(world)]
+    assert sum(int(r["n_local"]) for r in R) == K
+    assert sorted(int(r["n_local"]) for r in R) == sorted(len(sharded.shard_keyframes(K, world, q)) for q in range(world))
+    # every rank holds the same state, bit for bit, over both transports
+    for key in R[0].files:
+        if key in ("n_local", "fine_grained"):
+            continue
+        for r in R[1:]:
+            assert np.array_equal(R[0][key], r[key]), key
+    r0 = R[0]
+    # mailbox join = rank-order sum of the ranks' totals; the host transport's all-reduce is gloo's order: bits may differ, 1e-9
+    for a, b in (("p2p_X", "host_X"), ("p2p_sX", "host_sX"), ("p2p_s1X", "host_s1X")):
+        dt, da = _pose_err(capi.pose44(r0[a]), capi.pose44(r0[b]))
+        assert dt <= 1e-9 and da <= 1e-9, (a, dt, da)
+    for s in range(2):
+        dt, da = _pose_err(capi.pose44(r0["p2p_bX"][s]), capi.pose44(r0["host_bX"][s]))
+        assert dt <= 1e-9 and da <= 1e-9
+    # streamed == synchronous == eager == the registration after it, bit for bit, per transport
+    for t in ("host", "p2p"):
+        assert np.array_equal(r0[t + "_sX"], r0[t + "_X"]) and np.array_equal(r0[t + "_sm"], r0[t + "_m"])
+        assert int(r0[t + "_sn"]) == int(r0[t + "_m"].sum())
+        assert np.array_equal(r0[t + "_bn"], [r0[t + "_bm0"].sum(), r0[t + "_bm1"].sum()])
+    assert np.array_equal(r0["p2p_again_X"], r0["p2p_X"])
+    assert np.array_equal(r0["p2p_eager_X"], r0["p2p_X"]) and np.array_equal(r0["p2p_eager_m"], r0["p2p_m"])
+    # matched flags: OR over the ranks has no order — equal over both transports
+    assert np.array_equal(r0["p2p_m"], r0["host_m"]) and np.array_equal(r0["p2p_s1m"], r0["host_s1m"])
+    assert np.array_equal(r0["p2p_bm0"], r0["host_bm0"]) and np.array_equal(r0["p2p_bm1"], r0["host_bm1"])
+
+    # the single-context registration (all K trees on one rank, fused join) and the oracle
+    tids, otrees = [], []
+    for k in range(K):
+        T = pb["keyframe_poses"][k]
+        ht = capi.HostTree(pb["keyframe_scans"][k], B_MAX, B_MIN, 3)
+        ht.transform(T[:3, :3], T[:3, 3])
+        tids.append(ctx.upload(ht))
+        ot = O.Tree(pb["keyframe_scans"][k], B_MAX, B_MIN, 3)
+        ot.transform(T[:3, :3], T[:3, 3])
+        otrees.append(ot)
+    qh = [capi.HostTree(s, B_MAX, B_MIN, 3) for s in pb["query_scans"][:2]]
+    mids = [ctx.moving_upload(q.leaf_means()) for q in qh]
+    for s in range(2):
+        one = ctx.icp_register(mids[s], tids, pb["query_guess"][s], PARAMS, N_ITERS, qh[s].num_leaves)
+        orc = O.icp_register(O.Tree(pb["query_scans"][s], B_MAX, B_MIN, 3), otrees, pb["query_guess"][s], N_ITERS, B_MAX, RHO_KER,
+                             B_RATIO, num_threads=min(os.cpu_count() or 1, 16))
+        got = {"host": (r0["host_X"], r0["host_m"]), "p2p": (r0["p2p_X"], r0["p2p_m"])} if s == 0 else \
+              {"host": (r0["host_s1X"], r0["host_s1m"]), "p2p": (r0["p2p_s1X"], r0["p2p_s1m"])}
+        for t, (X, m) in got.items():
+            dt, da = _pose_err(one["T"], capi.pose44(X))
+            assert dt <= 1e-9 and da <= 1e-9, (t, s, dt, da)
+            dt, da = _pose_err(orc["T"], capi.pose44(X))
+            assert dt <= 1e-5 and da <= 1e-5, (t, s, dt, da)
+            assert (m != one["matched"]).sum() <= 1 and (m != orc["matched"]).sum() <= 1, (t, s)
+        if s == 0:  # the pose before every round, too
+            for it in range(N_ITERS):
+                dt, da = _pose_err(capi.pose44(one["X_iters"][it]), capi.pose44(r0["p2p_Xi"][it]))
+                assert dt <= 1e-9 and da <= 1e-9, it
+        # scan s of the batch of two: the same registration in another launch geometry
+        dt, da = _pose_err(one["T"], capi.pose44(r0["p2p_bX"][s]))
+        assert dt <= 1e-9 and da <= 1e-9
+    print("[configs3 on one GPU] world %d, K %d (trees per rank %s): ranks bit-equal; mailbox fine-grained: %s; p2p vs single context "
+          "%.1e m, vs oracle %.1e m / %.1e rad; matched %d of %d leaves" % (
+              world, K, [int(r["n_local"]) for r in R], [int(r["fine_grained"]) for r in R],
+              _pose_err(one["T"], capi.pose44(r0["p2p_s1X"]))[0], *_pose_err(orc["T"], capi.pose44(r0["p2p_s1X"])),
+              int(r0["p2p_s1m"].sum()), r0["p2p_s1m"].size))
+    for t in tids:
+        ctx.tree_release(t)
+    for m in mids:
+        ctx.moving_release(m)
+
+
+# ---- a rank that never shows up, and the session after it -----------------------------------------------------------------------
+def _lost_peer_worker(rank, world, port, K, path, out):
+    ctx, tids, leaves, guesses = _setup_rank(rank, world, port, K, path)
+    try:
+        import time
+
+        L = [a.shape[0] for a in leaves]
+        mids = [ctx.moving_upload(a) for a in leaves]
+        X2 = np.stack([capi.pose12(g) for g in guesses])
+        sharded.init_host_comm(ctx)
+        ref = ctx.icp_register_batch(mids, tids, X2, PARAMS, N_ITERS)  # host transport: the reference for the second session
+        sharded.attach_peer_mailboxes(ctx, allow_coarse=True)
+        ctx.set_option("shard_p2p", 1)
+        ctx.set_option("comm_timeout_ms", 1500)
+        res = {"ref_X": ref["X"], "ref_n": ref["n_matched"]}
+        # session 1: three one-scan registrations everybody joins (rows of epochs 1-3, scan row 0 only) ...
+        for _ in range(3):
+            first = ctx.icp_register(mids[0], tids, guesses[0], PARAMS, N_ITERS, L[0])
+        res["first_X"] = first["X"]
+        dist.barrier()
+        # ... then one the last rank never submits: everybody else must come back with MADICP_ERR_COMM after ONE bound
+        if rank != world - 1:
+            t0 = time.time()
+            try:
+                ctx.icp_register(mids[0], tids, guesses[0], PARAMS, N_ITERS, L[0])
+                res["lost"] = "no error"
+            except capi.MadIcpError as e:
+                res["lost"] = str(e)
+            res["lost_s"] = time.time() - t0
+            try:  # the session is over: the next sharded registration is refused at once, nothing is launched
+                ctx.icp_register(mids[0], tids, guesses[0], PARAMS, N_ITERS, L[0])
+                res["after"] = "no error"
+            except capi.MadIcpError as e:
+                res["after"] = str(e)
+        dist.barrier()
+        # session 2: export + attach again on EVERY rank; a batch of two at the epochs and rounds session 1 used, with scan row 1
+        # never written before: stale rows of session 1 would be taken for this session's if the mailboxes were not clean
+        ctx.set_option("comm_timeout_ms", 60000)
+        sharded.attach_peer_mailboxes(ctx, allow_coarse=True)
+        bt = ctx.icp_register_batch(mids, tids, X2, PARAMS, N_ITERS)
+        res["bt_X"], res["bt_n"] = bt["X"], bt["n_matched"]
+        one = ctx.icp_register(mids[0], tids, guesses[0], PARAMS, N_ITERS, L[0])
+        res["second_X"] = one["X"]
+        # an attach without a fresh export is refused (every rank: nobody is left waiting)
+        try:
+            ctx.p2p_attach([b"\0" * 64] * world, world, rank)
+            res["stale_attach"] = "no error"
+        except capi.MadIcpError as e:
+            res["stale_attach"] = str(e)
+        ctx.set_option("shard_p2p", 0)
+        ctx.comm_destroy()
+        np.savez(out % rank, **res)
+    finally:
+        ctx.close()
+        dist.destroy_process_group()
+
+
+def test_lost_peer_of_eight_and_the_session_after(ctx, problem, tmp_path):
+    pb, path = problem
+    world, K = 8, 16
+    out = str(tmp_path / "rank%d.npz")
+    port = 27500 + ((os.getpid() * 5) % 4000)
+    mp.spawn(_lost_peer_worker, args=(world, port, K, path, out), nprocs=world, join=True)
+    R = [np.load(out % r) for r in range(world)]
+    for r in R[:-1]:
+        assert "error -3" in str(r["lost"]), str(r["lost"])
+        assert 1.0 <= float(r["lost_s"]) <= 8.0, float(r["lost_s"])  # one bound of 1.5 s, not one per round and workgroup
+        assert "error -3" in str(r["after"]) and "export" in str(r["after"]), str(r["after"])
+    for r in R:
+        assert "export again" in str(r["stale_attach"]), str(r["stale_attach"])
+        for key in ("first_X", "bt_X", "bt_n", "second_X"):
+            assert np.array_equal(R[0][key], r[key]), key
+    r0 = R[0]
+    print("[lost peer of eight] ranks 0..6 came back with MADICP_ERR_COMM after %s s (comm_timeout_ms = 1500)" %
+          ", ".join("%.2f" % float(r["lost_s"]) for r in R[:-1]))
+    assert np.array_equal(r0["second_X"], r0["first_X"])  # the same registration in both sessions
+    assert np.array_equal(r0["bt_n"], r0["ref_n"])
+    for s in range(2):
+        dt, da = _pose_err(capi.pose44(r0["ref_X"][s]), capi.pose44(r0["bt_X"][s]))
+        assert dt <= 1e-9 and da <= 1e-9, (s, dt, da)
