@@ -50,7 +50,13 @@ struct FrontScratch {
     int quiet_from = -1;   // levels past this one are expected to be empty (FrontScratch::last_depth + 1)
     int seq = 0;           // what tb_finish_b will publish (direct scan path)
     DevCloud cloud;        // look-ahead only
+    // the emission enqueued behind the summary into a block sized from the previous scan's leaf count (tree_build_begin_on)
+    bool pre = false;
+    int pre_leaf_cap = 0;
+    int pre_steps = 0;     // levels_done when it was enqueued: extra levels afterwards make it worthless
+    DevTree pre_tree;
   } fly;
+  int last_leaves = 0;     // leaves of the previous build on this scratch (the next scan of the same sensor: within a few per cent)
   int last_depth = -1;     // deepest level of the previous build on this scratch (consecutive scans: the same +- 1)
   int64_t last_n = 0;      // ... and that build's point count (the hint is for consecutive scans of one sensor, not for any cloud)
 };
@@ -566,6 +572,30 @@ int tb_summary_wait(madicp_ctx* ctx, FrontScratch& fs, int next_step) {
   return MADICP_OK;
 }
 
+// a built tree's block: [nodes | top exit | top dfs | top link | screening records | leaf records | top records], laid out
+// for CAPACITIES (the exact counts when the host knows them, the previous scan's with head-room when it does not yet)
+size_t layout_built_tree(DevTree& t, char* blk, size_t node_cap, size_t leaf_cap, size_t top_cap) {
+  const size_t off_nodes = 0;
+  const size_t off_exit = align_up(off_nodes + sizeof(madicp_node) * node_cap);
+  const size_t off_dfs = align_up(off_exit + sizeof(int4) * top_cap);
+  const size_t off_link = align_up(off_dfs + sizeof(int) * top_cap);
+  const size_t off_cnodes = align_up(off_link + sizeof(unsigned int) * top_cap);
+  const size_t off_leaves = align_up(off_cnodes + sizeof(CNode) * node_cap);
+  const size_t off_top = align_up(off_leaves + sizeof(LeafRec) * leaf_cap);
+  const size_t total = align_up(off_top + sizeof(CNode) * std::max<size_t>(top_cap, 1));
+  if (blk) {
+    t.block = blk;
+    t.nodes = reinterpret_cast<madicp_node*>(blk + off_nodes);
+    t.top_exit = top_cap ? reinterpret_cast<int4*>(blk + off_exit) : nullptr;
+    t.top_dfs = top_cap ? reinterpret_cast<int*>(blk + off_dfs) : nullptr;
+    t.top_link = top_cap ? reinterpret_cast<unsigned int*>(blk + off_link) : nullptr;
+    t.cnodes = reinterpret_cast<CNode*>(blk + off_cnodes);
+    t.leaves = reinterpret_cast<LeafRec*>(blk + off_leaves);
+    t.top = top_cap ? reinterpret_cast<CNode*>(blk + off_top) : nullptr;
+  }
+  return total;
+}
+
 // first half of a construction: everything up to the summary of step 20 is enqueued on `s`; nothing is waited for
 int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, int64_t n, double b_max, double b_min, hipStream_t s) {
   FrontScratch::InFlight& f = fs.fly;
@@ -594,13 +624,50 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   // (a STEP lags the level it finishes by up to kChipLevels - 1: a small node born while the chip regime runs waits for step
   // first_step, and its descendants follow one step per level — so the steps up to last_depth + kChipLevels can hold real
   // queues and keep their grid; and a build on another cloud size than the last one forgets the hint)
-  f.quiet_from = (fs.last_depth >= 0 && fs.last_n > 0 && n >= fs.last_n - fs.last_n / 8 && n <= fs.last_n + fs.last_n / 8)
-                     ? fs.last_depth + tb::kChipLevels : -1;
+  const bool similar = fs.last_n > 0 && n >= fs.last_n - fs.last_n / 8 && n <= fs.last_n + fs.last_n / 8;
+  // the previous scan of this sensor was last_depth levels deep: one spare step behind it instead of the fixed twenty (a step
+  // that finds its queues empty is still a launch: ~5 us) — never fewer than the breadth-first layout of the top needs
+  // (kTopParts), and a deeper tree takes the loop in the second half as before
+  if (similar && fs.last_depth >= 0) f.levels_done = std::min(20, std::max(fs.last_depth + 2, kTopLevels + kTopLag + 1));
+  f.quiet_from = (fs.last_depth >= 0 && similar) ? fs.last_depth + tb::kChipLevels : -1;
   RC_TRY(tb_run_levels(fs, 0, f.levels_done));
   HIP_TRY(hipGetLastError());
   RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
+  // The emission, enqueued NOW — behind the summary, without the host's 10-11 us in between — into a block sized from the
+  // previous scan's leaf count: consecutive scans of one sensor differ by a few per cent.  tb_emit then takes the counts from
+  // the State on the device; a tree that does not fit writes nothing and tree_build_end_on emits again (the old sequence).
+  f.pre = false;
+  if (similar && fs.last_leaves > 0 && f.n_tiles <= tb::kScanDirectMax) {
+    const int leaf_cap = static_cast<int>(std::min<int64_t>(n, (int64_t)fs.last_leaves + fs.last_leaves / 8 + 256));
+    const size_t node_cap = 2 * (size_t)leaf_cap - 1, top_cap = (size_t)kTopMax - 1;
+    DevTree t;
+    void* blk = nullptr;
+    RC_TRY(pool_alloc(ctx, layout_built_tree(t, nullptr, node_cap, (size_t)leaf_cap, top_cap), s, &blk));
+    layout_built_tree(t, static_cast<char*>(blk), node_cap, (size_t)leaf_cap, top_cap);
+    hipLaunchKernelGGL(tb::tb_emit, dim3(((int)node_cap + 255) / 256 + ((int)top_cap + 255) / 256), dim3(256), 0, s, f.P, (int)node_cap, t.nodes,
+                       t.cnodes, t.leaves, (int)top_cap, t.top_dfs, t.top_link, t.top_exit, t.top, 0.0, 0.0, 0.0, leaf_cap);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      pool_free(ctx, blk, nullptr);
+      return fail(MADICP_ERR_DEVICE, std::string("tb_emit: ") + hipGetErrorString(e));
+    }
+    f.pre = true;
+    f.pre_leaf_cap = leaf_cap;
+    f.pre_steps = f.levels_done;
+    f.pre_tree = t;
+  }
   f.active = true;
   return MADICP_OK;
+}
+
+// the pre-sized emission of a construction that will not use it (too small, deeper tree, error, cancel): block back to the pool
+void drop_pre_tree(madicp_ctx* ctx, FrontScratch::InFlight& f) {
+  if (!f.pre) return;
+  EventRef after;
+  if (fence_event(ctx, &after) != MADICP_OK) after = nullptr;
+  pool_free(ctx, f.pre_tree.block, after);
+  f.pre = false;
+  f.pre_tree = DevTree{};
 }
 
 // second half: the host learns the leaf count (deeper trees: more levels first), the tree is sized, emitted, compacted
@@ -610,26 +677,43 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   const tb::Params& P = f.P;
   tb::HostLine& hl = *fs.h_line;
   f.active = false;  // (whatever happens below, the scratch is free again: every error path leaves the stream drained or dead)
-  RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
   auto pending = [&]() { return hl.pending_wave > 0 || hl.pending_quad > 0; };
-  while (hl.error == 0 && f.levels_done < tb::kMaxLevels && pending()) {
-    const int to = std::min(f.levels_done + 8, tb::kMaxLevels);
-    RC_TRY(tb_run_levels(fs, f.levels_done, to));
-    f.levels_done = to;
-    RC_TRY(tb_summary_enqueue(fs, f.levels_done, true));
-    RC_TRY(tb_summary_wait(ctx, fs, f.levels_done));
+  {
+    int rc = tb_summary_wait(ctx, fs, f.levels_done);
+    while (rc == MADICP_OK && hl.error == 0 && f.levels_done < tb::kMaxLevels && pending()) {
+      const int to = std::min(f.levels_done + 8, tb::kMaxLevels);
+      rc = tb_run_levels(fs, f.levels_done, to);
+      f.levels_done = to;
+      if (rc == MADICP_OK) rc = tb_summary_enqueue(fs, f.levels_done, true);
+      if (rc == MADICP_OK) rc = tb_summary_wait(ctx, fs, f.levels_done);
+    }
+    if (rc != MADICP_OK) {
+      drop_pre_tree(ctx, f);
+      return rc;
+    }
   }
   fs.state_stale = true;
   fs.last_depth = hl.error == 0 ? hl.max_level : -1;
   fs.last_n = f.n;
+  fs.last_leaves = hl.error == 0 ? hl.n_leaves : 0;
+  const bool pre_ok = f.pre && f.pre_steps == f.levels_done && hl.error == 0 && !pending() && hl.n_leaves >= 1 &&
+                      hl.n_leaves <= f.pre_leaf_cap;
+  if (!pre_ok) drop_pre_tree(ctx, f);
   if (hl.error == 1) return fail(MADICP_ERR_DEVICE, "tree build: node capacity exceeded");
   if (hl.error == 2 || pending()) return fail(MADICP_ERR_INVALID, "tree build: tree deeper than the supported 96 levels");
   const int32_t n_leaves = hl.n_leaves, n_nodes = 2 * hl.n_leaves - 1;
-  if (n_leaves < 1 || hl.n_nodes != n_nodes || hl.n_valid != n_nodes)
+  if (n_leaves < 1 || hl.n_nodes != n_nodes || hl.n_valid != n_nodes) {
+    drop_pre_tree(ctx, f);
     return fail(MADICP_ERR_DEVICE, "tree build: inconsistent node count (" + std::to_string(hl.n_nodes) + " nodes, " +
                                        std::to_string(hl.n_valid) + " finished, " + std::to_string(n_leaves) + " leaves)");
+  }
   struct { int32_t n_top; unsigned long long rho_bits; double origin[3]; } st{hl.n_top, hl.rho_bits, {hl.origin[0], hl.origin[1], hl.origin[2]}};
   DevTree t;
+  if (pre_ok) {  // already emitted (tree_build_begin_on), into a block with head-room
+    t = f.pre_tree;
+    f.pre = false;
+    f.pre_tree = DevTree{};
+  }
   t.n_nodes = n_nodes;
   t.n_leaves = n_leaves;
   t.n_top = std::min<int32_t>(st.n_top, kTopMax - 1);
@@ -637,29 +721,18 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   std::memcpy(&rho, &st.rho_bits, sizeof(rho));
   t.rho2 = rho;
   const size_t nt = (size_t)t.n_top;
-  const size_t off_nodes = 0;
-  const size_t off_exit = align_up(off_nodes + sizeof(madicp_node) * (size_t)n_nodes);
-  const size_t off_dfs = align_up(off_exit + sizeof(int4) * nt);
-  const size_t off_link = align_up(off_dfs + sizeof(int) * nt);
-  const size_t up_bytes = align_up(off_link + sizeof(unsigned int) * nt);
-  const size_t off_cnodes = up_bytes;
-  const size_t off_leaves = align_up(off_cnodes + sizeof(CNode) * (size_t)n_nodes);
-  const size_t off_top = align_up(off_leaves + sizeof(LeafRec) * (size_t)n_leaves);
-  const size_t total = align_up(off_top + sizeof(CNode) * std::max<size_t>(nt, 1));
-  void* blk = nullptr;
-  RC_TRY(pool_alloc(ctx, total, s, &blk));
-  t.block = static_cast<char*>(blk);
-  t.nodes = reinterpret_cast<madicp_node*>(t.block + off_nodes);
-  t.top_exit = nt ? reinterpret_cast<int4*>(t.block + off_exit) : nullptr;
-  t.top_dfs = nt ? reinterpret_cast<int*>(t.block + off_dfs) : nullptr;
-  t.top_link = nt ? reinterpret_cast<unsigned int*>(t.block + off_link) : nullptr;
-  t.cnodes = reinterpret_cast<CNode*>(t.block + off_cnodes);
-  t.leaves = reinterpret_cast<LeafRec*>(t.block + off_leaves);
-  t.top = nt ? reinterpret_cast<CNode*>(t.block + off_top) : nullptr;
-  set_desc(t, st.origin);
-  // ONE launch: the DFS-preorder node array, the screening / dense leaf records and the staged top (tree_build.hip.h)
-  hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256 + (t.n_top + 255) / 256), dim3(256), 0, s, P, n_nodes, t.nodes, t.cnodes, t.leaves,
-                     t.n_top, t.top_dfs, t.top_link, t.top_exit, t.top, st.origin[0], st.origin[1], st.origin[2]);
+  if (pre_ok) {
+    if (!nt) t.top_exit = nullptr, t.top_dfs = nullptr, t.top_link = nullptr, t.top = nullptr;
+    set_desc(t, st.origin);
+  } else {
+    void* blk = nullptr;
+    RC_TRY(pool_alloc(ctx, layout_built_tree(t, nullptr, (size_t)n_nodes, (size_t)n_leaves, nt), s, &blk));
+    layout_built_tree(t, static_cast<char*>(blk), (size_t)n_nodes, (size_t)n_leaves, nt);
+    set_desc(t, st.origin);
+    // ONE launch: the DFS-preorder node array, the screening / dense leaf records and the staged top (tree_build.hip.h)
+    hipLaunchKernelGGL(tb::tb_emit, dim3((n_nodes + 255) / 256 + (t.n_top + 255) / 256), dim3(256), 0, s, P, n_nodes, t.nodes, t.cnodes, t.leaves,
+                       t.n_top, t.top_dfs, t.top_link, t.top_exit, t.top, st.origin[0], st.origin[1], st.origin[2], 0);
+  }
   hipError_t e = hipGetLastError();
   int rc = MADICP_OK;
   if (e == hipSuccess && rc == MADICP_OK) e = hipEventCreateWithFlags(&t.ready, hipEventDisableTiming);
@@ -803,6 +876,7 @@ int madicp_tree_build_cancel(madicp_ctx* ctx) {
   const hipError_t e = hipStreamSynchronize(fs.fly.s);
   fs.fly.active = false;
   fs.state_stale = true;
+  drop_pre_tree(ctx, fs.fly);
   DevCloud c = fs.fly.cloud;
   fs.fly.cloud = DevCloud{};
   drop_cloud(ctx, c, MADICP_OK);

@@ -1977,12 +1977,25 @@ __device__ __forceinline__ madicp_node emit_node(const BNode& nd, const uint32_t
   }
   return o;
 }
+// leaf_cap > 0: the launch was enqueued BEHIND the summary without the host in between, into a tree block sized for leaf_cap
+// leaves (the previous scan's count with head-room): the node count, the size of the top and the origin are then read from
+// the State on the device (n_nodes / n_top / o0-o2 as passed are the block's capacities / unused), and a tree that does not
+// fit — or a build that went wrong — writes nothing: the host sees the same in its line and emits again into a block of
+// the right size.  What that saves is the host round trip between the summary and the emission (10-11 us of idle device).
 __global__ __launch_bounds__(256) void tb_emit(const Params P, int n_nodes, madicp_node* __restrict__ out, CNode* __restrict__ cnodes,
                                                LeafRec* __restrict__ leaves, int n_top, int* __restrict__ dfs,
                                                unsigned int* __restrict__ link, int4* __restrict__ exits, CNode* __restrict__ top,
-                                               double o0, double o1, double o2) {
+                                               double o0, double o1, double o2, int leaf_cap) {
   const uint32_t* __restrict__ S = P.S;
-  const int node_blocks = (n_nodes + 255) / 256;
+  const int node_blocks = (n_nodes + 255) / 256;  // (of the capacity when leaf_cap > 0: the launch geometry)
+  if (leaf_cap > 0) {
+    const State* st = P.st;
+    const int nl = st->n_leaves;
+    if (nl < 1 || nl > leaf_cap || st->n_nodes.error != 0) return;
+    n_nodes = 2 * nl - 1;
+    n_top = min(min(st->n_top, n_top), n_nodes);
+    o0 = st->origin[0]; o1 = st->origin[1]; o2 = st->origin[2];
+  }
   if ((int)blockIdx.x >= node_blocks) {  // ---- the staged top: entry e of the breadth-first order
     const int e = ((int)blockIdx.x - node_blocks) * 256 + (int)threadIdx.x;
     if (e >= n_top) return;

@@ -14,8 +14,8 @@ starts = [i for i, r in enumerate(rows) if "tb_init" in r["Kernel_Name"]]
 if not starts:
     sys.exit("no tb_init in the trace")
 seg = rows[starts[-1]:]
-# the build ends with the record build of the tree (tree_compact_top, or tree_compact for trees without a staged top)
-end = max((i for i, r in enumerate(seg) if "tree_compact" in r["Kernel_Name"]), default=len(seg) - 1)
+# the build ends with the emission of the tree (tb_emit: node array, screening / leaf records and the staged top in one launch)
+end = max((i for i, r in enumerate(seg) if "tb_emit" in r["Kernel_Name"]), default=len(seg) - 1)
 seg = seg[: end + 1]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
