@@ -56,7 +56,14 @@ sys.path.insert(0, ROOT)
 # one GPU with a world of one (tools/shard_world1.sh, two repetitions, same box): replica 4 027 -> 4 440, shard 3 487 -> 3 750,
 # shard_p2p 3 928 -> 4 290 registrations/s with eight queues; the one-process bench does not care (4 684 / 4 623).  Read by the
 # HIP runtime when it initialises, so it is set before anything imports torch; an explicit setting in the environment wins.
-if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("MADICP_BENCH_FORCE_MULTI") == "1":
+# Ranks that SHARE a device (MADICP_BENCH_BACKEND=gloo on a box with fewer GPUs than ranks) are the opposite case: every process's
+# queues compete for the device's hardware queue slots, and once the processes together hold more than the device maps at a time
+# its scheduler rotates them with a quantum of milliseconds — fatal for kernels that poll a peer's mailbox (measured: eight ranks
+# x eight queues, 345 ms per sharded registration; four ranks, 9 ms).  Few queues per process there.
+_world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+if _world > 1 and os.environ.get("MADICP_BENCH_BACKEND", "nccl") != "nccl":
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(2, min(8, 24 // _world))))
+elif _world > 1 or os.environ.get("MADICP_BENCH_FORCE_MULTI") == "1":
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 B_MAX, B_MIN, RHO_KER, B_RATIO, N_ITERS = 0.2, 0.1, 0.1, 0.02, 15
@@ -84,6 +91,7 @@ def parse():
     ap.add_argument("--no-rebuild", action="store_true", help="do not force-rebuild the HIP library first")
     ap.add_argument("--option", action="append", default=[], help="library option key=value (tuning)")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--build-child", default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -234,10 +242,106 @@ def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stre
 
 
 # ---------------------------------------------------------------------------------------------------------
+BUILD_REPS = 6
+
+
+def build_child(path):
+    """Sub-run under rocprofv3 --kernel-trace: a few device MAD-tree builds of the bench scan and nothing else."""
+    from mad_icp_amd import capi
+
+    scan = np.load(path)["scan"]
+    ctx = capi.Context(0)
+    cid = ctx.cloud_upload(scan)
+    for _ in range(BUILD_REPS):
+        t_, _nl = ctx.tree_build(cid, B_MAX, B_MIN)
+        ctx.synchronize()
+        ctx.tree_release(t_)
+    ctx.close()
+
+
+TB_FAMILIES = (("tb_init", "init"), ("tb_chip_stats", "chip_stats"), ("tb_chip_scatter", "chip_scatter"), ("tb_level", "level"),
+               ("tb_finish", "finish"), ("tb_emit", "emit"))
+
+
+def builder_roofline(scan, n_leaves, max_level):
+    """Per kernel family of ONE device tree build: launches, traced time (rocprofv3 --kernel-trace of a sub-run that builds
+    the bench scan's tree and nothing else; the last build of the trace), algorithmic bytes, and their rate against the HBM
+    peak.  Algorithmic bytes, an UPPER bound — every point is counted alive on every level, although a point
+    whose leaf is finished drops out: chip levels 0-5: a point is read by the statistics pass (24 B), read and written by the
+    scatter (48 B), its rank-table entry written and read (8 B); wave / quad steps: read + written once (48 B); a split reads
+    its 240-byte record and writes two; init: the cloud once + the leaf marks cleared; finish: marks twice, scan once, every
+    record once; emission: every record once, 80 B out per node (+ 64 B per leaf)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    tmp = tempfile.mkdtemp(prefix="madicp_tb_", dir="/tmp")
+    try:
+        npz = os.path.join(tmp, "scan.npz")
+        np.savez(npz, scan=scan)
+        d = os.path.join(tmp, "trace")
+        cmd = [rocprof, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__),
+               "--build-child", npz]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=240, check=True)
+        except Exception as e:  # noqa: BLE001
+            return {"error": "rocprofv3 kernel trace of the builder failed: %s" % str(e)[:160]}
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if not files:
+            return {"error": "no kernel trace written"}
+        with open(files[0]) as fh:
+            rows = sorted(csv.DictReader(fh), key=lambda r: int(r["Start_Timestamp"]))
+        starts = [i for i, r in enumerate(rows) if "tb_init" in r["Kernel_Name"]]
+        if not starts:
+            return {"error": "no tb_init in the trace"}
+        seg = rows[starts[-1]:]
+        end = max((i for i, r in enumerate(seg) if "tb_emit" in r["Kernel_Name"]), default=len(seg) - 1)
+        seg = seg[: end + 1]
+        N, L = int(scan.shape[0]), int(n_leaves)
+        n_nodes, n_int = 2 * L - 1, L - 1
+        chip_levels, steps = 6, max(0, int(max_level) + 1 - 6)
+        alg = {"init": N * 24 + N * 4,
+               "chip_stats": chip_levels * N * (24 + 4),
+               "chip_scatter": chip_levels * N * (24 + 24 + 4),
+               "level": steps * N * 48 + n_int * 3 * 240,
+               "finish": N * 4 * 3 + n_nodes * 240,
+               "emit": n_nodes * (240 + 80) + L * 64}
+        fam = {}
+        for r in seg:
+            for pat, key in TB_FAMILIES:
+                if pat in r["Kernel_Name"]:
+                    f = fam.setdefault(key, {"launches": 0, "us": 0.0})
+                    f["launches"] += 1
+                    f["us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                    break
+        span_us = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
+        out = {"bound": "latency", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traced_build_us": round(span_us, 1), "kernels": {}}
+        for key, f in fam.items():
+            gbs = alg[key] / (f["us"] * 1e-6) / 1e9 if f["us"] > 0 else 0.0
+            out["kernels"][key] = {"launches": f["launches"], "us": round(f["us"], 1), "algorithmic_bytes": int(alg[key]),
+                                   "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        tot = sum(alg[k] for k in fam)
+        out["algorithmic_bytes"] = int(tot)
+        out["achieved"] = round(tot / (span_us * 1e-6) / 1e9, 1)
+        out["frac"] = round(tot / (span_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["note"] = ("one madicp_tree_build of the bench scan, the last of %d in a rocprofv3 --kernel-trace sub-run; algorithmic bytes are "
+                       "an upper bound (every point counted alive on every level); the build is a chain of ~%d dependent launches whose "
+                       "working set (2 x 2.9 MB of points, ~10 MB of records) lives in L2 / Infinity Cache: what bounds it is the "
+                       "dependent-latency chain of a level (record -> sums -> eigen-solve -> extents -> partition), not HBM — "
+                       "profiles/r6_tree_build_pmc_summary.md has the wait fractions" % (BUILD_REPS, len(seg)))
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if args.pmc_child:
         pmc_child(args.pmc_child)
+        return
+    if args.build_child:
+        build_child(args.build_child)
         return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -672,6 +776,7 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                  "host_tree_build_ms_per_scan": round(t_build * 1e3, 2),
                  "points": int(scan0.shape[0]), "device_leaves": int(dev_leaves), "host_leaves": int(Ls[0]),
                  "levels": int(st["max_level"]),
+                 "roofline": builder_roofline(scan0, dev_leaves, st["max_level"]) if args.pmc == "auto" else None,
                  "note": "madicp_tree_build on a resident cloud (wall time incl. its one host synchronisation); upload = "
                          "pageable host memory -> pinned staging -> HBM; the host figure is the product's CPU builder on this "
                          "box's cores (bit-identical to the oracle's), which the streamed headline does NOT include either"}
@@ -697,7 +802,8 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         # ("default" is not run first: the first drive of a process also pays for the pool's and the builder's first allocations)
         for key, dev, ahead, dsk in (("host_path", False, 0, False), ("default", None, 0, False), ("host_path_lookahead", False, 2, False),
                                      ("device_front_end", True, 0, False), ("device_front_end_lookahead", True, 1, False),
-                                     ("host_path_deskew", False, 1, True), ("device_front_end_deskew", True, 0, True)):
+                                     ("host_path_deskew", False, 1, True), ("device_front_end_deskew", True, 0, True),
+                                     ("default_deskew", None, 0, True)):
             pl = pm.Pipeline(10.0, dsk, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)
             if dev is not None:
                 pl.setDeviceFrontEnd(dev)
@@ -739,7 +845,8 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         pipe["lookahead_in_a_plain_process"] = plain
         pipe["default_is_device_front_end"] = bool(pm.Pipeline(10.0, False, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False).deviceFrontEnd())
         pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: default = what an UNMODIFIED caller gets "
-                        "(no setDeviceFrontEnd call, MAD_ICP_GPU_BUILD unset; round 5: the device front-end for deskew = false); "
+                        "(no setDeviceFrontEnd call, MAD_ICP_GPU_BUILD unset: the device front-end — round 5 for deskew = false, round 6 "
+                        "for deskewed datasets too: default_deskew is the unmodified caller of a `deskew : True` configuration); "
                         "host_path = setDeviceFrontEnd(False) / MAD_ICP_GPU_BUILD=0 (host tree builder, "
                         "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(scan i + 2) issued "
                         "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "

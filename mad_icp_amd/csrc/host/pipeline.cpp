@@ -50,12 +50,14 @@ Pipeline::Pipeline(double sensor_hz, bool deskew, double b_max, double rho_ker, 
   loop_time_ = (1. / sensor_hz_) * 1000;
   max_parallel_levels_ = static_cast<int>(std::log2(num_threads));  // pipeline.cpp:64
   TaskPool::instance().set_limit(num_threads);  // omp_set_num_threads(num_threads), pipeline.cpp:65
-  // Round 5: the device front-end is the DEFAULT wherever the scan's tree does not depend on the previous poses
-  // (deskew = false: every dataset configuration of the reference but the deskewed ones) — an unmodified caller then gets
-  // tree construction on the MI355X (tests/test_gpu_frontend_oracle.py holds that path to the oracle pipeline directly).
-  // MAD_ICP_GPU_BUILD=0 keeps the host builder (the reference's trees bit for bit), =1 forces the device front-end for
-  // deskewed datasets too; setDeviceFrontEnd() overrides both.
-  device_frontend_ = !deskew;
+  // The device front-end is the DEFAULT: an unmodified caller gets deskew (where the dataset asks for it) and MAD-tree
+  // construction on the MI355X.  Round 5 made it so for deskew = false (tests/test_gpu_frontend_oracle.py holds that path to
+  // the oracle pipeline directly); round 6 for deskew = true too: ONE frame — deskew, build, registration — from the oracle's
+  // state is the oracle's frame to 1e-5 m / 1e-5 rad (tests/test_gpu_deskew_one_step.py), and over a drive neither path is
+  // bit-stable anyway (the reference is not against itself: tests/envelope.py), so nothing but 3 ms per frame spoke for the
+  // host path there.  MAD_ICP_GPU_BUILD=0 keeps the host builder (the reference's trees bit for bit); setDeviceFrontEnd()
+  // overrides the environment.
+  device_frontend_ = true;
   if (const char* e = std::getenv("MAD_ICP_GPU_BUILD")) {
     if (e[0] == '1') device_frontend_ = true;
     if (e[0] == '0') device_frontend_ = false;

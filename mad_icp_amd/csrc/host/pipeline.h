@@ -80,14 +80,16 @@ class Pipeline {
   void computeView(const double& curr_stamp, const Vector3d* curr_cloud, size_t n);
   void prefetchView(const Vector3d* next_cloud, size_t n);
 
-  // additive, opt-in: the device front-end.  When on, compute() uploads the scan once and
-  // deskew (pipeline.cpp:79-123) and MADtree::build (mad_tree.cpp:47-130) run on the MI355X; the tree never exists on
-  // the host unless currentLeaves() / modelLeaves() ask for it.  Default: the MAD_ICP_GPU_BUILD environment variable
-  // ("1" = on), else off.  Device-built trees have the host builder's topology, member order and leaf representatives
-  // and differ from host-built ones in the last bits of their larger nodes (mad_icp_amd/csrc/hip/tree_build.hip.h): over
-  // the full-size test drives poses differ from the host path's by ~1e-12 m (1e-2 m with deskew, where the compensated
-  // cloud depends on the previous poses' last bits and tree construction is chaotic in its input), while the error against
-  // GROUND TRUTH is the same for both (tests/test_gpu_frontend.py states and asserts the bars).
+  // additive: the device front-end.  When on, compute() uploads the scan once and deskew
+  // (pipeline.cpp:79-123) and MADtree::build (mad_tree.cpp:47-130) run on the MI355X; the tree never exists on the host
+  // unless currentLeaves() / modelLeaves() ask for it.  Default: ON (round 5: for deskew = false; round 6: for deskewed
+  // datasets too); the MAD_ICP_GPU_BUILD environment variable ("0" = the host builder, whose trees are the reference's bit
+  // for bit) and this call override it.  Device-built trees have the host builder's topology, member order and leaf
+  // representatives and differ from host-built ones in the last bits of their larger nodes (mad_icp_amd/csrc/hip/
+  // tree_build.hip.h): without deskew poses stay within ~1e-12 m of the oracle pipeline's over full-size drives; with deskew
+  // ONE frame from the oracle's state is the oracle's frame to 1e-5 (tests/test_gpu_deskew_one_step.py), and a drive stays
+  // inside the envelope the reference shows against itself (the compensated cloud depends on the previous poses' last bits
+  // and tree construction is chaotic in its input: tests/test_gpu_frontend_oracle.py).
   void setDeviceFrontEnd(bool on) {
     if (!on) dropDeviceLookAhead();
     device_frontend_ = on;

@@ -38,7 +38,8 @@ PYBIND11_MODULE(pypeline, m) {
            const Vector3d* pts = points_of_array(cloud);
            self.prefetchView(pts, static_cast<size_t>(cloud.shape(0)));
          })
-    // additive, opt-in: deskew + MAD-tree construction on the device; env MAD_ICP_GPU_BUILD=1
+    // additive: deskew + MAD-tree construction on the device — the default; MAD_ICP_GPU_BUILD=0 or
+    // setDeviceFrontEnd(False) keep the host builder
     .def("setDeviceFrontEnd", &Pipeline::setDeviceFrontEnd, py::arg("on"))
     .def("deviceFrontEnd", &Pipeline::deviceFrontEnd)
     // additive: a frame straight from sensor records, (n, >=3) float32 (a KITTI .bin is (n,4)): range filter, optional

@@ -440,6 +440,15 @@ static double now_ms() {
 }
 
 // pipeline.cpp:125-265
+Iso3 Pipeline::predict() const {  // (instrumentation: exactly compute()'s lines below, on the state as it stands)
+  Vec6 dx;
+  for (int i = 0; i < 6; ++i) dx[i] = current_velocity_[i] * 1. / sensor_hz_;
+  Iso3 dX = Iso3::Identity();
+  dX.R = expMapSO3({{dx[3], dx[4], dx[5]}});
+  dX.t = {{dx[0], dx[1], dx[2]}};
+  return compose(frame_to_map_, dX);
+}
+
 void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud_mem) {
   ContainerType* curr_cloud = &curr_cloud_mem;
   is_map_updated_ = false;
@@ -467,6 +476,7 @@ void Pipeline::compute(const double& curr_stamp, ContainerType curr_cloud_mem) {
 
   icp_.setMoving(current_leaves_);
   icp_.init(prediction);
+  last_guess_ = prediction;
 
   float icp_time = 0;
   float total_icp_time = 0;

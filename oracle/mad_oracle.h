@@ -146,6 +146,9 @@ class Pipeline {  // pipeline.h:45-103
   double last_icp_ms_ = 0.0;         // wall time of the GN loop, the region the reference itself times
   double last_inliers_ratio_ = 0.0;  // pipeline.cpp:204
   size_t numKeyframes() const { return keyframes_.size(); }
+  Iso3 last_guess_ = Iso3::Identity();  // the constant-velocity prediction the last frame's loop started from (pipeline.cpp:146-152)
+  const MADtree* keyframeTree(size_t k) const { return k < keyframes_.size() ? keyframes_[k]->tree_ : nullptr; }
+  Iso3 predict() const;  // the prediction the NEXT frame's loop would start from, without running it (pipeline.cpp:146-152)
 
  protected:
   void initialize(const double& curr_stamp, ContainerType* curr_cloud);

@@ -19,7 +19,8 @@ struct TreeHandle {
   MADtree* root = nullptr;
   LeafList leaves;                                       // DFS, left first (mad_tree.cpp:154-163)
   std::unordered_map<const MADtree*, uint32_t> ordinal;  // leaf -> DFS ordinal
-  ~TreeHandle() { delete root; }
+  bool owns = true;  // (false: a keyframe tree borrowed from a Pipeline, orc_pipeline_keyframe_borrow)
+  ~TreeHandle() { if (owns) delete root; }
 };
 
 Iso3 pose_from(const double* x) {
@@ -264,6 +265,32 @@ int64_t orc_pipeline_model_leaves(void* p, double* out, int64_t cap) {
   const ContainerType l = static_cast<Pipeline*>(p)->modelLeaves();
   if (out && int64_t(l.size()) <= cap && !l.empty()) std::memcpy(out, l.data(), l.size() * sizeof(Vec3));
   return int64_t(l.size());
+}
+
+// The state a ONE-STEP parity test starts a frame from (tests/test_gpu_deskew_one_step.py): the prediction the last frame's
+// loop started at, and keyframe tree k as it stands in the local map (map frame), in orc_tree_export's form.
+void orc_pipeline_last_guess(void* p, double* X12) { pose_to(static_cast<Pipeline*>(p)->last_guess_, X12); }
+void orc_pipeline_predict(void* p, double* X12) { pose_to(static_cast<Pipeline*>(p)->predict(), X12); }
+// keyframe tree k as a tree handle that does NOT own it: valid until the pipeline's next compute() (which may evict it)
+void* orc_pipeline_keyframe_borrow(void* p, int64_t k) {
+  const MADtree* t = static_cast<Pipeline*>(p)->keyframeTree(size_t(k));
+  if (!t) return nullptr;
+  TreeHandle* h = new TreeHandle;
+  h->root = const_cast<MADtree*>(t);
+  h->owns = false;
+  index_leaves(h);
+  return h;
+}
+int64_t orc_pipeline_keyframe_num_nodes(void* p, int64_t k) {
+  const MADtree* t = static_cast<Pipeline*>(p)->keyframeTree(size_t(k));
+  return t ? count_nodes(t) : 0;
+}
+void orc_pipeline_keyframe_export(void* p, int64_t k, double* mean, double* evecs, double* bbox, int32_t* left, int32_t* right,
+                                  int32_t* num_points) {
+  const MADtree* t = static_cast<Pipeline*>(p)->keyframeTree(size_t(k));
+  if (!t) return;
+  Exporter ex{mean, evecs, bbox, left, right, num_points};
+  ex.walk(t);
 }
 
 // Pipeline::deskew on its own (pipeline.cpp:79-123) — the checker of the device front-end's madicp_cloud_deskew.

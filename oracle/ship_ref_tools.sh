@@ -13,3 +13,14 @@ mkdir -p "$DST"
 [ -f "$REF/apps/__init__.py" ] && cp "$REF/apps/__init__.py" "$HERE/_ref/tools/mad_icp/apps/__init__.py"
 for f in nn_search.py mad_registration.py tools_utils.py; do cp "$REF/apps/utils/tools/$f" "$DST/$f"; done
 echo "ship_ref_tools.sh: $DST (nn_search.py, mad_registration.py, tools_utils.py: byte-for-byte copies from $REF/apps/utils/tools)"
+# The reference's Python LAUNCHER (apps/mad_icp.py: typer CLI -> dataset reader -> Pipeline.compute -> estimate.txt), the
+# readers and helpers it imports and the configuration tables it looks datasets up in — the other caller north_star names
+# ("drops into bin_runner and the Python launcher unchanged").  Same rule: byte for byte, git-ignored, test infrastructure.
+cp "$REF/apps/mad_icp.py" "$HERE/_ref/tools/mad_icp/apps/mad_icp.py"
+for f in utils.py kitti_reader.py ros_reader.py ros2_reader.py mcap_reader.py point_cloud2.py visualizer.py; do
+  cp "$REF/apps/utils/$f" "$HERE/_ref/tools/mad_icp/apps/utils/$f"
+done
+mkdir -p "$HERE/_ref/tools/mad_icp/configurations/datasets"
+cp "$REF/configurations/default.cfg" "$REF/configurations/mad_params.py" "$HERE/_ref/tools/mad_icp/configurations/"
+cp "$REF"/configurations/datasets/*.py "$REF"/configurations/datasets/*.cfg "$HERE/_ref/tools/mad_icp/configurations/datasets/"
+echo "ship_ref_tools.sh: $HERE/_ref/tools/mad_icp/apps/mad_icp.py + apps/utils/*.py + configurations/ (the Python launcher, unchanged)"

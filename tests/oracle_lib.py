@@ -80,6 +80,13 @@ def lib():
         L.orc_pipeline_model_leaves.restype = C.c_int64
         L.orc_pipeline_model_leaves.argtypes = [C.c_void_p, c_dp, C.c_int64]
         L.orc_deskew.argtypes = [c_dp, C.c_int64, c_dp, c_dp, C.c_double, c_dp]
+        L.orc_pipeline_last_guess.argtypes = [C.c_void_p, c_dp]
+        L.orc_pipeline_predict.argtypes = [C.c_void_p, c_dp]
+        L.orc_pipeline_keyframe_borrow.restype = C.c_void_p
+        L.orc_pipeline_keyframe_borrow.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_pipeline_keyframe_num_nodes.restype = C.c_int64
+        L.orc_pipeline_keyframe_num_nodes.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_pipeline_keyframe_export.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_i32p, c_i32p, c_i32p]
         _LIB = L
     return _LIB
 
@@ -178,6 +185,26 @@ def icp_register(moving, fixed_list, T, n_iters, min_ball, rho_ker, b_ratio, num
     ms = lib().orc_icp_register(moving._h, hs, K, _dp(X), n_iters, min_ball, rho_ker, b_ratio, num_threads, _dp(H),
                                 _dp(b), matched.ctypes.data_as(c_u8p), _dp(X_iters), C.byref(depth))
     return dict(T=pose44(X), H=H, b=b, matched=matched, X_iters=X_iters, depth_sum=depth.value, ms=ms)
+
+
+def export_to_nodes(ex):
+    """Tree.export() / Pipeline.keyframeTree() -> the 64-byte DFS-preorder node array of include/madicp_hip.h (what
+    madicp_tree_upload takes) and the leaf count: left child = i + 1, `right` = offset of the right child, a leaf carries its
+    surface point, its normal (eigenvector 0) and its getLeafs() ordinal; an internal node its centroid and split normal
+    (eigenvector 2) — the mapping tests/test_host_builder.py holds the product's host builder to."""
+    from mad_icp_amd import capi
+
+    n = ex["mean"].shape[0]
+    leaf = ex["left"] < 0
+    nodes = np.zeros(n, dtype=capi.NODE_DTYPE)
+    nodes["mean"] = ex["mean"]
+    nodes["dir"] = np.where(leaf[:, None], ex["evecs"][:, :, 0], ex["evecs"][:, :, 2])
+    idx = np.arange(n, dtype=np.int32)
+    nodes["right"] = np.where(leaf, 0, ex["right"] - idx)
+    nodes["leaf_id"] = -1
+    nodes["leaf_id"][leaf] = np.arange(int(leaf.sum()), dtype=np.int32)
+    nodes["bbox0"] = ex["bbox"][:, 0]
+    return nodes, int(leaf.sum())
 
 
 def eig3(A):
@@ -310,6 +337,38 @@ class Pipeline:
         n = lib().orc_pipeline_current_leaves(self._h, None, 0)
         out = np.empty((n, 3))
         lib().orc_pipeline_current_leaves(self._h, _dp(out), n)
+        return out
+
+    def lastGuess(self):
+        """the constant-velocity prediction the last frame's GN loop started from (pipeline.cpp:146-152)"""
+        x = np.empty(12)
+        lib().orc_pipeline_last_guess(self._h, _dp(x))
+        return pose44(x)
+
+    def predict(self):
+        """the prediction the NEXT frame's GN loop would start from, on the state as it stands (pipeline.cpp:146-152)"""
+        x = np.empty(12)
+        lib().orc_pipeline_predict(self._h, _dp(x))
+        return pose44(x)
+
+    def borrowKeyframe(self, k):
+        """keyframe tree k as a Tree that does not own it: valid until this pipeline's next compute()"""
+        t = Tree.__new__(Tree)
+        t._h = lib().orc_pipeline_keyframe_borrow(self._h, k)
+        if not t._h:
+            raise IndexError(k)
+        t.num_nodes = lib().orc_tree_num_nodes(t._h)
+        t.num_leaves = lib().orc_tree_num_leaves(t._h)
+        return t
+
+    def keyframeTree(self, k):
+        """keyframe tree k of the local map as it stands (map frame), in Tree.export()'s form"""
+        n = lib().orc_pipeline_keyframe_num_nodes(self._h, k)
+        out = dict(mean=np.empty((n, 3)), evecs=np.empty((n, 3, 3)), bbox=np.empty((n, 3)),
+                   left=np.empty(n, np.int32), right=np.empty(n, np.int32), num_points=np.empty(n, np.int32))
+        lib().orc_pipeline_keyframe_export(self._h, k, _dp(out["mean"]), _dp(out["evecs"]), _dp(out["bbox"]),
+                                           out["left"].ctypes.data_as(c_i32p), out["right"].ctypes.data_as(c_i32p),
+                                           out["num_points"].ctypes.data_as(c_i32p))
         return out
 
     def modelLeaves(self):

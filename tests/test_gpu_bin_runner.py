@@ -100,3 +100,56 @@ def test_reference_bin_runner_against_the_product(natives, tmp_path, kitti, gpu_
         got = Linv @ np.vstack([est[-1], [0, 0, 0, 1]]) @ LIDAR_TO_BASE
         assert np.linalg.norm(got[:3, 3] - gt[:3, 3]) < 0.1
     print("bin_runner vs oracle pipeline: worst coefficient difference %.2e" % worst)
+
+
+@pytest.mark.parametrize("gpu_build", [None, "0"])
+def test_reference_bin_runner_on_a_deskewed_dataset(natives, tmp_path, gpu_build):
+    """`deskew : True` in the dataset configuration (mad_icp/configurations/datasets/mulran.cfg:5, vbr_os1.cfg:5): since round 6
+    the unmodified runner deskews and builds on the device there too (MAD_ICP_GPU_BUILD unset), "0" keeps the host path.  A
+    deskewed DRIVE is not reproducible to 1e-5 by anybody — the reference differs from itself by millimetres under another
+    thread count (tests/envelope.py) — so the runner's trajectory is held inside three times the envelope the oracle pipeline
+    shows against itself on these very clouds, and to 1e-5 on the two frames that are not deskewed (pipeline.cpp:138-139);
+    the one-frame bar of the composition is tests/test_gpu_deskew_one_step.py."""
+    import envelope as E
+
+    if not os.path.exists(RUNNER):
+        pytest.skip("oracle/_ref/bin_runner not built (oracle/build_bin_runner.sh needs /root/reference)")
+    scene = synth.Scene(4)
+    n_frames = 10
+    data = tmp_path / "velodyne"
+    data.mkdir()
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    rng = np.random.default_rng(3)
+    clouds = []
+    for i in range(n_frames):
+        s = synth.render_scan(scene, synth.path_pose(0.8 * i), 300 + i, n_beams=32, n_azimuth=600)
+        s = s + rng.normal(scale=1e-4, size=s.shape)  # (no two float32 azimuths equal: a real sensor's noise)
+        rec = np.zeros((s.shape[0], 4), np.float32)
+        rec[:, :3] = s.astype(np.float32)
+        rec.tofile(str(data / ("%06d.bin" % i)))
+        clouds.append(O.ingest_f32(rec, 0.7, 120.0, 0))
+    (tmp_path / "kitti.cfg").write_text(DATASET_CFG.replace("deskew : False", "deskew : True"))
+    (tmp_path / "default.cfg").write_text(MAD_ICP_CFG)
+    cmd = [RUNNER, "-data_path", str(data), "-estimate_path", str(out_dir), "-dataset_config", str(tmp_path / "kitti.cfg"),
+           "-mad_icp_config", str(tmp_path / "default.cfg"), "-num_cores", "4", "-num_keyframes", "4"]
+    env = {k: v for k, v in os.environ.items() if k != "MAD_ICP_GPU_BUILD"}
+    if gpu_build is not None:
+        env["MAD_ICP_GPU_BUILD"] = gpu_build
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    est = np.loadtxt(str(out_dir / "estimate.txt")).reshape(-1, 3, 4)
+    assert est.shape[0] == n_frames
+    base, _, dt, da = E.self_envelope(clouds, deskew=True, base_threads=4, num_keyframes=4)
+    bound = E.running_bound(E.combined(dt, da))
+    Linv = np.linalg.inv(LIDAR_TO_BASE)
+    worst = 0.0
+    for i in range(n_frames):
+        got = Linv @ np.vstack([est[i], [0, 0, 0, 1]]) @ LIDAR_TO_BASE  # back from the base frame (bin_runner.cpp:253-269)
+        d_t, d_a = E.pose_dev(base[i], got)
+        worst = max(worst, d_t)
+        assert E.combined(d_t, d_a) <= 3.0 * bound[i] + 2e-5, (i, d_t, d_a, bound[i])
+        if i < 2:
+            assert d_t <= 1e-5 and d_a <= 1e-5, (i, d_t, d_a)
+    print("bin_runner (deskew : True, MAD_ICP_GPU_BUILD=%s) vs oracle pipeline: worst translation deviation %.2e m; the oracle's own "
+          "envelope reaches %.2e" % (gpu_build, worst, bound[-1]))

@@ -169,6 +169,8 @@ def test_deskewed_drive_with_the_azimuth_order_computed_ahead(pypeline, drive, c
     for tag, scans in (("distinct azimuths", [s + rng.normal(scale=1e-7, size=s.shape) for s in drive]), ("tied azimuths", drive)):
         clouds = [pypeline.VectorEigen3d(s) for s in scans]
         plain, ahead = pypeline.Pipeline(*args), pypeline.Pipeline(*args)
+        plain.setDeviceFrontEnd(False)  # (the HOST path's look-ahead; the default is the device front-end since round 6)
+        ahead.setDeviceFrontEnd(False)
         t_plain, t_ahead = [], []
         for i in range(N_FRAMES):
             t = time.perf_counter()

@@ -57,6 +57,9 @@ def _setup_rank(rank, world, port, K, path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["MADICP_CU_MASK"] = "%d/%d" % (rank, world)
+    # (processes that share a device compete for its hardware queue slots; beyond what it maps at a time its scheduler rotates
+    # them by the millisecond, which kernels polling a peer's mailbox wait out round by round: few queues per process)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = capi.Context(0)
