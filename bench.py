@@ -202,7 +202,9 @@ def measure_traffic(pb, tids_trees, moving, X0, copy_bytes=1 << 30, regs=6, stre
             arrays["leaves%d" % k] = ht.num_leaves
         npz = os.path.join(tmp, "problem.npz")
         np.savez(npz, **arrays)
-        env = dict(os.environ, TMPDIR="/tmp")
+        from mad_icp_amd import _build as _b
+
+        env = dict(os.environ, TMPDIR="/tmp", MADICP_NATIVE_DIR=_b.MEASURE_DIR)  # (the calibration probes are measurement aids)
         out = {}
         for name, counters in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"),
                                ("tcc", "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum")):
@@ -384,6 +386,8 @@ def main():
     if rank == 0:
         _build.build_hip(force=not args.no_rebuild)
         _build.build_host()
+        if world == 1:  # (the measurement build of the same sources: the roofline's launch times and the counter sub-runs)
+            _build.build_measure(force=not args.no_rebuild)
     if world > 1:
         dist.barrier()
 
@@ -476,7 +480,7 @@ def stress_problem(args, ctx, capi, synth, pb, kf_trees, tids):
                 gts=gts, X0=np.stack([capi.pose12(T) for T in guesses]))
 
 
-def stress_figures(args, ctx, capi, st, fence, hbm_copy):
+def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
     """registrations/s (8 NEW scans in -> 8 results out per step, and the resident loop), icp_round time and its
     bytes for the 64-keyframe / 8-in-flight configuration."""
     B = STRESS_B
@@ -510,7 +514,14 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy):
         ctx.icp_register_batch_enqueue(mids, st["tids"], X0, PARAMS, N_ITERS)
     fence()
     resident = B * n / (time.perf_counter() - t)
-    avg_us, final_us, visits, walked = ctx.icp_time_registration(mids, st["tids"], X0, PARAMS, N_ITERS, reps=10)
+    # launch times: the measurement build's identical kernels (the product library exports no timing aid), its own copy of the map
+    m_tids = [mctx.upload(ht) for ht in st["trees"]]
+    m_mids = [mctx.moving_upload(lm) for lm in st["moving"]]
+    avg_us, final_us, visits, walked = mctx.icp_time_registration(m_mids, m_tids, X0, PARAMS, N_ITERS, reps=10)
+    for m_ in m_mids:
+        mctx.moving_release(m_)
+    for t_ in m_tids:
+        mctx.tree_release(t_)
     pairs = float(sum(st["Ls"])) * STRESS_K
     layout = pairs * (32 + 8 + 64) + 16.0 * float(walked.sum()) + 240.0 * 256
     survey = pairs * (24 + 64 + 1) + 64.0 * float(visits.sum()) + 216.0 * B
@@ -633,8 +644,16 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         batch_value = resident(min(B, len(mids)), max(10, args.steps // B))
 
     # ---- roofline of the dominant kernel (icp_round), timed live with HIP events on the library's stream ---------
-    first_us, visits0 = ctx.icp_time_linearize(mids[:1], tids, X0[:1], PARAMS, 60)
-    avg_us, final_us, visits, walked = ctx.icp_time_registration(mids[:1], tids, X0[:1], PARAMS, N_ITERS, reps=40)
+    # The product library exports include/madicp_hip.h and nothing else; the timing aids (n launches of icp_round / a whole
+    # registration between two HIP events on the stream they run on) live in the MEASUREMENT build of the same sources
+    # (mad_icp_amd/_measure, -DMADICP_MEASURE: identical kernels, same flags), loaded beside it — its own context, its own
+    # copy of the map.  `value` and every registrations/s figure of this line come from the product library.
+    mc = capi.measure_variant()
+    mctx = mc.Context(ctx.device if hasattr(ctx, "device") else 0)
+    m_tids = [mctx.upload(ht) for ht in kf_trees]
+    m_mids = [mctx.moving_upload(leaves[0])]
+    first_us, visits0 = mctx.icp_time_linearize(m_mids, m_tids, X0[:1], PARAMS, 60)
+    avg_us, final_us, visits, walked = mctx.icp_time_registration(m_mids, m_tids, X0[:1], PARAMS, N_ITERS, reps=40)
     pairs = Ls[0] * K
     visits_pl, walked_pl = float(visits.sum()), float(walked.sum())
     # bytes one launch must move with THIS data layout: per (leaf, tree) pair the moving leaf (x,y,z,|p|: 32 B), its
@@ -646,11 +665,11 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
     # fixed cost of a round: the same registration on the first 1024 leaves only (16 trees x 16 ranges = 256 workgroups
     # of ONE wave of work each), started at the converged pose so that nothing is walked after round 0
     conv = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, N_ITERS, Ls[0])["X"]
-    small = ctx.moving_upload(leaves[0][:1024])
-    fixed_us, _, _, _ = ctx.icp_time_registration([small], tids, conv.reshape(1, 12), PARAMS, N_ITERS, reps=40)
-    conv_us, _, _, conv_walked = ctx.icp_time_registration(mids[:1], tids, conv.reshape(1, 12), PARAMS, N_ITERS, reps=40)
-    ctx.moving_release(small)
-    hbm_copy = ctx.stream_copy_gbs(1 << 30, 10)
+    small = mctx.moving_upload(leaves[0][:1024])
+    fixed_us, _, _, _ = mctx.icp_time_registration([small], m_tids, conv.reshape(1, 12), PARAMS, N_ITERS, reps=40)
+    conv_us, _, _, conv_walked = mctx.icp_time_registration(m_mids, m_tids, conv.reshape(1, 12), PARAMS, N_ITERS, reps=40)
+    mctx.moving_release(small)
+    hbm_copy = mctx.stream_copy_gbs(1 << 30, 10)
 
     # `achieved` / `frac` are what the memory counters saw (filled in below, once the PMC sub-runs have run): the only
     # figure of this kernel that is physically an HBM rate.  The bytes the data layout must move and SURVEY 8(d)'s contract
@@ -665,6 +684,10 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                                 "an upper bound of the HBM rate.  The kernel is not bandwidth-bound: see latency_budget",
         "limiter": "latency, not bandwidth: a chain of dependent steps per round at 3 waves/SIMD — see latency_budget",
         "avg_launch_us": round(avg_us, 2), "first_round_launch_us": round(first_us, 2), "final_launch_us": round(final_us, 2),
+        "launch_times_from": "HIP events around captured launch sequences on the library's own stream, through the timing aids of "
+                             "the MEASUREMENT build of the same sources (mad_icp_amd/_measure, -DMADICP_MEASURE: identical kernels and "
+                             "flags, built in this run) — the product library exports include/madicp_hip.h only; `value` and every "
+                             "registrations/s figure are the product library's",
         "rounds": N_ITERS, "pairs_per_launch": pairs,
         "nodes_walked_per_launch": int(walked_pl), "nodes_visited_per_launch_reference_count": int(visits_pl),
         "mean_descent_depth": round(visits_pl / pairs, 3),
@@ -697,7 +720,7 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
     if K == 16 and B == 1 and os.environ.get("MADICP_BENCH_STRESS", "1") != "0":
         try:
             st = stress_problem(args, ctx, capi, synth, pb, kf_trees, tids)
-            stress, stress_us, stress_layout = stress_figures(args, ctx, capi, st, fence, hbm_copy)
+            stress, stress_us, stress_layout = stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx)
         except Exception as e:  # noqa: BLE001 — a secondary figure never takes the bench line down
             stress, st = {"error": str(e)[:200]}, None
 
@@ -721,12 +744,12 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
 
     # ---- nn_descend (the pymadtree path: mad_tree_wrapper.h:48-67), 120k queries ------------------------------
     q_map = (pb["query_scans"][0] @ pb["query_gt"][0][:3, :3].T) + pb["query_gt"][0][:3, 3]
-    us_a, depth_a = ctx.nn_time_descend(tids[-1], q_map, 30)
+    us_a, depth_a = mctx.nn_time_descend(m_tids[-1], q_map, 30)
     dense = capi.HostTree(pb["keyframe_scans"][-1], 1e-5, B_MIN, 3)
     Tk = pb["keyframe_poses"][-1]
     dense.transform(Tk[:3, :3], Tk[:3, 3])
-    dense_id = ctx.upload(dense)
-    us_b, depth_b = ctx.nn_time_descend(dense_id, q_map, 30)
+    dense_id = mctx.upload(dense)
+    us_b, depth_b = mctx.nn_time_descend(dense_id, q_map, 30)
     nq = q_map.shape[0]
     nn = {"queries": nq,
           "keyframe_tree_b_max_0.2": {"leaves": kf_trees[-1].num_leaves, "us_per_launch": round(us_a, 2),
@@ -743,7 +766,8 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
             "bound": "latency", "roof": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": int(tr),
             "achieved": round(tr / (us_a * 1e-6) / 1e9, 1), "frac": round(tr / (us_a * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "layout_bytes": int(lay), "traffic_detail": det, "l2": l2n}
-    ctx.tree_release(dense_id)
+    mctx.tree_release(dense_id)
+    mctx.close()
 
     # ---- the device front-end: the query scan's MAD-tree built on the device ----------------
     front = None
@@ -877,13 +901,45 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
     streamed_loop(ctx, capi, leaves, guesses, tids, max(args.warmup, MIN_WARMUP))
     fence()
     results = []
-    t0 = time.perf_counter()
     stamps = [] if os.environ.get("MADICP_BENCH_DEBUG") else None
-    streamed_loop(ctx, capi, leaves, guesses, tids, args.steps, results, stamps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+
+    def timed(n_steps, res=None, st=None):
+        """EXACTLY n_steps registrations between two fences (device idle on both sides)"""
+        t0 = time.perf_counter()
+        streamed_loop(ctx, capi, leaves, guesses, tids, n_steps, res, st)
+        fence()
+        return time.perf_counter() - t0
+
+    # The timed region — exactly K steps between two fences — is repeated, back to back, and the line carries the spread:
+    # `value` / `ms_per_step` are the MEDIAN repetition, p10 / p90 beside it.  (One repetition of the driver's K = 20 is 4.5 ms:
+    # a single sample of that says little; rounds 4-5 reported 4 492 .. 4 547 from it against 4 665 .. 4 684 from 400 steps.)
+    reps = 5 if args.steps >= 400 else int(min(25, max(5, 2000 // max(1, args.steps))))
+    laps = []
+    for r_ in range(reps):
+        laps.append(timed(args.steps, results if r_ == 0 else None, stamps if r_ == 0 else None))
+    rates = np.array([args.steps / t for t in laps])
+    elapsed = float(np.median(laps))
     value = args.steps / elapsed
+    spread = {"repetitions": reps, "steps_each": args.steps, "median": round(float(np.median(rates)), 1),
+              "p10": round(float(np.percentile(rates, 10)), 1), "p90": round(float(np.percentile(rates, 90)), 1),
+              "min": round(float(rates.min()), 1), "max": round(float(rates.max()), 1),
+              "note": "registrations/s of each repetition of the timed region (exactly --steps steps between two fences, "
+                      "repeated back to back); `value` is the median repetition"}
+    # ... and the long-run interval beside it, so that a short run can be read against it
+    if args.steps != 400:
+        long_rates = np.array([400 / timed(400) for _ in range(5)])
+        spread["steps400"] = {"repetitions": 5, "median": round(float(np.median(long_rates)), 1),
+                              "p10": round(float(np.percentile(long_rates, 10)), 1), "p90": round(float(np.percentile(long_rates, 90)), 1)}
+        lo, hi = float(long_rates.min()), float(long_rates.max())
+        spread["stability"] = ("this run's %d-step median %.0f is %s the 400-step interval [%.0f, %.0f] measured in the same process "
+                               "(a short run ends with one registration of pipeline drain in %d)" % (
+                                   args.steps, value, "INSIDE" if lo <= value <= hi else ("%.1f %% below" % (100 * (lo - value) / lo) if value < lo
+                                                                                          else "%.1f %% above" % (100 * (value - hi) / hi)),
+                                   lo, hi, args.steps))
+    else:
+        spread["stability"] = "400-step repetitions: p10 .. p90 = %.0f .. %.0f (%.1f %% of the median)" % (
+            spread["p10"], spread["p90"], 100 * (spread["p90"] - spread["p10"]) / spread["median"])
+    gc.enable()
     if stamps:
         d = np.diff(np.array(stamps)) * 1e6
         print("step us: first50 %.1f mid %.1f last50 %.1f max %.1f n>400us %d ; slowest %s ; first %s" % (
@@ -920,6 +976,7 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
                             "provably unchanged are resolved without a walk — nodes really walked are in roofline",
         "max_translation_error_m": round(terr, 5),
         "matched_leaves_first_scans": matched,
+        "spread": spread,
         "resident_loop": {"registrations_per_s": round(resident1, 1), "scans8_in_flight_registrations_per_s": round(resident8, 1),
                           "batch_registrations_per_s": None if batch_value is None else round(batch_value, 1),
                           "note": "round-1 definition: same pre-uploaded scans re-registered, nothing read back"},
@@ -1164,6 +1221,7 @@ def cpu_baseline(pb, K, budget_s):
     ms = [O.icp_register(q, trees, T0, N_ITERS, B_MAX, RHO_KER, B_RATIO, num_threads=threads)["ms"] for _ in range(n)]
     med = float(np.median(ms)) * 1e-3
     out = {"value": round(1.0 / med, 3), "unit": "registrations/s", "cores": threads, "host_cores": cores,
+           "p10": round(1e3 / float(np.percentile(ms, 90)), 3), "p90": round(1e3 / float(np.percentile(ms, 10)), 3),
            "kind": "port",
            "sample": "%d registrations of the same workload (K=%d, L=%d, 15 rounds), median; GN loop only "
                      "(the region the reference stopwatches, pipeline.cpp:171-192)" % (n, K, q.num_leaves),
@@ -1189,7 +1247,8 @@ q = O.Tree(z["query"], 0.2, 0.1, 3)
 first = O.icp_register(q, trees, z["guess"], 15, 0.2, 0.1, 0.02, num_threads=threads)["ms"] * 1e-3
 n = int(max(3, min(40, budget / max(first, 1e-3))))
 ms = [O.icp_register(q, trees, z["guess"], 15, 0.2, 0.1, 0.02, num_threads=threads)["ms"] for _ in range(n)]
-print(json.dumps({"ms": float(np.median(ms)), "n": n, "leaves": int(q.num_leaves)}))
+print(json.dumps({"ms": float(np.median(ms)), "ms_p10": float(np.percentile(ms, 10)), "ms_p90": float(np.percentile(ms, 90)), "n": n,
+                  "leaves": int(q.num_leaves)}))
 """
 
 
@@ -1215,6 +1274,7 @@ def cpu_baseline_ref_tus(pb, K, threads, budget_s):
                            capture_output=True, text=True, timeout=300)
         d = json.loads(r.stdout.strip().splitlines()[-1])
         return {"value": round(1e3 / d["ms"], 3), "unit": "registrations/s", "cores": threads,
+                "p10": round(1e3 / d["ms_p90"], 3), "p90": round(1e3 / d["ms_p10"], 3),
                 "kind": "reference translation units + Eigen stand-in",
                 "sample": "%d registrations of the same workload, median; GN loop only" % d["n"],
                 "ms_per_registration": round(d["ms"], 2),

@@ -1,7 +1,9 @@
-/* Measurement and test aids of libmadicp_hip.so — NOT part of the drop-in boundary (include/madicp_hip.h): what bench.py
- * needs to time kernels with HIP events on the library's own stream and to calibrate rocprofv3's counters, and what tests/
- * need to look inside a device tree build.  A product build may leave them out; nothing in the host layer (csrc/host) or in
- * the pybind modules calls them. */
+/* Measurement and test aids — NOT part of the drop-in boundary (include/madicp_hip.h) and NOT in the product library: the
+ * default build of libmadicp_hip.so exports exactly include/madicp_hip.h (tests/test_abi.py).  These entry points exist only
+ * in the MEASUREMENT build of the same sources (-DMADICP_MEASURE; mad_icp_amd/_build.py puts it into mad_icp_amd/_measure/,
+ * mad_icp_amd.capi.measure_variant() loads it): what bench.py needs to time kernels with HIP events on the library's own
+ * stream and to calibrate rocprofv3's counters, and what a few tests need to look inside a device tree build.  Nothing in the
+ * host layer (csrc/host) or in the pybind modules calls them. */
 #ifndef MADICP_HIP_MEASURE_H
 #define MADICP_HIP_MEASURE_H
 #include "madicp_hip.h"

@@ -145,5 +145,28 @@ def build_all(force=False):
     return [build_hip(force), build_host(force)] + build_pybind(force)
 
 
+# The MEASUREMENT build: the same sources with -DMADICP_MEASURE — include/madicp_hip_measure.h's timing / calibration / test
+# aids and the realtime rule's test seam in pypeline — into mad_icp_amd/_measure/ (in-tree, git-ignored like every built file,
+# travels to the GPU box).  The default build above is the product: it exports include/madicp_hip.h and nothing else.
+# bench.py's roofline legs and the few tests that look inside a device tree build load it through capi.measure_variant().
+MEASURE_DIR = os.path.join(PKG, "_measure")
+
+
+def build_measure(force=False):
+    if os.path.abspath(OUT) == os.path.abspath(MEASURE_DIR):
+        return build_all(force)
+    os.makedirs(os.path.join(MEASURE_DIR, "pybind"), exist_ok=True)
+    env = dict(os.environ, MADICP_NATIVE_DIR=MEASURE_DIR,
+               MADICP_EXTRA_DEFINES=" ".join(_EXTRA + ["-DMADICP_MEASURE"]), PYTHONPATH=os.pathsep.join([ROOT] + sys.path))
+    # (force: the HIP library only — it holds the kernels a measurement is about; host library and bindings by content hash)
+    subprocess.check_call([sys.executable, "-c", "from mad_icp_amd import _build; _build.build_hip(%r); _build.build_host(); "
+                           "_build.build_pybind()" % bool(force)], env=env, cwd=ROOT, stdout=sys.stderr)
+    suffix = sysconfig.get_config_var("EXT_SUFFIX")
+    return [os.path.join(MEASURE_DIR, "libmadicp_hip.so"), os.path.join(MEASURE_DIR, "libmadicp_host.so")] + [
+        os.path.join(MEASURE_DIR, "pybind", m + suffix) for m in ("pyvector", "pymadtree", "pymadicp", "pypeline")]
+
+
 if __name__ == "__main__":
     build_all(force="--force" in sys.argv)
+    if "--no-measure" not in sys.argv and "-DMADICP_MEASURE" not in _EXTRA:
+        build_measure(force="--force" in sys.argv)

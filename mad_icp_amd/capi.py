@@ -7,6 +7,7 @@ the calls fail loudly.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -42,10 +43,38 @@ REDUCE_SUM_F64, REDUCE_MAX_U8 = 0, 1
 
 _hip = None
 _host = None
+_DIR_OVERRIDE = None  # set on the second instance of this module that measure_variant() makes
+_measure_mod = None
+
+
+def measure_variant():
+    """This module a second time, bound to the MEASUREMENT build of the libraries (mad_icp_amd/_measure: the same sources with
+    -DMADICP_MEASURE, built by _build.build_measure()): `capi.measure_variant().Context(0)` has include/madicp_hip_measure.h's
+    timing / calibration / test aids, which the product library the default `capi` loads does not export.  Both can be used
+    in one process (bench.py times the product and takes its roofline's launch times from the variant's identical kernels)."""
+    global _measure_mod
+    if _DIR_OVERRIDE is not None:
+        return sys.modules[__name__]
+    if os.environ.get("MADICP_NATIVE_DIR"):  # (a process already pointed at another build: that build is the variant)
+        return sys.modules[__name__]
+    if _measure_mod is None:
+        import importlib.util
+
+        from . import _build
+
+        spec = importlib.util.spec_from_file_location(__name__ + "_measure", os.path.abspath(__file__),
+                                                      submodule_search_locations=None)
+        m = importlib.util.module_from_spec(spec)
+        m.__package__ = __package__
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        m._DIR_OVERRIDE = _build.MEASURE_DIR
+        _measure_mod = m
+    return _measure_mod
 
 
 def _load(name):
-    path = os.path.join(os.environ.get("MADICP_NATIVE_DIR") or _PKG, name)  # (same variable as _build.OUT)
+    path = os.path.join(_DIR_OVERRIDE or os.environ.get("MADICP_NATIVE_DIR") or _PKG, name)  # (same variable as _build.OUT)
     if name == "libmadicp_hip.so" and os.environ.get("MADICP_HIP_LIB"):
         path = os.environ["MADICP_HIP_LIB"]  # an instrumented build of the same library (tools/stamps.py)
     if not os.path.exists(path):
@@ -78,8 +107,15 @@ def hip_lib():
         L.madicp_stream_submit.argtypes = [C.c_void_p, _dp, C.c_int32, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip]
         L.madicp_stream_submit_tree.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip]
         L.madicp_stream_collect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _u8p, _i32p, _u64p]
-        L.madicp_nn_time_descend.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, _dp, _u64p]
-        L.madicp_debug_stream_copy.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp]
+        # include/madicp_hip_measure.h: only the measurement build exports these (measure_variant())
+        if hasattr(L, "madicp_nn_time_descend"):
+            L.madicp_nn_time_descend.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, _dp, _u64p]
+            L.madicp_debug_stream_copy.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp]
+            L.madicp_icp_time_linearize.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
+                                                    _dp, _u64p]
+            L.madicp_icp_time_registration.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
+                                                       C.c_int, _dp, _dp, _u64p, _u64p]
+            L.madicp_debug_tree_build_points.argtypes = [C.c_void_p, _dp, C.c_int64]
         if hasattr(L, "madicp_debug_gather16"):  # (absent from an older build loaded through MADICP_HIP_LIB for an A/B)
             L.madicp_debug_gather16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int, _dp]
         L.madicp_icp_linearize.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), _dp, _dp,
@@ -90,10 +126,6 @@ def hip_lib():
                                                 C.c_int, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_register_batch_enqueue.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp,
                                                         C.POINTER(IcpParams), C.c_int]
-        L.madicp_icp_time_linearize.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
-                                                _dp, _u64p]
-        L.madicp_icp_time_registration.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int,
-                                                   C.c_int, _dp, _dp, _u64p, _u64p]
         L.madicp_icp_fetch.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
         L.madicp_icp_fetch_matched.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int32]
         L.madicp_cloud_upload.argtypes = [C.c_void_p, _dp, C.c_int64, _ip]
@@ -109,7 +141,6 @@ def hip_lib():
         L.madicp_tree_build_cancel.argtypes = [C.c_void_p]
         L.madicp_tree_info.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
         L.madicp_tree_build_stats.argtypes = [C.c_void_p, _i32p]
-        L.madicp_debug_tree_build_points.argtypes = [C.c_void_p, _dp, C.c_int64]
         L.madicp_comm_unique_id.argtypes = [_u8p]
         L.madicp_comm_init.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int]
         L.madicp_comm_destroy.argtypes = [C.c_void_p]
@@ -152,6 +183,15 @@ def host_lib():
         L.madicp_host_debug_partition.argtypes = [_dp, C.c_int64, _dp, _dp, C.c_int]
         _host = L
     return _host
+
+
+def _aid(name):
+    """an entry point of include/madicp_hip_measure.h: not in the product library"""
+    f = getattr(hip_lib(), name, None)
+    if f is None:
+        raise MadIcpError(name + " is a measurement / test aid: the product library does not export it — use "
+                          "mad_icp_amd.capi.measure_variant() (mad_icp_amd/_measure, built by _build.build_measure())")
+    return f
 
 
 def _check(rc):
@@ -414,7 +454,7 @@ class Context:
     def tree_build_points(self, n):
         """the points of the last synchronous device build in the order the construction left them (diagnostics)"""
         out = np.empty((int(n), 3))
-        _check(hip_lib().madicp_debug_tree_build_points(self._h, out.ctypes.data_as(_dp), int(n)))
+        _check(_aid("madicp_debug_tree_build_points")(self._h, out.ctypes.data_as(_dp), int(n)))
         return out
 
     # ---- moving ----
@@ -499,19 +539,19 @@ class Context:
         q = _f64(queries)
         us = C.c_double(0.0)
         depth = C.c_uint64(0)
-        _check(hip_lib().madicp_nn_time_descend(self._h, tid, q.ctypes.data_as(_dp), q.shape[0], reps, C.byref(us),
+        _check(_aid("madicp_nn_time_descend")(self._h, tid, q.ctypes.data_as(_dp), q.shape[0], reps, C.byref(us),
                                                 C.byref(depth)))
         return us.value, depth.value
 
     def gather16_us(self, region_bytes, n_gathers, seed=1, reps=3):
         """avg microseconds per launch of n_gathers random 16-byte loads over a region (madicp_debug_gather16)."""
         g = C.c_double(0.0)
-        _check(hip_lib().madicp_debug_gather16(self._h, int(region_bytes), int(n_gathers), int(seed), int(reps), C.byref(g)))
+        _check(_aid("madicp_debug_gather16")(self._h, int(region_bytes), int(n_gathers), int(seed), int(reps), C.byref(g)))
         return g.value
 
     def stream_copy_gbs(self, nbytes=1 << 30, reps=10):
         g = C.c_double(0.0)
-        _check(hip_lib().madicp_debug_stream_copy(self._h, nbytes, reps, C.byref(g)))
+        _check(_aid("madicp_debug_stream_copy")(self._h, nbytes, reps, C.byref(g)))
         return g.value
 
     def icp_register_batch_enqueue(self, mids, tree_ids, X0, params, n_iters):
@@ -526,7 +566,7 @@ class Context:
         p = IcpParams(*params)
         us = C.c_double(0.0)
         visits = np.zeros(len(mids), np.uint64)
-        _check(hip_lib().madicp_icp_time_linearize(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
+        _check(_aid("madicp_icp_time_linearize")(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
                                                    X0.ctypes.data_as(_dp), C.byref(p), n_launches, C.byref(us),
                                                    visits.ctypes.data_as(_u64p)))
         return us.value, visits
@@ -539,7 +579,7 @@ class Context:
         lin, sol = C.c_double(0.0), C.c_double(0.0)
         visits = np.zeros(len(mids), np.uint64)
         walked = np.zeros(len(mids), np.uint64)
-        _check(hip_lib().madicp_icp_time_registration(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
+        _check(_aid("madicp_icp_time_registration")(self._h, len(mids), self._ids(mids), self._ids(tree_ids), len(tree_ids),
                                                       X0.ctypes.data_as(_dp), C.byref(p), n_iters, reps, C.byref(lin),
                                                       C.byref(sol), visits.ctypes.data_as(_u64p), walked.ctypes.data_as(_u64p)))
         return lin.value, sol.value, visits, walked

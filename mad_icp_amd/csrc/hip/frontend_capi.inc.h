@@ -774,12 +774,26 @@ int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, doubl
   if (n < 1 || n > 0x3fffffff) return fail(MADICP_ERR_INVALID, "a cloud holds 1 .. 2^30 points");
   RC_TRY(busy_with_lookahead(ctx));
   HIP_TRY(hipSetDevice(ctx->device));
+  {
+    // The look-ahead pays when construction and registration run BACK TO BACK on the device (the runtime's default hardware
+    // queue map: 0.78 -> 0.65 ms per frame) and not when they run side by side and slow each other down — which is what
+    // GPU_MAX_HW_QUEUES > 4 gives (0.82 -> 0.82: DESIGN.md 9.4, bench.py's lookahead_in_a_plain_process).  A multi-rank process
+    // wants the many queues for its collectives: said once, so that the combination is a decision and not an accident.
+    static bool warned = false;
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    if (!warned && q && std::atoi(q) > 4) {
+      warned = true;
+      std::fprintf(stderr, "madicp: a look-ahead tree build was begun with GPU_MAX_HW_QUEUES=%s: measured on MI355X, the look-ahead "
+                           "shortens a frame under the runtime's default queue map (0.78 -> 0.65 ms) and does not with more than four "
+                           "hardware queues (0.82 -> 0.82 ms); without prefetch() the frame is the same either way\n", q);
+    }
+  }
   if (!ctx->build) {
     // MADICP_BUILD_CUS=<n> (experiment): the look-ahead construction only gets the first n CUs, so that its level
     // kernels cannot spread over the CUs a registration round wants all of — whatever hardware queues the runtime maps the two
     // streams to
-    // (a measurement aid: compiled out of product builds, -DMADICP_NO_MEASURE)
-#ifndef MADICP_NO_MEASURE
+    // (a measurement aid: only in the measurement build, -DMADICP_MEASURE)
+#ifdef MADICP_MEASURE
     const char* e = std::getenv("MADICP_BUILD_CUS");
     const int n_build = e ? std::atoi(e) : 0;
 #else
@@ -897,7 +911,7 @@ int madicp_tree_info(madicp_ctx* ctx, int tree_id, int32_t* out_n_nodes, int32_t
 // every leaf's members in the order the splits above it produced (reference: the caller's container after MADtree::build,
 // mad_tree.cpp:95-97 with utils.h:37-52, except that the reference also overwrites a leaf's first member with its
 // representative, mad_tree.cpp:76-84).  Valid until the next build, ingest or deskew on the context.
-#ifndef MADICP_NO_MEASURE
+#ifdef MADICP_MEASURE
 int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n) {
   if (!ctx || !out_xyz) return fail(MADICP_ERR_INVALID, "null argument");
   if (!ctx->front || !ctx->front->scratch.block || !ctx->front->scratch.h_line) return fail(MADICP_ERR_INVALID, "no build yet");
@@ -918,7 +932,7 @@ int madicp_debug_tree_build_points(madicp_ctx* ctx, double* out_xyz, int64_t n) 
     return fail(MADICP_ERR_DEVICE, std::string("tree build points: ") + hipGetErrorString(e != hipSuccess ? e : e2));
   return MADICP_OK;
 }
-#endif  // MADICP_NO_MEASURE
+#endif  // MADICP_MEASURE
 
 // per-level node counts of the last build on this context (diagnostics for tests / tools): out[0] = levels reached,
 // out[1] = lane-regime sub-trees, then 2 x 64 ints: wave-regime and chip-regime nodes per level

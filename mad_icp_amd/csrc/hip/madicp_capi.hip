@@ -1989,7 +1989,7 @@ int madicp_icp_linearize(madicp_ctx* ctx, int moving_id, const int* tree_ids, in
   return rc;
 }
 
-#ifndef MADICP_NO_MEASURE  // ---- measurement / test aids (include/madicp_hip_measure.h): a product build leaves them out
+#ifdef MADICP_MEASURE  // ---- measurement / test aids (include/madicp_hip_measure.h): only in the measurement build (mad_icp_amd/_measure)
 int madicp_icp_time_linearize(madicp_ctx* ctx, int n_scans, const int* moving_ids, const int* tree_ids, int K,
                               const double* X0, const madicp_icp_params* params, int n_launches, double* out_avg_us,
                               uint64_t* out_visits_per_launch) {
@@ -2203,7 +2203,7 @@ int madicp_debug_gather16(madicp_ctx* ctx, int64_t region_bytes, int64_t n_gathe
   return MADICP_OK;
 }
 
-#endif  // MADICP_NO_MEASURE
+#endif  // MADICP_MEASURE
 
 // ---- multi-GPU --------------------------------------------------------------------------------------
 int madicp_comm_unique_id(uint8_t out_id[128]) {

@@ -22,9 +22,9 @@ madicp_ctx* Device::ctx() {
     int dev = 0;
     if (const char* e = std::getenv("MAD_ICP_DEVICE")) dev = std::atoi(e);
     check(madicp_ctx_create(dev, nullptr, &g_ctx), "madicp_ctx_create (the HIP path has no CPU fallback)");
-#ifndef MADICP_NO_MEASURE
+#ifdef MADICP_MEASURE
     // MADICP_PUBLISH_SIDE=0|1 (probes: tools/lookahead_matrix.sh): the library option of the same name for the shared context
-    // (measurement aids: compiled out of product builds, -DMADICP_NO_MEASURE)
+    // (measurement aids: only in the measurement build, -DMADICP_MEASURE)
     if (const char* e = std::getenv("MADICP_PUBLISH_SIDE")) madicp_ctx_set_option(g_ctx, "publish_side", e[0] == '1' ? 1 : 0);
     if (const char* e = std::getenv("MADICP_BUILD_AFTER_REG")) madicp_ctx_set_option(g_ctx, "build_after_registration", e[0] == '1' ? 1 : 0);
 #endif

@@ -55,7 +55,7 @@ PYBIND11_MODULE(pypeline, m) {
     // instrumentation, not in the reference
     .def("lastInliersRatio", &Pipeline::lastInliersRatio)
     .def("lastRounds", &Pipeline::lastRounds)
-#ifndef MADICP_NO_MEASURE  // (test seam of the realtime budget rule: not in a product build)
+#ifdef MADICP_MEASURE  // (test seam of the realtime budget rule: measurement build only)
     .def("setTimingForTest", &Pipeline::setTimingForTest, py::arg("pre_ms"), py::arg("round_ms"))
 #endif
     .def("lastIcpMs", &Pipeline::lastIcpMs)

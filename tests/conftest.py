@@ -33,6 +33,8 @@ def natives():
     from mad_icp_amd import _build
 
     _build.build_all()
+    if not os.environ.get("MADICP_NATIVE_DIR"):  # (a variant run builds into its own directory: nothing else to make)
+        _build.build_measure()
     return True
 
 
@@ -41,5 +43,20 @@ def ctx(natives):
     from mad_icp_amd import capi
 
     c = capi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def mctx(natives):
+    """A context of the MEASUREMENT build (mad_icp_amd/_measure: the same sources + include/madicp_hip_measure.h's aids) for
+    the few tests that look inside a device tree build (madicp_debug_tree_build_points); everything else runs against the
+    product library, which exports the drop-in header only."""
+    from mad_icp_amd import capi
+
+    mc = capi.measure_variant()
+    if not hasattr(mc.hip_lib(), "madicp_debug_tree_build_points"):
+        pytest.skip("this build of the library has no measurement aids (a variant run without -DMADICP_MEASURE)")
+    c = mc.Context(0)
     yield c
     c.close()

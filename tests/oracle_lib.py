@@ -80,13 +80,14 @@ def lib():
         L.orc_pipeline_model_leaves.restype = C.c_int64
         L.orc_pipeline_model_leaves.argtypes = [C.c_void_p, c_dp, C.c_int64]
         L.orc_deskew.argtypes = [c_dp, C.c_int64, c_dp, c_dp, C.c_double, c_dp]
-        L.orc_pipeline_last_guess.argtypes = [C.c_void_p, c_dp]
-        L.orc_pipeline_predict.argtypes = [C.c_void_p, c_dp]
-        L.orc_pipeline_keyframe_borrow.restype = C.c_void_p
-        L.orc_pipeline_keyframe_borrow.argtypes = [C.c_void_p, C.c_int64]
-        L.orc_pipeline_keyframe_num_nodes.restype = C.c_int64
-        L.orc_pipeline_keyframe_num_nodes.argtypes = [C.c_void_p, C.c_int64]
-        L.orc_pipeline_keyframe_export.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_i32p, c_i32p, c_i32p]
+        if hasattr(L, "orc_pipeline_last_guess"):  # (instrumentation of the oracle: not in the reference-stand-in library)
+            L.orc_pipeline_last_guess.argtypes = [C.c_void_p, c_dp]
+            L.orc_pipeline_predict.argtypes = [C.c_void_p, c_dp]
+            L.orc_pipeline_keyframe_borrow.restype = C.c_void_p
+            L.orc_pipeline_keyframe_borrow.argtypes = [C.c_void_p, C.c_int64]
+            L.orc_pipeline_keyframe_num_nodes.restype = C.c_int64
+            L.orc_pipeline_keyframe_num_nodes.argtypes = [C.c_void_p, C.c_int64]
+            L.orc_pipeline_keyframe_export.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_i32p, c_i32p, c_i32p]
         _LIB = L
     return _LIB
 

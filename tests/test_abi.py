@@ -15,9 +15,10 @@ def declared_symbols(header):
     return sorted(set(re.findall(r"\b(madicp_[a-z0-9_]+)\s*\(", src)))
 
 
-@pytest.mark.parametrize("header,lib", [("madicp_hip.h", "libmadicp_hip.so"), ("madicp_hip_measure.h", "libmadicp_hip.so"),
-                                        ("madicp_host.h", "libmadicp_host.so")])
+@pytest.mark.parametrize("header,lib", [("madicp_hip.h", "libmadicp_hip.so"), ("madicp_hip_measure.h", "_measure/libmadicp_hip.so"),
+                                        ("madicp_hip.h", "_measure/libmadicp_hip.so"), ("madicp_host.h", "libmadicp_host.so")])
 def test_library_exports_every_declared_symbol(natives, header, lib):
+    """(the measurement aids: exported by the measurement build in mad_icp_amd/_measure only — see the last test of this file)"""
     L = ctypes.CDLL(os.path.join(ROOT, "mad_icp_amd", lib))
     syms = declared_symbols(header)
     assert len(syms) >= 6
@@ -59,32 +60,37 @@ def test_product_never_imports_oracle():
     assert not bad, bad
 
 
-def test_product_build_leaves_the_measurement_and_test_aids_out(natives, tmp_path):
-    """-DMADICP_NO_MEASURE (MADICP_EXTRA_DEFINES, built into a scratch directory through MADICP_NATIVE_DIR): the library still
-    exports every symbol of the drop-in header and NONE of include/madicp_hip_measure.h, and pypeline is compiled without the
-    realtime rule's test seam.  (The in-tree build keeps them: bench.py and the tests call them.)"""
+def test_product_build_leaves_the_measurement_and_test_aids_out(natives):
+    """The DEFAULT build is the product: the in-tree libmadicp_hip.so exports every symbol of the drop-in header and NONE of
+    include/madicp_hip_measure.h, and the in-tree pypeline has the reference's surface without the realtime rule's test seam.
+    The aids live in the MEASUREMENT build of the same sources (mad_icp_amd/_measure, -DMADICP_MEASURE: bench.py's roofline
+    legs, four tests), which exports them all."""
     import subprocess
-    import sys
 
-    d = str(tmp_path)
-    env = dict(os.environ, MADICP_NATIVE_DIR=d, MADICP_EXTRA_DEFINES="-DMADICP_NO_MEASURE",
-               PYTHONPATH=os.pathsep.join([ROOT] + sys.path))
-    r = subprocess.run([sys.executable, "-c", "from mad_icp_amd import _build; print(_build.build_hip())"], env=env, cwd=ROOT,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(d, "libmadicp_hip.so")], capture_output=True, text=True).stdout
-    exported = set(re.findall(r"\b(madicp_[a-z0-9_]+)\b", out))
-    missing = [s for s in declared_symbols("madicp_hip.h") if s not in exported]
+    from mad_icp_amd import _build
+
+    def exported_by(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        return set(re.findall(r"\b(madicp_[a-z0-9_]+)\b", out))
+
+    product = exported_by(os.path.join(_build.PKG, "libmadicp_hip.so"))
+    missing = [s for s in declared_symbols("madicp_hip.h") if s not in product]
     assert not missing, missing
-    leaked = [s for s in declared_symbols("madicp_hip_measure.h") if s in exported]
+    leaked = [s for s in declared_symbols("madicp_hip_measure.h") if s in product]
     assert not leaked, leaked
-    assert not [s for s in exported if s.startswith("madicp_debug_")]
-    # the binding: the preprocessed translation unit no longer registers the seam
+    assert not [s for s in product if s.startswith("madicp_debug_")]
+    measure = exported_by(os.path.join(_build.MEASURE_DIR, "libmadicp_hip.so"))
+    assert not [s for s in declared_symbols("madicp_hip.h") + declared_symbols("madicp_hip_measure.h") if s not in measure]
+    # the bindings: the seam is registered by the measurement build's translation unit only
     import pybind11
 
-    pp = subprocess.run(["g++", "-E", "-std=c++17", "-DMADICP_NO_MEASURE", "-I" + os.path.join(ROOT, "include"),
-                         "-I" + os.path.join(ROOT, "mad_icp_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "mad_icp_amd", "csrc", "pybind"),
-                         "-I" + pybind11.get_include(), "-I" + __import__("sysconfig").get_paths()["include"],
-                         os.path.join(ROOT, "mad_icp_amd", "csrc", "pybind", "pypeline.cpp")], capture_output=True, text=True)
-    assert pp.returncode == 0, pp.stderr[-2000:]
-    assert '"setTimingForTest"' not in pp.stdout and '"compute"' in pp.stdout
+    def preprocessed(extra):
+        pp = subprocess.run(["g++", "-E", "-std=c++17"] + extra + ["-I" + os.path.join(ROOT, "include"),
+                             "-I" + os.path.join(ROOT, "mad_icp_amd", "csrc", "host"), "-I" + os.path.join(ROOT, "mad_icp_amd", "csrc", "pybind"),
+                             "-I" + pybind11.get_include(), "-I" + __import__("sysconfig").get_paths()["include"],
+                             os.path.join(ROOT, "mad_icp_amd", "csrc", "pybind", "pypeline.cpp")], capture_output=True, text=True)
+        assert pp.returncode == 0, pp.stderr[-2000:]
+        return pp.stdout
+
+    assert '"setTimingForTest"' not in preprocessed([]) and '"compute"' in preprocessed([])
+    assert '"setTimingForTest"' in preprocessed(["-DMADICP_MEASURE"])

@@ -4,6 +4,7 @@ defaults (pypeline.cpp:57-74, tools/pymadtree.cpp:36-48, tools/pymadicp.cpp:36-5
 CPU part: surface + container semantics.  GPU part: the reference's own tool flows and Pipeline vs the oracle."""
 import copy
 import inspect
+import os
 
 import numpy as np
 import pytest
@@ -278,19 +279,12 @@ def test_keyframe_decisions_match_oracle_over_seeded_drives(mods, scene_seed, st
     assert promotions >= 2  # the drive did exercise the selection
 
 
-@pytest.mark.gpu
-def test_realtime_round_count_rule_matches_the_reference(mods):
-    """realtime = True: the reference re-checks its wall-clock budget before EVERY round (pipeline.cpp:166-169: round k runs
-    iff preprocessing + the rounds so far + the previous round's time once more still fit loop_time - 5 ms) and only resets
-    the matched flags in iteration MAX_ICP_ITS - 1 (:172-176), so a loop cut short leaves the OR of the rounds that ran.  The
-    product's device loop is ONE submission: it turns the same budget into a round count before it starts
-    (csrc/host/pipeline.cpp) and asks the kernels for the OR of the rounds.  Both sides get the same injected clock here
-    (preprocessing took P ms, a round takes R ms — test seams on the oracle and on Pipeline) and must run the same number of
-    rounds on every frame — all 15, a few, one, none — and land on the same pose, inlier ratio and keyframe decisions."""
+def _realtime_rule_body(pypeline):
+    """(the body of test_realtime_round_count_rule_matches_the_reference; `pypeline`: the MEASUREMENT build's module, which
+    has the realtime rule's test seam — Pipeline.setTimingForTest — the product's binding does not)"""
     import oracle_lib as O
     from mad_icp_amd import synth
 
-    pypeline = mods[3]
     scene = synth.Scene(5)
     schedule = [(1.0, 2.0, 15), (10.0, 10.0, 8), (20.3, 10.0, 7), (61.0, 10.0, 3), (90.0, 10.0, 1), (96.0, 10.0, 0),
                 (30.0, 10.0, 6), (5.0, 10.0, 9), (80.0, 7.0, 2), (94.9, 50.0, 1), (3.0, 6.2, 14)]  # (P, R, rounds the rule gives)
@@ -315,3 +309,28 @@ def test_realtime_round_count_rule_matches_the_reference(mods):
         assert np.linalg.norm(d[:3, 3]) <= 1e-5 and ang <= 1e-5, (i, d)
         assert gp.keyframeID() == op.keyframeID() and gp.isMapUpdated() == op.isMapUpdated(), i
     assert cut >= 8
+
+
+@pytest.mark.gpu
+def test_realtime_round_count_rule_matches_the_reference(natives):
+    """realtime = True: the reference re-checks its wall-clock budget before EVERY round (pipeline.cpp:166-169: round k runs
+    iff preprocessing + the rounds so far + the previous round's time once more still fit loop_time - 5 ms) and only resets
+    the matched flags in iteration MAX_ICP_ITS - 1 (:172-176), so a loop cut short leaves the OR of the rounds that ran.  The
+    product's device loop is ONE submission: it turns the same budget into a round count before it starts
+    (csrc/host/pipeline.cpp) and asks the kernels for the OR of the rounds.  Both sides get the same injected clock here
+    (preprocessing took P ms, a round takes R ms — test seams on the oracle and on Pipeline) and must run the same number of
+    rounds on every frame — all 15, a few, one, none — and land on the same pose, inlier ratio and keyframe decisions."""
+    # The injected clock is a test seam (Pipeline.setTimingForTest): compiled into the MEASUREMENT build's pypeline only
+    # (mad_icp_amd/_measure, -DMADICP_MEASURE) — the product's binding has the reference's surface and nothing else
+    # (tests/test_abi.py) — so the body runs in a process of its own that imports that module.
+    import subprocess
+    import sys
+
+    from mad_icp_amd import _build
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import pypeline; assert hasattr(pypeline.Pipeline, 'setTimingForTest'); "
+            "import test_boundary as T; T._realtime_rule_body(pypeline); print('REALTIME RULE OK')" % (
+                os.path.join(_build.MEASURE_DIR, "pybind"), os.path.dirname(here), here))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and "REALTIME RULE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -49,5 +49,8 @@ def test_valu_butterflies_give_the_bits_of_the_lds_crossbar_ones(natives, tmp_pa
     base = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")] + sys.path))
     d = str(tmp_path)
     os.makedirs(os.path.join(d, "pybind"), exist_ok=True)
-    variant = dict(base, MADICP_NATIVE_DIR=d, MADICP_EXTRA_DEFINES="-DMADICP_TB_BPERMUTE=1")
-    assert _digest(base) == _digest(variant)
+    # (both legs with the measurement aids: madicp_debug_tree_build_points, the member order the construction left)
+    from mad_icp_amd import _build
+
+    variant = dict(base, MADICP_NATIVE_DIR=d, MADICP_EXTRA_DEFINES="-DMADICP_TB_BPERMUTE=1 -DMADICP_MEASURE")
+    assert _digest(dict(base, MADICP_NATIVE_DIR=_build.MEASURE_DIR, MADICP_EXTRA_DEFINES="-DMADICP_MEASURE")) == _digest(variant)

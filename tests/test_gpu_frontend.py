@@ -66,7 +66,8 @@ def check_exact_properties(ctx, pts, tid, nodes):
 
 
 @pytest.mark.parametrize("name", ["1pt", "2pt", "dup40", "line100", "expline36", "gauss3000", "street19k", "scan120k"])
-def test_device_tree_build_vs_host_builder(ctx, name):
+def test_device_tree_build_vs_host_builder(mctx, name):
+    ctx = mctx  # (the measurement build's context: madicp_debug_tree_build_points below)
     rng = np.random.default_rng(5)
     pts = {
         "1pt": lambda: np.array([[1.0, 2.0, 3.0]]),
@@ -155,11 +156,12 @@ def test_device_tree_matches_host_builder_on_many_full_size_scans(ctx, capsys):
 
 @pytest.mark.parametrize("n", [31, 32, 33, 63, 64, 65, 127, 129, 511, 512, 513, 514, 767, 769, 1023, 1025, 2047, 2048, 2049, 4095,
                                4097, 6143, 6145, 20001])
-def test_device_tree_build_at_regime_boundaries(ctx, n):
+def test_device_tree_build_at_regime_boundaries(mctx, n):
     """Cloud sizes on both sides of every regime boundary of the device builder — four lanes / one wavefront (32 | 33), one
     wavefront / a team of four (512 | 513), one chunk / two (2048 | 2049), the lane-strided batches in between — on an
     anisotropic Gaussian cloud: exact properties, the host builder's topology and leaf representatives, and the
     construction's member order equal to the host builder's row for row (utils.h:37-52)."""
+    ctx = mctx  # (the measurement build's context: madicp_debug_tree_build_points below)
     rng = np.random.default_rng(1000 + n)
     pts = rng.normal(size=(n, 3)) * [6.0, 2.5, 0.4] + [3.0, -2.0, 1.0]
     ht, cid, tid, nodes = build_both(ctx, pts, 0.2, 0.1)

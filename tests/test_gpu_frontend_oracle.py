@@ -74,7 +74,7 @@ def test_default_pipeline_builds_on_the_device_and_matches_the_oracle(pypeline, 
 # ---- (c) deskew = true: both product paths inside the reference's own envelope -----------------------------------------------
 def _product_drive(pypeline, scans, device):
     p = pypeline.Pipeline(10.0, True, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, 16, 16, False)
-    assert not p.deviceFrontEnd()  # (deskewed datasets keep the host builder by default)
+    assert p.deviceFrontEnd()  # (round 6: the default for deskewed datasets too — tests/test_gpu_deskew_one_step.py is its bar)
     p.setDeviceFrontEnd(device)
     poses, kf = [], []
     for i, s in enumerate(scans):
@@ -210,11 +210,12 @@ def _reference_keeps_its_topology(pts, b_max, b_min, seed, trials=8, ulps=(1, 4,
     return out
 
 
-def test_device_builder_on_deskewed_clouds(ctx, capsys):
+def test_device_builder_on_deskewed_clouds(mctx, capsys):
     """Every builder-vs-builder test so far fed ring-ordered scans.  A deskewed cloud arrives sorted by azimuth
     (pipeline.cpp:88-92) — another member order into every sum — and motion-compensated.  Twelve of them (two scenes, the
     oracle's own deskew with the drive's motion), tied and distinct azimuths: the host builder's topology, EVERY leaf
     representative at its ordinal, the construction's member order row for row."""
+    ctx = mctx  # (the measurement build's context: madicp_debug_tree_build_points below)
     total = diff = 0
     for sc in (0, 3):
         scene = synth.Scene(sc)

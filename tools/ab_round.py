@@ -9,6 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mad_icp_amd import capi, synth  # noqa: E402
+capi = capi.measure_variant()  # (uses include/madicp_hip_measure.h's aids: the measurement build, mad_icp_amd/_measure)
 
 PARAMS = (0.2, 0.1, 0.02)
 label = sys.argv[1] if len(sys.argv) > 1 else os.environ.get("MADICP_HIP_LIB", "in-tree")

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from mad_icp_amd import capi, synth  # noqa: E402
+capi = capi.measure_variant()  # (uses include/madicp_hip_measure.h's aids: the measurement build, mad_icp_amd/_measure)
 
 B_MAX, B_MIN = 0.2, 0.1
 
