@@ -1117,6 +1117,7 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
             else:
                 try:
                     ctx.set_option("shard_p2p", 1)
+                    ctx.set_option("comm_timeout_ms", 10000)  # (a mailbox that never fills must not hold the line for a minute per wait)
                     e1p, _ = batched(1, tids, max(20, args.steps // 4), 5, mids[:1])
                     ep, lastp = batched(B, tids, args.steps, args.warmup, mids)
                     terr_p = max(pose_error(pb["query_gt"][q], capi.pose44(lastp[1]["X"][s])) for s, q in enumerate(lastp[0]))
@@ -1139,6 +1140,7 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
                     out_extra["shard_p2p"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
                 finally:
                     ctx.set_option("shard_p2p", 0)
+                    ctx.set_option("comm_timeout_ms", 60000)
             for m in mids:
                 ctx.moving_release(m)
             for t in tids:

@@ -83,8 +83,10 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * "leaf_major" (0: never; n > 0, default 8192: when a batch shares the chip — more keyframe trees than workgroups per XCD piece —
  * every workgroup gets one range of the scan's leaves and all the trees of its piece, and a round that follows one in which the
  * workgroup walked fewer than n nodes per pass runs LEAF-MAJOR: the moving leaf is read and transformed once per pass for all
- * those trees, and the pairs that still have to walk are queued per wavefront and walked densely.  Same decisions — leaf,
- * depth, gate, matched flags, visit count — bit for bit; H and b in another summation order, ~1e-16 relative),
+ * those trees, and the pairs that still have to walk are queued per wavefront and walked densely.  H and b come out in another
+ * summation order (~1e-16 relative), so the poses of later rounds differ by as much: the decisions — leaf, depth, gate, matched
+ * flags, visit count — are the same except where a pair sits exactly on a split plane or on the gate's radius (equal on every
+ * data set of the test suite, asserted there; not a structural guarantee)),
  * "publish_side" (0/1, default 1: a streamed registration leaves its results in a device-resident outbox and a one-workgroup
  * kernel on a side stream carries them, and the matched flags, to the caller's pinned block while the compute stream is already
  * running the next registration — the two PCIe round trips of that hand-over were 5 us of every registration; off: the

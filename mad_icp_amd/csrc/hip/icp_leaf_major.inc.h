@@ -20,7 +20,9 @@
 //
 // The ACCUMULATION ORDER is another one than the tree-major body's (pass-major, walkers last), so H and b differ from it in
 // their last bits (~1e-16 relative; the pose contract is 1e-5 and the reference's own order depends on its thread count) —
-// every DECISION (leaf, depth, gate, matched flag, visit count) is the same, bit for bit, and the launch is deterministic: which
+// every DECISION (leaf, depth, gate, matched flag, visit count) is the same on the data the tests hold it to — structurally so
+// except at exact ties: the pose of a later round differs from the tree-major one's by ~1e-16, so a pair that sits EXACTLY on a
+// split plane or on the gate's radius can fall on the other side — and the launch is deterministic: which
 // rounds run leaf-major is decided from the hint the previous round left (nodes walked), itself a function of the inputs.
 // tests/test_gpu_parity.py::test_deep_launches_leaf_major_rounds holds exactly that.  Chosen per round, per workgroup, without a
 // vote: not round 0, the workgroup walked fewer than `leaf_major` nodes per pass last round (the option; default 8192 of the
@@ -175,7 +177,6 @@
       const double q1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
       const double q2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
 #endif
-      const double wear_p = __builtin_fma(p.w, wear_alpha, wear_beta);
       for (int t0 = 0; t0 < n_my; t0 += 4) {  // the trees of this workgroup, four at a time: their cached records in flight together
         unsigned int cw[4];
         float cm[4], cg[4];
@@ -194,7 +195,10 @@
           if (t0 + a >= n_my) break;  // (uniform)
           const int tt = t0 + a;
           const TreeDesc& td = s_tds[tt];
-          const double wear = wear_p + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) + fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0));
+          // (ONE expression for a pair's wear in all three places — the tree-major body, the drain above, here — so that the stored
+          // thresholds and the walked counter are the same doubles whichever mode a round ran in)
+          const double wear = __builtin_fma(p.w, wear_alpha, wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) +
+                                                                                              fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0)));
           const bool keep = valid && (double)cm[a] > wear;
           const bool w = valid && !keep;
           // queue the walkers: pass, tree, lane — in pass, tree, lane order (a ballot and a prefix count: deterministic)
