@@ -502,7 +502,37 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
     for i in range(n):
         order, last = step(i)
     fence()
+    streamed_sync = B * n / (time.perf_counter() - t)
+    # The same step — 8 NEW scans in, 8 results out — with one batch ahead of the collection, like the headline's loop: the next
+    # batch's scans go up on the copy stream (a second set of moving buffers: madicp_moving_update_async) and are enqueued before
+    # the previous batch's results — carried out by one kernel behind it, madicp_icp_publish_enqueue — are collected.
+    sets = [mids, [ctx.moving_upload(lm) for lm in st["moving"]]]
+
+    def submit(i):
+        cur = sets[i % 2]
+        order_ = [(i + s_) % B for s_ in range(B)]
+        for s_ in range(B):
+            ctx.moving_update_async(cur[s_], st["moving"][order_[s_]])
+        ctx.icp_register_batch_enqueue(cur, st["tids"], X0[order_], PARAMS, N_ITERS)
+        return order_, ctx.icp_publish_enqueue(B)
+
+    def pipelined(count):
+        prev, out_ = None, None
+        for i in range(count):
+            cur = submit(i)
+            if prev is not None:
+                out_ = (prev[0], ctx.icp_publish_collect(prev[1], B))
+            prev = cur
+        return prev[0], ctx.icp_publish_collect(prev[1], B)
+
+    pipelined(4)
+    fence()
+    t = time.perf_counter()
+    order, last = pipelined(n)
+    fence()
     streamed = B * n / (time.perf_counter() - t)
+    for m_ in sets[1]:
+        ctx.moving_release(m_)
     terr = max(pose_error(st["gts"][q], capi.pose44(last["X"][s_])) for s_, q in enumerate(order))
     for s_ in range(B):
         ctx.moving_update(mids[s_], st["moving"][s_])
@@ -530,6 +560,11 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
                     "256 MB Infinity Cache), %d query scans batched in flight, 15 GN rounds"
                     % (STRESS_K, st["n_nodes"], (st["n_nodes"] * (64 + 16) + st["n_nodes"] // 2 * 64) >> 20, B),
         "registrations_per_s_new_scans_in_results_out": round(streamed, 1),
+        "registrations_per_s_new_scans_in_results_out_synchronous": round(streamed_sync, 1),
+        "streamed_note": "a step = 8 NEW scans' leaves in from host memory -> one batched registration -> 8 results out to host memory; "
+                         "the first figure keeps one batch ahead of the collection (uploads on the copy stream beside the batch in "
+                         "flight, results carried out by a kernel behind it: the headline's loop for batches), the second uploads, "
+                         "registers and fetches strictly one after the other (rounds 3-5 reported that one)",
         "registrations_per_s_resident": round(resident, 1),
         "max_translation_error_m": round(terr, 5),
         "icp_round_avg_launch_us": round(avg_us, 2), "icp_final_launch_us": round(final_us, 2),

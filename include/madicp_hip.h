@@ -159,6 +159,11 @@ int madicp_nn_search_device_enqueue(madicp_ctx* ctx, int tree_id, const double* 
 int madicp_moving_upload(madicp_ctx* ctx, const double* leaf_means, int32_t L, int* out_moving_id);
 /* The next scan into the SAME buffers (grow-only: no allocation, free or synchronisation in steady state). */
 int madicp_moving_update(madicp_ctx* ctx, int moving_id, const double* leaf_means, int32_t L);
+/* The same on the library's COPY stream: the transfer runs beside the batch the compute stream is working on — one that reads
+ * OTHER moving sets — instead of behind it.  Ordered by the library: the transfer waits for the last registration that read
+ * this set, the next registration that reads it waits for the transfer.  (Two sets of moving ids used alternately: the upload
+ * of batch i + 1 hides under batch i.) */
+int madicp_moving_update_async(madicp_ctx* ctx, int moving_id, const double* leaf_means, int32_t L);
 int madicp_moving_release(madicp_ctx* ctx, int moving_id);
 
 /* ---- registration ------------------------------------------------------------------------------- */
@@ -196,6 +201,15 @@ int madicp_icp_fetch(madicp_ctx* ctx, int n_scans, double* out_X, double* out_H,
                      int32_t* out_n_matched, uint64_t* out_visits);
 /* matched_ flags of scan `scan` of the last batch (L bytes). */
 int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, int32_t L);
+/* Batches in flight, results out without a stream synchronisation: madicp_icp_publish_enqueue puts ONE small kernel behind the
+ * batch that was enqueued last; it carries the batch's X / H / b / counts to a pinned host block and releases a sequence
+ * number.  madicp_icp_publish_collect(ticket) waits for that number (bounded like madicp_stream_collect: "wait_mode",
+ * "wait_timeout_ms", "comm_timeout_ms") and copies the results out — whenever the caller likes, typically after it has uploaded
+ * (madicp_moving_update_async) and enqueued the NEXT batch.  A ring of four result blocks: a ticket must be collected before
+ * the fourth batch after it is published. */
+int madicp_icp_publish_enqueue(madicp_ctx* ctx, int n_scans, int* out_ticket);
+int madicp_icp_publish_collect(madicp_ctx* ctx, int ticket, int n_scans, double* out_X, double* out_H, double* out_b,
+                               int32_t* out_n_matched, uint64_t* out_visits);
 
 /* ---- streamed registrations: new scan in -> X / H / b / matched flags out --------------------------- */
 /* What Pipeline::compute does per frame (pipeline.cpp:154-204), as one asynchronous submission: setMoving(leaf_means),

@@ -104,6 +104,10 @@ def hip_lib():
         L.madicp_moving_upload.argtypes = [C.c_void_p, _dp, C.c_int32, _ip]
         L.madicp_moving_update.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int32]
         L.madicp_moving_release.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "madicp_moving_update_async"):
+            L.madicp_moving_update_async.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int32]
+            L.madicp_icp_publish_enqueue.argtypes = [C.c_void_p, C.c_int, _ip]
+            L.madicp_icp_publish_collect.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _i32p, _u64p]
         L.madicp_stream_submit.argtypes = [C.c_void_p, _dp, C.c_int32, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip]
         L.madicp_stream_submit_tree.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, C.POINTER(IcpParams), C.c_int, _ip]
         L.madicp_stream_collect.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _u8p, _i32p, _u64p]
@@ -591,6 +595,25 @@ class Context:
         _check(hip_lib().madicp_icp_fetch(self._h, n_scans, X.ctypes.data_as(_dp), H.ctypes.data_as(_dp),
                                           b.ctypes.data_as(_dp), nm.ctypes.data_as(_i32p),
                                           visits.ctypes.data_as(_u64p)))
+        return dict(X=X, H=H, b=b, n_matched=nm, visits=visits)
+
+    def moving_update_async(self, mid, leaf_means):
+        """madicp_moving_update on the copy stream (beside the batch in flight; ordered by the library)"""
+        m = _f64(leaf_means)
+        _check(hip_lib().madicp_moving_update_async(self._h, mid, m.ctypes.data_as(_dp), m.shape[0]))
+
+    def icp_publish_enqueue(self, n_scans):
+        """ticket for the results of the batch enqueued last (carried to the host by a kernel behind it)"""
+        tk = C.c_int(-1)
+        _check(hip_lib().madicp_icp_publish_enqueue(self._h, n_scans, C.byref(tk)))
+        return tk.value
+
+    def icp_publish_collect(self, ticket, n_scans):
+        X, H, b = np.empty((n_scans, 12)), np.empty((n_scans, 6, 6)), np.empty((n_scans, 6))
+        nm = np.empty(n_scans, np.int32)
+        visits = np.empty(n_scans, np.uint64)
+        _check(hip_lib().madicp_icp_publish_collect(self._h, ticket, n_scans, X.ctypes.data_as(_dp), H.ctypes.data_as(_dp),
+                                                    b.ctypes.data_as(_dp), nm.ctypes.data_as(_i32p), visits.ctypes.data_as(_u64p)))
         return dict(X=X, H=H, b=b, n_matched=nm, visits=visits)
 
     def icp_fetch_matched(self, scan, L):

@@ -192,6 +192,10 @@ void front_destroy(madicp_ctx* ctx) {  // called by madicp_ctx_destroy (streams 
   for (auto& c : ctx->front->clouds)
     if (c.second.ready) hipEventDestroy(c.second.ready);  // (the device buffers belong to the pool)
   FrontScratch& fs = ctx->front->scratch;
+  if (fs.fly.pre) {  // (a construction that was begun and never ended: its pre-sized tree block goes back with the pool)
+    pool_free(ctx, fs.fly.pre_tree.block, nullptr);
+    fs.fly.pre = false;
+  }
   if (fs.block) hipFree(fs.block);
   if (fs.h_state) hipHostFree(fs.h_state);
   if (fs.h_line) hipHostFree(fs.h_line);

@@ -2406,6 +2406,29 @@ __global__ __launch_bounds__(256) void icp_publish(const Outbox* __restrict__ ob
   if (threadIdx.x == 0) __hip_atomic_store(&ho->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Results of a batch to the host (madicp_icp_publish_enqueue): one wavefront per scan, behind the batch's icp_final on the
+// compute stream, copies what madicp_icp_fetch reads of the Job into the caller-visible pinned block and releases the
+// sequence number at system scope — one launch instead of a copy command per scan and a stream synchronisation.
+__global__ __launch_bounds__(64) void batch_publish(const Job* __restrict__ jobs, HostResult* __restrict__ out, int seq) {
+  const Job* job = jobs + blockIdx.x;
+  HostResult* ho = out + blockIdx.x;
+  const int l = threadIdx.x;
+  if (l < 36) ho->H[l] = job->H[l];
+  if (l >= 36 && l < 48) ho->X[l - 36] = job->X[l - 36];
+  if (l >= 48 && l < 54) ho->b[l - 48] = job->b[l - 48];
+  if (l == 54) {
+    ho->n_pairs = job->n_pairs;
+    ho->visits = job->visits;
+    ho->walked = job->walked;
+    ho->n_matched = job->n_matched;
+    ho->iter = job->iter;
+    ho->error = job->error;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (l == 0) __hip_atomic_store(&ho->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // development (option "debug_collective_us"): stands where a collective would — one wavefront that waits for `ticks` of the
 // 100 MHz wall clock — so that the launch structure around an all-reduce can be timed on a box with one GPU
 __global__ void debug_delay(unsigned long long ticks) {

@@ -111,6 +111,8 @@ struct DevMoving {
   hipEvent_t h_in_read = nullptr;  // the transfer that reads h_in has run
   hipEvent_t ready = nullptr;      // xyzn valid (recorded on whichever stream prepared it)
   bool on_copy = false;            // `ready` was recorded on the copy stream and the compute stream has not waited yet
+  hipEvent_t last_use = nullptr;   // behind the last registration that read this set (compute stream): madicp_moving_update_async
+  bool used = false;
 };
 
 struct GraphKey {  // everything a captured launch sequence bakes in
@@ -173,6 +175,13 @@ struct madicp_ctx {
   hipEvent_t stage_ev[kStageSlots] = {nullptr, nullptr, nullptr, nullptr};
   int stage_next = 0;
   Job* h_fetch = nullptr;      // pinned read-back block
+  // results of whole batches published to the host by a kernel behind the batch (madicp_icp_publish_enqueue / _collect): a ring,
+  // so that the host can collect batch i after it has enqueued batch i + 1
+  static constexpr int kPubSlots = 4;
+  madicp::HostResult* h_pub[kPubSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int pub_n[kPubSlots] = {0, 0, 0, 0};
+  int pub_ticket[kPubSlots] = {-1, -1, -1, -1};
+  int pub_next = 0;
   double* d_partials = nullptr;
   size_t partials_cap = 0;     // doubles
   long long partials_key = -1;  // the launch shape(s) the zero padding rows of d_partials are valid for
@@ -841,6 +850,7 @@ void free_moving(madicp_ctx* ctx, DevMoving& m, const EventRef& after) {
   }
   if (m.h_in_read) hipEventDestroy(m.h_in_read);
   if (m.ready) hipEventDestroy(m.ready);
+  if (m.last_use) hipEventDestroy(m.last_use);
   m = DevMoving{};
 }
 
@@ -947,6 +957,21 @@ int prepare_partials(madicp_ctx* ctx, const Launch* shapes, int parts, size_t* o
   return MADICP_OK;
 }
 
+// behind the registration that has just been enqueued: the moving sets it reads may be rewritten from here on
+// (madicp_moving_update_async puts the copy stream behind this event)
+void mark_moving_used(madicp_ctx* ctx, const std::vector<int>& ids) {
+  for (int id : ids) {
+    auto it = ctx->movings.find(id);
+    if (it == ctx->movings.end()) continue;
+    DevMoving& m = it->second;
+    if (!m.last_use && hipEventCreateWithFlags(&m.last_use, hipEventDisableTiming) != hipSuccess) {
+      m.last_use = nullptr;
+      continue;
+    }
+    m.used = hipEventRecord(m.last_use, ctx->stream) == hipSuccess;
+  }
+}
+
 int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   RC_TRY(check_reg_args(ctx, a.moving_ids, a.X0, a.params, a.K, a.n_iters));
   if (a.K > 0 && !a.tree_ids) return fail(MADICP_ERR_INVALID, "null argument");
@@ -1003,8 +1028,9 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     for (int s = 0; s < a.n_scans; ++s) h_jobs[s].p2p_epoch = reg_epoch;
   }
   const size_t job_bytes = offsetof(Job, trees) + sizeof(TreeDesc) * (size_t)std::max(1, a.K);
-  for (int s = 0; s < a.n_scans; ++s)
-    HIP_TRY(hipMemcpyAsync(ctx->d_jobs + s, h_jobs + s, job_bytes, hipMemcpyHostToDevice, ctx->stream));
+  // (ONE transfer for the batch — the staged Jobs are contiguous, like the device array: a copy command per scan was 5-8 us of
+  // the compute stream each, 50 us of a 2 ms batch of eight; the tail of the last Job's tree list is not sent)
+  HIP_TRY(hipMemcpyAsync(ctx->d_jobs, h_jobs, sizeof(Job) * (size_t)(a.n_scans - 1) + job_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipEventRecord(ctx->stage_ev[slot], ctx->stream));
   ctx->last_batch = a.n_scans;
   if (a.time_launches > 0) {
@@ -1059,7 +1085,9 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
                kXchRowsMax * 2 * madicp::kRowGranules) {
       return fail(MADICP_ERR_CAPACITY, "sharded batch too large for the exchange rows of its two halves");
     }
-    return enqueue_rounds_split(ctx, halves, parts, ctx->last_moving.data());
+    const int rc_split = enqueue_rounds_split(ctx, halves, parts, ctx->last_moving.data());
+    if (rc_split == MADICP_OK) mark_moving_used(ctx, ctx->last_moving);
+    return rc_split;
   }
   // with a communicator a captured sequence would bake the matched-flag buffers of THESE scans: launch eagerly
   // (over the mailboxes with the flags in them there is no collective: captured like a single-GPU batch)
@@ -1068,6 +1096,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   const bool queued_behind = ctx->use_graph && ctx->eager_when_busy && hipStreamQuery(ctx->stream) == hipErrorNotReady;
   const int rc = run_rounds(ctx, launch, ctx->d_jobs, -1, ctx->last_moving, queued_behind);
   ctx->use_graph = saved;
+  if (rc == MADICP_OK) mark_moving_used(ctx, ctx->last_moving);
   return rc;
 }
 
@@ -1183,6 +1212,7 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     if (m.second.h_in) hipHostFree(m.second.h_in);
     if (m.second.h_in_read) hipEventDestroy(m.second.h_in_read);
     if (m.second.ready) hipEventDestroy(m.second.ready);
+    if (m.second.last_use) hipEventDestroy(m.second.last_use);
   }
   ctx->pool.clear();  // (drops the event holders)
   for (auto& a : ctx->alloc_bytes) hipFree(a.first);  // every pooled or live device buffer
@@ -1208,6 +1238,8 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     if (sl.ev_done) hipEventDestroy(sl.ev_done);
   }
   if (ctx->h_fetch) hipHostFree(ctx->h_fetch);
+  for (auto* hp : ctx->h_pub)
+    if (hp) hipHostFree(hp);
   if (ctx->d_partials) hipFree(ctx->d_partials);
   if (ctx->d_totals) hipFree(ctx->d_totals);
   if (ctx->d_tickets) hipFree(ctx->d_tickets);
@@ -1670,6 +1702,21 @@ int madicp_moving_update(madicp_ctx* ctx, int moving_id, const double* leaf_mean
   return load_moving(ctx, it->second, leaf_means, L, ctx->stream);
 }
 
+// The same on the COPY stream: the transfer runs beside whatever the compute stream is doing — a batch that reads OTHER
+// moving sets — instead of behind it; the copy stream first waits for the last registration that read THIS set, the next
+// registration that reads it waits for the transfer.  With two sets of moving ids used alternately the upload of batch i + 1
+// hides under batch i (bench.py's configs[4] loop; madicp_icp_publish_enqueue / _collect for the results).
+int madicp_moving_update_async(madicp_ctx* ctx, int moving_id, const double* leaf_means, int32_t L) {
+  if (!ctx || !leaf_means) return fail(MADICP_ERR_INVALID, "null argument");
+  if (L < 1) return fail(MADICP_ERR_INVALID, "L must be >= 1");
+  auto it = ctx->movings.find(moving_id);
+  if (it == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevMoving& m = it->second;
+  if (m.used) HIP_TRY(hipStreamWaitEvent(ctx->copy, m.last_use, 0));
+  return load_moving(ctx, m, leaf_means, L, ctx->copy);
+}
+
 int madicp_moving_release(madicp_ctx* ctx, int moving_id) {
   if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
   auto it = ctx->movings.find(moving_id);
@@ -1926,6 +1973,74 @@ int madicp_icp_fetch_matched(madicp_ctx* ctx, int scan, uint8_t* out_matched, in
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(out_matched, it->second.matched, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
   RC_TRY(bounded_sync(ctx, ctx->stream));
+  return MADICP_OK;
+}
+
+// Results of the batch that was enqueued last, carried to a pinned host block by ONE small kernel behind it (instead of a copy
+// command per scan and a stream synchronisation): the host collects them by ticket whenever it likes — typically after it has
+// uploaded and enqueued the NEXT batch (a ring of four blocks).
+int madicp_icp_publish_enqueue(madicp_ctx* ctx, int n_scans, int* out_ticket) {
+  if (!ctx || !out_ticket) return fail(MADICP_ERR_INVALID, "null argument");
+  if (n_scans < 1 || n_scans > ctx->last_batch) return fail(MADICP_ERR_INVALID, "n_scans exceeds the last batch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int ticket = ctx->pub_next++;
+  const int slot = ticket % madicp_ctx::kPubSlots;
+  if (!ctx->h_pub[slot]) {
+    HIP_TRY(hipHostMalloc(&ctx->h_pub[slot], sizeof(madicp::HostResult) * MADICP_MAX_BATCH, hipHostMallocDefault));
+    std::memset(ctx->h_pub[slot], 0, sizeof(madicp::HostResult) * MADICP_MAX_BATCH);
+  }
+  for (int s_ = 0; s_ < n_scans; ++s_) ctx->h_pub[slot][s_].seq = 0;
+  madicp::HostResult* d_out = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out), ctx->h_pub[slot], 0));
+  hipLaunchKernelGGL(batch_publish, dim3(n_scans), dim3(64), 0, ctx->stream, (const Job*)ctx->d_jobs, d_out, ticket + 1);
+  HIP_TRY(hipGetLastError());
+  ctx->pub_n[slot] = n_scans;
+  ctx->pub_ticket[slot] = ticket;
+  *out_ticket = ticket;
+  return MADICP_OK;
+}
+
+int madicp_icp_publish_collect(madicp_ctx* ctx, int ticket, int n_scans, double* out_X, double* out_H, double* out_b,
+                               int32_t* out_n_matched, uint64_t* out_visits) {
+  if (!ctx) return fail(MADICP_ERR_INVALID, "ctx is null");
+  if (ticket < 0) return fail(MADICP_ERR_INVALID, "unknown ticket");
+  const int slot = ticket % madicp_ctx::kPubSlots;
+  if (ctx->pub_ticket[slot] != ticket || n_scans < 1 || n_scans > ctx->pub_n[slot])
+    return fail(MADICP_ERR_INVALID, "unknown, overwritten or already collected ticket (a ring of four batches)");
+  const madicp::HostResult* h = ctx->h_pub[slot];
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int s_ = 0; s_ < n_scans; ++s_) {
+    for (unsigned spins = 1; __atomic_load_n(&h[s_].seq, __ATOMIC_ACQUIRE) != ticket + 1; ++spins) {
+      if ((spins & 0x3ffu) == 0) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) {
+          if (__atomic_load_n(&h[s_].seq, __ATOMIC_ACQUIRE) == ticket + 1) break;
+          return fail(MADICP_ERR_DEVICE, "batch finished without publishing its results");
+        }
+        if (q != hipErrorNotReady) return fail(MADICP_ERR_DEVICE, std::string("batch failed: ") + hipGetErrorString(q));
+        const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ctx->comm && ms > ctx->comm_timeout_ms)
+          return comm_abort(ctx, "a collective did not complete within " + std::to_string(ctx->comm_timeout_ms) + " ms (a rank did not join?)");
+        if (ctx->wait_timeout_ms > 0 && ms > ctx->wait_timeout_ms)
+          return fail(MADICP_ERR_TIMEOUT, "batch still in flight after wait_timeout_ms; collect the ticket again");
+      }
+      wait_pause(ctx);
+    }
+  }
+  ctx->pub_ticket[slot] = -1;
+  for (int s_ = 0; s_ < n_scans; ++s_) {
+    const madicp::HostResult& r = h[s_];
+    if (r.error == 4) {
+      ctx->p2p_broken = true;
+      return fail(MADICP_ERR_COMM, "sharded registration: a peer's adders never arrived in this rank's mailbox (comm_timeout_ms)");
+    }
+    if (r.error) return fail(MADICP_ERR_DEVICE, "registration aborted on the device (code " + std::to_string(r.error) + ")");
+    if (out_X) std::memcpy(out_X + 12 * s_, r.X, sizeof(r.X));
+    if (out_H) std::memcpy(out_H + 36 * s_, r.H, sizeof(r.H));
+    if (out_b) std::memcpy(out_b + 6 * s_, r.b, sizeof(r.b));
+    if (out_n_matched) out_n_matched[s_] = r.n_matched;
+    if (out_visits) out_visits[s_] = r.visits;
+  }
   return MADICP_OK;
 }
 
