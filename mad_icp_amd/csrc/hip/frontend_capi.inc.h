@@ -48,6 +48,7 @@ struct FrontScratch {
     bool chip = false;
     int chip_grid = 0, level_grid = 0, n_tiles = 0, levels_done = 0;
     int quiet_from = -1;   // levels past this one are expected to be empty (FrontScratch::last_depth + 1)
+    bool use_need = false; // size the steps' launches from the previous build's HostLine::need
     int seq = 0;           // what tb_finish_b will publish (direct scan path)
     DevCloud cloud;        // look-ahead only
     // the emission enqueued behind the summary into a block sized from the previous scan's leaf count (tree_build_begin_on)
@@ -56,6 +57,8 @@ struct FrontScratch {
     int pre_steps = 0;     // levels_done when it was enqueued: extra levels afterwards make it worthless
     DevTree pre_tree;
   } fly;
+  int last_need[tb::kNeedSteps] = {};  // workgroups every step of the previous build had work for (HostLine::need); -1: unknown
+  bool have_need = false;
   int last_leaves = 0;     // leaves of the previous build on this scratch (the next scan of the same sensor: within a few per cent)
   int last_depth = -1;     // deepest level of the previous build on this scratch (consecutive scans: the same +- 1)
   int64_t last_n = 0;      // ... and that build's point count (the hint is for consecutive scans of one sensor, not for any cloud)
@@ -519,6 +522,9 @@ int tb_run_levels(FrontScratch& fs, int from, int to) {
     // levels the previous build did not reach are launched all the same (this tree may be deeper) but with a small grid — the
     // queues are walked with a stride, so any grid is correct, and 1 600 workgroups that find an empty queue cost 4.6 us
     if (f.quiet_from >= 0 && level > f.quiet_from) grid = std::min(grid, 96);
+    // ... and a step the previous scan of this sensor had little work for gets a launch of that size + half (the queues are
+    // walked with a stride: a larger crop is slower for one build, never wrong)
+    if (f.use_need && level < tb::kNeedSteps) grid = std::min(grid, fs.last_need[level] + fs.last_need[level] / 2 + 24);
     // the breadth-first layout of the tree's LDS-staged top: the FIRST workgroup of three level launches (kTopParts above)
     int bfs_from = 0, bfs_to = 0;
     for (const TopPart& tp : kTopParts)
@@ -634,6 +640,7 @@ int tree_build_begin_on(madicp_ctx* ctx, FrontScratch& fs, const double* d_xyz, 
   // (kTopParts), and a deeper tree takes the loop in the second half as before
   if (similar && fs.last_depth >= 0) f.levels_done = std::min(20, std::max(fs.last_depth + 2, kTopLevels + kTopLag + 1));
   f.quiet_from = (fs.last_depth >= 0 && similar) ? fs.last_depth + tb::kChipLevels : -1;
+  f.use_need = similar && fs.have_need;
   RC_TRY(tb_run_levels(fs, 0, f.levels_done));
   HIP_TRY(hipGetLastError());
   RC_TRY(tb_summary_enqueue(fs, f.levels_done, false));
@@ -700,6 +707,8 @@ int tree_build_end_on(madicp_ctx* ctx, FrontScratch& fs, int* out_tree_id, int32
   fs.last_depth = hl.error == 0 ? hl.max_level : -1;
   fs.last_n = f.n;
   fs.last_leaves = hl.error == 0 ? hl.n_leaves : 0;
+  fs.have_need = hl.error == 0 && f.n_tiles <= tb::kScanDirectMax;
+  if (fs.have_need) std::memcpy(fs.last_need, hl.need, sizeof(fs.last_need));
   const bool pre_ok = f.pre && f.pre_steps == f.levels_done && hl.error == 0 && !pending() && hl.n_leaves >= 1 &&
                       hl.n_leaves <= f.pre_leaf_cap;
   if (!pre_ok) drop_pre_tree(ctx, f);

@@ -1916,12 +1916,15 @@ __global__ __launch_bounds__(256) void tb_summary(const Params P, int top_levels
 // sums in front of its own, no third kernel for that — and the last workgroup publishes what the host is waiting for in
 // its pinned block, sequence number last (system-scope release): the host polls it, no copy command, no event.
 constexpr int kScanDirectMax = 4096;
+constexpr int kNeedSteps = 32;
 struct HostLine {
   int32_t n_nodes, error, n_leaves, n_top, max_level, n_valid;
   int32_t pending_wave, pending_quad;  // queue counts of the first step that was not launched
   unsigned long long rho_bits;
   double origin[3];
   int32_t seq, pad_;
+  int32_t need[kNeedSteps];  // workgroups step s of THIS build had work for (team nodes + wave nodes / 4 + quad nodes / 64): the next
+                             // build of a similar cloud sizes its launches from it (a workgroup that finds nothing still costs its dispatch)
 };
 __global__ __launch_bounds__(256) void tb_finish_a(const Params P, int top_levels, int n_tiles) {
   if ((int)blockIdx.x < n_tiles)
@@ -1940,6 +1943,15 @@ __global__ __launch_bounds__(256) void tb_finish_b(const Params P, int n_tiles, 
   before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
   __syncthreads();
   const uint32_t own = scan_apply_body(P.leaf_start, P.n_points, before, P.S, blockIdx.x);
+  if ((int)blockIdx.x == n_tiles - 1) {  // (workgroup-uniform)
+    if (threadIdx.x < kNeedSteps) {
+      const State* st = P.st;
+      const int t = threadIdx.x;
+      host->need[t] = st->team_count[t].v + (st->q_count[t].v + 3) / 4 + (st->small_count[t].v + 63) / 64;
+    }
+    __threadfence_system();
+    __syncthreads();
+  }
   if ((int)blockIdx.x == n_tiles - 1 && threadIdx.x == 0) {
     State* st = P.st;
     st->n_leaves = (int32_t)(before + own);

@@ -98,3 +98,28 @@ def test_product_build_leaves_the_measurement_and_test_aids_out(natives):
 
     assert '"setTimingForTest"' not in preprocessed([]) and '"compute"' in preprocessed([])
     assert '"setTimingForTest"' in preprocessed(["-DMADICP_MEASURE"])
+
+
+def test_measure_variant_is_a_second_binding_of_the_same_surface(natives):
+    """capi.measure_variant(): this module a second time, bound to mad_icp_amd/_measure — the same C ABI plus the aids; the
+    default binding refuses an aid with a message that says where it lives (no silent fallback, no AttributeError)."""
+    from mad_icp_amd import _build, capi
+
+    if os.environ.get("MADICP_NATIVE_DIR"):
+        pytest.skip("a variant run: the process is already pointed at another build")
+    mc = capi.measure_variant()
+    assert mc is not capi and mc is capi.measure_variant() and mc.measure_variant() is mc
+    assert mc._DIR_OVERRIDE == _build.MEASURE_DIR
+    for aid in ("madicp_icp_time_registration", "madicp_debug_gather16", "madicp_debug_tree_build_points"):
+        assert hasattr(mc.hip_lib(), aid) and not hasattr(capi.hip_lib(), aid), aid
+    for sym in declared_symbols("madicp_hip.h"):
+        assert hasattr(mc.hip_lib(), sym) and hasattr(capi.hip_lib(), sym), sym
+    with pytest.raises(capi.MadIcpError, match="measure_variant"):
+        capi._aid("madicp_icp_time_registration")
+    assert mc._aid("madicp_icp_time_registration") is not None
+    # host-side classes work from either binding (the tree builder has no aids: same bytes)
+    import numpy as np
+
+    pts = np.random.default_rng(0).normal(size=(500, 3))
+    a, b = capi.HostTree(pts, 0.2, 0.1, 0), mc.HostTree(pts, 0.2, 0.1, 0)
+    assert np.array_equal(a.nodes, b.nodes)
