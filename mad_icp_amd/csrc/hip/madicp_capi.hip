@@ -1983,8 +1983,11 @@ int madicp_icp_publish_enqueue(madicp_ctx* ctx, int n_scans, int* out_ticket) {
   if (!ctx || !out_ticket) return fail(MADICP_ERR_INVALID, "null argument");
   if (n_scans < 1 || n_scans > ctx->last_batch) return fail(MADICP_ERR_INVALID, "n_scans exceeds the last batch");
   HIP_TRY(hipSetDevice(ctx->device));
-  const int ticket = ctx->pub_next++;
+  const int ticket = ctx->pub_next;
   const int slot = ticket % madicp_ctx::kPubSlots;
+  if (ctx->pub_ticket[slot] >= 0)  // (its kernel may not have run yet: the block it will write is not free)
+    return fail(MADICP_ERR_CAPACITY, "publish ring full: collect the oldest ticket first (four batches may be outstanding)");
+  ++ctx->pub_next;
   if (!ctx->h_pub[slot]) {
     HIP_TRY(hipHostMalloc(&ctx->h_pub[slot], sizeof(madicp::HostResult) * MADICP_MAX_BATCH, hipHostMallocDefault));
     std::memset(ctx->h_pub[slot], 0, sizeof(madicp::HostResult) * MADICP_MAX_BATCH);

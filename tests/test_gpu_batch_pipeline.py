@@ -55,6 +55,12 @@ def test_pipelined_batches_are_the_synchronous_batches(ctx):
     got.append(ctx.icp_publish_collect(prev, B))
     with pytest.raises(capi.MadIcpError):
         ctx.icp_publish_collect(prev, B)  # (a ticket is collected once)
+    # the ring holds four outstanding tickets: a fifth is refused until the oldest has been collected
+    held = [ctx.icp_publish_enqueue(B) for _ in range(4)]
+    with pytest.raises(capi.MadIcpError, match="ring full"):
+        ctx.icp_publish_enqueue(B)
+    for tk in held:
+        assert np.array_equal(ctx.icp_publish_collect(tk, B)["X"], got[-1]["X"])  # (the last batch's results, four times)
     assert len(got) == n_steps
     for i in range(n_steps):
         for k in ("X", "H", "b", "n_matched", "visits"):
