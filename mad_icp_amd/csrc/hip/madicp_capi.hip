@@ -95,6 +95,13 @@ struct DevTree {
   hipEvent_t ready = nullptr; // recorded on the copy stream behind the upload + record build
   bool compute_waited = false;  // the compute stream is already ordered behind `ready`
 };
+struct UseEvent {
+  hipEvent_t ev = nullptr;
+  ~UseEvent() {
+    if (ev) hipEventDestroy(ev);
+  }
+};
+
 struct DevMoving {
   double* xyzn = nullptr;  // (L,4)
   uint8_t* matched = nullptr;
@@ -111,8 +118,10 @@ struct DevMoving {
   hipEvent_t h_in_read = nullptr;  // the transfer that reads h_in has run
   hipEvent_t ready = nullptr;      // xyzn valid (recorded on whichever stream prepared it)
   bool on_copy = false;            // `ready` was recorded on the copy stream and the compute stream has not waited yet
-  hipEvent_t last_use = nullptr;   // behind the last registration that read this set (compute stream): madicp_moving_update_async
-  bool used = false;
+  // behind the last registration that read this set (compute stream; ONE event per batch, shared by its sets):
+  // madicp_moving_update_async puts the copy stream behind it
+  std::shared_ptr<UseEvent> last_use;
+  unsigned long long copy_seq = 0;  // `ready` is the copy_seq-th event recorded on the copy stream for a moving set
 };
 
 struct GraphKey {  // everything a captured launch sequence bakes in
@@ -182,6 +191,7 @@ struct madicp_ctx {
   int pub_n[kPubSlots] = {0, 0, 0, 0};
   int pub_ticket[kPubSlots] = {-1, -1, -1, -1};
   int pub_next = 0;
+  unsigned long long copy_seq = 0;  // moving sets made ready on the copy stream so far (DevMoving::copy_seq)
   double* d_partials = nullptr;
   size_t partials_cap = 0;     // doubles
   long long partials_key = -1;  // the launch shape(s) the zero padding rows of d_partials are valid for
@@ -836,6 +846,7 @@ int load_moving(madicp_ctx* ctx, DevMoving& m, const double* leaf_means, int L, 
   if (!m.ready) HIP_TRY(hipEventCreateWithFlags(&m.ready, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(m.ready, s));
   m.on_copy = (s != ctx->stream);
+  if (m.on_copy) m.copy_seq = ++ctx->copy_seq;
   return MADICP_OK;
 }
 
@@ -850,7 +861,6 @@ void free_moving(madicp_ctx* ctx, DevMoving& m, const EventRef& after) {
   }
   if (m.h_in_read) hipEventDestroy(m.h_in_read);
   if (m.ready) hipEventDestroy(m.ready);
-  if (m.last_use) hipEventDestroy(m.last_use);
   m = DevMoving{};
 }
 
@@ -960,15 +970,15 @@ int prepare_partials(madicp_ctx* ctx, const Launch* shapes, int parts, size_t* o
 // behind the registration that has just been enqueued: the moving sets it reads may be rewritten from here on
 // (madicp_moving_update_async puts the copy stream behind this event)
 void mark_moving_used(madicp_ctx* ctx, const std::vector<int>& ids) {
+  auto ue = std::make_shared<UseEvent>();
+  if (hipEventCreateWithFlags(&ue->ev, hipEventDisableTiming) != hipSuccess) {
+    ue->ev = nullptr;
+    return;
+  }
+  if (hipEventRecord(ue->ev, ctx->stream) != hipSuccess) return;
   for (int id : ids) {
     auto it = ctx->movings.find(id);
-    if (it == ctx->movings.end()) continue;
-    DevMoving& m = it->second;
-    if (!m.last_use && hipEventCreateWithFlags(&m.last_use, hipEventDisableTiming) != hipSuccess) {
-      m.last_use = nullptr;
-      continue;
-    }
-    m.used = hipEventRecord(m.last_use, ctx->stream) == hipSuccess;
+    if (it != ctx->movings.end()) it->second.last_use = ue;
   }
 }
 
@@ -986,11 +996,25 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
   int max_L = 0;
   ctx->last_moving.assign(a.moving_ids, a.moving_ids + a.n_scans);
   const bool use_cache = a.n_iters > 1 && !a.time_launches;
+  {
+    // the batch's sets that were made ready on the copy stream: that stream runs in order, so ONE wait — for the set whose
+    // event was recorded last — covers them all (a wait per set was a barrier packet each on the compute stream)
+    DevMoving* latest = nullptr;
+    for (int s = 0; s < a.n_scans; ++s) {
+      auto mit = ctx->movings.find(a.moving_ids[s]);
+      if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
+      DevMoving& mv = mit->second;
+      if (mv.on_copy && (!latest || mv.copy_seq > latest->copy_seq)) latest = &mv;
+    }
+    if (latest) {
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, latest->ready, 0));
+      for (int s = 0; s < a.n_scans; ++s) ctx->movings.at(a.moving_ids[s]).on_copy = false;
+    }
+  }
   for (int s = 0; s < a.n_scans; ++s) {
     auto mit = ctx->movings.find(a.moving_ids[s]);
     if (mit == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
     DevMoving& mv = mit->second;
-    RC_TRY(wait_moving(ctx, mv));
     if (use_cache) RC_TRY(reserve_cache(ctx, mv, std::max(1, a.K)));
     Job& j = h_jobs[s];
     RC_TRY(fill_job(ctx, j, mv, a.tree_ids, a.K, a.X0 + 12 * s, a.params, a.n_iters, a.flags, use_cache));
@@ -1212,7 +1236,6 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     if (m.second.h_in) hipHostFree(m.second.h_in);
     if (m.second.h_in_read) hipEventDestroy(m.second.h_in_read);
     if (m.second.ready) hipEventDestroy(m.second.ready);
-    if (m.second.last_use) hipEventDestroy(m.second.last_use);
   }
   ctx->pool.clear();  // (drops the event holders)
   for (auto& a : ctx->alloc_bytes) hipFree(a.first);  // every pooled or live device buffer
@@ -1713,7 +1736,7 @@ int madicp_moving_update_async(madicp_ctx* ctx, int moving_id, const double* lea
   if (it == ctx->movings.end()) return fail(MADICP_ERR_INVALID, "unknown moving id");
   HIP_TRY(hipSetDevice(ctx->device));
   DevMoving& m = it->second;
-  if (m.used) HIP_TRY(hipStreamWaitEvent(ctx->copy, m.last_use, 0));
+  if (m.last_use && m.last_use->ev) HIP_TRY(hipStreamWaitEvent(ctx->copy, m.last_use->ev, 0));
   return load_moving(ctx, m, leaf_means, L, ctx->copy);
 }
 
