@@ -904,12 +904,14 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         for key, dev, ahead, dsk in (("host_path", False, 0, False), ("default", None, 0, False), ("host_path_lookahead", False, 2, False),
                                      ("device_front_end", True, 0, False), ("device_front_end_lookahead", True, 1, False),
                                      ("host_path_deskew", False, 1, True), ("device_front_end_deskew", True, 0, True),
-                                     ("default_deskew", None, 0, True)):
+                                     ("default_deskew", None, 0, True), ("default_f32_origin", None, 0, False)):
             pl = pm.Pipeline(10.0, dsk, B_MAX, RHO_KER, 0.8, B_MIN, B_RATIO, K, threads, False)
             if dev is not None:
                 pl.setDeviceFrontEnd(dev)
             ts = []
             scans_ = drive_j if dsk else drive
+            if key.endswith("_f32_origin"):  # what a sensor driver / a KITTI .bin delivers: float32 coordinates, converted by the caller
+                scans_ = [sc.astype(np.float32).astype(np.float64) for sc in drive]
             for d in range(ahead):
                 pl.prefetch(scans_[d])
             for i, sc in enumerate(scans_):
@@ -948,6 +950,9 @@ def single_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, q_trees, fence, 
         pipe["note"] = ("Pipeline.compute(stamp, cloud) per frame, cloud in host memory: default = what an UNMODIFIED caller gets "
                         "(no setDeviceFrontEnd call, MAD_ICP_GPU_BUILD unset: the device front-end — round 5 for deskew = false, round 6 "
                         "for deskewed datasets too: default_deskew is the unmodified caller of a `deskew : True` configuration); "
+                        "default_f32_origin = the default again on the same scans rounded to float32 and handed over as doubles — "
+                        "what every LiDAR driver, KITTI .bin or PointCloud2 delivers: such a cloud crosses PCIe as floats and is widened "
+                        "on the device, the same doubles bit for bit (option upload_f32); "
                         "host_path = setDeviceFrontEnd(False) / MAD_ICP_GPU_BUILD=0 (host tree builder, "
                         "bit-identical to the oracle's, + upload); host_path_lookahead = the same with prefetch(scan i + 2) issued "
                         "before compute(scan i): the frame PERIOD of a caller that reads ahead (a dataset), same poses bit for bit; "

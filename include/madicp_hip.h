@@ -118,7 +118,10 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * have the same value on every rank of the communicator, as must the batch sizes the ranks submit), "shard_tail" (0/1, default 0: the sharded round kernel leaves
  * the rank's adders itself instead of a separate icp_reduce launch; bit-identical, measured slower —
  * profiles/r4_c_shard_probe.md), "xcd_fold" (0/1, default 0: per-round launches with the XCD-hierarchical join at the
- * end of each launch; bit-identical, measured slower — profiles/r3_j_xcd_fold_negative.md), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
+ * end of each launch; bit-identical, measured slower — profiles/r3_j_xcd_fold_negative.md), "upload_f32" (0/1, default 1: a cloud
+ * handed to madicp_cloud_upload / madicp_tree_build_begin whose coordinates are ALL exactly floats — what a sensor driver, a KITTI
+ * .bin or a PointCloud2 delivers — crosses PCIe as floats and is widened on the device: the same doubles bit for bit, half the
+ * transfer in front of the builder's first kernel; any other cloud goes as doubles), "comm_timeout_ms" (default 60000: with a communicator, how long the host waits for a
  * registration's collectives before it aborts the communicator and returns MADICP_ERR_COMM)}. */
 int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value);
 /* the current value of one of the keys above (a caller that changes an option of a context it shares puts it back) */

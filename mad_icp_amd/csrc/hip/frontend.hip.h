@@ -17,6 +17,18 @@
 namespace madicp {
 namespace fe {
 
+// ---- upload of a cloud whose coordinates are all exactly floats (every LiDAR driver delivers float32: a KITTI .bin, a
+// PointCloud2): half the bytes cross PCIe and are widened here — the same doubles, bit for bit ----------------------
+__global__ __launch_bounds__(256) void cloud_widen_f32(const float* __restrict__ in, double* __restrict__ out, long n3) {
+  const long i = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i + 3 < n3) {
+    const float4 v = *reinterpret_cast<const float4*>(in + i);
+    out[i] = (double)v.x; out[i + 1] = (double)v.y; out[i + 2] = (double)v.z; out[i + 3] = (double)v.w;
+  } else {
+    for (long k = i; k < n3; ++k) out[k] = (double)in[k];
+  }
+}
+
 // ---- ingest ----------------------------------------------------------------------------------------------------
 // keep[i] = the record survives bin_runner.cpp:149-151: NOT (|p| < min_range or |p| > max_range or a NaN coordinate),
 // |p| evaluated in float like Eigen::Vector3f::norm() (squares summed as x^2 + (y^2 + z^2): the unrolled scalar

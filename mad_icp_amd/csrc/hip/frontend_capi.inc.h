@@ -247,6 +247,131 @@ int scan_marks(hipStream_t s, FrontScratch& fs, const uint32_t* marks, int64_t n
   return MADICP_OK;
 }
 
+// dst[i] = (float)src[i] for a block of values; false as soon as a block holds a value that is not exactly a float (NaN included:
+// it compares unequal to itself; -0.0 and +-inf pass and survive the round trip).  Four doubles per instruction where the host
+// has AVX2 (the plain loop, two per instruction with SSE2, was slower than the copy it replaces: 95 us against 58 for a scan).
+bool block_to_f32_exact_plain(const double* src, float* dst, size_t count) {
+  int bad = 0;
+  for (size_t i = 0; i < count; ++i) {
+    const float f = static_cast<float>(src[i]);
+    dst[i] = f;
+    bad |= (static_cast<double>(f) != src[i]);
+  }
+  return bad == 0;
+}
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+}  // namespace
+#include <immintrin.h>
+namespace {
+__attribute__((target("avx2"))) bool block_to_f32_exact_avx2(const double* src, float* dst, size_t count) {
+  __m256d bad = _mm256_setzero_pd();
+  size_t i = 0;
+  for (; i + 8 <= count; i += 8) {
+    const __m256d x0 = _mm256_loadu_pd(src + i), x1 = _mm256_loadu_pd(src + i + 4);
+    const __m128 f0 = _mm256_cvtpd_ps(x0), f1 = _mm256_cvtpd_ps(x1);
+    _mm_storeu_ps(dst + i, f0);
+    _mm_storeu_ps(dst + i + 4, f1);
+    bad = _mm256_or_pd(bad, _mm256_or_pd(_mm256_cmp_pd(_mm256_cvtps_pd(f0), x0, _CMP_NEQ_UQ), _mm256_cmp_pd(_mm256_cvtps_pd(f1), x1, _CMP_NEQ_UQ)));
+  }
+  return _mm256_movemask_pd(bad) == 0 && block_to_f32_exact_plain(src + i, dst + i, count - i);
+}
+__attribute__((target("avx512f"))) bool block_to_f32_exact_avx512(const double* src, float* dst, size_t count) {
+  __mmask8 bad = 0;
+  size_t i = 0;
+  for (; i + 16 <= count; i += 16) {
+    const __m512d x0 = _mm512_loadu_pd(src + i), x1 = _mm512_loadu_pd(src + i + 8);
+    const __m256 f0 = _mm512_cvtpd_ps(x0), f1 = _mm512_cvtpd_ps(x1);
+    _mm256_storeu_ps(dst + i, f0);
+    _mm256_storeu_ps(dst + i + 8, f1);
+    bad |= _mm512_cmp_pd_mask(_mm512_cvtps_pd(f0), x0, _CMP_NEQ_UQ) | _mm512_cmp_pd_mask(_mm512_cvtps_pd(f1), x1, _CMP_NEQ_UQ);
+  }
+  return bad == 0 && block_to_f32_exact_plain(src + i, dst + i, count - i);
+}
+int host_simd_level() {  // 2: AVX-512F, 1: AVX2, 0: neither
+  static const int level = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
+  return level;
+}
+#else
+bool block_to_f32_exact_avx2(const double* src, float* dst, size_t count) { return block_to_f32_exact_plain(src, dst, count); }
+bool block_to_f32_exact_avx512(const double* src, float* dst, size_t count) { return block_to_f32_exact_plain(src, dst, count); }
+int host_simd_level() { return 0; }
+#endif
+bool block_to_f32_exact(const double* src, float* dst, size_t count) {
+  constexpr size_t kBlock = 8192;  // (a cloud of genuine doubles is found out in its first block)
+  const int simd = host_simd_level();
+  for (size_t b = 0; b < count; b += kBlock) {
+    const size_t len = std::min(kBlock, count - b);
+    const bool ok = simd == 2 ? block_to_f32_exact_avx512(src + b, dst + b, len)
+                              : (simd == 1 ? block_to_f32_exact_avx2(src + b, dst + b, len) : block_to_f32_exact_plain(src + b, dst + b, len));
+    if (!ok) return false;
+  }
+  return true;
+}
+
+// The caller's cloud (pageable host memory) -> pinned staging -> `d_xyz` on stream `s`, staged and sent in pieces: the copy
+// engine moves piece k while the host stages piece k + 1.  A cloud whose coordinates are ALL exactly floats — what a sensor
+// driver, a KITTI .bin or a PointCloud2 delivers, converted to double by the caller — crosses PCIe as floats (half the
+// bytes, half the transfer time in front of the builder's first kernel) and is widened on the device: the same doubles, bit
+// for bit.  The first value that is not a float (synthetic double-precision noise: the first point) sends the rest the plain way.
+int stage_and_send_cloud(madicp_ctx* ctx, const double* xyz, int64_t n, double* d_xyz, hipStream_t s) {
+  const size_t n3 = 3 * (size_t)n;
+  const size_t bytes = sizeof(double) * n3;
+  const int hb = ctx->h_tree_next;
+  ctx->h_tree_next ^= 1;
+  HIP_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
+  if (ctx->h_tree_cap[hb] < bytes) {
+    if (ctx->h_tree[hb]) HIP_TRY(hipHostFree(ctx->h_tree[hb]));
+    ctx->h_tree[hb] = nullptr;
+    ctx->h_tree_cap[hb] = 0;
+    const size_t cap = bytes + bytes / 4;
+    HIP_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
+    ctx->h_tree_cap[hb] = cap;
+  }
+  char* stage = ctx->h_tree[hb];
+  size_t done3 = 0;  // values already on their way as floats
+  void* d_f32 = nullptr;
+  if (ctx->upload_f32 && n3 >= 4096) {
+    float* hf = reinterpret_cast<float*>(stage);
+    const size_t piece3 = std::max<size_t>((n3 / 2 + 3) / 4 * 4, (size_t)64 << 10);  // two pieces (half the bytes: half the pieces)
+    for (size_t off = 0; off < n3; off += piece3) {
+      const size_t len = std::min(piece3, n3 - off);
+      if (!block_to_f32_exact(xyz + off, hf + off, len)) break;
+      if (!d_f32) {  // (one device block per staging block: the event that frees the staging block is behind the widening too)
+        if (ctx->d_f32_cap[hb] < sizeof(float) * n3) {
+          if (ctx->d_f32[hb]) HIP_TRY(hipFree(ctx->d_f32[hb]));
+          ctx->d_f32[hb] = nullptr;
+          ctx->d_f32_cap[hb] = 0;
+          const size_t cap = sizeof(float) * (n3 + n3 / 4);
+          HIP_TRY(hipMalloc(&ctx->d_f32[hb], cap));
+          ctx->d_f32_cap[hb] = cap;
+        }
+        d_f32 = ctx->d_f32[hb];
+      }
+      HIP_TRY(hipMemcpyAsync(static_cast<float*>(d_f32) + off, hf + off, sizeof(float) * len, hipMemcpyHostToDevice, s));
+      done3 = off + len;
+    }
+    if (done3 > 0) {
+      hipLaunchKernelGGL(fe::cloud_widen_f32, dim3((unsigned)((done3 / 4 + 256) / 256)), dim3(256), 0, s, (const float*)d_f32, d_xyz, (long)done3);
+      HIP_TRY(hipGetLastError());
+    }
+    if (done3 == n3) {
+      HIP_TRY(hipEventRecord(ctx->h_tree_ev[hb], s));
+      return MADICP_OK;
+    }
+  }
+  {  // (the rest — everything, for a cloud of genuine doubles — as doubles, behind the floats' region of the staging block)
+    const size_t off0 = sizeof(double) * done3;
+    const size_t piece = std::max<size_t>(align_up(bytes / 4), 256 << 10);
+    for (size_t off = off0; off < bytes; off += piece) {
+      const size_t len = std::min(piece, bytes - off);
+      std::memcpy(stage + off, reinterpret_cast<const char*>(xyz) + off, len);
+      HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(d_xyz) + off, stage + off, len, hipMemcpyHostToDevice, s));
+    }
+  }
+  HIP_TRY(hipEventRecord(ctx->h_tree_ev[hb], s));
+  return MADICP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -258,28 +383,10 @@ int madicp_cloud_upload(madicp_ctx* ctx, const double* xyz, int64_t n, int* out_
   DevCloud c;
   RC_TRY(new_cloud(ctx, n, &c));
   // pinned staging shared with the tree uploads (two buffers, alternating)
-  const size_t bytes = sizeof(double) * 3 * (size_t)n;
-  const int hb = ctx->h_tree_next;
-  ctx->h_tree_next ^= 1;
-  CLOUD_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
-  if (ctx->h_tree_cap[hb] < bytes) {
-    if (ctx->h_tree[hb]) CLOUD_TRY(hipHostFree(ctx->h_tree[hb]));
-    ctx->h_tree[hb] = nullptr;
-    ctx->h_tree_cap[hb] = 0;
-    const size_t cap = bytes + bytes / 4;
-    CLOUD_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
-    ctx->h_tree_cap[hb] = cap;
-  }
-  // staged and sent in pieces: the copy engine moves piece k while the host stages piece k + 1
   {
-    const size_t piece = std::max<size_t>(align_up(bytes / 4), 256 << 10);
-    for (size_t off = 0; off < bytes; off += piece) {
-      const size_t len = std::min(piece, bytes - off);
-      std::memcpy(ctx->h_tree[hb] + off, reinterpret_cast<const char*>(xyz) + off, len);
-      CLOUD_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c.xyz) + off, ctx->h_tree[hb] + off, len, hipMemcpyHostToDevice, ctx->copy));
-    }
+    const int rc = stage_and_send_cloud(ctx, xyz, n, c.xyz, ctx->copy);
+    if (rc != MADICP_OK) return drop_cloud(ctx, c, rc);
   }
-  CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], ctx->copy));
   CLOUD_TRY(hipEventRecord(c.ready, ctx->copy));
   const int id = ctx->next_id++;
   front_of(ctx).clouds[id] = c;
@@ -840,27 +947,10 @@ int madicp_tree_build_begin(madicp_ctx* ctx, const double* xyz, int64_t n, doubl
     c.xyz = static_cast<double*>(p);
     c.n = n;
   }
-  const size_t bytes = sizeof(double) * 3 * (size_t)n;
-  const int hb = ctx->h_tree_next;
-  ctx->h_tree_next ^= 1;
-  CLOUD_TRY(hipEventSynchronize(ctx->h_tree_ev[hb]));
-  if (ctx->h_tree_cap[hb] < bytes) {
-    if (ctx->h_tree[hb]) CLOUD_TRY(hipHostFree(ctx->h_tree[hb]));
-    ctx->h_tree[hb] = nullptr;
-    ctx->h_tree_cap[hb] = 0;
-    const size_t cap = bytes + bytes / 4;
-    CLOUD_TRY(hipHostMalloc(&ctx->h_tree[hb], cap, hipHostMallocDefault));
-    ctx->h_tree_cap[hb] = cap;
-  }
   {
-    const size_t piece = std::max<size_t>(align_up(bytes / 4), 256 << 10);
-    for (size_t off = 0; off < bytes; off += piece) {
-      const size_t len = std::min(piece, bytes - off);
-      std::memcpy(ctx->h_tree[hb] + off, reinterpret_cast<const char*>(xyz) + off, len);
-      CLOUD_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c.xyz) + off, ctx->h_tree[hb] + off, len, hipMemcpyHostToDevice, s));
-    }
+    const int rc = stage_and_send_cloud(ctx, xyz, n, c.xyz, s);
+    if (rc != MADICP_OK) return drop_cloud(ctx, c, rc);
   }
-  CLOUD_TRY(hipEventRecord(ctx->h_tree_ev[hb], s));
   // Option "build_after_registration" (experiment, default off): the construction's KERNELS wait for whatever the compute stream
   // holds right now — the registration this look-ahead was begun beside.  Built to test the hypothesis that the look-ahead
   // cliff (0.67 ms per frame in one process configuration, 1.5 in the others) is the two kernel sets fighting for the CUs;

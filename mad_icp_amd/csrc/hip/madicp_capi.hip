@@ -258,6 +258,9 @@ struct madicp_ctx {
   bool p2p_fresh = false;    // the own mailbox has been zeroed and exported since the last attach (madicp_p2p_export)
   bool p2p_fine = false;     // ... and it is fine-grained device memory (peers' stores are visible to a running kernel)
   bool p2p_broken = false;   // a registration of this mailbox session lost a peer: the ranks' counters may disagree from here on
+  void* d_f32[2] = {nullptr, nullptr};  // device landing blocks of float uploads, one per pinned staging block (h_tree)
+  size_t d_f32_cap[2] = {0, 0};
+  int upload_f32 = 1;        // option "upload_f32": a cloud of float-exact coordinates crosses PCIe as floats (frontend_capi.inc.h)
   int p2p_allow_coarse = 0;  // option "p2p_allow_coarse": accept a coarse-grained mailbox (ranks that share ONE device only)
   unsigned int p2p_epoch = 0;                             // sharded registrations so far (the same count on every rank)
   int shard_split = 1;     // a sharded batch of >= 4 scans runs as two halves on two streams: one half's all-reduce under the
@@ -1261,6 +1264,8 @@ int madicp_ctx_destroy(madicp_ctx* ctx) {
     if (sl.ev_done) hipEventDestroy(sl.ev_done);
   }
   if (ctx->h_fetch) hipHostFree(ctx->h_fetch);
+  for (void* p : ctx->d_f32)
+    if (p) hipFree(p);
   for (auto* hp : ctx->h_pub)
     if (hp) hipHostFree(hp);
   if (ctx->d_partials) hipFree(ctx->d_partials);
@@ -1355,6 +1360,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     }
   } else if (k == "p2p_allow_coarse") {
     ctx->p2p_allow_coarse = value ? 1 : 0;
+  } else if (k == "upload_f32") {
+    ctx->upload_f32 = value ? 1 : 0;
   } else if (k == "nn_lds_top") {
     ctx->nn_lds_top = value ? 1 : 0;
   } else if (k == "queries_per_lane") {
@@ -1395,6 +1402,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "wait_timeout_ms") v = ctx->wait_timeout_ms;
   else if (k == "comm_timeout_ms") v = ctx->comm_timeout_ms;
   else if (k == "p2p_allow_coarse") v = ctx->p2p_allow_coarse;
+  else if (k == "upload_f32") v = ctx->upload_f32;
   else if (k == "p2p_fine_grained") v = (ctx->p2p_box && ctx->p2p_fine) ? 1 : 0;  // (read-only: what madicp_p2p_export obtained)
   else if (k == "nn_lds_top") v = ctx->nn_lds_top;
   else if (k == "queries_per_lane") v = ctx->qpt_override;

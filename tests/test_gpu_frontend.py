@@ -756,3 +756,46 @@ def test_bindings_read_the_callers_points_only_during_the_call(natives, drive):
         m.Pipeline(*args).compute(0.0, np.zeros((0, 3)))
     with pytest.raises(Exception):
         m.Pipeline(*args).compute(0.0, np.zeros((5, 4)))
+
+
+def test_float_exact_clouds_cross_pcie_as_floats_and_arrive_as_the_same_doubles(ctx):
+    """Option "upload_f32" (default on): a cloud whose coordinates are all exactly floats — what a sensor driver, a KITTI .bin or
+    a PointCloud2 delivers once the caller has converted it to double — is staged and sent as floats and widened on the device.
+    The resident cloud is the caller's doubles bit for bit (-0.0 and infinities included), a cloud with ONE value that is not a
+    float (NaN, a genuine double, a value beyond the float range) goes the plain way — from that piece on —, and the tree
+    built from either is the same array."""
+    rng = np.random.default_rng(12)
+    base = (rng.normal(size=(50_000, 3)) * [20.0, 15.0, 2.0]).astype(np.float32).astype(np.float64)
+    base[7] = [-0.0, np.inf, -np.inf]
+    cases = {"float-exact": base.copy()}
+    c = base.copy(); c[40_001, 1] = np.nextafter(c[40_001, 1], 1.0); cases["a double in the second piece"] = c
+    c = base.copy(); c[3, 0] = np.nan; cases["a NaN in the first piece"] = c
+    c = base.copy(); c[10, 2] = 1e300; cases["beyond the float range"] = c
+    c = base.copy(); c[9, 0] = 1e-320; cases["a double denormal"] = c
+    cases["genuine doubles"] = rng.normal(size=(50_000, 3))
+    cases["small (below the threshold of the float path)"] = base[:1000].copy()
+    for name, pts in cases.items():
+        for opt in (1, 0):
+            ctx.set_option("upload_f32", opt)
+            cid = ctx.cloud_upload(pts)
+            back = ctx.cloud_download(cid)
+            ctx.cloud_release(cid)
+            assert np.array_equal(back.view(np.uint64), pts.view(np.uint64)), (name, opt)
+    # the tree of a float-exact scan: the same array both ways (and the look-ahead entry stages the same way)
+    from mad_icp_amd import synth
+
+    scan = synth.render_scan(synth.Scene(2), synth.path_pose(3.0), 77).astype(np.float32).astype(np.float64)
+    trees = []
+    for opt in (1, 0):
+        ctx.set_option("upload_f32", opt)
+        cid = ctx.cloud_upload(scan)
+        tid, nl = ctx.tree_build(cid, B_MAX, B_MIN)
+        trees.append(ctx.tree_download(tid, 2 * nl - 1))
+        ctx.tree_release(tid)
+        ctx.cloud_release(cid)
+    ctx.set_option("upload_f32", 1)
+    ctx.tree_build_begin(scan, B_MAX, B_MIN)
+    tid, nl = ctx.tree_build_end()
+    trees.append(ctx.tree_download(tid, 2 * nl - 1))
+    ctx.tree_release(tid)
+    assert trees[0].tobytes() == trees[1].tobytes() == trees[2].tobytes()
