@@ -103,6 +103,67 @@ def test_staged_sharded_registration_world2_gloo(natives, tmp_path, K):
     assert np.allclose(r0["H"], ref["H"], rtol=1e-9, atol=1e-9 * np.abs(ref["H"]).max())
 
 
+class _FakeMailboxCtx:
+    """stands in for capi.Context in the CPU test of the mailbox hand-shake: records what attach_peer_mailboxes does with it"""
+
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.calls, self.attached = rank, fail, [], None
+
+    def set_option(self, key, value):
+        self.calls.append(("set_option", key, value))
+
+    def p2p_detach(self):
+        self.calls.append(("detach",))
+
+    def p2p_export(self):
+        self.calls.append(("export",))
+        if self.fail:
+            raise capi.MadIcpError("madicp error -2: mailbox: no exportable fine-grained device memory on this runtime")
+        return bytes([self.rank]) * 64
+
+    def p2p_attach(self, handles, world, rank):
+        self.calls.append(("attach",))
+        self.attached = (list(handles), world, rank)
+
+
+def _mailbox_worker(rank, world, port, failing_rank, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake = _FakeMailboxCtx(rank, rank == failing_rank)
+        res = {"raised": "", "order": "", "handles_ok": False}
+        try:
+            sharded.attach_peer_mailboxes(fake, allow_coarse=(failing_rank < 0))
+            hs, w, r = fake.attached
+            res["handles_ok"] = (w == world and r == rank and hs == [bytes([q]) * 64 for q in range(world)])
+        except capi.MadIcpError as e:
+            res["raised"] = str(e)
+        res["order"] = ",".join(c[0] for c in fake.calls)
+        np.savez(out % rank, **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing_rank", [-1, 1])
+def test_mailbox_handshake_world3_gloo(tmp_path, failing_rank):
+    """sharded.attach_peer_mailboxes with three gloo ranks on the CPU (a stand-in context): every rank detaches, exports, gathers
+    and attaches the handles in RANK order; when one rank's export fails, EVERY rank raises — with that rank's message — and
+    nobody is left waiting in the gather or attaches half a session."""
+    world = 3
+    out = str(tmp_path / "rank%d.npz")
+    port = 25500 + ((os.getpid() * 3 + failing_rank) % 3000)
+    mp.spawn(_mailbox_worker, args=(world, port, failing_rank, out), nprocs=world, join=True)
+    R = [np.load(out % r) for r in range(world)]
+    for r, z in enumerate(R):
+        if failing_rank < 0:
+            assert bool(z["handles_ok"]) and str(z["raised"]) == "", (r, str(z["raised"]))
+            assert str(z["order"]) == "set_option,detach,export,attach", str(z["order"])
+        else:
+            assert "rank %d" % failing_rank in str(z["raised"]) and "fine-grained" in str(z["raised"]), (r, str(z["raised"]))
+            assert str(z["order"]) == "detach,export" and not bool(z["handles_ok"]), str(z["order"])
+
+
 @pytest.mark.gpu
 def test_native_rccl_path_single_rank(ctx):
     """World size 1 on the one GPU of the test box: the reduce -> ncclAllReduce -> update launch sequence must give
