@@ -39,7 +39,7 @@
           ((const __attribute__((address_space(1))) long long*)(uintptr_t)&job->trees[k_first + tt])[ww];
     }
     __syncthreads();
-    const int i_lo = r_first * S, i_hi = min(L, (r_first + 1) * S);
+    const int i_lo = r_first * S, i_hi = min(Lv, (r_first + 1) * S);  // (virtual indices: kernels.hip.h, "Ranges")
     int qn = 0;  // entries in this wavefront's queue (wave-uniform)
 
     // the evaluation of one pair whose leaf is known: record, gate (mad_icp.cpp:81-83), e, J, weights, accumulation
@@ -126,7 +126,7 @@
         const bool has = b + q_lane < qn;
         const int e = has ? (int)s_queue[q_wave][b + q_lane] : 0;
         const int tt = (e >> 6) & (kDeepTrees - 1), pc = e >> (6 + kDeepTreesLog2);
-        const int i = i_lo + pc * kBlock + q_wave * 64 + (e & 63);
+        const int i = phys(r_first, i_lo + pc * kBlock + q_wave * 64 + (e & 63));
         const TreeDesc& td = s_tds[has ? tt : 0];
         const vd4 p = has ? ((gptr_d4)(uintptr_t)moving)[i] : vd4{0.0, 0.0, 0.0, 0.0};
 #ifdef MADICP_XFORM_HOMOGENEOUS
@@ -163,8 +163,8 @@
     for (int base = i_lo; base < i_hi; base += kBlock, ++pc) {
       // (a pass queues at most 64 walkers per tree and wavefront: room is made HERE, where no pair is in registers)
       if (qn + 64 * n_my > kQueueCap) drain();
-      const int i = base + MADICP_TID;
-      const bool valid = i < i_hi;
+      const int i = phys(r_first, base + MADICP_TID);
+      const bool valid = base + MADICP_TID < i_hi && i < L;
       vd4 p = vd4{0.0, 0.0, 0.0, 0.0};
       if (pc == 0) p = pv0[0];  // (fetched before the solve prologue; clamped index: harmless for an invalid lane)
       else if (valid) p = ((gptr_d4)(uintptr_t)moving)[i];

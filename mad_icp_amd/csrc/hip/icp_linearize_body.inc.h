@@ -4,7 +4,7 @@
 // launch) so that both kernels run the same instructions in the same order; not a translation unit of its own.
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
-// s_td, cache_gate; per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
+// s_td, cache_gate, Lv, phys ("Ranges", kernels.hip.h); per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
 // cgate0 / cword0 (the first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
@@ -14,7 +14,7 @@
       r -= RPT;
       ++k;
     }
-    const int i_end = min(L, (r + 1) * S);
+    const int i_end = min(Lv, (r + 1) * S);  // (virtual indices: kernels.hip.h, "Ranges")
     if (k != desc_tree) {  // (workgroup-uniform; only workgroups with several units get here)
       __syncthreads();     // nobody still reads the previous descriptor
       if (MADICP_TID < 11)
@@ -43,8 +43,9 @@
       double wearv[QPT];
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * kBlock + MADICP_TID;
-        valid[j] = i < i_end;
+        const int v = base + j * kBlock + MADICP_TID;
+        const int i = phys(r, v);
+        valid[j] = v < i_end && i < L;
         pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
         cmar[j] = 0.f;
         cgate[j] = 0.f;
@@ -71,7 +72,7 @@
 #endif
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
-        const int i = base + j * kBlock + MADICP_TID;
+        const int i = phys(r, base + j * kBlock + MADICP_TID);
         const vd4 p = pv[j];
         px[j] = p.x; py[j] = p.y; pz[j] = p.z; pn[j] = p.w;
         // ml = X * p  (Isometry3d * Vector3d: linear()*p + translation(), mad_icp.cpp:78)
@@ -143,7 +144,7 @@
             depth[j] = wdepth[j];
             walked_visits += (unsigned int)wdepth[j];
             if (cache_leaf) {
-              const long long ci = (long long)k * L + (base + j * kBlock + MADICP_TID);
+              const long long ci = (long long)k * L + phys(r, base + j * kBlock + MADICP_TID);
               const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
               cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
               cache_margin[ci] = cacheable ? __double2float_rd(margin[j] + wearv[j]) : 0.f;
@@ -159,7 +160,7 @@
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
         if (!valid[j]) continue;
-        const int i = base + j * kBlock + MADICP_TID;
+        const int i = phys(r, base + j * kBlock + MADICP_TID);
         if (skip[j]) {  // still rejected (gate reuse): mad_icp.cpp:83 `continue`
           if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | 0x80000000u;
           continue;

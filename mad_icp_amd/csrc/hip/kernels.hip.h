@@ -201,6 +201,7 @@ struct Job {
 constexpr int kFlagNoUpdate = 1;
 constexpr int kFlagNoReuse = 512;  // never reuse a cached correspondence (option cache_correspondences = 0)
 constexpr int kFlagNoGateReuse = 2048;  // never skip a pair on its cached gate slack (option cache_gate = 0)
+constexpr int kFlagInterleave = 8192;   // a range is every RPT-th group of 64 leaves, not a contiguous stretch (option interleave_ranges)
 constexpr int kFlagMatchAll = 1024;  // matched_ flags are the OR over ALL rounds (the host cleared them), not the last round's:
                                      // what the reference leaves behind when its realtime check ends the loop before
                                      // iteration MAX_ICP_ITS - 1, the only one that resets them (pipeline.cpp:167-176)
@@ -1616,7 +1617,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
   float* __restrict__ cache_gate = cache_margin ? cache_margin + (long long)K * L : nullptr;  // (second half of the margin array)
   const bool gate_reuse = reuse && !(flags & kFlagNoGateReuse);
-  const int S = (L + RPT - 1) / RPT;  // leaves per range
+  // Ranges.  Contiguous: range r is leaves [r S, (r + 1) S).  Interleaved (kFlagInterleave; round 6): the scan's groups of 64
+  // consecutive leaves are DEALT over the ranges — group g of range r is the scan's group g RPT + r — because a contiguous stretch
+  // of the leaf order is a stretch of space, and stretches differ by a factor of four in how many of their pairs pass the gate
+  // (behind the sensor every keyframe of the map answers, ahead of it only the last few: BASELINE configs[4], 7.6 k .. 30.9 k
+  // accepted pairs per range over 16 sampled keyframes): the launch waited for the workgroups that drew the busy stretch.
+  // The loops run over a range's VIRTUAL indices v in [r S, (r + 1) S), S a multiple of 64, and phys(r, v) is the leaf behind v
+  // (contiguous: v itself); a virtual index is valid when its leaf exists.  Everything indexed by leaf — coordinates, cached
+  // correspondence, matched flags, trace — goes by the leaf; which workgroup adds which pairs changes, hence the order of the
+  // sums: H and b differ from the contiguous launch in their last bits, every decision is the same.
+  const bool inter = (flags & kFlagInterleave) != 0;
+  const int S = inter ? ((((L + 63) >> 6) + RPT - 1) / RPT) << 6 : (L + RPT - 1) / RPT;  // leaves per range
+  const int Lv = inter ? RPT * S : L;
+  auto phys = [&](int r_, int v) -> int {
+    const int n = v - r_ * S;
+    return inter ? ((((n >> 6) * RPT + r_) << 6) | (n & 63)) : v;
+  };
 
   // The first pass's loads that do not depend on the pose (leaf coordinates, cached correspondence) are issued NOW,
   // so they are in flight while the workgroup joins and solves the previous round.  Branch-free (clamped index): a
@@ -1626,11 +1642,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   float cmar0[QPT], cgate0[QPT];
   unsigned int cword0[QPT];
   {
-    const int i_end = have_first ? min(L, (r_first + 1) * S) : 0;
+    const int i_end = have_first ? min(Lv, (r_first + 1) * S) : 0;
     const int i_last = max(i_end - 1, 0);
 #pragma unroll
     for (int j = 0; j < QPT; ++j) {
-      const int i = min(r_first * S + j * kBlock + threadIdx.x, i_last);
+      const int i = max(min(phys(r_first, min(r_first * S + j * kBlock + (int)threadIdx.x, i_last)), L - 1), 0);
       pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
       cmar0[j] = 0.f;
       cgate0[j] = 0.f;
@@ -1677,7 +1693,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     // The barrier above also published the first unit's descriptor and the walk hint.  While wave 0 solves (2-3 us),
     // the other eleven waves have nothing to do: if lanes of this workgroup had to walk last round they copy the
     // tree's top levels into LDS NOW instead of after the prologue (~1 us of every walking round).
-    const int unit_len = have_first ? min(L, (r_first + 1) * S) - r_first * S : 0;
+    const int unit_len = have_first ? min(Lv, (r_first + 1) * S) - r_first * S : 0;
     const int n_top_first = (opt_lds_top && unit_len >= opt_stage_min) ? min(s_td.n_top, kTopMax) : 0;
     if (s_hint > 0.0 && n_top_first > 0) {  // (workgroup-uniform)
       if (threadIdx.x >= 64) {
@@ -2017,7 +2033,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
 #endif
     uint32_t* __restrict__ cache_leaf = job->cache_leaf;
     float* __restrict__ cache_margin = job->cache_margin;
-    const int S = (L + RPT - 1) / RPT;
+    // (contiguous or dealt ranges: "Ranges" in icp_round)
+    const bool inter = (flags & kFlagInterleave) != 0;
+    const int S = inter ? ((((L + 63) >> 6) + RPT - 1) / RPT) << 6 : (L + RPT - 1) / RPT;
+    const int Lv = inter ? RPT * S : L;
+    auto phys = [&](int r_, int v) -> int {
+      const int n = v - r_ * S;
+      return inter ? ((((n >> 6) * RPT + r_) << 6) | (n & 63)) : v;
+    };
     const bool leader = slot == 0;
     const bool last_round = (round == n_iters - 1);
     const bool mark_matched = last_round || (flags & kFlagMatchAll);
@@ -2038,11 +2061,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     float cmar0[QPT], cgate0[QPT];
     unsigned int cword0[QPT];
     {
-      const int i_end0 = have_first ? min(L, (r_first + 1) * S) : 0;
+      const int i_end0 = have_first ? min(Lv, (r_first + 1) * S) : 0;
       const int i_last0 = max(i_end0 - 1, 0);
 #pragma unroll
       for (int j = 0; j < QPT; ++j) {
-        const int i = min(r_first * S + j * kBlock + tid, i_last0);
+        const int i = max(min(phys(r_first, min(r_first * S + j * kBlock + tid, i_last0)), L - 1), 0);
         pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
         cmar0[j] = 0.f;
         cgate0[j] = 0.f;

@@ -226,6 +226,8 @@ struct madicp_ctx {
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
+  int interleave = 2;    // option "interleave_ranges": a range is every RPT-th group of 64 leaves instead of a contiguous stretch of the
+                         // scan (kernels.hip.h, "Ranges"): 0 never, 1 DEEP launches (a batch shares the chip), 2 every launch
   int cache_gate = 1;   // option "cache_gate": a pair that keeps its leaf and was rejected with more slack than it has moved since is
                         // not evaluated again (kernels.hip.h, "Gate reuse")
   int queue_walks = 8192; // option "leaf_major": a DEEP launch (a batch shares the chip) runs a round leaf-major — moving leaf once per
@@ -1041,6 +1043,7 @@ int enqueue_registration(madicp_ctx* ctx, const RegArgs& a) {
     halves[h] = Launch{geo.grid, count, a.n_iters, geo.qpt, geo.lds_bytes, a.K, geo.ranges_per_tree, a.d_corr ? 1 : 0, geo.queue};
     for (int s = first; s < first + count; ++s) {
       h_jobs[s].ranges_per_tree = geo.ranges_per_tree;
+      if (ctx->interleave == 2 || (ctx->interleave == 1 && geo.queue)) h_jobs[s].flags |= kFlagInterleave;
       h_jobs[s].stage_min_leaves = ctx->stage_min_leaves;
       h_jobs[s].lds_top = geo.lds_bytes ? 1 : 0;
     }
@@ -1316,6 +1319,9 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->cache_corr = value ? 1 : 0;
   } else if (k == "cache_gate") {
     ctx->cache_gate = value ? 1 : 0;
+  } else if (k == "interleave_ranges") {
+    if (value < 0 || value > 2) return fail(MADICP_ERR_INVALID, "interleave_ranges is 0 (never), 1 (batches that share the chip) or 2 (always)");
+    ctx->interleave = (int)value;
   } else if (k == "leaf_major") {
     if (value < 0 || value > (1 << 20)) return fail(MADICP_ERR_INVALID, "leaf_major must be 0 (never) or a node count per pass");
     ctx->queue_walks = (int)value;
@@ -1385,6 +1391,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "comm_graph") v = ctx->comm_graph;
   else if (k == "cache_correspondences") v = ctx->cache_corr;
   else if (k == "cache_gate") v = ctx->cache_gate;
+  else if (k == "interleave_ranges") v = ctx->interleave;
   else if (k == "leaf_major") v = ctx->queue_walks;
   else if (k == "lds_stage_min_leaves") v = ctx->stage_min_leaves;
   else if (k == "eager_when_busy") v = ctx->eager_when_busy;
@@ -1827,6 +1834,7 @@ int stream_submit_impl(madicp_ctx* ctx, const double* leaf_means, int32_t L, int
   RC_TRY(fill_job(ctx, j, mv, tree_ids, K, X0, params, n_iters, 0, use_cache));
   const Geometry geo = pick_geometry(ctx, L, K, 1);
   j.ranges_per_tree = geo.ranges_per_tree;
+  if (ctx->interleave == 2 || (ctx->interleave == 1 && geo.queue)) j.flags |= kFlagInterleave;
   j.stage_min_leaves = ctx->stage_min_leaves;
   j.lds_top = geo.lds_bytes ? 1 : 0;
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&j.host_out), sl.h_out, 0));
