@@ -219,7 +219,7 @@ struct madicp_ctx {
 
   // options
   int blocks_per_cu = 1;  // icp_round workgroups (768 threads) per CU
-  int deal_trees = 1;     // a Job lists the caller's trees dealt round-robin over the eight XCD pieces (fill_job)
+  int deal_trees = 2;     // a Job lists the caller's trees dealt over the eight XCD pieces, rows of eight in alternating direction (fill_job)
   int units_per_wg = 1;   // when a scan has more trees than workgroups: cut every tree's leaves into enough ranges for at least
                           // this many (tree, range) units per workgroup (see pick_geometry)
   int use_graph = 1;
@@ -925,9 +925,16 @@ int fill_job(madicp_ctx* ctx, Job& j, DevMoving& mv, const int* tree_ids, int K,
   // over them — position p holds the caller's tree order[p], trees 0, 8, 16, .. first — so that neighbours in the caller's
   // list (keyframes along a trajectory: similar cost for a given scan) land on different XCDs.  Everything the kernels index
   // by tree is internal and follows the Job's positions; the one per-tree OUTPUT (the correspondence trace) goes by `slot`.
+  // (deal_trees = 2: boustrophedon — rows of eight alternate their direction, so that the piece that drew the newest keyframe of
+  // one row draws the oldest of the next: along a trajectory the newest keyframes are the dear ones, accepted pairs grow by a
+  // quarter every four keyframes at BASELINE configs[4], and round-robin hands piece 7 a tree seven places newer than piece 0's
+  // in EVERY row)
   int p = 0;
-  for (int c = 0; c < (ctx->deal_trees ? 8 : 1); ++c)
-    for (int k = c; k < K; k += (ctx->deal_trees ? 8 : 1)) {
+  const int cols = ctx->deal_trees ? 8 : 1;
+  for (int c = 0; c < cols; ++c)
+    for (int row = 0; row * cols < K; ++row) {
+      const int k = row * cols + ((ctx->deal_trees == 2 && (row & 1)) ? cols - 1 - c : c);
+      if (k >= K) continue;
       auto tit = ctx->trees.find(tree_ids[k]);
       if (tit == ctx->trees.end()) return fail(MADICP_ERR_INVALID, "unknown tree id");
       RC_TRY(wait_tree(ctx, tit->second));
@@ -1307,7 +1314,8 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "publish_side") {
     ctx->publish_side = value ? 1 : 0;
   } else if (k == "deal_trees") {
-    ctx->deal_trees = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(MADICP_ERR_INVALID, "deal_trees is 0 (as listed), 1 (round-robin over the XCD pieces) or 2 (alternating rows)");
+    ctx->deal_trees = (int)value;
   } else if (k == "units_per_workgroup") {
     if (value < 1 || value > 64) return fail(MADICP_ERR_INVALID, "units_per_workgroup must be in 1..64");
     ctx->units_per_wg = (int)value;

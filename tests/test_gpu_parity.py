@@ -204,35 +204,109 @@ def test_linearize_correspondences_bit_exact(ctx, K):
 
 
 def test_trees_dealt_over_the_xcd_pieces_keep_the_callers_indices(ctx):
-    """A Job lists the caller's trees dealt round-robin over the kernel's eight XCD pieces (fill_job; option deal_trees).
-    Nothing the caller sees may depend on it: the correspondence trace is indexed by the CALLER's tree index — checked
-    against the oracle tree by tree, with a tree count that is not a multiple of eight — the matched flags and the visit
-    count are identical with the option off and on, H and b equal to summation-order rounding, and a registration ends at
-    the same pose to 1e-12."""
+    """A Job lists the caller's trees dealt over the kernel's eight XCD pieces (fill_job; option deal_trees: 2 = rows of eight in
+    alternating direction, the default since round 6; 1 = round-robin; 0 = as listed).  Nothing the caller sees may depend on it:
+    the correspondence trace is indexed by the CALLER's tree index — checked against the oracle tree by tree, with a tree count
+    that is not a multiple of eight — the matched flags and the visit count are identical whatever the option, H and b equal to
+    summation-order rounding, and a registration ends at the same pose to 1e-12."""
     K = 11
     pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
     T = pb["query_guess"][0]
     L = qh[0].num_leaves
-    assert ctx.get_option("deal_trees") == 1
+    assert ctx.get_option("deal_trees") == 2
     res = {}
-    for deal in (1, 0):
+    for deal in (2, 1, 0):
         ctx.set_option("deal_trees", deal)
         res[deal] = (ctx.icp_linearize(mids[0], tids, T, PARAMS, L), ctx.icp_register(mids[0], tids, T, PARAMS, 6, L))
-    ctx.set_option("deal_trees", 1)
-    g, _ = res[1]
+    ctx.set_option("deal_trees", 2)
+    g, _ = res[2]
     for k in range(K):
         _, _, corr, rej, _, _ = O.icp_linearize(qo[0], ots[k], T, B_MAX, RHO_KER, B_RATIO)
         assert np.array_equal(g["corr"][k] & 0x7FFFFFFF, corr), f"tree {k}: the trace is not in the caller's order"
         assert np.array_equal((g["corr"][k] >> 31).astype(np.uint8), rej)
-    assert np.array_equal(res[1][0]["corr"], res[0][0]["corr"])
-    assert np.array_equal(res[1][0]["matched"], res[0][0]["matched"])
-    assert res[1][0]["visits"] == res[0][0]["visits"]
-    scale = np.abs(res[0][0]["H"]).max()
-    assert np.allclose(res[1][0]["H"], res[0][0]["H"], rtol=0, atol=1e-12 * scale)
-    assert np.allclose(res[1][0]["b"], res[0][0]["b"], rtol=0, atol=1e-12 * max(1.0, np.abs(res[0][0]["b"]).max()))
-    assert np.abs(res[1][1]["X"] - res[0][1]["X"]).max() < 1e-12
-    assert np.array_equal(res[1][1]["matched"], res[0][1]["matched"])
+    for deal in (2, 1):
+        assert np.array_equal(res[deal][0]["corr"], res[0][0]["corr"]), deal
+        assert np.array_equal(res[deal][0]["matched"], res[0][0]["matched"]), deal
+        assert res[deal][0]["visits"] == res[0][0]["visits"], deal
+        scale = np.abs(res[0][0]["H"]).max()
+        assert np.allclose(res[deal][0]["H"], res[0][0]["H"], rtol=0, atol=1e-12 * scale), deal
+        assert np.allclose(res[deal][0]["b"], res[0][0]["b"], rtol=0, atol=1e-12 * max(1.0, np.abs(res[0][0]["b"]).max())), deal
+        assert np.abs(res[deal][1]["X"] - res[0][1]["X"]).max() < 1e-12, deal
+        assert np.array_equal(res[deal][1]["matched"], res[0][1]["matched"]), deal
     _teardown(ctx, tids, mids)
+
+
+@pytest.mark.parametrize("K,n_queries", [(1, 1), (3, 1), (16, 1), (32, 8)])
+def test_ranges_dealt_in_groups_of_64_leaves_same_decisions(ctx, K, n_queries):
+    """Option interleave_ranges (kernels.hip.h, "Ranges"; default 2 since round 6): the ranges a scan is cut into are every RPT-th
+    group of 64 leaves instead of contiguous stretches, so that every workgroup draws a sample of the whole scan and not one
+    stretch of space.  Which workgroup adds which pair changes — H and b agree with the contiguous launch to summation-order
+    rounding (1e-12), the pose to 1e-12 — and nothing else does: the correspondence trace (leaf indices and gate decisions, every
+    tree), the matched flags, their count and the visit counter are the same bit for bit; in a one-scan launch, in a batch that
+    shares the chip (DEEP launches: tree-major and leaf-major rounds), with option 1 (batches only) too.  The poses are the
+    oracle's (mad_icp.cpp:74-117 under pipeline.cpp:166-193)."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K, n_queries=n_queries)
+    Ls = [h.num_leaves for h in qh]
+    X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
+    assert ctx.get_option("interleave_ranges") == 2
+    res = {}
+    try:
+        for mode in (2, 1, 0):
+            ctx.set_option("interleave_ranges", mode)
+            r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+            r["matched"] = [ctx.icp_fetch_matched(i, L) for i, L in enumerate(Ls)]
+            r["lin"] = ctx.icp_linearize(mids[0], tids, pb["query_guess"][0], PARAMS, Ls[0])
+            res[mode] = r
+    finally:
+        ctx.set_option("interleave_ranges", 2)
+    ref = res[0]
+    for mode in (2, 1):
+        o = res[mode]
+        assert np.array_equal(o["lin"]["corr"], ref["lin"]["corr"]), mode
+        assert np.array_equal(o["lin"]["matched"], ref["lin"]["matched"]) and o["lin"]["visits"] == ref["lin"]["visits"], mode
+        scale = np.abs(ref["lin"]["H"]).max()
+        assert np.allclose(o["lin"]["H"], ref["lin"]["H"], rtol=0, atol=1e-12 * scale), mode
+        assert np.array_equal(o["n_matched"], ref["n_matched"]) and np.array_equal(o["visits"], ref["visits"]), mode
+        for a, b in zip(o["matched"], ref["matched"]):
+            assert np.array_equal(a, b), mode
+        assert np.abs(o["X"] - ref["X"]).max() <= 1e-12, (mode, np.abs(o["X"] - ref["X"]).max())
+        assert np.abs(o["H"] - ref["H"]).max() <= 1e-12 * np.abs(ref["H"]).max(), mode
+    if n_queries == 1:  # (a one-scan launch is not a batch: option 1 leaves it contiguous — the same bits as option 0)
+        assert np.array_equal(res[1]["X"], ref["X"]) and np.array_equal(res[1]["H"], ref["H"])
+    q = n_queries - 1
+    o = O.icp_register(qo[q], ots, pb["query_guess"][q], 15, B_MAX, RHO_KER, B_RATIO, num_threads=4)
+    terr, rerr = pose_err(o["T"], capi.pose44(res[2]["X"][q]))
+    assert terr <= POSE_TOL_M and rerr <= POSE_TOL_RAD
+    assert np.array_equal(res[2]["matched"][q], o["matched"]) and res[2]["visits"][q] == o["depth_sum"]
+    _teardown(ctx, tids, mids)
+
+
+def test_interleaved_ranges_with_fewer_groups_than_ranges(ctx):
+    """A scan of a few hundred leaves against many workgroups: most ranges of the dealt layout hold one group of 64 leaves or none
+    (their virtual indices have no leaf behind them).  Same trace, flags and visit count as the contiguous layout; the visit count
+    is the oracle's (mad_tree.cpp:144-152 per query)."""
+    rng = np.random.default_rng(7)
+    cloud = four_walls(6000)
+    ht, ot = build_pair(cloud)
+    tid = ctx.tree_upload(ht.nodes, ht.num_leaves)
+    for n in (1, 63, 64, 65, 200, 777):
+        moving = cloud[rng.choice(cloud.shape[0], n, replace=False)] + rng.normal(scale=0.01, size=(n, 3))
+        mid = ctx.moving_upload(moving)
+        T = np.eye(4)
+        T[:3, 3] = [0.02, -0.01, 0.005]
+        res = {}
+        for mode in (2, 0):
+            ctx.set_option("interleave_ranges", mode)
+            res[mode] = (ctx.icp_linearize(mid, [tid], T, PARAMS, n), ctx.icp_register(mid, [tid], T, PARAMS, 5, n))
+        ctx.set_option("interleave_ranges", 2)
+        assert np.array_equal(res[2][0]["corr"], res[0][0]["corr"]), n
+        assert np.array_equal(res[2][0]["matched"], res[0][0]["matched"]) and res[2][0]["visits"] == res[0][0]["visits"], n
+        assert np.array_equal(res[2][1]["matched"], res[0][1]["matched"]) and res[2][1]["visits"] == res[0][1]["visits"], n
+        assert np.abs(res[2][1]["X"] - res[0][1]["X"]).max() <= 1e-12, n
+        leaf, depth = ot.search(moving @ T[:3, :3].T + T[:3, 3])
+        assert res[2][0]["visits"] == int(depth.sum()), n
+        ctx.moving_release(mid)
+    ctx.tree_release(tid)
 
 
 @pytest.mark.parametrize("K", [1, 4])
