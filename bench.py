@@ -17,7 +17,7 @@ trees are resident before the timed region starts (they are the local map).  The
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1 (one rank per GPU) — `value` is BASELINE configs[3], the north-star's multi-GPU configuration:
-  shard     (value) the 16 keyframe trees are sharded round-robin over the ranks (16/N per GPU); every rank holds the
+  shard     (value) the 16 keyframe trees are dealt over the ranks (16/N per GPU, sharded.keyframe_owner); every rank holds the
             moving leaves of the N scans in flight (one per GPU: per-GPU work fixed as N grows, "scaling": "weak"),
             linearises them against ITS trees, and every GN round ends with ONE RCCL all-reduce of [H(21) b(6) n v w]
             per scan over xGMI, enqueued by the library between its kernels; the matched flags are OR-ed once.  Every
@@ -1130,7 +1130,8 @@ def multi_gpu(args, ctx, capi, synth, pb, leaves, Ls, guesses, fence, max_over_r
         # library's bounded wait) must not cost the run its line: every rank catches, the ranks agree, the line then reports
         # the replica figure and says why
         try:
-            my = [k for k in range(K) if k % world == rank]
+            from mad_icp_amd import sharded as _shard_plan
+            my = _shard_plan.shard_keyframes(K, world, rank)  # (rows of `world` keyframes in alternating direction)
             tids, n_nodes = upload_map(ctx, capi, pb, my)
             n_local = len(tids)
             from mad_icp_amd import sharded as _sh

@@ -27,11 +27,22 @@ import numpy as np
 from . import capi
 
 
+def keyframe_owner(k, world_size):
+    """The rank that owns keyframe id `k` (promotion order, pipeline.cpp:253): the ids are dealt in rows of `world_size`,
+    alternate rows in opposite directions — a function of the id alone, so a keyframe never changes hands while the window
+    slides.  Along a trajectory the newest keyframes are the dear ones (at BASELINE configs[4] the accepted pairs grow by a
+    quarter every four keyframes): plain round-robin hands the last rank a tree world_size - 1 places newer than the first
+    rank's in EVERY row and every round then waits for that rank; alternating rows pair the newest of one row with the oldest
+    of the next (the same deal the library makes over its eight XCD pieces: option deal_trees)."""
+    row, col = divmod(int(k), world_size)
+    return col if row % 2 == 0 else world_size - 1 - col
+
+
 def shard_keyframes(n_keyframes, world_size, rank):
-    """Keyframe indices owned by `rank`: round-robin by keyframe id (promotion order, pipeline.cpp:253)."""
+    """Keyframe indices owned by `rank` (keyframe_owner)."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
-    return [k for k in range(n_keyframes) if k % world_size == rank]
+    return [k for k in range(n_keyframes) if keyframe_owner(k, world_size) == rank]
 
 
 def init_native_comm(ctx, group=None, device=None):

@@ -23,6 +23,13 @@ def test_shard_plan_partitions_keyframes():
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     with pytest.raises(ValueError):
         sharded.shard_keyframes(4, 2, 2)
+    # rows of `world` ids in alternating direction: BASELINE configs[3] pairs the newest keyframe with the oldest ...
+    assert [sharded.shard_keyframes(16, 8, r) for r in range(8)] == [[r, 15 - r] for r in range(8)]
+    # ... and a keyframe never changes hands while the window slides (ownership is a function of the id alone)
+    for W in (2, 4, 8):
+        for k in range(100):
+            assert k in sharded.shard_keyframes(k + 1, W, sharded.keyframe_owner(k, W))
+            assert k in sharded.shard_keyframes(k + 37, W, sharded.keyframe_owner(k, W))
 
 
 def test_host_gn_update_matches_oracle_update_state(natives):
