@@ -91,9 +91,14 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * kernel on a side stream carries them, and the matched flags, to the caller's pinned block while the compute stream is already
  * running the next registration — the two PCIe round trips of that hand-over were 5 us of every registration; off: the
  * closing kernel writes them itself),
- * "deal_trees" (0/1, default 1: a registration lists the caller's trees dealt round-robin over the eight XCD pieces of the
- * round kernel — neighbours in the caller's list, e.g. keyframes along a trajectory, cost a given scan about the same, and
- * with them in one piece one XCD worked while seven waited; results keep the caller's indices),
+ * "deal_trees" (0/1/2, default 2: a registration lists the caller's trees dealt over the eight XCD pieces of the round kernel —
+ * neighbours in the caller's list, e.g. keyframes along a trajectory, cost a given scan about the same, and with them in one
+ * piece one XCD worked while seven waited; 1 = round-robin, 2 = rows of eight in alternating direction, so that the piece that
+ * drew the newest (dearest) keyframe of one row draws the oldest of the next; results keep the caller's indices),
+ * "interleave_ranges" (0/1/2, default 2: the ranges a scan's leaves are cut into for the workgroups are every n-th group of 64
+ * leaves instead of contiguous stretches — a stretch of the leaf order is a stretch of space, and stretches differ several-fold
+ * in how many of their pairs pass the gate: the launch waited for the workgroups that drew the busy stretch; 1 = only in batches
+ * that share the chip, 2 = every launch.  Another summation order for H and b (~1e-16), the same decisions),
  * "units_per_workgroup" (1..64, default 1: with more trees than workgroups per scan, cut the leaves into enough ranges for at
  * least this many (tree, range) units per workgroup; measured: no gain),
  * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves),
