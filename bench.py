@@ -539,12 +539,15 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
     for i in range(3):
         step(i)
     fence()
-    n = 12
-    t = time.perf_counter()
-    for i in range(n):
-        order, last = step(i)
-    fence()
-    streamed_sync = B * n / (time.perf_counter() - t)
+    n, reps = 12, 5  # (every figure below: the median of `reps` repetitions of n steps — a step is ~2 ms, one hiccup is a tenth of a repetition)
+    rates = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        for i in range(n):
+            order, last = step(i)
+        fence()
+        rates.append(B * n / (time.perf_counter() - t))
+    streamed_sync, sync_spread = float(np.median(rates)), [round(min(rates), 1), round(max(rates), 1)]
     # The same step — 8 NEW scans in, 8 results out — with one batch ahead of the collection, like the headline's loop: the next
     # batch's scans go up on the copy stream (a second set of moving buffers: madicp_moving_update_async) and are enqueued before
     # the previous batch's results — carried out by one kernel behind it, madicp_icp_publish_enqueue — are collected.
@@ -569,10 +572,13 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
 
     pipelined(4)
     fence()
-    t = time.perf_counter()
-    order, last = pipelined(n)
-    fence()
-    streamed = B * n / (time.perf_counter() - t)
+    rates = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        order, last = pipelined(n)
+        fence()
+        rates.append(B * n / (time.perf_counter() - t))
+    streamed, streamed_spread = float(np.median(rates)), [round(min(rates), 1), round(max(rates), 1)]
     for m_ in sets[1]:
         ctx.moving_release(m_)
     terr = max(pose_error(st["gts"][q], capi.pose44(last["X"][s_])) for s_, q in enumerate(order))
@@ -581,11 +587,14 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
     for _ in range(3):
         ctx.icp_register_batch_enqueue(mids, st["tids"], X0, PARAMS, N_ITERS)
     fence()
-    t = time.perf_counter()
-    for _ in range(n):
-        ctx.icp_register_batch_enqueue(mids, st["tids"], X0, PARAMS, N_ITERS)
-    fence()
-    resident = B * n / (time.perf_counter() - t)
+    rates = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        for _ in range(n):
+            ctx.icp_register_batch_enqueue(mids, st["tids"], X0, PARAMS, N_ITERS)
+        fence()
+        rates.append(B * n / (time.perf_counter() - t))
+    resident, resident_spread = float(np.median(rates)), [round(min(rates), 1), round(max(rates), 1)]
     # launch times: the measurement build's identical kernels (the product library exports no timing aid), its own copy of the map
     m_tids = [mctx.upload(ht) for ht in st["trees"]]
     m_mids = [mctx.moving_upload(lm) for lm in st["moving"]]
@@ -608,6 +617,12 @@ def stress_figures(args, ctx, capi, st, fence, hbm_copy, mctx=None):
                          "flight, results carried out by a kernel behind it: the headline's loop for batches), the second uploads, "
                          "registers and fetches strictly one after the other (rounds 3-5 reported that one)",
         "registrations_per_s_resident": round(resident, 1),
+        "spread": {"repetitions": reps, "steps_each": n, "what": "each registrations/s figure is the median repetition; [min, max] here",
+                   "new_scans_in_results_out": streamed_spread, "synchronous": sync_spread, "resident": resident_spread},
+        "work_distribution": {"deal_trees": int(ctx.get_option("deal_trees")), "interleave_ranges": int(ctx.get_option("interleave_ranges")),
+                              "note": "round 6: the scan's leaves go to the workgroups in groups of 64 dealt over the ranges, the keyframe "
+                                      "trees to the XCD pieces in alternating rows — no workgroup draws only the busy stretch of the scan "
+                                      "or only the newest keyframes (profiles/r6_range_balance.md)"},
         "max_translation_error_m": round(terr, 5),
         "icp_round_avg_launch_us": round(avg_us, 2), "icp_final_launch_us": round(final_us, 2),
         "pairs_per_launch": int(pairs), "nodes_walked_per_launch": int(walked.sum()),
