@@ -79,7 +79,8 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
 /* Tuning knobs (all optional): key in {"grid_blocks_per_cu" (1..4), "use_graph" (0/1), "queries_per_lane" (1,2),
  * "cache_correspondences" (0/1: reuse a correspondence in later GN rounds when it is provably unchanged),
  * "cache_gate" (0/1, default 1: a pair that keeps its leaf and was rejected by the gate of mad_icp.cpp:81-83 with more slack than it
- * has moved since is not evaluated again — its leaf record is not fetched; same bits either way),
+ * has moved since is not evaluated again — its leaf record is not fetched; the same decisions either way, and the same bits
+ * wherever the pairs are added in scan order (every launch but the leaf-major rounds of a batch, which add their walkers last)),
  * "leaf_major" (0: never; n > 0, default 8192: when a batch shares the chip — more keyframe trees than workgroups per XCD piece —
  * every workgroup gets one range of the scan's leaves and all the trees of its piece, and a round that follows one in which the
  * workgroup walked fewer than n nodes per pass runs LEAF-MAJOR: the moving leaf is read and transformed once per pass for all

@@ -44,7 +44,8 @@
 
     // the evaluation of one pair whose leaf is known: record, gate (mad_icp.cpp:81-83), e, J, weights, accumulation
     // (mad_icp.cpp:59-101) — the arithmetic of the tree-major body, statement for statement
-    auto evaluate = [&](const TreeDesc& td, int kk, int i, int lf, bool walked_now, float slack_on_file, double wear, double px,
+    // (t_file: the pair's threshold on file, t_keep: its leaf's own — kernels.hip.h, "One threshold per pair")
+    auto evaluate = [&](const TreeDesc& td, int kk, int i, int lf, bool walked_now, float t_file, float t_keep, double wear, double px,
                         double py, double pz, double pnorm, double q0, double q1, double q2) {
       gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + lf);
       const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
@@ -53,8 +54,9 @@
       const double dist = sqrt(dotc(g0, g1, g2, g0, g1, g2));
       const bool rejected = dist > src_ball;
       {
-        const float slack = rejected ? __double2float_rd((dist - src_ball) + wear) : 0.f;
-        if (walked_now || slack != slack_on_file) cache_gate[(long long)kk * L + i] = slack;
+        float tnew = t_keep;
+        if (rejected && gate_file) tnew = -fminf(t_keep, __double2float_rd((dist - src_ball) + wear));
+        if (walked_now || tnew != t_file) cache_margin[(long long)kk * L + i] = tnew;
       }
       if (rejected) return;
       if (mark_matched) matched[i] = 1;
@@ -151,8 +153,8 @@
           const long long ci = (long long)kk * L + i;
           const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
           cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
-          cache_margin[ci] = cacheable ? __double2float_rd(xm[0] + wear) : 0.f;
-          evaluate(td, kk, i, xl[0], true, 0.f, wear, p.x, p.y, p.z, p.w, a0[0], a1[0], a2[0]);
+          evaluate(td, kk, i, xl[0], true, 0.f, cacheable ? __double2float_rd(xm[0] + wear) : 0.f, wear, p.x, p.y, p.z, p.w, a0[0], a1[0],
+                   a2[0]);
         }
       }
       qn = 0;
@@ -179,15 +181,14 @@
 #endif
       for (int t0 = 0; t0 < n_my; t0 += 4) {  // the trees of this workgroup, four at a time: their cached records in flight together
         unsigned int cw[4];
-        float cm[4], cg[4];
+        float cm[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          cw[a] = 0u; cm[a] = 0.f; cg[a] = 0.f;
+          cw[a] = 0u; cm[a] = 0.f;
           if (valid && t0 + a < n_my) {
             const long long ci = (long long)(k_first + t0 + a) * L + i;
             cw[a] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
             cm[a] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
-            if (gate_reuse) cg[a] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_gate)[ci];
           }
         }
 #pragma unroll
@@ -199,7 +200,8 @@
           // thresholds and the walked counter are the same doubles whichever mode a round ran in)
           const double wear = __builtin_fma(p.w, wear_alpha, wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) +
                                                                                               fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0)));
-          const bool keep = valid && (double)cm[a] > wear;
+          const float t_keep = fabsf(cm[a]);
+          const bool keep = valid && (double)t_keep > wear;
           const bool w = valid && !keep;
           // queue the walkers: pass, tree, lane — in pass, tree, lane order (a ballot and a prefix count: deterministic)
           const unsigned long long wm = __ballot(w);
@@ -211,8 +213,8 @@
           }
           if (keep) {
             visits += cw[a] >> 26;
-            if (!(gate_reuse && (double)cg[a] > wear))
-              evaluate(td, k_first + tt, i, (int)(cw[a] & kCacheIdxMask), false, cg[a], wear, p.x, p.y, p.z, p.w, q0, q1, q2);
+            if (!(gate_reuse && cm[a] < 0.f))  // (a negative threshold above the wear: same leaf, still rejected)
+              evaluate(td, k_first + tt, i, (int)(cw[a] & kCacheIdxMask), false, cm[a], t_keep, wear, p.x, p.y, p.z, p.w, q0, q1, q2);
           }
         }
       }

@@ -4,8 +4,8 @@
 // launch) so that both kernels run the same instructions in the same order; not a translation unit of its own.
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
-// s_td, cache_gate, Lv, phys ("Ranges", kernels.hip.h); per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
-// cgate0 / cword0 (the first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
+// s_td, gate_file, Lv, phys ("Ranges", kernels.hip.h); per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
+// cword0 (the first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
   int k = k_first, r = r_first;
@@ -37,7 +37,8 @@
       // every load of this pass that does not depend on another one is issued first — the leaf's coordinates and
       // its cached correspondence — so a walk-free pass is two memory round trips (these, then the leaf record)
       vd4 pv[QPT];
-      float cmar[QPT], cgate[QPT];
+      float cmar[QPT];   // the pair's threshold on file (kernels.hip.h, "One threshold per pair"): |T| = how far it may wear, T < 0: rejected
+      float tkeep[QPT];  // the leaf's own threshold (what the pair keeps when the gate lets it through)
       unsigned int cword[QPT];
       bool skip[QPT];  // gate reuse: the pair keeps its leaf and is still rejected — nothing to fetch, nothing to add
       double wearv[QPT];
@@ -48,13 +49,11 @@
         valid[j] = v < i_end && i < L;
         pv[j] = vd4{0.0, 0.0, 0.0, 0.0};
         cmar[j] = 0.f;
-        cgate[j] = 0.f;
         cword[j] = 0u;
         skip[j] = false;
         if (u == u_first && base == r * S) {  // (workgroup-uniform) already fetched before the solve prologue
           pv[j] = pv0[j];
           cmar[j] = cmar0[j];
-          cgate[j] = cgate0[j];
           cword[j] = cword0[j];
         } else if (valid[j]) {
           pv[j] = ((gptr_d4)(uintptr_t)moving)[i];
@@ -62,7 +61,6 @@
             const long long ci = (long long)k * L + i;
             cmar[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_margin)[ci];
             cword[j] = ((const __attribute__((address_space(1))) unsigned int*)(uintptr_t)cache_leaf)[ci];
-            if (gate_reuse) cgate[j] = ((const __attribute__((address_space(1))) float*)(uintptr_t)cache_gate)[ci];
           }
         }
       }
@@ -93,13 +91,15 @@
         // grows: thresholds measured against it are never rewritten while they hold)
         const double wear = __builtin_fma(p.w, wear_alpha, wear_k);
         wearv[j] = wear;
-        if (reuse && valid[j] && (double)cmar[j] > wear) {  // every side test of the old path keeps its sign: same leaf, same depth
+        tkeep[j] = fabsf(cmar[j]);
+        if (reuse && valid[j] && (double)tkeep[j] > wear) {  // every side test of the old path keeps its sign: same leaf, same depth
           leaf[j] = (int)(cword[j] & kCacheIdxMask);
           depth[j] = (int)(cword[j] >> 26);
           walk[j] = false;
         }
-        // same leaf as when the slack was measured, and still further outside its ball than it can have moved since?
-        skip[j] = gate_reuse && valid[j] && !walk[j] && (double)cgate[j] > wear;
+        // same leaf as when the slack was measured, and still further outside its ball than it can have moved since?  (a negative
+        // threshold is min(the leaf's, the slack's): above the wear, both hold)
+        skip[j] = gate_reuse && valid[j] && !walk[j] && cmar[j] < 0.f;
       }
       if (u == u_first && base == r * S) { MADICP_STAMP(3); }
       if (u == u_first && base == r * S + QPT * kBlock) { MADICP_STAMP(11); }
@@ -147,7 +147,7 @@
               const long long ci = (long long)k * L + phys(r, base + j * kBlock + MADICP_TID);
               const bool cacheable = wdepth[j] <= kCacheMaxDepth && (unsigned int)wleaf[j] <= kCacheIdxMask;
               cache_leaf[ci] = (unsigned int)wleaf[j] | ((unsigned int)wdepth[j] << 26);
-              cache_margin[ci] = cacheable ? __double2float_rd(margin[j] + wearv[j]) : 0.f;
+              tkeep[j] = cacheable ? __double2float_rd(margin[j] + wearv[j]) : 0.f;  // (filed below, once the gate has spoken)
             }
           }
         }
@@ -179,11 +179,12 @@
         // launch at BASELINE configs[4], nothing at the headline — the wave-wide vote costs more than the root; profiles/r5_e_ab.md)
         const double dist = sqrt(dotc(g0, g1, g2, g0, g1, g2));
         const bool rejected = dist > src_ball;
-        // gate reuse: how far outside its ball the pair is (0: inside — it is evaluated every round)
-        // (as a threshold on the pair's wear; stored only when it changes — an accepted pair stays 0 and is never written)
-        if (cache_gate) {
-          const float slack = rejected ? __double2float_rd((dist - src_ball) + wearv[j]) : 0.f;
-          if (walk[j] || slack != cgate[j]) cache_gate[(long long)k * L + i] = slack;
+        // the pair's threshold: its leaf's — and, rejected, no more than how far outside its ball it is (gate reuse), marked by
+        // the sign; stored only when it changes (an accepted pair that keeps its leaf is never written)
+        if (cache_margin) {
+          float tnew = tkeep[j];
+          if (rejected && gate_file) tnew = -fminf(tkeep[j], __double2float_rd((dist - src_ball) + wearv[j]));
+          if (walk[j] || tnew != cmar[j]) cache_margin[(long long)k * L + i] = tnew;
         }
         if (TRACE && corr) corr[(long long)td.slot * L + i] = static_cast<uint32_t>(leaf[j]) | (rejected ? 0x80000000u : 0u);
         if (rejected) continue;

@@ -355,9 +355,12 @@ __device__ __forceinline__ int descend(const TreeDesc& td, double q0, double q1,
 // keeps its leaf (margin > displacement, above) the distance changes by at most the displacement.  So a pair rejected with
 // slack g = distance - ball stays rejected as long as the leaf has moved by less than g since — and a rejected pair
 // contributes NOTHING (mad_icp.cpp:83 `continue`), so it needs neither its leaf record (four 16-byte gathers: what a converged
-// pass is bound by) nor the gate nor the Jacobian.  The slack is cached per (tree, leaf) as a float rounded down (0: not
-// rejected, evaluate), in the second half of the margin array, and wears off with the same per-round displacement bound and
-// rounding floor as the margin.  At BASELINE configs[4] 79 % of the pairs are rejected at the converged pose, at the headline's
+// pass is bound by) nor the gate nor the Jacobian.  One threshold per pair (round 6; it was two floats): a rejected pair files
+// T = -min(the leaf's threshold, fl32_down(slack + wear)) — negative marks "rejected", and |T| above the wear says BOTH that the
+// pair keeps its leaf and that it is still outside its ball; an accepted pair files the leaf's threshold, positive.  What the
+// single float gives up: a rejected pair whose slack wears off before its leaf's threshold walks again (and arrives at the same
+// leaf) instead of being evaluated in place — the same decisions, a few more walks in rounds 1-3 (measured: DESIGN.md 3.1), for
+// 4 of the 12 bytes every pair reads in every round.  At BASELINE configs[4] 79 % of the pairs are rejected at the converged pose, at the headline's
 // 16 keyframes 44 % (oracle count) — whole wavefronts of a far keyframe's unit skip their gathers.  Same bits on or off: the
 // pairs that are evaluated are accumulated in the same order.
 constexpr unsigned int kCacheIdxMask = 0x03ffffffu;
@@ -1615,8 +1618,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   uint32_t* __restrict__ cache_leaf = job->cache_leaf;
   float* __restrict__ cache_margin = job->cache_margin;
   const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
-  float* __restrict__ cache_gate = cache_margin ? cache_margin + (long long)K * L : nullptr;  // (second half of the margin array)
-  const bool gate_reuse = reuse && !(flags & kFlagNoGateReuse);
+  const bool gate_file = !(flags & kFlagNoGateReuse);  // rejected pairs are filed with min(leaf's, slack's) threshold, negative
+  const bool gate_reuse = reuse && gate_file;
   // Ranges.  Contiguous: range r is leaves [r S, (r + 1) S).  Interleaved (kFlagInterleave; round 6): the scan's groups of 64
   // consecutive leaves are DEALT over the ranges — group g of range r is the scan's group g RPT + r — because a contiguous stretch
   // of the leaf order is a stretch of space, and stretches differ by a factor of four in how many of their pairs pass the gate
@@ -1639,7 +1642,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
   // divergent region would wait for its loads where it ends.  (Also touching the second pass's lines and the cached
   // leaf records here was measured: no gain.)
   vd4 pv0[QPT];
-  float cmar0[QPT], cgate0[QPT];
+  float cmar0[QPT];
   unsigned int cword0[QPT];
   {
     const int i_end = have_first ? min(Lv, (r_first + 1) * S) : 0;
@@ -1649,13 +1652,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
       const int i = max(min(phys(r_first, min(r_first * S + j * kBlock + (int)threadIdx.x, i_last)), L - 1), 0);
       pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
       cmar0[j] = 0.f;
-      cgate0[j] = 0.f;
       cword0[j] = 0u;
       if (reuse) {  // (uniform)
         const long long ci = (long long)k_first * L + i;
         cmar0[j] = ((gptr_f1)(uintptr_t)cache_margin)[ci];
         cword0[j] = ((gptr_u1)(uintptr_t)cache_leaf)[ci];
-        if (gate_reuse) cgate0[j] = ((gptr_f1)(uintptr_t)cache_gate)[ci];
       }
     }
   }
@@ -2045,8 +2046,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     const bool last_round = (round == n_iters - 1);
     const bool mark_matched = last_round || (flags & kFlagMatchAll);
     const bool reuse = cache_leaf != nullptr && round > 0 && !(flags & kFlagNoReuse);
-    float* __restrict__ cache_gate = cache_margin ? cache_margin + (long long)K * L : nullptr;
-    const bool gate_reuse = reuse && !(flags & kFlagNoGateReuse);
+    const bool gate_file = !(flags & kFlagNoGateReuse);
+    const bool gate_reuse = reuse && gate_file;
     const unsigned tag_prev = tag0 + (unsigned)round;  // rows of round - 1 carry (round - 1) + 1
     const unsigned tag_now = tag_prev + 1u;
     // exchange rows of this scan
@@ -2058,7 +2059,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
     // the first pass's pose-independent loads (leaf coordinates, cached correspondence: L1/L2 hits from the second round
     // on): in flight during the wait below
     vd4 pv0[QPT];
-    float cmar0[QPT], cgate0[QPT];
+    float cmar0[QPT];
     unsigned int cword0[QPT];
     {
       const int i_end0 = have_first ? min(Lv, (r_first + 1) * S) : 0;
@@ -2068,13 +2069,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) voi
         const int i = max(min(phys(r_first, min(r_first * S + j * kBlock + tid, i_last0)), L - 1), 0);
         pv0[j] = ((gptr_d4)(uintptr_t)moving)[i];
         cmar0[j] = 0.f;
-        cgate0[j] = 0.f;
-        cword0[j] = 0u;
+          cword0[j] = 0u;
         if (reuse) {  // (uniform)
           const long long ci = (long long)k_first * L + i;
           cmar0[j] = ((gptr_f1)(uintptr_t)cache_margin)[ci];
           cword0[j] = ((gptr_u1)(uintptr_t)cache_leaf)[ci];
-          if (gate_reuse) cgate0[j] = ((gptr_f1)(uintptr_t)cache_gate)[ci];
         }
       }
     }

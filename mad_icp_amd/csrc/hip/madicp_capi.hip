@@ -806,7 +806,7 @@ int reserve_cache(madicp_ctx* ctx, DevMoving& m, int K) {
   void* p = nullptr;
   RC_TRY(pool_alloc(ctx, sizeof(uint32_t) * need, ctx->stream, &p));
   m.cache_leaf = static_cast<uint32_t*>(p);
-  RC_TRY(pool_alloc(ctx, sizeof(float) * 2 * need, ctx->stream, &p));  // margins, then the gate slacks (kernels.hip.h, "Gate reuse")
+  RC_TRY(pool_alloc(ctx, sizeof(float) * need, ctx->stream, &p));  // one threshold per pair (kernels.hip.h, "Gate reuse")
   m.cache_margin = static_cast<float*>(p);
   m.cache_cap = need;
   return MADICP_OK;

@@ -493,7 +493,11 @@ def test_deep_launches_leaf_major_rounds(ctx):
     for key in ("X", "H", "b", "n_matched", "visits"):
         assert np.array_equal(ref[key], res["default again"][key]), key  # deterministic
         assert np.array_equal(res["never"][key], res["never, no gate reuse"][key]), key  # gate reuse: the same bits
-        assert np.array_equal(res["every round"][key], res["every round, no gate reuse"][key]), key
+    # (in leaf-major rounds the walkers are added last: with gate reuse a rejected pair whose slack has worn off walks again — one
+    # threshold per pair since round 6 — so the ORDER of the sums differs from the run without it, nothing else)
+    a, b = res["every round"], res["every round, no gate reuse"]
+    assert np.array_equal(a["n_matched"], b["n_matched"]) and np.array_equal(a["visits"], b["visits"])
+    assert np.abs(a["X"] - b["X"]).max() <= 1e-12 and np.abs(a["H"] - b["H"]).max() <= 1e-12 * np.abs(a["H"]).max()
     for other in ("every round", "every round, no gate reuse", "never", "never, no gate reuse", "no reuse"):
         o = res[other]
         assert np.array_equal(ref["n_matched"], o["n_matched"]) and np.array_equal(ref["visits"], o["visits"]), other
