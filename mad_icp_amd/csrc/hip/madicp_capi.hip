@@ -226,6 +226,8 @@ struct madicp_ctx {
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
+  int deep_min_leaves = 512;  // option "deep_min_leaves": with 24 keyframes or more, a launch with more trees than workgroups per XCD piece is
+                         // DEEP (one range x all the piece's trees per workgroup) when a range holds at least this many leaves (pick_geometry)
   int interleave = 2;    // option "interleave_ranges": a range is every RPT-th group of 64 leaves instead of a contiguous stretch of the
                          // scan (kernels.hip.h, "Ranges"): 0 never, 1 DEEP launches (a batch shares the chip), 2 every launch
   int cache_gate = 1;   // option "cache_gate": a pair that keeps its leaf and was rejected with more slack than it has moved since is
@@ -492,13 +494,18 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   // of the scan and ALL the trees of its piece — ranges_per_tree = workgroups per piece, so that its units u_first, u_first +
   // nslots, ... are the same range of consecutive trees — which is what the leaf-major rounds need (icp_leaf_major.inc.h)
   const int nslots = g.grid / 8;
+  // (how many leaves a range must hold for that: two passes of a workgroup — below, the leaf-major queue has nothing to compact —
+  // unless the piece holds three trees or more: then one unit per workgroup means the launch waits for the workgroups that drew
+  // the newest keyframes, and one range of ALL the piece's trees per workgroup pays from 512 leaves on; measured,
+  // profiles/r6_deep_threshold.md: 24-64 keyframes x 1-2 scans in flight + 3 .. + 40 %, 16 keyframes - 9 %)
+  const int deep_min = (K >= 24) ? ctx->deep_min_leaves : std::max(ctx->deep_min_leaves, madicp::kQueueMinPasses * madicp::kBlock);
   if (K >= 8 && ctx->queue_walks > 0 && g.qpt == 1 && g.ranges_per_tree < nslots &&
-      max_L / nslots >= madicp::kQueueMinPasses * madicp::kBlock && (K + 7) / 8 + 1 <= madicp::kDeepTrees)
+      max_L / nslots >= deep_min && (K + 7) / 8 + 1 <= madicp::kDeepTrees)
     g.ranges_per_tree = nslots;
   const int per_range = (max_L + g.ranges_per_tree - 1) / g.ranges_per_tree;
   g.lds_bytes = (K > 0 && per_range >= ctx->stage_min_leaves) ? kTopLdsBytes : 0;
   g.queue = (K >= 8 && ctx->queue_walks > 0 && g.qpt == 1 && g.ranges_per_tree == nslots &&
-             per_range >= madicp::kQueueMinPasses * madicp::kBlock) ? 1 : 0;
+             per_range >= deep_min) ? 1 : 0;
   return g;
 }
 
@@ -1327,6 +1334,9 @@ int madicp_ctx_set_option(madicp_ctx* ctx, const char* key, int64_t value) {
     ctx->cache_corr = value ? 1 : 0;
   } else if (k == "cache_gate") {
     ctx->cache_gate = value ? 1 : 0;
+  } else if (k == "deep_min_leaves") {
+    if (value < 64 || value > (1 << 24)) return fail(MADICP_ERR_INVALID, "deep_min_leaves must be in 64 .. 2^24");
+    ctx->deep_min_leaves = (int)value;
   } else if (k == "interleave_ranges") {
     if (value < 0 || value > 2) return fail(MADICP_ERR_INVALID, "interleave_ranges is 0 (never), 1 (batches that share the chip) or 2 (always)");
     ctx->interleave = (int)value;
@@ -1400,6 +1410,7 @@ int madicp_ctx_get_option(madicp_ctx* ctx, const char* key, int64_t* out_value) 
   else if (k == "cache_correspondences") v = ctx->cache_corr;
   else if (k == "cache_gate") v = ctx->cache_gate;
   else if (k == "interleave_ranges") v = ctx->interleave;
+  else if (k == "deep_min_leaves") v = ctx->deep_min_leaves;
   else if (k == "leaf_major") v = ctx->queue_walks;
   else if (k == "lds_stage_min_leaves") v = ctx->stage_min_leaves;
   else if (k == "eager_when_busy") v = ctx->eager_when_busy;

@@ -281,6 +281,38 @@ def test_ranges_dealt_in_groups_of_64_leaves_same_decisions(ctx, K, n_queries):
     _teardown(ctx, tids, mids)
 
 
+def test_deep_launch_with_ranges_of_less_than_a_pass(ctx):
+    """From 24 keyframes on a launch is DEEP — one range of the scan and all the trees of its XCD piece per workgroup — as soon as a
+    range holds 512 leaves (option deep_min_leaves; pick_geometry), i.e. less than one pass of a workgroup: three scans in flight
+    here, ten workgroups per XCD piece, ranges of ~640 leaves.  Same decisions as the unit-per-workgroup launch of the same
+    registration (deep_min_leaves out of reach), poses and H to summation-order rounding, and the oracle's poses."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 24, n_queries=3)
+    Ls = [h.num_leaves for h in qh]
+    assert 512 * 10 <= min(Ls) < 1536 * 10  # (DEEP under the round-6 rule, not under the two-pass rule)
+    X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
+    assert ctx.get_option("deep_min_leaves") == 512
+    res = {}
+    try:
+        for name, v in (("deep", 512), ("units", 1 << 20)):
+            ctx.set_option("deep_min_leaves", v)
+            r = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+            r["matched"] = [ctx.icp_fetch_matched(i, L) for i, L in enumerate(Ls)]
+            res[name] = r
+    finally:
+        ctx.set_option("deep_min_leaves", 512)
+    a, b = res["deep"], res["units"]
+    assert np.array_equal(a["n_matched"], b["n_matched"]) and np.array_equal(a["visits"], b["visits"])
+    for x, y in zip(a["matched"], b["matched"]):
+        assert np.array_equal(x, y)
+    assert np.abs(a["X"] - b["X"]).max() <= 1e-12 and np.abs(a["H"] - b["H"]).max() <= 1e-12 * np.abs(b["H"]).max()
+    for q in (0, 2):
+        o = O.icp_register(qo[q], ots, pb["query_guess"][q], 15, B_MAX, RHO_KER, B_RATIO, num_threads=4)
+        terr, rerr = pose_err(o["T"], capi.pose44(a["X"][q]))
+        assert terr <= POSE_TOL_M and rerr <= POSE_TOL_RAD
+        assert np.array_equal(a["matched"][q], o["matched"]) and a["visits"][q] == o["depth_sum"]
+    _teardown(ctx, tids, mids)
+
+
 def test_interleaved_ranges_with_fewer_groups_than_ranges(ctx):
     """A scan of a few hundred leaves against many workgroups: most ranges of the dealt layout hold one group of 64 leaves or none
     (their virtual indices have no leaf behind them).  Same trace, flags and visit count as the contiguous layout; the visit count
