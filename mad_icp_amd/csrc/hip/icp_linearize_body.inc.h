@@ -4,8 +4,9 @@
 // launch) so that both kernels run the same instructions in the same order; not a translation unit of its own.
 // Names it expects in scope — launch constants: QPT, TRACE, RPT, S, L, hi, nslots, u_first, k_first, r_first, job, moving,
 // matched, corr, cache_leaf, cache_margin, min_ball, rho, b_ratio, inv_min_ball, opt_lds_top, opt_stage_min, s_top, s_exit,
-// s_td, gate_file, Lv, phys ("Ranges", kernels.hip.h); per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3], wear_alpha, wear_beta, pv0 / cmar0 /
-// cword0 (the first pass's pose-independent loads, already issued); state it updates: desc_tree, staged_tree, acc[kAcc], visits,
+// s_td, gate_file, Lv, phys ("Ranges", kernels.hip.h); per round: round, reuse, gate_reuse, mark_matched, stage_hint, R[9], t[3],
+// wear_alpha, wear_beta, pv0 / cmar0 / cword0 (the first pass's pose-independent loads, already issued); state it updates:
+// desc_tree, staged_tree, acc[kAcc], visits,
 // walked_visits, walked.  MADICP_TID: the thread index (threadIdx.x; icp_persist hands in a per-round copy the compiler
 // cannot prove loop-invariant, so that per-lane addresses are recomputed every round instead of hoisted and spilled).
   int k = k_first, r = r_first;
