@@ -45,10 +45,9 @@
     // the evaluation of one pair whose leaf is known: record, gate (mad_icp.cpp:81-83), e, J, weights, accumulation
     // (mad_icp.cpp:59-101) — the arithmetic of the tree-major body, statement for statement
     // (t_file: the pair's threshold on file, t_keep: its leaf's own — kernels.hip.h, "One threshold per pair")
-    auto evaluate = [&](const TreeDesc& td, int kk, int i, int lf, bool walked_now, float t_file, float t_keep, double wear, double px,
-                        double py, double pz, double pnorm, double q0, double q1, double q2) {
-      gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + lf);
-      const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+    // (la .. ld: the leaf's record, one 64-byte line as four 16-byte loads, requested by the caller)
+    auto evaluate = [&](const vd2 la, const vd2 lb, const vd2 lc, const vd2 ld, int kk, int i, bool walked_now, float t_file, float t_keep,
+                        double wear, double px, double py, double pz, double pnorm, double q0, double q1, double q2) {
       const double g0 = q0 - la.x, g1 = q1 - la.y, g2 = q2 - lb.x;
       const double src_ball = min_ball + b_ratio * pnorm;
       const double dist = sqrt(dotc(g0, g1, g2, g0, g1, g2));
@@ -153,11 +152,64 @@
           const long long ci = (long long)kk * L + i;
           const bool cacheable = xd[0] <= kCacheMaxDepth && (unsigned int)xl[0] <= kCacheIdxMask;
           cache_leaf[ci] = (unsigned int)xl[0] | ((unsigned int)xd[0] << 26);
-          evaluate(td, kk, i, xl[0], true, 0.f, cacheable ? __double2float_rd(xm[0] + wear) : 0.f, wear, p.x, p.y, p.z, p.w, a0[0], a1[0],
-                   a2[0]);
+          gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + xl[0]);
+          const vd2 la = lp[0], lb = lp[1], lc = lp[2], ld = lp[3];
+          evaluate(la, lb, lc, ld, kk, i, true, 0.f, cacheable ? __double2float_rd(xm[0] + wear) : 0.f, wear, p.x, p.y, p.z, p.w, a0[0],
+                   a1[0], a2[0]);
         }
       }
       qn = 0;
+      wave_lds_order();
+    };
+
+    // the pairs that keep their leaf and have to be evaluated: not where they stand — at BASELINE configs[4] a fifth of a wavefront's
+    // lanes per tree, and the evaluation is two hundred fp64 instructions for all 64 — but queued like the walkers (in pass, tree,
+    // lane order: deterministic) and evaluated 64 at a time: the lane that evaluates an entry fetches the leaf's coordinates and
+    // its record together (the entry carries the leaf ordinal), transforms, evaluates.  count <= 64 entries from the head; the
+    // rest moves to the front.
+    int qe = 0;
+    auto eval_flush = [&](int count) {
+      wave_lds_order();
+      const bool has = q_lane < count;
+      const int rest = qe - count;  // (< 64)
+      const int e = has ? (int)s_eq_id[q_wave][q_lane] : 0;
+      const unsigned int lf = has ? s_eq_leaf[q_wave][q_lane] : 0u;
+      const float t_file = has ? s_eq_t[q_wave][q_lane] : 0.f;
+      const bool mv = q_lane < rest;
+      const unsigned short m_id = mv ? s_eq_id[q_wave][count + q_lane] : (unsigned short)0;
+      const unsigned int m_lf = mv ? s_eq_leaf[q_wave][count + q_lane] : 0u;
+      const float m_t = mv ? s_eq_t[q_wave][count + q_lane] : 0.f;
+      wave_lds_order();
+      if (mv) {
+        s_eq_id[q_wave][q_lane] = m_id;
+        s_eq_leaf[q_wave][q_lane] = m_lf;
+        s_eq_t[q_wave][q_lane] = m_t;
+      }
+      qe = rest;
+      const int tt = (e >> 6) & (kDeepTrees - 1), pce = e >> (6 + kDeepTreesLog2);
+      const int i = phys(r_first, i_lo + pce * kBlock + q_wave * 64 + (e & 63));
+      const TreeDesc& td = s_tds[has ? tt : 0];
+      vd4 p = vd4{0.0, 0.0, 0.0, 0.0};
+      vd2 la = vd2{0.0, 0.0}, lb = la, lc = la, ld = la;
+      if (has) {  // (coordinates and record are independent loads: one round trip)
+        p = ((gptr_d4)(uintptr_t)moving)[i];
+        gptr_d2 lp = (gptr_d2)(uintptr_t)(td.leaves + (int)lf);
+        la = lp[0]; lb = lp[1]; lc = lp[2]; ld = lp[3];
+      }
+#ifdef MADICP_XFORM_HOMOGENEOUS
+      const double e0 = ((R[0] * p.x + R[1] * p.y) + R[2] * p.z) + t[0];
+      const double e1 = ((R[3] * p.x + R[4] * p.y) + R[5] * p.z) + t[1];
+      const double e2 = ((R[6] * p.x + R[7] * p.y) + R[8] * p.z) + t[2];
+#else
+      const double e0 = t[0] + dots(R[0], R[1], R[2], p.x, p.y, p.z);
+      const double e1 = t[1] + dots(R[3], R[4], R[5], p.x, p.y, p.z);
+      const double e2 = t[2] + dots(R[6], R[7], R[8], p.x, p.y, p.z);
+#endif
+      if (has) {
+        const double wear = __builtin_fma(p.w, wear_alpha, wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) +
+                                                                                                  fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0)));
+        evaluate(la, lb, lc, ld, k_first + tt, i, false, t_file, fabsf(t_file), wear, p.x, p.y, p.z, p.w, e0, e1, e2);
+      }
       wave_lds_order();
     };
 
@@ -200,8 +252,7 @@
           // thresholds and the walked counter are the same doubles whichever mode a round ran in)
           const double wear = __builtin_fma(p.w, wear_alpha, wear_beta + (double)round * (1e-11 * (td.rho + fabs(td.origin[0]) +
                                                                                               fabs(td.origin[1]) + fabs(td.origin[2]) + 1.0)));
-          const float t_keep = fabsf(cm[a]);
-          const bool keep = valid && (double)t_keep > wear;
+          const bool keep = valid && (double)fabsf(cm[a]) > wear;
           const bool w = valid && !keep;
           // queue the walkers: pass, tree, lane — in pass, tree, lane order (a ballot and a prefix count: deterministic)
           const unsigned long long wm = __ballot(w);
@@ -211,13 +262,23 @@
             qn += __popcll(wm);
             walked |= w;
           }
-          if (keep) {
-            visits += cw[a] >> 26;
-            if (!(gate_reuse && cm[a] < 0.f))  // (a negative threshold above the wear: same leaf, still rejected)
-              evaluate(td, k_first + tt, i, (int)(cw[a] & kCacheIdxMask), false, cm[a], t_keep, wear, p.x, p.y, p.z, p.w, q0, q1, q2);
+          if (keep) visits += cw[a] >> 26;
+          // (a negative threshold above the wear: same leaf, still rejected — nothing to evaluate)
+          const bool ev = keep && !(gate_reuse && cm[a] < 0.f);
+          const unsigned long long em = __ballot(ev);
+          if (em) {  // (wave-uniform)
+            if (ev) {
+              const int at = qe + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
+              s_eq_id[q_wave][at] = (unsigned short)((pc << (6 + kDeepTreesLog2)) | (tt << 6) | q_lane);
+              s_eq_leaf[q_wave][at] = cw[a] & kCacheIdxMask;
+              s_eq_t[q_wave][at] = cm[a];
+            }
+            qe += __popcll(em);
+            if (qe >= 64) eval_flush(64);
           }
         }
       }
     }
+    if (qe > 0) eval_flush(qe);
     drain();
   } else
