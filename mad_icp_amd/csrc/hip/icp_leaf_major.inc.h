@@ -16,9 +16,14 @@
 // a pair that has to walk is not walked in place but QUEUED — per wavefront, 2 bytes in LDS — and the queue is walked DENSELY
 // (64 walkers per descent, from global memory: the LDS-staged top belongs to one tree) when it is full or the range is done;
 // the walker's leaf record, gate and accumulation follow its descent.  The number of descents a wavefront waits for is
-// ceil(walkers / 64), not the number of passes that hold one.
+// ceil(walkers / 64), not the number of passes that hold one.  Round 6: the pairs that keep their leaf and have to be EVALUATED
+// are queued the same way (pass | tree | lane, leaf ordinal, threshold on file: 10 bytes in LDS) and evaluated 64 at a time as
+// soon as 64 are there — where they stood, a fifth of a wavefront's lanes per tree were active through the two hundred fp64
+// instructions of gate, Jacobian and 28 accumulations (the counters of profiles/r6_k64_pmc_summary.md: the vector ALU is the
+// busiest unit of this kernel), now all 64 are.
 //
-// The ACCUMULATION ORDER is another one than the tree-major body's (pass-major, walkers last), so H and b differ from it in
+// The ACCUMULATION ORDER is another one than the tree-major body's (queue order: pass, tree, lane, over the lanes of a wavefront as
+// they come; walkers last), so H and b differ from it in
 // their last bits (~1e-16 relative; the pose contract is 1e-5 and the reference's own order depends on its thread count) —
 // every DECISION (leaf, depth, gate, matched flag, visit count) is the same on the data the tests hold it to — structurally so
 // except at exact ties: the pose of a later round differs from the tree-major one's by ~1e-16, so a pair that sits EXACTLY on a
