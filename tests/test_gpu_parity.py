@@ -313,6 +313,34 @@ def test_deep_launch_with_ranges_of_less_than_a_pass(ctx):
     _teardown(ctx, tids, mids)
 
 
+@pytest.mark.parametrize("K", [1, 5])
+def test_two_leaves_per_lane_same_decisions(ctx, K):
+    """Option queries_per_lane = 2 (two leaves per lane and pass share their loads; the default is one): another instantiation of
+    the round kernel over the same ranges — dealt or contiguous — with the same correspondence trace, matched flags and visit
+    counter, H / b / pose to summation-order rounding."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, K)
+    T = pb["query_guess"][0]
+    L = qh[0].num_leaves
+    res = {}
+    try:
+        for qpt in (1, 2):
+            for inter in (2, 0):
+                ctx.set_option("queries_per_lane", qpt)
+                ctx.set_option("interleave_ranges", inter)
+                res[qpt, inter] = (ctx.icp_linearize(mids[0], tids, T, PARAMS, L), ctx.icp_register(mids[0], tids, T, PARAMS, 15, L))
+    finally:
+        ctx.set_option("queries_per_lane", 1)
+        ctx.set_option("interleave_ranges", 2)
+    ref = res[1, 2]
+    for key, (lin, reg) in res.items():
+        assert np.array_equal(lin["corr"], ref[0]["corr"]), key
+        assert np.array_equal(lin["matched"], ref[0]["matched"]) and lin["visits"] == ref[0]["visits"], key
+        assert np.allclose(lin["H"], ref[0]["H"], rtol=0, atol=1e-12 * np.abs(ref[0]["H"]).max()), key
+        assert np.array_equal(reg["matched"], ref[1]["matched"]) and reg["visits"] == ref[1]["visits"], key
+        assert np.abs(reg["X"] - ref[1]["X"]).max() <= 1e-12, key
+    _teardown(ctx, tids, mids)
+
+
 def test_interleaved_ranges_with_fewer_groups_than_ranges(ctx):
     """A scan of a few hundred leaves against many workgroups: most ranges of the dealt layout hold one group of 64 leaves or none
     (their virtual indices have no leaf behind them).  Same trace, flags and visit count as the contiguous layout; the visit count
