@@ -341,6 +341,42 @@ def test_two_leaves_per_lane_same_decisions(ctx, K):
     _teardown(ctx, tids, mids)
 
 
+@pytest.mark.parametrize("option,value,default", [("units_per_workgroup", 3, 1), ("grid_blocks_per_cu", 2, 1), ("publish_side", 0, 1),
+                                                  ("lds_stage_min_leaves", 1 << 30, 1024)])
+def test_launch_shape_options_change_no_decision(ctx, option, value, default):
+    """The launch-shape knobs of include/madicp_hip.h that no other test turns: more (tree, range) units per workgroup, more workgroups
+    per CU, results written by the closing kernel itself instead of the side stream, no LDS-staged top.  Synchronous, batched and
+    streamed registrations of the same scans end with the same flags and visit counters, poses to summation-order rounding."""
+    pb, hts, ots, tids, qh, qo, mids = _setup_registration(ctx, 5, n_queries=3)
+    Ls = [h.num_leaves for h in qh]
+    X0 = np.stack([capi.pose12(T) for T in pb["query_guess"]])
+    leaves = [h.leaf_means() for h in qh]
+    assert ctx.get_option(option) == default
+    res = {}
+    try:
+        for v in (default, value):
+            ctx.set_option(option, v)
+            one = ctx.icp_register(mids[0], tids, pb["query_guess"][0], PARAMS, 15, Ls[0])
+            bat = ctx.icp_register_batch(mids, tids, X0, PARAMS, 15)
+            bat["matched"] = [ctx.icp_fetch_matched(i, L) for i, L in enumerate(Ls)]
+            tk = [ctx.stream_submit(leaves[q], tids, pb["query_guess"][q], PARAMS, 15) for q in range(2)]
+            st = [ctx.stream_collect(t, Ls[q]) for q, t in enumerate(tk)]
+            res[v] = (one, bat, st)
+    finally:
+        ctx.set_option(option, default)
+    (a1, ab, as_), (b1, bb, bs) = res[default], res[value]
+    assert np.array_equal(a1["matched"], b1["matched"]) and a1["visits"] == b1["visits"] and np.abs(a1["X"] - b1["X"]).max() <= 1e-12
+    assert np.array_equal(ab["n_matched"], bb["n_matched"]) and np.array_equal(ab["visits"], bb["visits"])
+    assert np.abs(ab["X"] - bb["X"]).max() <= 1e-12
+    for x, y in zip(ab["matched"], bb["matched"]):
+        assert np.array_equal(x, y)
+    for x, y in zip(as_, bs):
+        assert np.array_equal(x["matched"], y["matched"]) and x["visits"] == y["visits"] and np.abs(x["X"] - y["X"]).max() <= 1e-12
+    # (and the streamed registration is the synchronous one)
+    assert np.array_equal(as_[0]["matched"], a1["matched"]) and np.abs(as_[0]["X"] - a1["X"]).max() <= 1e-12
+    _teardown(ctx, tids, mids)
+
+
 def test_interleaved_ranges_with_fewer_groups_than_ranges(ctx):
     """A scan of a few hundred leaves against many workgroups: most ranges of the dealt layout hold one group of 64 leaves or none
     (their virtual indices have no leaf behind them).  Same trace, flags and visit count as the contiguous layout; the visit count
