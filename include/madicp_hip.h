@@ -100,9 +100,9 @@ int madicp_ctx_synchronize(madicp_ctx* ctx);
  * leaves instead of contiguous stretches — a stretch of the leaf order is a stretch of space, and stretches differ several-fold
  * in how many of their pairs pass the gate: the launch waited for the workgroups that drew the busy stretch; 1 = only in batches
  * that share the chip, 2 = every launch.  Another summation order for H and b (~1e-16), the same decisions),
- * "deep_min_leaves" (default 512: from 24 keyframes on, a launch with more trees than workgroups per XCD piece gives every workgroup one
- * range of the scan and all the trees of its piece as soon as a range holds this many leaves; with fewer keyframes the rule stays
- * two passes of a workgroup, 1536 leaves — measured, profiles/r6_deep_threshold.md),
+ * "deep_min_leaves" (default 512: from 24 keyframes on with two or more scans in flight — from 48 on with one — a launch with more
+ * trees than workgroups per XCD piece gives every workgroup one range of the scan and all the trees of its piece as soon as a range
+ * holds this many leaves; otherwise the rule stays two passes of a workgroup, 1536 leaves — measured, profiles/r6_deep_threshold.md),
  * "units_per_workgroup" (1..64, default 1: with more trees than workgroups per scan, cut the leaves into enough ranges for at
  * least this many (tree, range) units per workgroup; measured: no gain),
  * "lds_stage_min_leaves" (a workgroup copies a tree's top levels into LDS when its unit holds at least this many leaves),

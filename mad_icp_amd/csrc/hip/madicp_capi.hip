@@ -226,8 +226,9 @@ struct madicp_ctx {
   int comm_graph = 0;     // capture the RCCL calls too (off: rounds are launched eagerly with a communicator)
   int qpt_override = 0;
   int cache_corr = 1;  // reuse correspondences across GN rounds when provably unchanged
-  int deep_min_leaves = 512;  // option "deep_min_leaves": with 24 keyframes or more, a launch with more trees than workgroups per XCD piece is
-                         // DEEP (one range x all the piece's trees per workgroup) when a range holds at least this many leaves (pick_geometry)
+  int deep_min_leaves = 512;  // option "deep_min_leaves": with 24 keyframes or more and two scans in flight (48 or more and one), a launch with
+                         // more trees than workgroups per XCD piece is DEEP (one range x all the piece's trees per workgroup) when a range
+                         // holds at least this many leaves (pick_geometry)
   int interleave = 2;    // option "interleave_ranges": a range is every RPT-th group of 64 leaves instead of a contiguous stretch of the
                          // scan (kernels.hip.h, "Ranges"): 0 never, 1 DEEP launches (a batch shares the chip), 2 every launch
   int cache_gate = 1;   // option "cache_gate": a pair that keeps its leaf and was rejected with more slack than it has moved since is
@@ -498,7 +499,9 @@ Geometry pick_geometry(const madicp_ctx* ctx, int max_L, int K, int batch) {
   // unless the piece holds three trees or more: then one unit per workgroup means the launch waits for the workgroups that drew
   // the newest keyframes, and one range of ALL the piece's trees per workgroup pays from 512 leaves on; measured,
   // profiles/r6_deep_threshold.md: 24-64 keyframes x 1-2 scans in flight + 3 .. + 40 %, 16 keyframes - 9 %)
-  const int deep_min = (K >= 24) ? ctx->deep_min_leaves : std::max(ctx->deep_min_leaves, madicp::kQueueMinPasses * madicp::kBlock);
+  // (one scan in flight against 24-47 keyframes stays as it was: - 2 .. - 4 % that way at 32 keyframes, + 3 % at 24)
+  const bool small_ranges_pay = K >= 24 && (batch >= 2 || K >= 48);
+  const int deep_min = small_ranges_pay ? ctx->deep_min_leaves : std::max(ctx->deep_min_leaves, madicp::kQueueMinPasses * madicp::kBlock);
   if (K >= 8 && ctx->queue_walks > 0 && g.qpt == 1 && g.ranges_per_tree < nslots &&
       max_L / nslots >= deep_min && (K + 7) / 8 + 1 <= madicp::kDeepTrees)
     g.ranges_per_tree = nslots;
