@@ -377,6 +377,54 @@ def test_launch_shape_options_change_no_decision(ctx, option, value, default):
     _teardown(ctx, tids, mids)
 
 
+def test_work_distribution_over_random_geometries(ctx):
+    """Round 6's work distribution — ranges dealt in groups of 64 leaves, trees in alternating rows, DEEP launches from 512 leaves
+    per range, leaf-major rounds with their two queues — against the plain layout (contiguous ranges, trees as listed, one unit per
+    workgroup, every round tree-major) over forty seeded draws of the launch geometry: 1-40 keyframes picked at random from a map,
+    1-8 scans in flight with ragged sizes from a few hundred to 8 700 leaves, 2 / 5 / 15 rounds.  Every draw: the same matched
+    flags, matched counts and visit counters, poses to summation-order rounding."""
+    rng = np.random.default_rng(123)
+    pb = street_problem(40, n_queries=8)
+    all_tids = []
+    for s_, T in zip(pb["keyframe_scans"], pb["keyframe_poses"]):
+        ht, _ = build_pair(s_, T=T)
+        all_tids.append(ctx.tree_upload(ht.nodes, ht.num_leaves))
+    qh = [capi.HostTree(s_, B_MAX, B_MIN, 2) for s_ in pb["query_scans"]]
+    plain = dict(interleave_ranges=0, deal_trees=0, deep_min_leaves=1 << 20, leaf_major=0)
+    default = dict(interleave_ranges=2, deal_trees=2, deep_min_leaves=512, leaf_major=8192)
+    for k_, v_ in default.items():
+        assert ctx.get_option(k_) == v_, k_
+    try:
+        for trial in range(40):
+            K, B, iters = int(rng.integers(1, 41)), int(rng.integers(1, 9)), int(rng.choice([2, 5, 15]))
+            cut = int(rng.integers(200, qh[0].num_leaves))
+            tids = [int(t) for t in rng.choice(all_tids, K, replace=False)]
+            leaves = [h.leaf_means()[: cut + 37 * b] for b, h in enumerate(qh[:B])]
+            Ls = [l.shape[0] for l in leaves]
+            mids = [ctx.moving_upload(l) for l in leaves]
+            X0 = np.stack([capi.pose12(T) for T in pb["query_guess"][:B]])
+            res = []
+            for opts in (plain, default):
+                for k_, v_ in opts.items():
+                    ctx.set_option(k_, v_)
+                r = ctx.icp_register_batch(mids, tids, X0, PARAMS, iters)
+                r["matched"] = [ctx.icp_fetch_matched(i, L) for i, L in enumerate(Ls)]
+                res.append(r)
+            a, b = res
+            what = (trial, K, B, iters, min(Ls), max(Ls))
+            assert np.array_equal(a["n_matched"], b["n_matched"]) and np.array_equal(a["visits"], b["visits"]), what
+            for x, y in zip(a["matched"], b["matched"]):
+                assert np.array_equal(x, y), what
+            assert np.abs(a["X"] - b["X"]).max() <= 1e-11, (what, np.abs(a["X"] - b["X"]).max())
+            for m in mids:
+                ctx.moving_release(m)
+    finally:
+        for k_, v_ in default.items():
+            ctx.set_option(k_, v_)
+    for t_ in all_tids:
+        ctx.tree_release(t_)
+
+
 def test_interleaved_ranges_with_fewer_groups_than_ranges(ctx):
     """A scan of a few hundred leaves against many workgroups: most ranges of the dealt layout hold one group of 64 leaves or none
     (their virtual indices have no leaf behind them).  Same trace, flags and visit count as the contiguous layout; the visit count
